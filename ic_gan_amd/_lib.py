@@ -1,0 +1,111 @@
+"""ctypes binding of libicgan_hip.so (the C-ABI in include/icgan_hip.h).
+
+The signatures are parsed from the header itself, so the binding cannot drift from
+the declared ABI.  There is NO fallback: if the shared library is missing or a call
+fails, a RuntimeError is raised (the product path never routes around the HIP kernels).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "icgan_hip.h")
+LIB_PATH = os.path.join(_HERE, "lib", "libicgan_hip.so")
+
+ICG_PRE_RELU, ICG_PRE_AFFINE, ICG_UPSAMPLE2X, ICG_RES_UPSAMPLE2X = 1, 2, 4, 8
+
+_SCALARS = {
+    "int": ctypes.c_int, "unsigned": ctypes.c_uint, "float": ctypes.c_float, "double": ctypes.c_double,
+    "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t,
+}
+
+
+class AdamTensor(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("numel", ctypes.c_int64)]
+
+
+class EmaTensor(ctypes.Structure):
+    _fields_ = [("target", ctypes.c_void_p), ("source", ctypes.c_void_p), ("numel", ctypes.c_int64)]
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[str, List[Tuple[str, str]]]]:
+    """-> {function name: (return type, [(arg type, arg name), ...])} for every prototype."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"^\s*#.*$", "", src, flags=re.M)
+    src = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(icg_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        alist = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.+?)\s*(\w+)$", a)
+                alist.append((mm.group(1).strip(), mm.group(2)))
+        protos[name] = (ret, alist)
+    return protos
+
+
+def _ctype(t: str):
+    t = t.replace("const ", "").strip()
+    if t.endswith("*"):
+        return ctypes.c_char_p if t == "char*" else ctypes.c_void_p
+    return _SCALARS[t]
+
+
+_lib = None
+_protos = None
+
+
+def lib():
+    global _lib, _protos
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"ic_gan_amd: HIP library not built: {LIB_PATH} missing. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (ic_gan_amd/csrc/build.sh). There is no CPU/PyTorch fallback for the hot path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _protos = parse_header()
+        for name, (ret, args) in _protos.items():
+            fn = getattr(_lib, name)      # AttributeError if the .so lacks a declared symbol
+            fn.restype = ctypes.c_char_p if "char" in ret else _ctype(ret)
+            fn.argtypes = [_ctype(t) for t, _ in args]
+    return _lib
+
+
+def protos():
+    lib()
+    return _protos
+
+
+def _conv(a):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    return a
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    """Call an `int icg_*` entry point on the current stream; raise on a non-zero status."""
+    l = lib()
+    rc = getattr(l, name)(*[_conv(a) for a in args], stream_ptr())
+    if rc != 0:
+        msg = l.icg_strerror(rc).decode()
+        raise RuntimeError(f"{name} failed: {msg} (code {rc}, hip error {l.icg_last_hip_error()})")
+
+
+def query(name: str, *args) -> int:
+    """Call a `size_t icg_*_bytes` query."""
+    return int(getattr(lib(), name)(*[_conv(a) for a in args]))

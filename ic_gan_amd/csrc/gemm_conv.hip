@@ -1,0 +1,545 @@
+// fp32 MFMA implicit-GEMM for gfx950: fused convolution (fprop / dgrad / wgrad), every Linear and the
+// attention contractions of the IC-GAN BigGAN G+D step.
+//
+// Replaces cuDNN/ATen behind F.conv2d / F.linear / torch.bmm at BigGAN_PyTorch/layers.py:144-153,
+// 164-165, 237-243 together with the elementwise glue around them (BN apply, ReLU, nearest upsample,
+// residual add: layers.py:542-552, 587-613).
+//
+// Design (MI355X-first):
+//   * one workgroup = 4 wavefronts (64 lanes each) computes a 128 x (32*TN) tile of C; wave w owns rows
+//     32w..32w+31 and TN accumulators of v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain)
+//   * both operands are staged K-major in LDS ([k][m], [k][n]) so every MFMA operand fetch is one
+//     conflict-free ds_read_b32 of 32 consecutive floats per half-wave
+//   * global->register prefetch of tile t+1 is issued before the 8*TN MFMAs of tile t (2 LDS buffers,
+//     one barrier per K-tile); the BN/ccbn affine, ReLU, zero padding and the nearest-upsample index
+//     map are applied in registers on the way into LDS, so the normalised / upsampled tensor never
+//     exists in HBM
+//   * NHWC activations: the K-slice of an im2col row is contiguous (coalesced 16-byte loads)
+#include "icg_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { A_K = 0, A_M = 1 };  // A: K-contiguous rows (im2col gather) | M-contiguous rows (transposed gather)
+enum { B_K = 0, B_N = 1 };  // B: [N][K] | [K][N]
+
+struct GemmP {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  int H, W, Cin, R, up, Hs, Ws;  // gather geometry of the A operand (pixel grid = conv OUTPUT grid)
+  const float* scale;
+  const float* shift;
+  long ss_bstride;
+  int pre_affine, pre_relu;
+  long ldb, ldc;
+  const float* bias;
+  const float* res;
+  int res_up;
+  float alpha;
+  long strideA, strideB, strideC;  // per blockIdx.z
+  int kchunk;                      // >0: split-K, z selects the K range
+  int ntiles_n;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int AMODE, int BMODE, int TN, bool VEC>
+__global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
+  constexpr int BM = 128, BN = 32 * TN, BK = 16;
+  constexpr int LDA = (AMODE == A_K) ? BM + 1 : BM + 4;
+  constexpr int LDB = (BMODE == B_K) ? BN + 1 : BN + 4;
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+  const int tid = threadIdx.x;
+  const int nt = blockIdx.x % p.ntiles_n;
+  const int mt = blockIdx.x / p.ntiles_n;
+  const int z = blockIdx.z;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const float* __restrict__ Ag = p.A + (long)z * p.strideA;
+  const float* __restrict__ Bg = p.B + (long)z * p.strideB;
+  float* __restrict__ Cg = p.C + (long)z * p.strideC;
+  int kbeg = 0, kend = p.K;
+  if (p.kchunk > 0) {
+    kbeg = z * p.kchunk;
+    kend = min(p.K, kbeg + p.kchunk);
+  }
+  const int pad = p.R >> 1;
+  const int Cin = p.Cin;
+
+  // ------------------------------------------------------------------ loader state
+  float4 ra[2], rsc[2], rsh[2], rb[2];
+  // A_K : thread -> (k quad kq, rows arow + 64 i);  A_M : thread -> (m quad mq, k rows krow + 8 i)
+  const int kq = tid & 3, arow = tid >> 2;
+  const int mq = tid & 31, krow = tid >> 5;
+  int ab[2], ah[2], aw[2];
+  bool amv[2];
+  int am_tap_r[4], am_tap_s[4], am_c[4];
+  bool am_mv[4];
+  if (AMODE == A_K) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int m = m0 + arow + 64 * i;
+      amv[i] = m < p.M;
+      int mm = amv[i] ? m : 0;
+      aw[i] = mm % p.W;
+      int t = mm / p.W;
+      ah[i] = t % p.H;
+      ab[i] = t / p.H;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int m = m0 + 4 * mq + j;
+      am_mv[j] = m < p.M;
+      int mm = am_mv[j] ? m : 0;
+      int tap = mm / Cin;
+      am_c[j] = mm - tap * Cin;
+      am_tap_r[j] = tap / p.R;
+      am_tap_s[j] = tap - am_tap_r[j] * p.R;
+    }
+  }
+
+  auto src_index = [&](int b, int hi, int wi, int c) -> long {
+    return (((long)b * p.Hs + (hi >> p.up)) * p.Ws + (wi >> p.up)) * Cin + c;
+  };
+
+  auto load_A = [&](int k0) {
+    if (AMODE == A_K) {
+      const int kg = k0 + 4 * kq;
+      if (VEC) {
+        const bool kv = kg < kend;
+        const int tap = kv ? kg / Cin : 0;
+        const int c = kg - tap * Cin;
+        const int r = tap / p.R, s = tap - r * p.R;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int hi = ah[i] + r - pad, wi = aw[i] + s - pad;
+          const bool ok = kv && amv[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+          ra[i] = zero4();
+          rsc[i] = zero4();
+          rsh[i] = zero4();
+          if (ok) {
+            ra[i] = ld4(Ag + src_index(ab[i], hi, wi, c));
+            if (p.pre_affine) {
+              rsc[i] = ld4(p.scale + (long)ab[i] * p.ss_bstride + c);
+              rsh[i] = ld4(p.shift + (long)ab[i] * p.ss_bstride + c);
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float v[4], sc[4], sh[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = 0.f; sc[j] = 0.f; sh[j] = 0.f;
+            const int kj = kg + j;
+            if (kj < kend && amv[i]) {
+              const int tap = kj / Cin;
+              const int c = kj - tap * Cin;
+              const int r = tap / p.R, s = tap - r * p.R;
+              const int hi = ah[i] + r - pad, wi = aw[i] + s - pad;
+              if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
+                v[j] = Ag[src_index(ab[i], hi, wi, c)];
+                if (p.pre_affine) {
+                  sc[j] = p.scale[(long)ab[i] * p.ss_bstride + c];
+                  sh[j] = p.shift[(long)ab[i] * p.ss_bstride + c];
+                }
+              }
+            }
+          }
+          ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+          rsc[i] = make_float4(sc[0], sc[1], sc[2], sc[3]);
+          rsh[i] = make_float4(sh[0], sh[1], sh[2], sh[3]);
+        }
+      }
+    } else {  // A_M : rows are pixels (k), columns are (tap, c) (m)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kp = k0 + krow + 8 * i;
+        ra[i] = zero4();
+        rsc[i] = zero4();
+        rsh[i] = zero4();
+        if (kp < kend) {
+          const int w = kp % p.W;
+          const int t = kp / p.W;
+          const int h = t % p.H;
+          const int b = t / p.H;
+          if (VEC) {
+            const int hi = h + am_tap_r[0] - pad, wi = w + am_tap_s[0] - pad;
+            if (am_mv[0] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
+              ra[i] = ld4(Ag + src_index(b, hi, wi, am_c[0]));
+              if (p.pre_affine) {
+                rsc[i] = ld4(p.scale + (long)b * p.ss_bstride + am_c[0]);
+                rsh[i] = ld4(p.shift + (long)b * p.ss_bstride + am_c[0]);
+              }
+            }
+          } else {
+            float v[4], sc[4], sh[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] = 0.f; sc[j] = 0.f; sh[j] = 0.f;
+              const int hi = h + am_tap_r[j] - pad, wi = w + am_tap_s[j] - pad;
+              if (am_mv[j] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
+                v[j] = Ag[src_index(b, hi, wi, am_c[j])];
+                if (p.pre_affine) {
+                  sc[j] = p.scale[(long)b * p.ss_bstride + am_c[j]];
+                  sh[j] = p.shift[(long)b * p.ss_bstride + am_c[j]];
+                }
+              }
+            }
+            ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+            rsc[i] = make_float4(sc[0], sc[1], sc[2], sc[3]);
+            rsh[i] = make_float4(sh[0], sh[1], sh[2], sh[3]);
+          }
+        }
+      }
+    }
+  };
+
+  auto act4 = [&](float4 v, float4 sc, float4 sh) -> float4 {
+    if (p.pre_affine) {
+      v.x = fmaf(v.x, sc.x, sh.x);
+      v.y = fmaf(v.y, sc.y, sh.y);
+      v.z = fmaf(v.z, sc.z, sh.z);
+      v.w = fmaf(v.w, sc.w, sh.w);
+    }
+    if (p.pre_relu) {
+      v.x = fmaxf(v.x, 0.f);
+      v.y = fmaxf(v.y, 0.f);
+      v.z = fmaxf(v.z, 0.f);
+      v.w = fmaxf(v.w, 0.f);
+    }
+    return v;
+  };
+
+  auto store_A = [&](int buf) {
+    float* as = As[buf];
+    if (AMODE == A_K) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 v = act4(ra[i], rsc[i], rsh[i]);
+        const int row = arow + 64 * i;
+        as[(4 * kq + 0) * LDA + row] = v.x;
+        as[(4 * kq + 1) * LDA + row] = v.y;
+        as[(4 * kq + 2) * LDA + row] = v.z;
+        as[(4 * kq + 3) * LDA + row] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 v = act4(ra[i], rsc[i], rsh[i]);
+        *reinterpret_cast<float4*>(&as[(krow + 8 * i) * LDA + 4 * mq]) = v;
+      }
+    }
+  };
+
+  auto load_B = [&](int k0) {
+    if (BMODE == B_K) {
+      const int kg = k0 + 4 * kq;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int nl = arow + 64 * i;
+        const int n = n0 + nl;
+        rb[i] = zero4();
+        if (nl < BN && n < p.N) {
+          const float* src = Bg + (long)n * p.ldb + kg;
+          if (VEC) {
+            if (kg < kend) rb[i] = ld4(src);
+          } else {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (kg + j < kend) ? src[j] : 0.f;
+            rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    } else {
+      const int nl = 4 * mq;
+      const int n = n0 + nl;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kp = k0 + krow + 8 * i;
+        rb[i] = zero4();
+        if (nl < BN && kp < kend) {
+          const float* src = Bg + (long)kp * p.ldb + n;
+          if (VEC) {
+            if (n < p.N) rb[i] = ld4(src);
+          } else {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (n + j < p.N) ? src[j] : 0.f;
+            rb[i] = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    }
+  };
+
+  auto store_B = [&](int buf) {
+    float* bs = Bs[buf];
+    if (BMODE == B_K) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int nl = arow + 64 * i;
+        if (nl < BN) {
+          bs[(4 * kq + 0) * LDB + nl] = rb[i].x;
+          bs[(4 * kq + 1) * LDB + nl] = rb[i].y;
+          bs[(4 * kq + 2) * LDB + nl] = rb[i].z;
+          bs[(4 * kq + 3) * LDB + nl] = rb[i].w;
+        }
+      }
+    } else {
+      if (4 * mq < BN) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          *reinterpret_cast<float4*>(&bs[(krow + 8 * i) * LDB + 4 * mq]) = rb[i];
+      }
+    }
+  };
+
+  // ------------------------------------------------------------------ main loop
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int lane = tid & 63, wv = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  if (nk > 0) {
+    load_A(kbeg);
+    load_B(kbeg);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    store_A(buf);
+    store_B(buf);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      load_A(kbeg + (kt + 1) * BK);
+      load_B(kbeg + (kt + 1) * BK);
+    }
+    const float* as = As[buf] + 32 * wv + li;
+    const float* bs = Bs[buf] + li;
+#pragma unroll
+    for (int t = 0; t < BK / 2; ++t) {
+      const float a = as[(2 * t + lh) * LDA];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float b = bs[(2 * t + lh) * LDB + 32 * j];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int m = m0 + 32 * wv + row;
+    if (m >= p.M) continue;
+    long res_row = (long)m;
+    if (p.res != nullptr && p.res_up) {
+      const int w = m % p.W;
+      const int t = m / p.W;
+      const int h = t % p.H;
+      const int b = t / p.H;
+      res_row = ((long)b * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + 32 * j + li;
+      if (n < p.N) {
+        float v = p.alpha * acc[j][r];
+        if (p.bias != nullptr) v += p.bias[n];
+        if (p.res != nullptr) v += p.res[res_row * p.ldc + n];
+        Cg[(long)m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
+// deterministic second stage of split-K: out[i] = sum_z slab[z][i]
+__global__ void icg_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n,
+                                         int splits) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(long)z * n + i];
+    out[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------- host side
+static int pick_tn(int N) {
+  if (N <= 32) return 1;
+  if (N <= 64) return 2;
+  if (N % 128 == 0) return 4;
+  if (N % 96 == 0) return 3;
+  if (N <= 96) return 3;
+  return 4;
+}
+
+template <int AMODE, int BMODE>
+static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st) {
+  GemmP p = p0;
+  const int tn = pick_tn(p.N);
+  const int bn = 32 * tn;
+  p.ntiles_n = (int)icg_cdiv(p.N, bn);
+  const long tiles = icg_cdiv(p.M, 128) * p.ntiles_n;
+  if (tiles <= 0 || tiles > 0x7fffffffL || zdim <= 0 || zdim > 65535) return ICG_ERR_ARG;
+  dim3 grid((unsigned)tiles, 1, (unsigned)zdim), block(256);
+#define ICG_LAUNCH(TN_, VEC_) \
+  hipLaunchKernelGGL((icg_gemm_kernel<AMODE, BMODE, TN_, VEC_>), grid, block, 0, st, p)
+  if (vec) {
+    switch (tn) {
+      case 1: ICG_LAUNCH(1, true); break;
+      case 2: ICG_LAUNCH(2, true); break;
+      case 3: ICG_LAUNCH(3, true); break;
+      default: ICG_LAUNCH(4, true); break;
+    }
+  } else {
+    switch (tn) {
+      case 1: ICG_LAUNCH(1, false); break;
+      case 2: ICG_LAUNCH(2, false); break;
+      case 3: ICG_LAUNCH(3, false); break;
+      default: ICG_LAUNCH(4, false); break;
+    }
+  }
+#undef ICG_LAUNCH
+  return icg_check_launch();
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int icg_conv2d_fprop(const float* x, const float* w, const float* bias, const float* residual,
+                                float* out, const float* scale, const float* shift, int64_t ss_bstride, int B,
+                                int H, int W, int Cin, int Cout, int R, unsigned flags, float alpha,
+                                void* stream) {
+  ICG_REQUIRE(x && w && out);
+  ICG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (R == 1 || R == 3));
+  const int up = (flags & ICG_UPSAMPLE2X) ? 1 : 0;
+  if (up) ICG_REQUIRE((H % 2 == 0) && (W % 2 == 0));
+  if (flags & ICG_RES_UPSAMPLE2X) ICG_REQUIRE(residual && (H % 2 == 0) && (W % 2 == 0));
+  if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift);
+  const long M = (long)B * H * W;
+  ICG_REQUIRE(M < 0x7fffffffL);
+  GemmP p{};
+  p.A = x; p.B = w; p.C = out;
+  p.M = (int)M; p.N = Cout; p.K = R * R * Cin;
+  p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.up = up; p.Hs = H >> up; p.Ws = W >> up;
+  p.scale = scale; p.shift = shift; p.ss_bstride = ss_bstride;
+  p.pre_affine = (flags & ICG_PRE_AFFINE) ? 1 : 0;
+  p.pre_relu = (flags & ICG_PRE_RELU) ? 1 : 0;
+  p.ldb = p.K; p.ldc = Cout;
+  p.bias = bias; p.res = residual; p.res_up = (flags & ICG_RES_UPSAMPLE2X) ? 1 : 0;
+  p.alpha = alpha;
+  p.kchunk = 0;
+  bool vec = (Cin % 4 == 0) && aligned16(x) && aligned16(w);
+  if (p.pre_affine) vec = vec && (ss_bstride % 4 == 0) && aligned16(scale) && aligned16(shift);
+  return launch_gemm<A_K, B_K>(p, vec, 1, (hipStream_t)stream);
+}
+
+struct WgradPlan {
+  int splits;
+  int kchunk;
+};
+
+static WgradPlan wgrad_plan(long K, int M, int N) {
+  const int tn = pick_tn(N);
+  const long tiles = icg_cdiv(M, 128) * icg_cdiv(N, 32 * tn);
+  long splits = 2048 / (tiles > 0 ? tiles : 1);
+  const long ksteps = icg_cdiv(K, 16);
+  if (splits > ksteps / 8) splits = ksteps / 8;
+  if (splits > 1024) splits = 1024;
+  if (splits < 1) splits = 1;
+  long kchunk = icg_cdiv(icg_cdiv(K, splits), 16) * 16;
+  splits = icg_cdiv(K, kchunk);
+  WgradPlan pl;
+  pl.splits = (int)splits;
+  pl.kchunk = (int)kchunk;
+  return pl;
+}
+
+extern "C" size_t icg_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int R) {
+  const long K = (long)B * H * W;
+  const int M = R * R * Cin;
+  WgradPlan pl = wgrad_plan(K, M, Cout);
+  if (pl.splits <= 1) return 16;
+  return (size_t)pl.splits * (size_t)M * (size_t)Cout * sizeof(float);
+}
+
+extern "C" int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* scale,
+                                const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin, int Cout,
+                                int R, unsigned flags, void* workspace, size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(x && dy && dw);
+  ICG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (R == 1 || R == 3));
+  const int up = (flags & ICG_UPSAMPLE2X) ? 1 : 0;
+  if (up) ICG_REQUIRE((H % 2 == 0) && (W % 2 == 0));
+  if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift);
+  const long K = (long)B * H * W;
+  ICG_REQUIRE(K < 0x7fffffffL);
+  const int M = R * R * Cin;
+  WgradPlan pl = wgrad_plan(K, M, Cout);
+  const size_t need = (pl.splits <= 1) ? 0 : (size_t)pl.splits * M * Cout * sizeof(float);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) return ICG_ERR_WORKSPACE;
+  GemmP p{};
+  p.A = x; p.B = dy;
+  p.C = (pl.splits <= 1) ? dw : (float*)workspace;
+  p.M = M; p.N = Cout; p.K = (int)K;
+  p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.up = up; p.Hs = H >> up; p.Ws = W >> up;
+  p.scale = scale; p.shift = shift; p.ss_bstride = ss_bstride;
+  p.pre_affine = (flags & ICG_PRE_AFFINE) ? 1 : 0;
+  p.pre_relu = (flags & ICG_PRE_RELU) ? 1 : 0;
+  p.ldb = Cout; p.ldc = Cout;
+  p.alpha = 1.f;
+  p.kchunk = pl.kchunk;
+  p.strideA = 0; p.strideB = 0; p.strideC = (long)M * Cout;
+  bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && aligned16(x) && aligned16(dy);
+  if (p.pre_affine) vec = vec && (ss_bstride % 4 == 0) && aligned16(scale) && aligned16(shift);
+  int rc = launch_gemm<A_M, B_N>(p, vec, pl.splits, (hipStream_t)stream);
+  if (rc != ICG_OK) return rc;
+  if (pl.splits > 1) {
+    const long n = (long)M * Cout;
+    int blocks = (int)(icg_cdiv(n, 256) > 2048 ? 2048 : icg_cdiv(n, 256));
+    hipLaunchKernelGGL(icg_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, dw, n, pl.splits);
+    rc = icg_check_launch();
+  }
+  return rc;
+}
+
+extern "C" int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int transA,
+                                int transB, int64_t strideA, int64_t strideB, int64_t strideC, int batch,
+                                float alpha, void* stream) {
+  ICG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0);
+  GemmP p{};
+  p.A = A; p.B = B; p.C = C;
+  p.M = M; p.N = N; p.K = K;
+  p.H = 1; p.W = 1; p.R = 1; p.up = 0; p.Hs = 1; p.Ws = 1;
+  p.ldc = N;
+  p.alpha = alpha;
+  p.kchunk = 0;
+  p.strideA = strideA; p.strideB = strideB; p.strideC = strideC;
+  const bool al = aligned16(A) && aligned16(B) && (strideA % 4 == 0) && (strideB % 4 == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (transA == 0 && transB == 1) {        // A [M][K], B [N][K]
+    p.Cin = K; p.ldb = K;
+    return launch_gemm<A_K, B_K>(p, al && (K % 4 == 0), batch, st);
+  } else if (transA == 0 && transB == 0) { // A [M][K], B [K][N]
+    p.Cin = K; p.ldb = N;
+    return launch_gemm<A_K, B_N>(p, al && (K % 4 == 0) && (N % 4 == 0), batch, st);
+  } else if (transA == 1 && transB == 0) { // A [K][M], B [K][N]
+    p.Cin = M; p.ldb = N;
+    return launch_gemm<A_M, B_N>(p, al && (M % 4 == 0) && (N % 4 == 0), batch, st);
+  }
+  return ICG_ERR_ARG;
+}

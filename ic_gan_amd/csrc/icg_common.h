@@ -1,0 +1,42 @@
+// Shared helpers for the gfx950 kernels of libicgan_hip.so (internal header).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/icgan_hip.h"
+
+extern int g_icg_last_hip_error;
+
+static inline int icg_check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_icg_last_hip_error = (int)e;
+    return ICG_ERR_LAUNCH;
+  }
+  return ICG_OK;
+}
+
+#define ICG_REQUIRE(cond) \
+  do {                    \
+    if (!(cond)) return ICG_ERR_ARG; \
+  } while (0)
+
+static inline int64_t icg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// 64-wide wavefront reductions (gfx950: wave = 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,417 @@
+// HBM-bound glue of the IC-GAN BigGAN step that is not folded into a convolution prologue/epilogue:
+// layout change at the module boundary, tanh tail (BigGAN.py:386), 2x2 avg/max pooling (BigGAN.py:528,
+// layers.py:230-231), the attention row softmax (layers.py:237) with wavefront-shuffle reductions,
+// relu+sum-pool head (BigGAN.py:625), gamma*o + x (layers.py:244) and column sums for bias gradients.
+// Everything is NHWC fp32; kernels are grid-stride with 16-byte-per-lane accesses where C % 4 == 0.
+#include "icg_common.h"
+
+#define GRID_1D(n, per) ((unsigned)(icg_cdiv((n), (per)) > 4096 ? 4096 : (icg_cdiv((n), (per)) < 1 ? 1 : icg_cdiv((n), (per)))))
+
+// ---------------------------------------------------------------- batched transpose  [b][R][S] -> [b][S][R]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int R,
+                                                        int S) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, s0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* xb = x + (long)b * R * S;
+  float* yb = y + (long)b * R * S;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, s = s0 + tx;
+    if (r < R && s < S) tile[ty + 8 * k][tx] = xb[(long)r * S + s];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int s = s0 + ty + 8 * k, r = r0 + tx;
+    if (r < R && s < S) yb[(long)s * R + r] = tile[tx][ty + 8 * k];
+  }
+}
+
+static int transpose_batched(const float* x, float* y, int batch, int R, int S, hipStream_t st) {
+  if (batch <= 0 || R <= 0 || S <= 0 || batch > 65535) return ICG_ERR_ARG;
+  const long gy = icg_cdiv(R, 32), gx = icg_cdiv(S, 32);
+  if (gy > 65535) return ICG_ERR_ARG;
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)gx, (unsigned)gy, batch), dim3(256), 0, st, x, y, R, S);
+  return icg_check_launch();
+}
+
+extern "C" int icg_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, void* stream) {
+  ICG_REQUIRE(x && y);
+  return transpose_batched(x, y, B, C, H * W, (hipStream_t)stream);
+}
+extern "C" int icg_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, void* stream) {
+  ICG_REQUIRE(x && y);
+  return transpose_batched(x, y, B, H * W, C, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- elementwise
+template <int OP>
+__global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                 float* __restrict__ y, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 va = reinterpret_cast<const float4*>(a)[i];
+    float4 vb = make_float4(0, 0, 0, 0);
+    if (OP != 0 && OP != 3) vb = reinterpret_cast<const float4*>(b)[i];
+    float4 o;
+    if (OP == 0) {  // tanh
+      o.x = tanhf(va.x); o.y = tanhf(va.y); o.z = tanhf(va.z); o.w = tanhf(va.w);
+    } else if (OP == 1) {  // tanh bwd: a = y, b = dy
+      o.x = vb.x * (1.f - va.x * va.x); o.y = vb.y * (1.f - va.y * va.y);
+      o.z = vb.z * (1.f - va.z * va.z); o.w = vb.w * (1.f - va.w * va.w);
+    } else if (OP == 2) {  // relu bwd: a = x, b = dy
+      o.x = va.x > 0.f ? vb.x : 0.f; o.y = va.y > 0.f ? vb.y : 0.f;
+      o.z = va.z > 0.f ? vb.z : 0.f; o.w = va.w > 0.f ? vb.w : 0.f;
+    } else if (OP == 3) {  // relu
+      o.x = fmaxf(va.x, 0.f); o.y = fmaxf(va.y, 0.f); o.z = fmaxf(va.z, 0.f); o.w = fmaxf(va.w, 0.f);
+    } else {  // add
+      o.x = va.x + vb.x; o.y = va.y + vb.y; o.z = va.z + vb.z; o.w = va.w + vb.w;
+    }
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+  // tail
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float va = a[i];
+    const float vb = (OP != 0 && OP != 3) ? b[i] : 0.f;
+    float o;
+    if (OP == 0) o = tanhf(va);
+    else if (OP == 1) o = vb * (1.f - va * va);
+    else if (OP == 2) o = va > 0.f ? vb : 0.f;
+    else if (OP == 3) o = fmaxf(va, 0.f);
+    else o = va + vb;
+    y[i] = o;
+  }
+}
+
+template <int OP>
+static int launch_ew(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  if (!a || !y || n <= 0) return ICG_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b)) & 15)
+    return ICG_ERR_ARG;
+  hipLaunchKernelGGL(ew_kernel<OP>, dim3(GRID_1D(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long)n);
+  return icg_check_launch();
+}
+
+extern "C" int icg_tanh_fwd(const float* x, float* y, int64_t n, void* stream) { return launch_ew<0>(x, nullptr, y, n, stream); }
+extern "C" int icg_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream) {
+  ICG_REQUIRE(dy);
+  return launch_ew<1>(y, dy, dx, n, stream);
+}
+extern "C" int icg_relu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+  ICG_REQUIRE(dy);
+  return launch_ew<2>(x, dy, dx, n, stream);
+}
+extern "C" int icg_relu_fwd(const float* x, float* y, int64_t n, void* stream) { return launch_ew<3>(x, nullptr, y, n, stream); }
+extern "C" int icg_add(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  ICG_REQUIRE(b);
+  return launch_ew<4>(a, b, y, n, stream);
+}
+
+// ---------------------------------------------------------------- 2x2 pooling (NHWC, scalar over c: C may be any)
+// MODE 0: avg fwd (+add)  1: avg bwd  2: max fwd  3: max bwd
+template <int MODE>
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x, const float* __restrict__ aux,
+                                                   const float* __restrict__ dy, float* __restrict__ out, int B, int H,
+                                                   int W, int C, float scale) {
+  // (H, W) = full-resolution dims; pooled dims are H/2, W/2.  One thread per pooled element.
+  const int Hp = H >> 1, Wp = W >> 1;
+  const long total = (long)B * Hp * Wp * C;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int wp = (int)(t % Wp);
+    t /= Wp;
+    const int hp = (int)(t % Hp);
+    const long b = t / Hp;
+    const long base = ((b * H + 2 * hp) * W + 2 * wp) * C + c;
+    const long o01 = C, o10 = (long)W * C, o11 = (long)W * C + C;
+    if (MODE == 0) {
+      float v = ((x[base] + x[base + o01]) + (x[base + o10] + x[base + o11])) * scale;
+      if (aux) v += aux[i];
+      out[i] = v;
+    } else if (MODE == 1) {
+      const float g = scale * dy[i];
+      out[base] = g; out[base + o01] = g; out[base + o10] = g; out[base + o11] = g;
+    } else if (MODE == 2) {
+      float m = x[base];
+      m = fmaxf(m, x[base + o01]);
+      m = fmaxf(m, x[base + o10]);
+      m = fmaxf(m, x[base + o11]);
+      out[i] = m;
+    } else {
+      const float v0 = x[base], v1 = x[base + o01], v2 = x[base + o10], v3 = x[base + o11];
+      int arg = 0;
+      float m = v0;
+      if (v1 > m) { m = v1; arg = 1; }
+      if (v2 > m) { m = v2; arg = 2; }
+      if (v3 > m) { m = v3; arg = 3; }
+      const float g = dy[i];
+      out[base] = arg == 0 ? g : 0.f;
+      out[base + o01] = arg == 1 ? g : 0.f;
+      out[base + o10] = arg == 2 ? g : 0.f;
+      out[base + o11] = arg == 3 ? g : 0.f;
+    }
+  }
+}
+
+template <int MODE>
+static int launch_pool(const float* x, const float* aux, const float* dy, float* out, int B, int H, int W, int C,
+                       void* stream, float scale = 0.25f) {
+  if (!out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) return ICG_ERR_ARG;
+  const long total = (long)B * (H / 2) * (W / 2) * C;
+  hipLaunchKernelGGL(pool_kernel<MODE>, dim3(GRID_1D(total, 256)), dim3(256), 0, (hipStream_t)stream, x, aux, dy, out,
+                     B, H, W, C, scale);
+  return icg_check_launch();
+}
+
+extern "C" int icg_sumpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+  ICG_REQUIRE(x);
+  return launch_pool<0>(x, nullptr, nullptr, y, B, H, W, C, stream, 1.0f);
+}
+extern "C" int icg_avgpool2_fwd(const float* x, const float* add, float* y, int B, int H, int W, int C, void* stream) {
+  ICG_REQUIRE(x);
+  return launch_pool<0>(x, add, nullptr, y, B, H, W, C, stream);
+}
+extern "C" int icg_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+  ICG_REQUIRE(dy);
+  return launch_pool<1>(nullptr, nullptr, dy, dx, B, H, W, C, stream);
+}
+extern "C" int icg_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+  ICG_REQUIRE(x);
+  return launch_pool<2>(x, nullptr, nullptr, y, B, H, W, C, stream);
+}
+extern "C" int icg_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+  ICG_REQUIRE(x && dy);
+  return launch_pool<3>(x, nullptr, dy, dx, B, H, W, C, stream);
+}
+
+// ---------------------------------------------------------------- row softmax: one wavefront per row
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long rows,
+                                                          int cols) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  for (long r = wave; r < rows; r += nwaves) {
+    const float* xr = x + r * cols;
+    float* yr = y + r * cols;
+    float m = -INFINITY;
+    for (int j = lane; j < cols; j += 64) m = fmaxf(m, xr[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < cols; j += 64) s += expf(xr[j] - m);
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int j = lane; j < cols; j += 64) yr[j] = expf(xr[j] - m) * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, long rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  for (long r = wave; r < rows; r += nwaves) {
+    const float* yr = y + r * cols;
+    const float* gr = dy + r * cols;
+    float* dr = dx + r * cols;
+    float s = 0.f;
+    for (int j = lane; j < cols; j += 64) s = fmaf(yr[j], gr[j], s);
+    s = wave_sum(s);
+    for (int j = lane; j < cols; j += 64) dr[j] = yr[j] * (gr[j] - s);
+  }
+}
+
+extern "C" int icg_softmax_fwd(const float* x, float* y, int64_t rows, int cols, void* stream) {
+  ICG_REQUIRE(x && y && rows > 0 && cols > 0);
+  long blocks = icg_cdiv(rows, 4);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, (long)rows,
+                     cols);
+  return icg_check_launch();
+}
+extern "C" int icg_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int cols, void* stream) {
+  ICG_REQUIRE(y && dy && dx && rows > 0 && cols > 0);
+  long blocks = icg_cdiv(rows, 4);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, dy, dx,
+                     (long)rows, cols);
+  return icg_check_launch();
+}
+
+// ---------------------------------------------------------------- relu + spatial sum pool
+__global__ void relu_sumpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int HW, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * C) return;
+  const int c = (int)(i % C);
+  const long b = i / C;
+  float s = 0.f;
+  for (int p = 0; p < HW; ++p) s += fmaxf(x[(b * HW + p) * C + c], 0.f);
+  y[i] = s;
+}
+__global__ void relu_sumpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                        float* __restrict__ dx, int B, int HW, int C) {
+  const long total = (long)B * HW * C;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    const long b = i / ((long)HW * C);
+    dx[i] = x[i] > 0.f ? dy[b * C + c] : 0.f;
+  }
+}
+extern "C" int icg_relu_sumpool_fwd(const float* x, float* y, int B, int HW, int C, void* stream) {
+  ICG_REQUIRE(x && y && B > 0 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(relu_sumpool_fwd_kernel, dim3((unsigned)icg_cdiv((long)B * C, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, B, HW, C);
+  return icg_check_launch();
+}
+extern "C" int icg_relu_sumpool_bwd(const float* x, const float* dy, float* dx, int B, int HW, int C, void* stream) {
+  ICG_REQUIRE(x && dy && dx && B > 0 && HW > 0 && C > 0);
+  hipLaunchKernelGGL(relu_sumpool_bwd_kernel, dim3(GRID_1D((long)B * HW * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                     x, dy, dx, B, HW, C);
+  return icg_check_launch();
+}
+
+// ---------------------------------------------------------------- out = gamma*o + x
+__global__ void scale_add_fwd_kernel(const float* __restrict__ gamma, const float* __restrict__ o,
+                                     const float* __restrict__ x, float* __restrict__ out, long n) {
+  const float g = gamma[0];
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = fmaf(g, o[i], x[i]);
+}
+__global__ __launch_bounds__(256) void scale_add_bwd_kernel(const float* __restrict__ gamma,
+                                                            const float* __restrict__ o,
+                                                            const float* __restrict__ dout, float* __restrict__ d_o,
+                                                            double* __restrict__ part, long n) {
+  __shared__ double red[4];
+  const float g = gamma[0];
+  const long stride = (long)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = dout[i];
+    acc += (double)d * (double)o[i];
+    d_o[i] = g * d;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sum_parts_kernel(const double* __restrict__ part, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) s += part[k];
+    out[0] = (float)s;
+  }
+}
+extern "C" int icg_scale_add_fwd(const float* gamma, const float* o, const float* x, float* out, int64_t n,
+                                 void* stream) {
+  ICG_REQUIRE(gamma && o && x && out && n > 0);
+  hipLaunchKernelGGL(scale_add_fwd_kernel, dim3(GRID_1D(n, 256)), dim3(256), 0, (hipStream_t)stream, gamma, o, x, out,
+                     (long)n);
+  return icg_check_launch();
+}
+extern "C" int icg_scale_add_bwd(const float* gamma, const float* o, const float* dout, float* d_o, float* dgamma,
+                                 int64_t n, void* scratch, size_t scratch_bytes, void* stream) {
+  ICG_REQUIRE(gamma && o && dout && d_o && dgamma && scratch && n > 0);
+  int blocks = (int)(icg_cdiv(n, 1024) > 512 ? 512 : icg_cdiv(n, 1024));
+  if (scratch_bytes < (size_t)blocks * sizeof(double)) return ICG_ERR_WORKSPACE;
+  hipLaunchKernelGGL(scale_add_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gamma, o, dout, d_o,
+                     (double*)scratch, (long)n);
+  hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)scratch, blocks,
+                     dgamma);
+  return icg_check_launch();
+}
+
+// ---------------------------------------------------------------- column sums (bias gradients), any C
+// Every thread walks the flat [rows*C] array with a stride that is a multiple of C, so it always sees one
+// channel; the per-block combine is a deterministic ordered sum.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long n, int C,
+                                                             float* __restrict__ part) {
+  __shared__ float buf[256];
+  const long T = (long)gridDim.x * 256;  // host guarantees T % C == 0
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  float s = 0.f;
+  for (long i = g; i < n; i += T) s += x[i];
+  buf[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    // channel handled by this thread = threadIdx.x; members are threads t with (block*256 + t) % C == c
+    const int c = threadIdx.x;
+    const int first = (int)(((long)c - ((long)blockIdx.x * 256) % C + C) % C);
+    float acc = 0.f;
+    for (int t = first; t < 256; t += C) acc += buf[t];
+    part[(long)blockIdx.x * C + c] = acc;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nblocks, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int k = 0; k < nblocks; ++k) s += (double)part[(long)k * C + c];
+  out[c] = (float)s;
+}
+
+static int colsum_blocks(int64_t rows, int C) {
+  long n = rows * C;
+  long want = icg_cdiv(n, 256 * 16);
+  if (want > 1024) want = 1024;
+  if (want < 1) want = 1;
+  // T = 256*blocks must be a multiple of C: round blocks up to a multiple of C / gcd(256, C)
+  int a = 256, b = C;
+  while (b) { int t = a % b; a = b; b = t; }
+  const int q = C / a;
+  want = icg_cdiv(want, q) * q;
+  return (int)want;
+}
+
+// wide case (C > 256, few rows): one thread per column, row chunks over blockIdx.y
+__global__ __launch_bounds__(256) void colsum_wide_partial_kernel(const float* __restrict__ x, long rows, int C,
+                                                                  long rows_per_chunk, float* __restrict__ part) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  const long r1 = min(rows, r0 + rows_per_chunk);
+  float s = 0.f;
+  for (long r = r0; r < r1; ++r) s += x[r * C + c];
+  part[(long)blockIdx.y * C + c] = s;
+}
+
+static int colsum_wide_chunks(int64_t rows) {
+  long ch = icg_cdiv(rows, 8);
+  if (ch > 256) ch = 256;
+  if (ch < 1) ch = 1;
+  return (int)ch;
+}
+
+extern "C" size_t icg_colsum_workspace_bytes(int64_t rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  if (C > 256) return (size_t)colsum_wide_chunks(rows) * C * sizeof(float);
+  return (size_t)colsum_blocks(rows, C) * C * sizeof(float);
+}
+
+extern "C" int icg_colsum(const float* x, int64_t rows, int C, float* out, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  ICG_REQUIRE(x && out && workspace && rows > 0 && C > 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (C > 256) {
+    const int ch = colsum_wide_chunks(rows);
+    if (workspace_bytes < (size_t)ch * C * sizeof(float)) return ICG_ERR_WORKSPACE;
+    const long rpc = icg_cdiv(rows, ch);
+    const int chunks = (int)icg_cdiv(rows, rpc);
+    hipLaunchKernelGGL(colsum_wide_partial_kernel, dim3((unsigned)icg_cdiv(C, 256), chunks), dim3(256), 0, st, x,
+                       (long)rows, C, rpc, (float*)workspace);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)icg_cdiv(C, 64)), dim3(64), 0, st,
+                       (const float*)workspace, chunks, C, out);
+    return icg_check_launch();
+  }
+  const int blocks = colsum_blocks(rows, C);
+  if (workspace_bytes < (size_t)blocks * C * sizeof(float)) return ICG_ERR_WORKSPACE;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), 0, st, x, (long)rows * C, C, (float*)workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)icg_cdiv(C, 64)), dim3(64), 0, st, (const float*)workspace,
+                     blocks, C, out);
+  return icg_check_launch();
+}

@@ -1,0 +1,232 @@
+// Spectral normalisation: one power-iteration step + W/sigma, and its backward.
+// Replaces power_iteration / SN.W_ (BigGAN_PyTorch/layers.py:39-61, 98-112) and the autograd graph
+//   sigma = (v W^T) u'^T  (u', v constant)  ->  dW = (dW_ - <dW_, W_> u'^T v) / sigma.
+// HBM-bound GEMV-shaped work: W is read three times (u W, W v^T, W/sigma) with coalesced row-major accesses;
+// the normalised weight is emitted directly in the two layouts the MFMA kernels consume:
+//   OHWI  [Cout][R][R][Cin]            (fprop:  B operand rows are K-contiguous)
+//   dgrad [Cin][R][R][Cout], taps flipped (data gradient = the same fprop kernel on dy)
+#include "icg_common.h"
+
+// part[yc][j] = sum_{i in row chunk yc} u[i] * w[i][j]
+__global__ __launch_bounds__(256) void sn_uw_partial_kernel(const float* __restrict__ w, const float* __restrict__ u,
+                                                            int rows, int cols, int rows_per_chunk,
+                                                            float* __restrict__ part) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int yc = blockIdx.y;
+  if (j >= cols) return;
+  const int i0 = yc * rows_per_chunk, i1 = min(rows, i0 + rows_per_chunk);
+  float s = 0.f;
+  for (int i = i0; i < i1; ++i) s = fmaf(u[i], w[(long)i * cols + j], s);
+  part[(long)yc * cols + j] = s;
+}
+
+// single block: t = sum_yc part ; v = t / max(||t||, eps)
+__global__ __launch_bounds__(1024) void sn_v_kernel(const float* __restrict__ part, int ychunks, int cols, float eps,
+                                                    float* __restrict__ v) {
+  __shared__ double red[16];
+  __shared__ float s_inv;
+  double ss = 0.0;
+  for (int j = threadIdx.x; j < cols; j += 1024) {
+    float t = 0.f;
+    for (int y = 0; y < ychunks; ++y) t += part[(long)y * cols + j];
+    v[j] = t;
+    ss += (double)t * (double)t;
+  }
+  ss = wave_sum_d(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < 16; ++k) tot += red[k];
+    const float nrm = (float)sqrt(tot);
+    s_inv = 1.0f / fmaxf(nrm, eps);
+  }
+  __syncthreads();
+  const float inv = s_inv;
+  for (int j = threadIdx.x; j < cols; j += 1024) v[j] *= inv;
+}
+
+// s[i] = sum_j w[i][j] v[j]; one wavefront per row
+__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ v, int rows,
+                                                    int cols, float* __restrict__ s) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rows) return;
+  const float* wr = w + (long)i * cols;
+  float acc = 0.f;
+  for (int j = lane; j < cols; j += 64) acc = fmaf(wr[j], v[j], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) s[i] = acc;
+}
+
+// single block: u' = s / max(||s||, eps); sigma = s . u'
+__global__ __launch_bounds__(1024) void sn_u_kernel(const float* __restrict__ s, int rows, float eps, int training,
+                                                    float* __restrict__ u, float* __restrict__ sv,
+                                                    float* __restrict__ u_out, float* __restrict__ sigma_out) {
+  __shared__ double red[16];
+  __shared__ float s_inv;
+  double ss = 0.0;
+  for (int i = threadIdx.x; i < rows; i += 1024) ss += (double)s[i] * (double)s[i];
+  ss = wave_sum_d(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < 16; ++k) tot += red[k];
+    s_inv = 1.0f / fmaxf((float)sqrt(tot), eps);
+  }
+  __syncthreads();
+  const float inv = s_inv;
+  double dot = 0.0;
+  for (int i = threadIdx.x; i < rows; i += 1024) {
+    const float un = s[i] * inv;
+    u_out[i] = un;
+    if (training) u[i] = un;
+    dot += (double)s[i] * (double)un;
+  }
+  __syncthreads();
+  dot = wave_sum_d(dot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < 16; ++k) tot += red[k];
+    sigma_out[0] = (float)tot;
+    if (training && sv) sv[0] = (float)tot;
+  }
+}
+
+// w_ohwi[co][r][s][ci] = w[co][ci][r][s]/sigma ; w_dgrad[ci][R-1-r][R-1-s][co] = same
+__global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__ w, const float* __restrict__ sigma,
+                                                       int rows, int Cin, int R, float* __restrict__ w_ohwi,
+                                                       float* __restrict__ w_dgrad) {
+  const int RR = R * R;
+  const long total = (long)rows * Cin * RR;
+  const float sg = sigma[0];
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    // idx enumerates the OHWI destination so that the stores are coalesced
+    const int ci = (int)(idx % Cin);
+    long t = idx / Cin;
+    const int tap = (int)(t % RR);
+    const int co = (int)(t / RR);
+    const float val = w[((long)co * Cin + ci) * RR + tap] / sg;
+    w_ohwi[idx] = val;
+    if (w_dgrad) w_dgrad[((long)ci * RR + (RR - 1 - tap)) * rows + co] = val;
+  }
+}
+
+extern "C" size_t icg_sn_scratch_bytes(int rows, int Cin, int R) {
+  const long cols = (long)Cin * R * R;
+  return (size_t)(16 * cols + rows + 512) * sizeof(float);
+}
+
+extern "C" int icg_sn_forward(const float* w, float* u, float* sv, int rows, int Cin, int R, float eps, int training,
+                              float* v_out, float* u_out, float* sigma_out, float* w_ohwi, float* w_dgrad,
+                              void* scratch, size_t scratch_bytes, void* stream) {
+  ICG_REQUIRE(w && u && v_out && u_out && sigma_out && w_ohwi && scratch);
+  ICG_REQUIRE(rows > 0 && Cin > 0 && R >= 1);
+  if (scratch_bytes < icg_sn_scratch_bytes(rows, Cin, R)) return ICG_ERR_WORKSPACE;
+  const int cols = Cin * R * R;
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)scratch;
+  float* svec = part + 16L * cols;
+  int ychunks = (int)icg_cdiv(rows, 64);
+  if (ychunks > 16) ychunks = 16;
+  const int rpc = (int)icg_cdiv(rows, ychunks);
+  ychunks = (int)icg_cdiv(rows, rpc);
+  hipLaunchKernelGGL(sn_uw_partial_kernel, dim3((unsigned)icg_cdiv(cols, 256), ychunks), dim3(256), 0, st, w, u, rows,
+                     cols, rpc, part);
+  hipLaunchKernelGGL(sn_v_kernel, dim3(1), dim3(1024), 0, st, (const float*)part, ychunks, cols, eps, v_out);
+  hipLaunchKernelGGL(sn_wv_kernel, dim3((unsigned)icg_cdiv(rows, 4)), dim3(256), 0, st, w, (const float*)v_out, rows,
+                     cols, svec);
+  hipLaunchKernelGGL(sn_u_kernel, dim3(1), dim3(1024), 0, st, (const float*)svec, rows, eps, training, u, sv, u_out,
+                     sigma_out);
+  const long total = (long)rows * cols;
+  long blocks = icg_cdiv(total, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sn_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, (const float*)sigma_out, rows, Cin,
+                     R, w_ohwi, w_dgrad);
+  return icg_check_launch();
+}
+
+// ---------------------------------------------------------------- backward
+// element idx of the PARAMETER layout [co][ci][tap]  ->  g = dw_hwio[tap][ci][co] + dw_ohwi[co][tap][ci]
+__device__ __forceinline__ float sn_gather_g(const float* __restrict__ dw_hwio, const float* __restrict__ dw_ohwi,
+                                              int co, int ci, int tap, int rows, int Cin, int RR) {
+  float g = 0.f;
+  if (dw_hwio) g += dw_hwio[((long)tap * Cin + ci) * rows + co];
+  if (dw_ohwi) g += dw_ohwi[((long)co * RR + tap) * Cin + ci];
+  return g;
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ dw_hwio,
+                                                         const float* __restrict__ dw_ohwi,
+                                                         const float* __restrict__ w_ohwi, int rows, int Cin, int RR,
+                                                         double* __restrict__ part) {
+  __shared__ double red[4];
+  const long total = (long)rows * Cin * RR;
+  const long stride = (long)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    // idx enumerates OHWI
+    const int ci = (int)(idx % Cin);
+    long t = idx / Cin;
+    const int tap = (int)(t % RR);
+    const int co = (int)(t / RR);
+    const float g = sn_gather_g(dw_hwio, dw_ohwi, co, ci, tap, rows, Cin, RR);
+    acc += (double)g * (double)w_ohwi[idx];
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dw_hwio,
+                                                           const float* __restrict__ dw_ohwi,
+                                                           const float* __restrict__ u, const float* __restrict__ v,
+                                                           const float* __restrict__ sigma,
+                                                           const double* __restrict__ part, int nparts, int rows,
+                                                           int Cin, int RR, float* __restrict__ dw, int accumulate) {
+  __shared__ double s_dot;
+  if (threadIdx.x == 0) {
+    double d = 0.0;
+    for (int k = 0; k < nparts; ++k) d += part[k];
+    s_dot = d;
+  }
+  __syncthreads();
+  const float dot = (float)s_dot;
+  const float inv_sigma = 1.0f / sigma[0];
+  const long total = (long)rows * Cin * RR;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+    // idx enumerates the parameter layout [co][ci][tap] (coalesced stores); column j = ci*RR + tap
+    const int j = (int)(idx % ((long)Cin * RR));
+    const int co = (int)(idx / ((long)Cin * RR));
+    const int ci = j / RR, tap = j - ci * RR;
+    const float g = sn_gather_g(dw_hwio, dw_ohwi, co, ci, tap, rows, Cin, RR);
+    const float corr = (u != nullptr && v != nullptr) ? dot * u[co] * v[j] : 0.f;
+    const float val = (g - corr) * inv_sigma;
+    dw[idx] = accumulate ? dw[idx] + val : val;
+  }
+}
+
+extern "C" int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* w_ohwi, const float* u_saved,
+                               const float* v_saved, const float* sigma, int rows, int Cin, int R, float* dw,
+                               int accumulate, void* scratch, size_t scratch_bytes, void* stream) {
+  ICG_REQUIRE((dw_hwio || dw_ohwi) && w_ohwi && sigma && dw && scratch);
+  ICG_REQUIRE(rows > 0 && Cin > 0 && R >= 1);
+  if (scratch_bytes < 256 * sizeof(double)) return ICG_ERR_WORKSPACE;
+  const int RR = R * R;
+  const long total = (long)rows * Cin * RR;
+  int nparts = (int)(icg_cdiv(total, 1024) > 256 ? 256 : icg_cdiv(total, 1024));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(nparts), dim3(256), 0, st, dw_hwio, dw_ohwi, w_ohwi, rows, Cin, RR,
+                     (double*)scratch);
+  long blocks = icg_cdiv(total, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dw_hwio, dw_ohwi, u_saved,
+                     v_saved, sigma, (const double*)scratch, nparts, rows, Cin, RR, dw, accumulate);
+  return icg_check_launch();
+}

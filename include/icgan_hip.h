@@ -1,0 +1,230 @@
+/*
+ * icgan_hip.h — C ABI of libicgan_hip.so: the MI355X (gfx950) kernels behind the
+ * IC-GAN G+D forward/backward hot path.
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocations);
+ *     the library never allocates, never synchronises, keeps no mutable global state
+ *   - activations are fp32 NHWC:  x[b][h][w][c]
+ *   - `stream` is a hipStream_t (the caller's current stream)
+ *   - return 0 on success, a negative ICG_ERR_* otherwise; icg_strerror() explains
+ *   - the reference file:line each entry point replaces is cited next to it
+ *     (paths relative to the reference repository root)
+ */
+#ifndef ICGAN_HIP_H
+#define ICGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICG_OK 0
+#define ICG_ERR_ARG (-1)      /* bad argument (null pointer, unsupported shape) */
+#define ICG_ERR_LAUNCH (-2)   /* hipLaunch failed, see icg_last_hip_error() */
+#define ICG_ERR_WORKSPACE (-3)/* workspace too small */
+
+const char* icg_strerror(int code);
+int icg_last_hip_error(void);
+int icg_version(void);
+
+/* ---- flags for the fused convolution ---------------------------------- */
+#define ICG_PRE_RELU 1u       /* a = max(a, 0) after the optional affine            */
+#define ICG_PRE_AFFINE 2u     /* a = x*scale[b][c] + shift[b][c] (BN / ccbn apply)  */
+#define ICG_UPSAMPLE2X 4u     /* conv input is nearest-upsampled x2 on read         */
+#define ICG_RES_UPSAMPLE2X 8u /* residual is at half resolution, upsampled on read  */
+
+/*
+ * Fused implicit-GEMM convolution, stride 1, pad R/2, R in {1,3}; also every Linear
+ * (H = W = 1, R = 1, B = rows).  fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32.
+ *
+ *   out[b,h,w,co] = alpha * sum_{r,s,ci} act(x)[b, h+r-p, w+s-p, ci] * w[co][r][s][ci]
+ *                   + bias[co] + residual[b,h,w,co]
+ *   act(x) = relu?( x*scale[b][ci] + shift[b][ci] )?   (zero padding applies AFTER act)
+ *
+ * H, W are the OUTPUT spatial dims; with ICG_UPSAMPLE2X x is [B][H/2][W/2][Cin].
+ * w is OHWI ([Cout][R][R][Cin]).  scale/shift are [ss_rows][Cin], ss_rows in {1, B}
+ * (ss_bstride = 0 or Cin).
+ * Data-gradient = the same call with dy as x, w = [Cin][R][R][Cout] tap-flipped, Cin<->Cout.
+ *
+ * Replaces: F.conv2d in SNConv2d.forward (BigGAN_PyTorch/layers.py:144-153), F.linear in
+ * SNLinear.forward (layers.py:164-165), the BN apply + ReLU + F.interpolate + residual add of
+ * GBlock.forward (layers.py:542-552) and the ReLU / residual add of DBlock.forward (587-613).
+ */
+int icg_conv2d_fprop(const float* x, const float* w, const float* bias, const float* residual,
+                     float* out, const float* scale, const float* shift, int64_t ss_bstride,
+                     int B, int H, int W, int Cin, int Cout, int R, unsigned flags, float alpha,
+                     void* stream);
+
+/*
+ * Weight gradient of the same fused convolution (the activation prologue is re-applied to x):
+ *   dw[r][s][ci][co] = sum_{b,h,w} act(x)[b,h+r-p,w+s-p,ci] * dy[b,h,w,co]        (HWIO layout)
+ * Split-K over pixels with a deterministic two-stage reduction through `workspace`.
+ * Replaces the weight-gradient half of autograd's ConvolutionBackward for layers.py:144-153.
+ */
+size_t icg_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int R);
+int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* scale,
+                     const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin, int Cout,
+                     int R, unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Batched fp32 GEMM  C[z] = alpha * op(A[z]) * op(B[z]) for the attention
+ * contractions (layers.py:237-243: theta^T phi, g beta^T and their gradients).
+ *   transA = 0: A is [M][K] row-major;  1: A is [K][M]
+ *   transB = 0: B is [K][N] row-major;  1: B is [N][K]   (supported: (0,1) (0,0) (1,0))
+ */
+int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int transA,
+                     int transB, int64_t strideA, int64_t strideB, int64_t strideC, int batch,
+                     float alpha, void* stream);
+
+/* ---- BatchNorm / ccbn statistics  (layers.py:398-437 ccbn.forward, 485-503 bn.forward,
+ *      sync_batchnorm/batchnorm.py:61-193 for the cross-replica variant) ---------------- */
+/* number of float partial slots per channel pair produced by icg_bn_partial_stats */
+size_t icg_bn_workspace_bytes(int64_t rows, int C);
+/* stage 1: per-chunk shifted sums  S1 = sum(x-k[c]), S2 = sum((x-k[c])^2) over `rows` x C */
+int icg_bn_partial_stats(const float* x, const float* shift_k, int64_t rows, int C, void* workspace,
+                         size_t workspace_bytes, void* stream);
+/* stage 2: reduce the partials in fp64 to sums[2][C] (double); all-reduce these for SyncBN */
+int icg_bn_reduce_partials(const void* workspace, int64_t rows, int C, double* sums, void* stream);
+/*
+ * stage 3: finalize. count = total rows over all replicas.  training != 0: mean/var from sums,
+ * running stats updated in place (momentum, unbiased var); training == 0: use running stats.
+ * Writes mean[C], invstd[C] and the fused per-sample affine
+ *   scale[b][c] = invstd[c]*gain[b][c],  shift[b][c] = bias[b][c] - mean[c]*scale[b][c]
+ * gain/bias (and scale/shift) are [gb_rows][C] (gb_rows in {1,B}); gain_offset is added to gain
+ * (ccbn: 1 + gain(y)).  shift_k may alias running_mean.
+ */
+int icg_bn_finalize(const double* sums, const float* shift_k, double count, float* running_mean,
+                    float* running_var, float momentum, float eps, int training, const float* gain,
+                    const float* bias, int gb_rows, float gain_offset, int C, float* mean,
+                    float* invstd, float* scale, float* shift, void* stream);
+
+/*
+ * Backward of  a = relu?(x*scale[b][c] + shift[b][c])  feeding a convolution (x is [B][Hs][Ws][C]; `da`, the
+ * data gradient of the convolution input, is [B][2Hs][2Ws][C] when ICG_UPSAMPLE2X is set — the adjoint of the
+ * nearest upsample (2x2 sum) is folded in — else [B][Hs][Ws][C]).  With  dy = (sum_2x2 da) * relu-mask:
+ *
+ *   stage 1  icg_bn_bwd_reduce       Sd[b][c] = sum_hw dy,  Sxc[b][c] = sum_hw dy*(x - mean[c])
+ *   stage 2  icg_bn_bwd_channel_sums chan[0][c] = sum_b g[b][c]*Sd,  chan[1][c] = sum_b g[b][c]*invstd[c]*Sxc
+ *            (g = gain_offset + gain;  double[2][C]; all-reduce(sum) these across replicas for SyncBN)
+ *   stage 3  icg_bn_bwd_coefs        dgain = invstd*Sxc, dbias = Sd   ([gb_rows][C]; summed over b if gb_rows==1)
+ *                                    coefA[c] = invstd*chan[0]/count, coefB[c] = invstd^2*chan[1]/count
+ *                                    (both 0 when batch_stats == 0, i.e. eval-mode running statistics)
+ *   stage 4  icg_bn_bwd_apply        dx = dy*scale[b][c] - coefA[c] - coefB[c]*(x - mean[c])
+ *
+ * Without ICG_PRE_AFFINE (plain ReLU in front of a D convolution, layers.py:587-604) only stage 4 is needed:
+ * dx = da * (x > 0), coefA = coefB = NULL.
+ */
+size_t icg_bn_bwd_workspace_bytes(int B, int Hs, int Ws, int C);
+int icg_bn_bwd_reduce(const float* x, const float* da, const float* scale, const float* shift,
+                      int64_t ss_bstride, const float* mean, int B, int Hs, int Ws, int C, unsigned flags,
+                      void* workspace, size_t workspace_bytes, float* sum_dy, float* sum_dyx, void* stream);
+int icg_bn_bwd_channel_sums(const float* sum_dy, const float* sum_dyx, const float* gain, int gb_rows,
+                            float gain_offset, const float* invstd, int B, int C, double* chan_sums,
+                            void* stream);
+int icg_bn_bwd_coefs(const float* sum_dy, const float* sum_dyx, const double* chan_sums, const float* invstd,
+                     double count, int batch_stats, int gb_rows, int B, int C, float* dgain, float* dbias,
+                     float* coefA, float* coefB, void* stream);
+int icg_bn_bwd_apply(const float* x, const float* da, const float* scale, const float* shift,
+                     int64_t ss_bstride, const float* mean, const float* coefA, const float* coefB, int B,
+                     int Hs, int Ws, int C, unsigned flags, float* dx, void* stream);
+
+/* ---- spectral norm  (layers.py:39-61 power_iteration, 98-112 SN.W_) ------------------ */
+/*
+ * One power-iteration step and the normalised weight for ONE layer.  w is the parameter in its
+ * PyTorch layout [rows = Cout][Cin][R][R]; u is [rows] (updated in place when training);
+ * sv (1 float, optional) receives sigma when training; v_out [Cin*R*R], u_out [rows] and
+ * sigma_out[1] are saved for backward.  w_ohwi = w/sigma as [Cout][R][R][Cin]; w_dgrad (optional)
+ * = w/sigma as [Cin][R][R][Cout] with taps flipped.  scratch: icg_sn_scratch_bytes().
+ */
+size_t icg_sn_scratch_bytes(int rows, int Cin, int R);
+int icg_sn_forward(const float* w, float* u, float* sv, int rows, int Cin, int R, float eps,
+                   int training, float* v_out, float* u_out, float* sigma_out, float* w_ohwi,
+                   float* w_dgrad, void* scratch, size_t scratch_bytes, void* stream);
+/*
+ * Backward of w_ = w/sigma with u,v constant:  dw = (dw_ - <dw_, w_> u^T v) / sigma.
+ * dw_ is given in HWIO ([R][R][Cin][Cout], layout=1) or OHWI (layout=0) or both summed
+ * (dw_hwio and dw_ohwi may each be NULL); dw is written/accumulated (accumulate != 0) in the
+ * parameter layout.
+ */
+int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* w_ohwi,
+                    const float* u_saved, const float* v_saved, const float* sigma, int rows, int Cin,
+                    int R, float* dw, int accumulate, void* scratch, size_t scratch_bytes, void* stream);
+
+/* ---- pointwise / pooling / softmax ---------------------------------------------------- */
+int icg_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, void* stream);
+int icg_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, void* stream);
+/* y = tanh(x) (BigGAN.py:386); dx = dy*(1-y^2) */
+int icg_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
+int icg_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
+/* 2x2 average pool (nn.AvgPool2d(2), BigGAN.py:528) with optional fused add: y = pool(x) + add */
+int icg_avgpool2_fwd(const float* x, const float* add, float* y, int B, int H, int W, int C, void* stream);
+/* y = sum over the 2x2 window (adjoint of the nearest x2 upsample of a residual branch) */
+int icg_sumpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+/* dx = 0.25 * dy broadcast over the 2x2 window */
+int icg_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+/* 2x2 max pool (F.max_pool2d, layers.py:230-231); backward routes to the first maximum */
+int icg_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int icg_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+/* row softmax over the last dim (layers.py:237) */
+int icg_softmax_fwd(const float* x, float* y, int64_t rows, int cols, void* stream);
+int icg_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int cols, void* stream);
+/* h[b][c] = sum_hw relu(x[b,h,w,c])   (BigGAN.py:625) and its backward */
+int icg_relu_sumpool_fwd(const float* x, float* y, int B, int HW, int C, void* stream);
+int icg_relu_sumpool_bwd(const float* x, const float* dy, float* dx, int B, int HW, int C, void* stream);
+/* out = gamma[0]*o + x (layers.py:244); backward: do_ = gamma*dout, dgamma = sum(dout*o) */
+int icg_scale_add_fwd(const float* gamma, const float* o, const float* x, float* out, int64_t n, void* stream);
+int icg_scale_add_bwd(const float* gamma, const float* o, const float* dout, float* d_o, float* dgamma,
+                      int64_t n, void* scratch, size_t scratch_bytes, void* stream);
+/* column sums: out[c] = sum_rows x[row][c]  (bias gradients) */
+size_t icg_colsum_workspace_bytes(int64_t rows, int C);
+int icg_colsum(const float* x, int64_t rows, int C, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* relu forward/backward (stand-alone uses) */
+int icg_relu_fwd(const float* x, float* y, int64_t n, void* stream);
+int icg_relu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* y = a + b */
+int icg_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+
+/* ---- optimiser / EMA  (trainer.py:158-171 optim.Adam, utils.py:1055-1067 ema.update) --- */
+typedef struct {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+} icg_adam_tensor;
+/* torch.optim.Adam semantics (weight_decay = 0, amsgrad = false); step is 1-based */
+int icg_adam_multi(const icg_adam_tensor* tensors, int n, float lr, float beta1, float beta2, float eps,
+                   int step, void* stream);
+typedef struct {
+  float* target;
+  const float* source;
+  int64_t numel;
+} icg_ema_tensor;
+/* target = target*decay + source*(1-decay) */
+int icg_ema_multi(const icg_ema_tensor* tensors, int n, float decay, void* stream);
+
+/* ---- StyleGAN2 custom ops (stylegan2_ada_pytorch/torch_utils/ops) ---------------------- */
+/*
+ * bias_act: same contract as the reference plugin's bias_act(x,b,xref,yref,dy,grad,dim,act,alpha,
+ * gain,clamp) (bias_act.cpp:35-100, bias_act.cu:26-150), on a flat contiguous fp32 buffer.
+ * bias index of element i is (i / step_b) % size_b; empty inputs are NULL.
+ */
+int icg_bias_act(const float* x, const float* b, const float* xref, const float* yref, const float* dy,
+                 float* y, int64_t n, int64_t step_b, int size_b, int grad, int act, float alpha, float gain,
+                 float clamp, void* stream);
+/*
+ * upfirdn2d: same contract as the reference plugin's upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,
+ * pady0,pady1,flip,gain) (upfirdn2d.cpp:19-104, upfirdn2d.cu:32-203) for NCHW fp32 x [N][C][H][W]
+ * and a 2-D filter f [fh][fw]; y is [N][C][outH][outW] with the reference's output-size formula.
+ */
+int icg_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw,
+                  int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1,
+                  int flip, float gain, int outH, int outW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICGAN_HIP_H */
