@@ -453,3 +453,34 @@ extern "C" int icg_bn_bwd_apply(const float* x, const float* da, const float* sc
                      shift, (long)ss_bstride, mean, coefA, coefB, B, Hs, Ws, C, up, affine, relu, dx);
   return icg_check_launch();
 }
+
+// ---------------------------------------------------------------- stand-alone apply (API parity: ccbn / bn called
+// outside a fused block).  y = relu?(x*scale[b][c] + shift[b][c])
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, long ss_bstride, long HW, int C,
+                                                       long total4, int relu, float* __restrict__ y) {
+  const int cv = C / 4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+    const int c = 4 * (int)(i % cv);
+    const long pix = i / cv;
+    const long b = pix / HW;
+    const float4 v = ld4n(x + pix * C + c);
+    const float4 sc = ld4n(scale + b * ss_bstride + c), sh = ld4n(shift + b * ss_bstride + c);
+    float4 o;
+    o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    *reinterpret_cast<float4*>(y + pix * C + c) = o;
+  }
+}
+
+extern "C" int icg_bn_apply(const float* x, const float* scale, const float* shift, int64_t ss_bstride, int B,
+                            int64_t HW, int C, unsigned flags, float* y, void* stream) {
+  ICG_REQUIRE(x && scale && shift && y && B > 0 && HW > 0 && C > 0 && (C % 4) == 0 && (ss_bstride % 4) == 0);
+  const long total4 = (long)B * HW * (C / 4);
+  long blocks = icg_cdiv(total4, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                     (long)ss_bstride, (long)HW, C, total4, (flags & ICG_PRE_RELU) ? 1 : 0, y);
+  return icg_check_launch();
+}

@@ -1,0 +1,254 @@
+"""MI355X-native layer set for IC-GAN's BigGAN backbone.
+
+Mirrors the public surface of the reference's ``BigGAN_PyTorch/layers.py`` (class names, constructor
+arguments, parameter / buffer names -> identical ``state_dict`` layout) but every forward is a short
+sequence of fused HIP kernels (``ic_gan_amd.ops``):
+
+  reference op graph (layers.py:542-552)            here
+  ---------------------------------------------     ---------------------------------------------------
+  ccbn -> ReLU -> F.interpolate -> conv3x3          1 statistics pass + 1 conv whose operand loader applies
+                                                    the per-sample affine, ReLU and the upsample index map
+  conv_sc on the upsampled input, h + x             1x1 conv at LOW resolution, added (upsample-on-read) in
+                                                    the epilogue of conv2
+  SN.W_ per layer: 8 tiny ATen kernels              icg_sn_forward: W/sigma emitted in the two MFMA layouts
+
+Unsupported reference options (never used by a shipped config) raise NotImplementedError instead of
+silently taking another path: num_svs/num_itrs != 1, mybn, the reference's `cross_replica` nn.BatchNorm2d
+variant (use `sync_bn=True`: cross-replica statistics over RCCL with the same buffers), norm_style != 'bn'.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn import Parameter as P
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------------
+# Spectral norm  (reference layers.py:66-112)
+# ------------------------------------------------------------------------------------------------
+class SN(object):
+    """Mixin holding the power-iteration buffers ``u0`` / ``sv0`` (same names as the reference)."""
+
+    def _sn_init(self, num_svs, num_itrs, num_outputs, transpose=False, eps=1e-12):
+        if num_svs != 1 or num_itrs != 1 or transpose:
+            raise NotImplementedError("ic_gan_amd implements the shipped setting num_svs = num_itrs = 1")
+        self.num_itrs, self.num_svs, self.transpose, self.eps = num_itrs, num_svs, transpose, eps
+        self.register_buffer("u0", torch.randn(1, num_outputs))
+        self.register_buffer("sv0", torch.ones(1))
+
+    @property
+    def u(self):
+        return [self.u0]
+
+    @property
+    def sv(self):
+        return [self.sv0]
+
+    def sn_state(self, need_dgrad=None) -> ops.SNState:
+        """One power-iteration step (in place on u0/sv0 in training mode) + W/sigma in kernel layouts."""
+        if need_dgrad is None:
+            need_dgrad = torch.is_grad_enabled()
+        return ops.sn_prepare(self.weight, self.u0, self.sv0, self.eps, self.training, need_dgrad)
+
+    def W_(self):
+        """Spectrally normalised weight in the parameter layout (debug / API parity; not on the hot path)."""
+        st = self.sn_state(False)
+        w = self.weight
+        if w.dim() == 4:
+            return st.w_ohwi.view(w.shape[0], w.shape[2], w.shape[3], w.shape[1]).permute(0, 3, 1, 2).contiguous()
+        return st.w_ohwi.view_as(w)
+
+
+class SNConv2d(nn.Conv2d, SN):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 num_svs=1, num_itrs=1, eps=1e-12):
+        nn.Conv2d.__init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        k = self.kernel_size[0]
+        if self.kernel_size != (k, k) or k not in (1, 3) or self.stride != (1, 1) or self.padding != (k // 2, k // 2) \
+                or self.dilation != (1, 1) or groups != 1:
+            raise NotImplementedError("ic_gan_amd.SNConv2d: 1x1 / 3x3, stride 1, 'same' padding only")
+        self._sn_init(num_svs, num_itrs, out_channels, eps=eps)
+
+    def forward(self, x, **fuse):
+        return ops.fused_conv(x, self.weight, self.bias, self.sn_state(), **fuse)
+
+
+class SNLinear(nn.Linear, SN):
+    def __init__(self, in_features, out_features, bias=True, num_svs=1, num_itrs=1, eps=1e-12):
+        nn.Linear.__init__(self, in_features, out_features, bias)
+        self._sn_init(num_svs, num_itrs, out_features, eps=eps)
+
+    def forward(self, x):
+        lead = x.shape[:-1]
+        out = ops.linear(x.reshape(-1, x.shape[-1]), self.weight, self.bias, self.sn_state())
+        return out.view(*lead, self.out_features)
+
+
+class SNEmbedding(nn.Embedding, SN):
+    def __init__(self, num_embeddings, embedding_dim, padding_idx=None, max_norm=None, norm_type=2,
+                 scale_grad_by_freq=False, sparse=False, _weight=None, num_svs=1, num_itrs=1, eps=1e-12):
+        nn.Embedding.__init__(self, num_embeddings, embedding_dim, padding_idx, max_norm, norm_type,
+                              scale_grad_by_freq, sparse, _weight)
+        self._sn_init(num_svs, num_itrs, num_embeddings, eps=eps)
+
+    def forward(self, x):
+        return ops.SNEmbeddingFn.apply(x, self.weight, self.sn_state(False))
+
+
+class identity(nn.Module):
+    def forward(self, input):
+        return input
+
+
+# ------------------------------------------------------------------------------------------------
+# Normalisation  (reference layers.py:359-503)
+# ------------------------------------------------------------------------------------------------
+def _check_bn_variant(cross_replica, mybn, norm_style="bn"):
+    if mybn or norm_style != "bn":
+        raise NotImplementedError("ic_gan_amd: only norm_style='bn' with mybn=False (all shipped configs)")
+    if cross_replica:
+        raise NotImplementedError(
+            "the reference's cross_replica=True builds a plain nn.BatchNorm2d (SURVEY F2); use sync_bn=True for "
+            "cross-replica statistics over RCCL")
+
+
+class ccbn(nn.Module):
+    """Class / instance-conditional BatchNorm.  The normalise + affine (+ReLU, + upsample) is applied inside the
+    next convolution; this module owns the parameters / running statistics and produces the per-sample
+    gain and bias."""
+
+    def __init__(self, output_size, input_size, which_linear, eps=1e-5, momentum=0.1, cross_replica=False,
+                 mybn=False, norm_style="bn", sync_bn=False):
+        super().__init__()
+        _check_bn_variant(cross_replica, mybn, norm_style)
+        self.output_size, self.input_size = output_size, input_size
+        self.gain = which_linear(input_size, output_size)
+        self.bias = which_linear(input_size, output_size)
+        self.eps, self.momentum = eps, momentum
+        self.cross_replica, self.mybn, self.norm_style, self.sync_bn = cross_replica, mybn, norm_style, sync_bn
+        self.register_buffer("stored_mean", torch.zeros(output_size))
+        self.register_buffer("stored_var", torch.ones(output_size))
+
+    def affine(self, y):
+        """-> (gain(y), bias(y)), each [B, C]; the '1 +' of the reference is folded in as gain_offset."""
+        return self.gain(y), self.bias(y)
+
+    def bn_opt(self) -> ops.BNOpt:
+        # the reference hard-codes momentum 0.1 in this branch (layers.py:412-421)
+        return ops.BNOpt(self.stored_mean, self.stored_var, self.eps, 0.1, self.training, 1.0,
+                         True if self.sync_bn else None)
+
+    def forward(self, x, y):
+        gain, beta = self.affine(y)
+        return ops.norm_act(x, self.bn_opt(), gain, beta, relu=False)
+
+    def extra_repr(self):
+        return f"out: {self.output_size}, in: {self.input_size}, sync_bn={self.sync_bn}"
+
+
+class bn(nn.Module):
+    """Plain affine BatchNorm (generator output layer)."""
+
+    def __init__(self, output_size, eps=1e-5, momentum=0.1, cross_replica=False, mybn=False, sync_bn=False, **kwargs):
+        super().__init__()
+        _check_bn_variant(cross_replica, mybn)
+        self.output_size, self.eps, self.momentum = output_size, eps, momentum
+        self.cross_replica, self.mybn, self.sync_bn = cross_replica, mybn, sync_bn
+        self.register_buffer("stored_mean", torch.zeros(output_size))
+        self.register_buffer("stored_var", torch.ones(output_size))
+        self.gain = P(torch.ones(output_size), requires_grad=True)
+        self.bias = P(torch.zeros(output_size), requires_grad=True)
+
+    def bn_opt(self) -> ops.BNOpt:
+        return ops.BNOpt(self.stored_mean, self.stored_var, self.eps, self.momentum, self.training, 0.0,
+                         True if self.sync_bn else None)
+
+    def forward(self, x, y=None):
+        return ops.norm_act(x, self.bn_opt(), self.gain, self.bias, relu=False)
+
+
+# ------------------------------------------------------------------------------------------------
+# Self-attention  (reference layers.py:206-244)
+# ------------------------------------------------------------------------------------------------
+class Attention(nn.Module):
+    def __init__(self, ch, which_conv=SNConv2d, name="attention"):
+        super().__init__()
+        self.ch, self.which_conv = ch, which_conv
+        self.theta = which_conv(ch, ch // 8, kernel_size=1, padding=0, bias=False)
+        self.phi = which_conv(ch, ch // 8, kernel_size=1, padding=0, bias=False)
+        self.g = which_conv(ch, ch // 2, kernel_size=1, padding=0, bias=False)
+        self.o = which_conv(ch // 2, ch, kernel_size=1, padding=0, bias=False)
+        self.gamma = P(torch.tensor(0.0), requires_grad=True)
+
+    def forward(self, x, y=None):
+        theta = self.theta(x)
+        phi = ops.MaxPool2Fn.apply(self.phi(x))
+        g = ops.MaxPool2Fn.apply(self.g(x))
+        o = self.o(ops.AttnCoreFn.apply(theta, phi, g))
+        return ops.ScaleAddFn.apply(self.gamma, o, x)
+
+
+# ------------------------------------------------------------------------------------------------
+# Residual blocks  (reference layers.py:512-613)
+# ------------------------------------------------------------------------------------------------
+def _is_relu(act):
+    return isinstance(act, nn.ReLU) or act is F.relu or act is torch.relu
+
+
+class GBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, which_conv=SNConv2d, which_bn=bn, activation=None, upsample=None):
+        super().__init__()
+        if not _is_relu(activation):
+            raise NotImplementedError("ic_gan_amd.GBlock fuses ReLU; other G_nl settings are not implemented")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.which_conv, self.which_bn = which_conv, which_bn
+        self.activation = activation
+        self.conv1 = which_conv(in_channels, out_channels)
+        self.conv2 = which_conv(out_channels, out_channels)
+        self.learnable_sc = in_channels != out_channels or upsample
+        if self.learnable_sc:
+            self.conv_sc = which_conv(in_channels, out_channels, kernel_size=1, padding=0)
+        self.bn1 = which_bn(in_channels)
+        self.bn2 = which_bn(out_channels)
+        self.upsample = upsample   # truthiness only: nearest x2 is folded into conv1 / the residual read
+
+    def forward(self, x, y):
+        up = bool(self.upsample)
+        g1, b1 = self.bn1.affine(y) if isinstance(self.bn1, ccbn) else (self.bn1.gain, self.bn1.bias)
+        g2, b2 = self.bn2.affine(y) if isinstance(self.bn2, ccbn) else (self.bn2.gain, self.bn2.bias)
+        # 1x1 shortcut commutes with nearest upsampling: run it at the input resolution
+        sc = self.conv_sc(x) if self.learnable_sc else x
+        h = self.conv1(x, relu=True, upsample=up, bn=self.bn1.bn_opt(), gain=g1, beta=b1)
+        return self.conv2(h, relu=True, bn=self.bn2.bn_opt(), gain=g2, beta=b2, residual=sc, res_up=up)
+
+
+class DBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, which_conv=SNConv2d, wide=True, preactivation=False,
+                 activation=None, downsample=None):
+        super().__init__()
+        if not _is_relu(activation):
+            raise NotImplementedError("ic_gan_amd.DBlock fuses ReLU; other D_nl settings are not implemented")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.hidden_channels = out_channels if wide else in_channels
+        self.which_conv, self.preactivation, self.activation = which_conv, preactivation, activation
+        self.downsample = downsample   # truthiness only: 2x2 average pooling kernel
+        self.conv1 = which_conv(in_channels, self.hidden_channels)
+        self.conv2 = which_conv(self.hidden_channels, out_channels)
+        self.learnable_sc = True if (in_channels != out_channels) or downsample else False
+        if self.learnable_sc:
+            self.conv_sc = which_conv(in_channels, out_channels, kernel_size=1, padding=0)
+
+    def forward(self, x):
+        h = self.conv1(x, relu=bool(self.preactivation))
+        if self.downsample:
+            # avg-pool and the 1x1 shortcut are both linear: pool first (4x fewer MACs) for either block kind
+            s = ops.AvgPool2Fn.apply(x, None)
+            if self.learnable_sc:
+                s = self.conv_sc(s)
+            h = self.conv2(h, relu=True)
+            return ops.AvgPool2Fn.apply(h, s)
+        s = self.conv_sc(x) if self.learnable_sc else x
+        return self.conv2(h, relu=True, residual=s)

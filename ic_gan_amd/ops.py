@@ -1,0 +1,527 @@
+"""Autograd operators of the IC-GAN hot path, each a thin shim over the C-ABI of
+libicgan_hip.so (include/icgan_hip.h).  PyTorch supplies device memory, the current
+HIP stream and the autograd tape; all arithmetic on activations and weights runs in the
+hand-written gfx950 kernels.  No operator has a CPU / eager fallback.
+
+Layout: activations are logical NCHW tensors stored channels-last (NHWC memory), which
+is what the kernels address; `_cl` makes that true at module boundaries.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+
+from . import _lib as L
+
+
+def _cl(x: torch.Tensor) -> torch.Tensor:
+    if x.dim() != 4:
+        raise ValueError("expected a 4-D activation")
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def _empty_cl(b, c, h, w, dev):
+    return torch.empty((b, c, h, w), device=dev, dtype=torch.float32, memory_format=torch.channels_last)
+
+
+def _bytes(n, dev):
+    return torch.empty(max(int(n), 16), device=dev, dtype=torch.uint8)
+
+
+def _f32(n, dev):
+    return torch.empty(int(n), device=dev, dtype=torch.float32)
+
+
+def _require_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("ic_gan_amd operators run on an AMD GPU only (tensor is on %s); there is no CPU path"
+                           % t.device)
+
+
+# ----------------------------------------------------------------------------------------------
+# spectral norm state  (reference: layers.py:39-61, 98-112)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class SNState:
+    w_ohwi: torch.Tensor            # W/sigma, [Cout][R][R][Cin]
+    w_dgrad: Optional[torch.Tensor]  # W/sigma, [Cin][R][R][Cout], taps flipped
+    u: torch.Tensor                 # u' used for sigma (saved copy)
+    v: torch.Tensor
+    sigma: torch.Tensor
+    rows: int
+    cin: int
+    R: int
+
+
+def sn_prepare(weight: torch.Tensor, u: torch.Tensor, sv: Optional[torch.Tensor], eps: float, training: bool,
+               need_dgrad: bool) -> SNState:
+    """One power iteration (updates `u`/`sv` in place when training) and W/sigma in kernel layouts."""
+    _require_gpu(weight)
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    rows = w.shape[0]
+    if w.dim() == 4:
+        cin, R = w.shape[1], w.shape[2]
+        assert w.shape[2] == w.shape[3]
+    else:
+        cin, R = w[0].numel(), 1
+    dev = w.device
+    n = rows * cin * R * R
+    st = SNState(_f32(n, dev), _f32(n, dev) if need_dgrad else None, _f32(rows, dev), _f32(cin * R * R, dev),
+                 _f32(1, dev), rows, cin, R)
+    nb = L.query("icg_sn_scratch_bytes", rows, cin, R)
+    scratch = _bytes(nb, dev)
+    L.call("icg_sn_forward", w, u, sv, rows, cin, R, float(eps), int(bool(training)), st.v, st.u, st.sigma,
+           st.w_ohwi, st.w_dgrad, scratch, nb)
+    return st
+
+
+def _sn_backward(dw_hwio, dw_ohwi, sn: SNState, like: torch.Tensor) -> torch.Tensor:
+    dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+    scratch = _bytes(256 * 8, like.device)
+    L.call("icg_sn_backward", dw_hwio, dw_ohwi, sn.w_ohwi, sn.u, sn.v, sn.sigma, sn.rows, sn.cin, sn.R, dw, 0,
+           scratch, 256 * 8)
+    return dw
+
+
+# ----------------------------------------------------------------------------------------------
+# fused [BN/ccbn apply + ReLU + nearest-upsample] -> conv / linear -> [+bias +residual]
+# (reference: layers.py:144-153, 164-165, 398-437, 485-503, 542-552, 587-613)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class BNOpt:
+    running_mean: torch.Tensor
+    running_var: torch.Tensor
+    eps: float
+    momentum: float
+    training: bool
+    gain_offset: float          # 1.0 for ccbn (1 + gain(y)), 0.0 for plain bn (gain is the parameter)
+    sync_group: object = None   # torch.distributed process group (or True for WORLD) -> cross-replica statistics
+
+
+@dataclass
+class ConvOpt:
+    sn: SNState
+    relu: bool = False
+    upsample: bool = False
+    res_up: bool = False
+    bn: Optional[BNOpt] = None
+
+
+def _sync_enabled(bn: Optional[BNOpt]) -> bool:
+    return bn is not None and bn.sync_group is not None and dist.is_available() and dist.is_initialized() \
+        and dist.get_world_size(None if bn.sync_group is True else bn.sync_group) > 1
+
+
+def _group(bn: BNOpt):
+    return None if bn.sync_group is True else bn.sync_group
+
+
+class FusedConvFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, gain, beta, opt: ConvOpt):
+        _require_gpu(x)
+        x = _cl(x)
+        sn = opt.sn
+        B, Cin, Hs, Ws = x.shape
+        assert Cin == sn.cin, (Cin, sn.cin)
+        up = 1 if opt.upsample else 0
+        H, W = Hs << up, Ws << up
+        Cout, R = sn.rows, sn.R
+        dev = x.device
+        flags = (L.ICG_PRE_RELU if opt.relu else 0) | (L.ICG_UPSAMPLE2X if up else 0)
+        scale = shift = mean = invstd = None
+        ssb = 0
+        count = float(B * Hs * Ws)
+        bn = opt.bn
+        gb_rows = 1
+        if bn is not None:
+            gain, beta, gb_rows, ssb, count, mean, invstd, scale, shift = _bn_forward_stats(x, bn, gain, beta)
+            flags |= L.ICG_PRE_AFFINE
+        res = None
+        fflags = flags
+        if residual is not None:
+            res = _cl(residual)
+            if opt.res_up:
+                fflags |= L.ICG_RES_UPSAMPLE2X
+                assert res.shape == (B, Cout, H // 2, W // 2)
+            else:
+                assert res.shape == (B, Cout, H, W)
+        out = _empty_cl(B, Cout, H, W, dev)
+        L.call("icg_conv2d_fprop", x, sn.w_ohwi, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, fflags, 1.0)
+        ctx.opt, ctx.flags, ctx.dims = opt, flags, (B, Cin, Hs, Ws, H, W, Cout, R, gb_rows, ssb, count)
+        ctx.has = (bias is not None, residual is not None, gain is not None, beta is not None)
+        ctx.weight_like = weight
+        ctx.save_for_backward(x, scale, shift, mean, invstd, gain)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, scale, shift, mean, invstd, gain = ctx.saved_tensors
+        opt, flags = ctx.opt, ctx.flags
+        sn, bn = opt.sn, opt.bn
+        B, Cin, Hs, Ws, H, W, Cout, R, gb_rows, ssb, count = ctx.dims
+        has_bias, has_res, has_gain, has_beta = ctx.has
+        dev = x.device
+        dout = _cl(dout)
+        need = ctx.needs_input_grad
+        dx = dweight = dbias = dres = dgain = dbeta = None
+        if need[0] or (bn is not None and (need[4] or need[5])):
+            if sn.w_dgrad is None:
+                raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
+            da = _empty_cl(B, Cin, H, W, dev)
+            L.call("icg_conv2d_fprop", dout, sn.w_dgrad, None, None, da, None, None, 0, B, H, W, Cout, Cin, R, 0, 1.0)
+            if bn is not None:
+                dx, dgain, dbeta = _bn_backward(x, da, bn, gain, scale, shift, ssb, mean, invstd, gb_rows, count,
+                                                flags, has_gain, has_beta, (B, Cin, Hs, Ws))
+            elif opt.relu or opt.upsample:
+                dx = _empty_cl(B, Cin, Hs, Ws, dev)
+                L.call("icg_bn_bwd_apply", x, da, None, None, 0, None, None, None, B, Hs, Ws, Cin, flags, dx)
+            else:
+                dx = da
+            if not need[0]:
+                dx = None
+        if need[1]:
+            nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, Cin, Cout, R)
+            ws = _bytes(nb, dev)
+            dw_hwio = _f32(R * R * Cin * Cout, dev)
+            L.call("icg_conv2d_wgrad", x, dout, dw_hwio, scale, shift, ssb, B, H, W, Cin, Cout, R, flags, ws, nb)
+            dweight = _sn_backward(dw_hwio, None, sn, ctx.weight_like)
+        if has_bias and need[2]:
+            rows = B * H * W
+            nb = L.query("icg_colsum_workspace_bytes", rows, Cout)
+            ws = _bytes(nb, dev)
+            dbias = _f32(Cout, dev)
+            L.call("icg_colsum", dout, rows, Cout, dbias, ws, nb)
+        if has_res and need[3]:
+            if opt.res_up:
+                dres = _empty_cl(B, Cout, H // 2, W // 2, dev)
+                L.call("icg_sumpool2_fwd", dout, dres, B, H, W, Cout)
+            else:
+                dres = dout
+        return dx, dweight, dbias, dres, dgain, dbeta, None
+
+
+def _bn_forward_stats(x, bn: BNOpt, gain, beta):
+    """Statistics + finalize shared by the fused and the stand-alone normalisation."""
+    B, C, Hs, Ws = x.shape
+    dev = x.device
+    gb_rows = 1
+    if gain is not None:
+        gain = gain.contiguous()
+        gb_rows = gain.shape[0] if gain.dim() == 2 else 1
+    if beta is not None:
+        beta = beta.contiguous()
+    mean, invstd = _f32(C, dev), _f32(C, dev)
+    scale, shift = _f32(gb_rows * C, dev), _f32(gb_rows * C, dev)
+    ssb = C if gb_rows > 1 else 0
+    count = float(B * Hs * Ws)
+    sums = None
+    if bn.training:
+        rows = B * Hs * Ws
+        nb = L.query("icg_bn_workspace_bytes", rows, C)
+        ws = _bytes(nb, dev)
+        L.call("icg_bn_partial_stats", x, bn.running_mean, rows, C, ws, nb)
+        sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
+        L.call("icg_bn_reduce_partials", ws, rows, C, sums)
+        if _sync_enabled(bn):
+            # equal per-replica batch (DDP): the global count needs no exchange and no host sync
+            dist.all_reduce(sums, group=_group(bn))
+            count = float(rows) * dist.get_world_size(_group(bn))
+    L.call("icg_bn_finalize", sums, bn.running_mean, count, bn.running_mean, bn.running_var, float(bn.momentum),
+           float(bn.eps), int(bn.training), gain, beta, gb_rows, float(bn.gain_offset), C, mean, invstd, scale, shift)
+    return gain, beta, gb_rows, ssb, count, mean, invstd, scale, shift
+
+
+def _bn_backward(x, da, bn: BNOpt, gain, scale, shift, ssb, mean, invstd, gb_rows, count, flags, has_gain, has_beta,
+                 dims):
+    """Shared BN backward: returns dx, dgain, dbeta (see include/icgan_hip.h, stages 1-4)."""
+    B, C, Hs, Ws = dims
+    dev = x.device
+    nb = L.query("icg_bn_bwd_workspace_bytes", B, Hs, Ws, C)
+    ws = _bytes(nb, dev)
+    sd, sx = _f32(B * C, dev), _f32(B * C, dev)
+    L.call("icg_bn_bwd_reduce", x, da, scale, shift, ssb, mean, B, Hs, Ws, C, flags, ws, nb, sd, sx)
+    chan = None
+    if bn.training:
+        chan = torch.empty(2 * C, device=dev, dtype=torch.float64)
+        L.call("icg_bn_bwd_channel_sums", sd, sx, gain, gb_rows, float(bn.gain_offset), invstd, B, C, chan)
+        if _sync_enabled(bn):
+            dist.all_reduce(chan, group=_group(bn))
+    dgain = _f32(gb_rows * C, dev).view(gb_rows, C) if has_gain else None
+    dbeta = _f32(gb_rows * C, dev).view(gb_rows, C) if has_beta else None
+    coef_a, coef_b = _f32(C, dev), _f32(C, dev)
+    L.call("icg_bn_bwd_coefs", sd, sx, chan, invstd, float(count), int(bn.training), gb_rows, B, C, dgain, dbeta,
+           coef_a, coef_b)
+    dx = _empty_cl(B, C, Hs, Ws, dev)
+    L.call("icg_bn_bwd_apply", x, da, scale, shift, ssb, mean, coef_a, coef_b, B, Hs, Ws, C, flags, dx)
+    return dx, dgain, dbeta
+
+
+class NormActFn(Function):
+    """Stand-alone  y = relu?(BN(x)*gain + bias)  (ccbn.forward / bn.forward called outside a fused block)."""
+
+    @staticmethod
+    def forward(ctx, x, gain, beta, bn: BNOpt, relu: bool):
+        _require_gpu(x)
+        x = _cl(x)
+        B, C, H, W = x.shape
+        gain, beta, gb_rows, ssb, count, mean, invstd, scale, shift = _bn_forward_stats(x, bn, gain, beta)
+        flags = L.ICG_PRE_AFFINE | (L.ICG_PRE_RELU if relu else 0)
+        y = torch.empty_like(x)
+        L.call("icg_bn_apply", x, scale, shift, ssb, B, H * W, C, flags, y)
+        ctx.bn, ctx.meta = bn, (gb_rows, ssb, count, flags, gain is not None, beta is not None, (B, C, H, W))
+        ctx.save_for_backward(x, scale, shift, mean, invstd, gain)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift, mean, invstd, gain = ctx.saved_tensors
+        gb_rows, ssb, count, flags, has_gain, has_beta, dims = ctx.meta
+        dx, dgain, dbeta = _bn_backward(x, _cl(dy), ctx.bn, gain, scale, shift, ssb, mean, invstd, gb_rows, count,
+                                        flags, has_gain, has_beta, dims)
+        return dx, dgain, dbeta, None, None
+
+
+def norm_act(x, bn: BNOpt, gain, beta, relu=False):
+    g2 = gain if gain is None or gain.dim() == 2 else gain.view(1, -1)
+    b2 = beta if beta is None or beta.dim() == 2 else beta.view(1, -1)
+    return NormActFn.apply(x, g2, b2, bn, relu)
+
+
+def fused_conv(x, weight, bias, sn: SNState, *, relu=False, upsample=False, residual=None, res_up=False,
+               bn: Optional[BNOpt] = None, gain=None, beta=None):
+    """conv(act(x)) with act = [BN affine] -> [ReLU] -> [nearest x2]; `gain`/`beta` are [B,C] (ccbn) or [C] (bn)."""
+    opt = ConvOpt(sn=sn, relu=relu, upsample=upsample, res_up=res_up, bn=bn)
+    if bn is not None:
+        g2 = gain if gain is None or gain.dim() == 2 else gain.view(1, -1)
+        b2 = beta if beta is None or beta.dim() == 2 else beta.view(1, -1)
+        out = FusedConvFn.apply(x, weight, bias, residual, g2, b2, opt)
+        return out
+    return FusedConvFn.apply(x, weight, bias, residual, None, None, opt)
+
+
+def linear(x2d: torch.Tensor, weight, bias, sn: SNState):
+    """F.linear(x, W/sigma, b) as a 1x1 'convolution' over M rows (reference layers.py:164-165)."""
+    m, k = x2d.shape
+    out = fused_conv(x2d.contiguous().view(m, k, 1, 1), weight, bias, sn)
+    return out.reshape(m, sn.rows)
+
+
+# ----------------------------------------------------------------------------------------------
+# SN embedding  (reference layers.py:171-200)
+# ----------------------------------------------------------------------------------------------
+class SNEmbeddingFn(Function):
+    @staticmethod
+    def forward(ctx, idx, weight, sn: SNState):
+        w = sn.w_ohwi.view(sn.rows, sn.cin)
+        ctx.sn, ctx.weight_like = sn, weight
+        ctx.save_for_backward(idx)
+        return w.index_select(0, idx.reshape(-1)).view(*idx.shape, sn.cin)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        sn = ctx.sn
+        dw_ = torch.zeros(sn.rows, sn.cin, device=dout.device, dtype=torch.float32)
+        dw_.index_add_(0, idx.reshape(-1), dout.reshape(-1, sn.cin).float())
+        return None, _sn_backward(None, dw_, sn, ctx.weight_like), None
+
+
+# ----------------------------------------------------------------------------------------------
+# pooling / pointwise
+# ----------------------------------------------------------------------------------------------
+class AvgPool2Fn(Function):
+    """y = avgpool2x2(x) (+ add)   (nn.AvgPool2d(2), BigGAN.py:528; residual add of layers.py:613)."""
+
+    @staticmethod
+    def forward(ctx, x, add):
+        x = _cl(x)
+        B, C, H, W = x.shape
+        y = _empty_cl(B, C, H // 2, W // 2, x.device)
+        a = _cl(add) if add is not None else None
+        L.call("icg_avgpool2_fwd", x, a, y, B, H, W, C)
+        ctx.dims = (B, C, H, W)
+        ctx.has_add = add is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.dims
+        dy = _cl(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty_cl(B, C, H, W, dy.device)
+            L.call("icg_avgpool2_bwd", dy, dx, B, H, W, C)
+        return dx, (dy if ctx.has_add and ctx.needs_input_grad[1] else None)
+
+
+class MaxPool2Fn(Function):
+    """F.max_pool2d(x, [2,2])  (layers.py:230-231)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl(x)
+        B, C, H, W = x.shape
+        y = _empty_cl(B, C, H // 2, W // 2, x.device)
+        L.call("icg_maxpool2_fwd", x, y, B, H, W, C)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dx = _empty_cl(B, C, H, W, x.device)
+        L.call("icg_maxpool2_bwd", x, _cl(dy), dx, B, H, W, C)
+        return dx
+
+
+class TanhFn(Function):
+    """torch.tanh tail of the generator (BigGAN.py:386)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl(x)
+        y = torch.empty_like(x)
+        L.call("icg_tanh_fwd", x, y, x.numel())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _cl(dy)
+        dx = torch.empty_like(y)
+        L.call("icg_tanh_bwd", y, dy, dx, y.numel())
+        return dx
+
+
+class ReluSumPoolFn(Function):
+    """h = sum(relu(x), [2,3])   (BigGAN.py:625)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl(x)
+        B, C, H, W = x.shape
+        y = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        L.call("icg_relu_sumpool_fwd", x, y, B, H * W, C)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        L.call("icg_relu_sumpool_bwd", x, dy.contiguous(), dx, B, H * W, C)
+        return dx
+
+
+class ScaleAddFn(Function):
+    """gamma * o + x   (layers.py:244)."""
+
+    @staticmethod
+    def forward(ctx, gamma, o, x):
+        o, x = _cl(o), _cl(x)
+        out = torch.empty_like(x)
+        g = gamma.detach().reshape(1).contiguous()
+        L.call("icg_scale_add_fwd", g, o, x, out, x.numel())
+        ctx.save_for_backward(g, o)
+        ctx.gshape = gamma.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g, o = ctx.saved_tensors
+        dout = _cl(dout)
+        d_o = torch.empty_like(o)
+        dgamma = _f32(1, o.device)
+        nb = 512 * 8
+        L.call("icg_scale_add_bwd", g, o, dout, d_o, dgamma, o.numel(), _bytes(nb, o.device), nb)
+        return dgamma.view(ctx.gshape), d_o, dout
+
+
+# ----------------------------------------------------------------------------------------------
+# attention core: beta = softmax(theta^T phi); o = g beta^T   (layers.py:233-243)
+# ----------------------------------------------------------------------------------------------
+class AttnCoreFn(Function):
+    @staticmethod
+    def forward(ctx, theta, phi, g):
+        theta, phi, g = _cl(theta), _cl(phi), _cl(g)
+        B, d, H, W = theta.shape
+        dv = g.shape[1]
+        n, m = H * W, phi.shape[2] * phi.shape[3]
+        dev = theta.device
+        # NHWC memory: theta = Q [B][n][d], phi = K [B][m][d], g = V [B][m][dv]
+        s = torch.empty(B, n, m, device=dev, dtype=torch.float32)
+        L.call("icg_gemm_batched", theta, phi, s, n, m, d, 0, 1, n * d, m * d, n * m, B, 1.0)
+        beta = torch.empty_like(s)
+        L.call("icg_softmax_fwd", s, beta, B * n, m)
+        del s
+        o = _empty_cl(B, dv, H, W, dev)
+        L.call("icg_gemm_batched", beta, g, o, n, dv, m, 0, 0, n * m, m * dv, n * dv, B, 1.0)
+        ctx.save_for_backward(theta, phi, g, beta)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        theta, phi, g, beta = ctx.saved_tensors
+        B, d, H, W = theta.shape
+        dv = g.shape[1]
+        n, m = H * W, phi.shape[2] * phi.shape[3]
+        dev = theta.device
+        do = _cl(do)
+        dg = torch.empty_like(g)           # dV = beta^T dO
+        L.call("icg_gemm_batched", beta, do, dg, m, dv, n, 1, 0, n * m, n * dv, m * dv, B, 1.0)
+        dbeta = torch.empty_like(beta)     # dP = dO V^T
+        L.call("icg_gemm_batched", do, g, dbeta, n, m, dv, 0, 1, n * dv, m * dv, n * m, B, 1.0)
+        ds = torch.empty_like(beta)
+        L.call("icg_softmax_bwd", beta, dbeta, ds, B * n, m)
+        del dbeta
+        dtheta = torch.empty_like(theta)   # dQ = dS K
+        L.call("icg_gemm_batched", ds, phi, dtheta, n, d, m, 0, 0, n * m, m * d, n * d, B, 1.0)
+        dphi = torch.empty_like(phi)       # dK = dS^T Q
+        L.call("icg_gemm_batched", ds, theta, dphi, m, d, n, 1, 0, n * m, n * d, m * d, B, 1.0)
+        return dtheta, dphi, dg
+
+
+def gemm(a, b, c, m, n, k, trans_a: bool, trans_b: bool, alpha=1.0):
+    """Single fp32 GEMM on the MFMA kernel (ortho regularisation, utils.py:1073-1083)."""
+    L.call("icg_gemm_batched", a, b, c, m, n, k, int(trans_a), int(trans_b), 0, 0, 0, 1, float(alpha))
+
+
+# ----------------------------------------------------------------------------------------------
+# optimiser / EMA kernels
+# ----------------------------------------------------------------------------------------------
+def adam_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step):
+    import ctypes
+    n = len(params)
+    if n == 0:
+        return
+    arr = (L.AdamTensor * n)()
+    for i, (p, g, m, v) in enumerate(zip(params, grads, exp_avgs, exp_avg_sqs)):
+        assert p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32
+        arr[i].param, arr[i].grad = p.data_ptr(), g.data_ptr()
+        arr[i].exp_avg, arr[i].exp_avg_sq, arr[i].numel = m.data_ptr(), v.data_ptr(), p.numel()
+    L.call("icg_adam_multi", ctypes.cast(arr, ctypes.c_void_p), n, float(lr), float(beta1), float(beta2), float(eps),
+           int(step))
+
+
+def ema_multi(targets, sources, decay):
+    import ctypes
+    n = len(targets)
+    if n == 0:
+        return
+    arr = (L.EmaTensor * n)()
+    for i, (t, s) in enumerate(zip(targets, sources)):
+        assert t.is_contiguous() and s.is_contiguous() and t.dtype == torch.float32 and s.dtype == torch.float32
+        arr[i].target, arr[i].source, arr[i].numel = t.data_ptr(), s.data_ptr(), t.numel()
+    L.call("icg_ema_multi", ctypes.cast(arr, ctypes.c_void_p), n, float(decay))

@@ -1,0 +1,102 @@
+"""The IC-GAN G+D training step closure — same entry point and schedule as the reference's
+``train_fns.GAN_training_function`` (BigGAN_PyTorch/train_fns.py:28-193):
+
+    D phase: for each D step: zero D grads; for each accumulation: sample conditionings on the host,
+             G forward without grad, D on fake++real, hinge loss / n_acc, backward; Adam(D)
+    G phase: zero G grads; for each accumulation: sample, G forward, D forward, -mean(D_fake)/n_acc, backward
+             (requires_grad of D is off, so only data-gradients flow through D); Adam(G); EMA
+
+Every forward/backward op, both Adam steps and the EMA run in the HIP kernels; this file is host control
+flow only.  Returns the same three floats (three device->host reads per step, as in the reference).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import losses, utils
+
+
+def dummy_training_function():
+    def train(x, y):
+        return {}
+
+    return train
+
+
+def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditionings, embedded_optimizers=True,
+                          device="cuda", batch_size=0):
+    def optimizers():
+        if embedded_optimizers:
+            return G.optim, D.optim
+        return GD.optimizer_G, GD.optimizer_D
+
+    def draw(features, y, truncate):
+        """Host-side conditioning draw -> device tensors (train_fns.py:70-85 / 135-149)."""
+        cond = sample_conditionings()
+        labels_g = f_g = None
+        if features is not None and y is not None:
+            z_, labels_g, f_g = cond
+        elif y is not None:
+            z_, labels_g = cond
+        elif features is not None:
+            z_, f_g = cond
+        else:
+            z_ = cond
+        if truncate:
+            z_ = z_[:batch_size]
+            labels_g = labels_g[:batch_size] if labels_g is not None else None
+            f_g = f_g[:batch_size] if f_g is not None else None
+        z_ = z_.to(device, non_blocking=True)
+        if labels_g is not None:
+            labels_g = labels_g.to(device, non_blocking=True).long()
+        if f_g is not None:
+            f_g = f_g.to(device, non_blocking=True)
+        return z_, labels_g, f_g
+
+    def train(x, y=None, features=None):
+        opt_G, opt_D = optimizers()
+        opt_G.zero_grad()
+        opt_D.zero_grad()
+        x = torch.split(x, batch_size)
+        y = torch.split(y, batch_size) if y is not None else None
+        f_ = torch.split(features, batch_size) if features is not None else None
+        counter = 0
+        if config["toggle_grads"]:
+            utils.toggle_grad(D, True)
+            utils.toggle_grad(G, False)
+        for _ in range(config["num_D_steps"]):
+            opt_D.zero_grad()
+            for _ in range(config["num_D_accumulations"]):
+                z_, labels_g, f_g = draw(features, y, truncate=True)
+                D_fake, D_real = GD(z_, labels_g, f_g, x[counter], y[counter] if y is not None else None,
+                                    f_[counter] if f_ is not None else None, train_G=False,
+                                    split_D=config["split_D"], policy=config["DiffAugment"], DA=config["DA"])
+                D_loss_real, D_loss_fake = losses.discriminator_loss(D_fake, D_real)
+                D_loss = (D_loss_real + D_loss_fake) / float(config["num_D_accumulations"])
+                D_loss.backward()
+                counter += 1
+            if config["D_ortho"] > 0.0:
+                print("using modified ortho reg in D")
+                utils.ortho(D, config["D_ortho"])
+            opt_D.step()
+        if config["toggle_grads"]:
+            utils.toggle_grad(D, False)
+            utils.toggle_grad(G, True)
+        opt_G.zero_grad()
+        for _ in range(config["num_G_accumulations"]):
+            z_, labels_g, f_g = draw(features, y, truncate=False)
+            D_fake = GD(z_, labels_g, f_g, train_G=True, split_D=config["split_D"], policy=config["DiffAugment"],
+                        DA=config["DA"])
+            G_loss = losses.generator_loss(D_fake) / float(config["num_G_accumulations"])
+            G_loss.backward()
+        if config["G_ortho"] > 0.0:
+            print("using modified ortho reg in G")
+            module = G.module if hasattr(G, "module") else G
+            utils.ortho(G, config["G_ortho"], blacklist=[param for param in module.shared.parameters()])
+        opt_G.step()
+        if config["ema"]:
+            ema.update(state_dict["itr"])
+        return {"G_loss": float(G_loss.item()), "D_loss_real": float(D_loss_real.item()),
+                "D_loss_fake": float(D_loss_fake.item())}
+
+    return train

@@ -101,6 +101,10 @@ int icg_bn_finalize(const double* sums, const float* shift_k, double count, floa
                     const float* bias, int gb_rows, float gain_offset, int C, float* mean,
                     float* invstd, float* scale, float* shift, void* stream);
 
+/* stand-alone apply  y = relu?(x*scale[b][c] + shift[b][c])  (ccbn / bn used outside a fused block) */
+int icg_bn_apply(const float* x, const float* scale, const float* shift, int64_t ss_bstride, int B, int64_t HW,
+                 int C, unsigned flags, float* y, void* stream);
+
 /*
  * Backward of  a = relu?(x*scale[b][c] + shift[b][c])  feeding a convolution (x is [B][Hs][Ws][C]; `da`, the
  * data gradient of the convolution input, is [B][2Hs][2Ws][C] when ICG_UPSAMPLE2X is set — the adjoint of the

@@ -1,0 +1,430 @@
+"""TEST INFRASTRUCTURE: plain-PyTorch fp32 (CPU) reference of every entry point of the C-ABI in
+include/icgan_hip.h, one function per ``icg_*`` symbol, same argument order (minus the stream).
+
+Two uses, both in tests only:
+  * per-kernel parity on the GPU: run the HIP kernel on device buffers, this reference on host copies
+  * `install(monkeypatch)`: route ``ic_gan_amd._lib.call`` to these functions so the *host-side* logic of the
+    product (autograd wiring, layouts, schedules) can be exercised on a CPU-only box.  The product itself
+    never imports this module and has no such route.
+
+Arguments arrive as the torch tensors the product passes (their memory is interpreted exactly as the
+kernels do: NHWC for activations), Python scalars, or None for absent pointers.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+PRE_RELU, PRE_AFFINE, UPSAMPLE2X, RES_UPSAMPLE2X = 1, 2, 4, 8
+
+
+def mem(t: torch.Tensor) -> torch.Tensor:
+    """Flat 1-D *view* of a tensor in memory order (contiguous or channels-last 4-D)."""
+    if t.is_contiguous():
+        return t.view(-1)
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return t.permute(0, 2, 3, 1).reshape(-1)
+    raise ValueError("tensor is neither contiguous nor channels-last")
+
+
+def _nhwc(t, b, h, w, c):
+    return mem(t)[: b * h * w * c].view(b, h, w, c)
+
+
+def _act(x, scale, shift, ss_bstride, flags, b, hs, ws, c):
+    a = _nhwc(x, b, hs, ws, c)
+    if flags & PRE_AFFINE:
+        rows = b if ss_bstride else 1
+        sc = mem(scale)[: rows * c].view(rows, 1, 1, c)
+        sh = mem(shift)[: rows * c].view(rows, 1, 1, c)
+        a = a * sc + sh
+    if flags & PRE_RELU:
+        a = F.relu(a)
+    a = a.permute(0, 3, 1, 2)
+    if flags & UPSAMPLE2X:
+        a = F.interpolate(a, scale_factor=2)
+    return a
+
+
+def icg_conv2d_fprop(x, w, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, R, flags, alpha):
+    up = 1 if flags & UPSAMPLE2X else 0
+    a = _act(x, scale, shift, ss_bstride, flags, B, H >> up, W >> up, Cin)
+    wt = mem(w)[: Cout * R * R * Cin].view(Cout, R, R, Cin).permute(0, 3, 1, 2)
+    y = F.conv2d(a, wt, None, 1, R // 2) * alpha
+    if bias is not None:
+        y = y + mem(bias)[:Cout].view(1, -1, 1, 1)
+    if residual is not None:
+        if flags & RES_UPSAMPLE2X:
+            r = _nhwc(residual, B, H // 2, W // 2, Cout).permute(0, 3, 1, 2)
+            r = F.interpolate(r, scale_factor=2)
+        else:
+            r = _nhwc(residual, B, H, W, Cout).permute(0, 3, 1, 2)
+        y = y + r
+    mem(out)[: B * H * W * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, R):
+    return 16
+
+
+def icg_conv2d_wgrad(x, dy, dw, scale, shift, ss_bstride, B, H, W, Cin, Cout, R, flags, workspace, workspace_bytes):
+    up = 1 if flags & UPSAMPLE2X else 0
+    a = _act(x, scale, shift, ss_bstride, flags, B, H >> up, W >> up, Cin)
+    g = _nhwc(dy, B, H, W, Cout).permute(0, 3, 1, 2)
+    gw = torch.nn.grad.conv2d_weight(a.contiguous(), (Cout, Cin, R, R), g.contiguous(), padding=R // 2)
+    mem(dw)[: R * R * Cin * Cout].copy_(gw.permute(2, 3, 1, 0).reshape(-1))       # HWIO
+
+
+def icg_gemm_batched(A, Bm, C, M, N, K, transA, transB, strideA, strideB, strideC, batch, alpha):
+    a, b, c = mem(A), mem(Bm), mem(C)
+    for z in range(batch):
+        az = a[z * strideA: z * strideA + M * K]
+        bz = b[z * strideB: z * strideB + N * K]
+        am = az.view(K, M).t() if transA else az.view(M, K)
+        bm = bz.view(N, K).t() if transB else bz.view(K, N)
+        c[z * strideC: z * strideC + M * N].copy_((alpha * (am @ bm)).reshape(-1))
+
+
+# ---------------------------------------------------------------- BN
+def icg_bn_workspace_bytes(rows, C):
+    return 2 * C * 4
+
+
+def icg_bn_partial_stats(x, shift_k, rows, C, workspace, workspace_bytes):
+    v = mem(x)[: rows * C].view(rows, C).double()
+    k = mem(shift_k)[:C].double() if shift_k is not None else torch.zeros(C, dtype=torch.float64)
+    d = v - k
+    ws = workspace.view(torch.float32)
+    ws[:C] = d.sum(0).float()
+    ws[C: 2 * C] = (d * d).sum(0).float()
+    workspace._emu_sums = torch.cat([d.sum(0), (d * d).sum(0)])    # keep full precision for the next stage
+
+
+def icg_bn_reduce_partials(workspace, rows, C, sums):
+    sums[: 2 * C].copy_(workspace._emu_sums)
+
+
+def icg_bn_finalize(sums, shift_k, count, running_mean, running_var, momentum, eps, training, gain, bias, gb_rows,
+                    gain_offset, C, mean, invstd, scale, shift):
+    if training:
+        k = mem(shift_k)[:C].double() if shift_k is not None else torch.zeros(C, dtype=torch.float64)
+        m1 = sums[:C] / count
+        var = (sums[C: 2 * C] / count - m1 * m1).clamp_min(0.0)
+        mu = k + m1
+        istd = 1.0 / torch.sqrt(var + eps)
+        if running_mean is not None:
+            unb = var * count / (count - 1.0) if count > 1 else var
+            running_mean.copy_(((1 - momentum) * running_mean.double() + momentum * mu).float())
+            running_var.copy_(((1 - momentum) * running_var.double() + momentum * unb).float())
+    else:
+        mu = running_mean.double()
+        istd = 1.0 / torch.sqrt(running_var.double() + eps)
+    mean.copy_(mu.float())
+    invstd.copy_(istd.float())
+    g = gain_offset + (mem(gain)[: gb_rows * C].view(gb_rows, C) if gain is not None else torch.zeros(gb_rows, C))
+    be = mem(bias)[: gb_rows * C].view(gb_rows, C) if bias is not None else torch.zeros(gb_rows, C)
+    sc = invstd.view(1, C) * g
+    mem(scale)[: gb_rows * C].copy_(sc.reshape(-1))
+    mem(shift)[: gb_rows * C].copy_((be - mean.view(1, C) * sc).reshape(-1))
+
+
+def icg_bn_apply(x, scale, shift, ss_bstride, B, HW, C, flags, y):
+    a = _act(x, scale, shift, ss_bstride, flags | PRE_AFFINE, B, HW, 1, C)
+    mem(y)[: B * HW * C].copy_(a.permute(0, 2, 3, 1).reshape(-1))
+
+
+def _bwd_dy(x, da, scale, shift, ss_bstride, B, Hs, Ws, C, flags):
+    xv = _nhwc(x, B, Hs, Ws, C)
+    if flags & UPSAMPLE2X:
+        d = _nhwc(da, B, 2 * Hs, 2 * Ws, C).view(B, Hs, 2, Ws, 2, C).sum((2, 4))
+    else:
+        d = _nhwc(da, B, Hs, Ws, C)
+    sc = sh = None
+    if flags & PRE_AFFINE:
+        rows = B if ss_bstride else 1
+        sc = mem(scale)[: rows * C].view(rows, 1, 1, C)
+        sh = mem(shift)[: rows * C].view(rows, 1, 1, C)
+    if flags & PRE_RELU:
+        y = xv * sc + sh if sc is not None else xv
+        d = d * (y > 0)
+    return xv, d, sc
+
+
+def icg_bn_bwd_workspace_bytes(B, Hs, Ws, C):
+    return 16
+
+
+def icg_bn_bwd_reduce(x, da, scale, shift, ss_bstride, mean, B, Hs, Ws, C, flags, workspace, workspace_bytes, sum_dy,
+                      sum_dyx):
+    xv, d, _ = _bwd_dy(x, da, scale, shift, ss_bstride, B, Hs, Ws, C, flags)
+    mu = mem(mean)[:C].view(1, 1, 1, C) if mean is not None else 0.0
+    mem(sum_dy)[: B * C].copy_(d.double().sum((1, 2)).float().reshape(-1))
+    mem(sum_dyx)[: B * C].copy_((d.double() * (xv - mu).double()).sum((1, 2)).float().reshape(-1))
+
+
+def icg_bn_bwd_channel_sums(sum_dy, sum_dyx, gain, gb_rows, gain_offset, invstd, B, C, chan_sums):
+    g = gain_offset + (mem(gain)[: gb_rows * C].view(gb_rows, C).double() if gain is not None
+                       else torch.zeros(gb_rows, C, dtype=torch.float64))
+    sd = mem(sum_dy)[: B * C].view(B, C).double()
+    sx = mem(sum_dyx)[: B * C].view(B, C).double()
+    chan_sums[:C] = (g * sd).sum(0)
+    chan_sums[C: 2 * C] = (g * invstd.double().view(1, C) * sx).sum(0)
+
+
+def icg_bn_bwd_coefs(sum_dy, sum_dyx, chan_sums, invstd, count, batch_stats, gb_rows, B, C, dgain, dbias, coefA, coefB):
+    sd = mem(sum_dy)[: B * C].view(B, C).double()
+    sx = mem(sum_dyx)[: B * C].view(B, C).double()
+    istd = invstd.double().view(1, C)
+    dg, db = istd * sx, sd
+    if gb_rows == 1:
+        dg, db = dg.sum(0, keepdim=True), db.sum(0, keepdim=True)
+    if dgain is not None:
+        mem(dgain)[: gb_rows * C].copy_(dg.float().reshape(-1))
+    if dbias is not None:
+        mem(dbias)[: gb_rows * C].copy_(db.float().reshape(-1))
+    if batch_stats:
+        coefA.copy_((invstd.double() * chan_sums[:C] / count).float())
+        coefB.copy_((invstd.double() ** 2 * chan_sums[C: 2 * C] / count).float())
+    else:
+        coefA.zero_()
+        coefB.zero_()
+
+
+def icg_bn_bwd_apply(x, da, scale, shift, ss_bstride, mean, coefA, coefB, B, Hs, Ws, C, flags, dx):
+    xv, d, sc = _bwd_dy(x, da, scale, shift, ss_bstride, B, Hs, Ws, C, flags)
+    o = d * sc if sc is not None else d
+    if coefA is not None:
+        o = o - coefA.view(1, 1, 1, C) - coefB.view(1, 1, 1, C) * (xv - mem(mean)[:C].view(1, 1, 1, C))
+    mem(dx)[: B * Hs * Ws * C].copy_(o.reshape(-1))
+
+
+# ---------------------------------------------------------------- spectral norm
+def icg_sn_scratch_bytes(rows, Cin, R):
+    return 16
+
+
+def icg_sn_forward(w, u, sv, rows, Cin, R, eps, training, v_out, u_out, sigma_out, w_ohwi, w_dgrad, scratch,
+                   scratch_bytes):
+    wm = mem(w)[: rows * Cin * R * R].view(rows, -1)
+    uu = mem(u)[:rows].view(1, rows)
+    v = F.normalize(uu @ wm, eps=eps)
+    s = v @ wm.t()
+    un = F.normalize(s, eps=eps)
+    sigma = (s * un).sum()
+    v_out.copy_(v.view(-1))
+    u_out.copy_(un.view(-1))
+    sigma_out.fill_(float(sigma))
+    if training:
+        mem(u)[:rows].copy_(un.view(-1))
+        if sv is not None:
+            sv.fill_(float(sigma))
+    w4 = wm.view(rows, Cin, R, R) / sigma
+    w_ohwi.copy_(w4.permute(0, 2, 3, 1).reshape(-1))
+    if w_dgrad is not None:
+        w_dgrad.copy_(w4.flip(2, 3).permute(1, 2, 3, 0).reshape(-1))
+
+
+def icg_sn_backward(dw_hwio, dw_ohwi, w_ohwi, u_saved, v_saved, sigma, rows, Cin, R, dw, accumulate, scratch,
+                    scratch_bytes):
+    g = torch.zeros(rows, Cin, R, R)
+    if dw_hwio is not None:
+        g = g + mem(dw_hwio)[: rows * Cin * R * R].view(R, R, Cin, rows).permute(3, 2, 0, 1)
+    if dw_ohwi is not None:
+        g = g + mem(dw_ohwi)[: rows * Cin * R * R].view(rows, R, R, Cin).permute(0, 3, 1, 2)
+    w_ = w_ohwi.view(rows, R, R, Cin).permute(0, 3, 1, 2)
+    dot = (g.double() * w_.double()).sum().float()
+    corr = 0.0
+    if u_saved is not None and v_saved is not None:
+        corr = dot * (u_saved.view(rows, 1) * v_saved.view(1, -1)).view(rows, Cin, R, R)
+    val = (g - corr) / sigma
+    d = mem(dw)[: rows * Cin * R * R]
+    d.copy_(d + val.reshape(-1) if accumulate else val.reshape(-1))
+
+
+# ---------------------------------------------------------------- pointwise
+def icg_nchw_to_nhwc(x, y, B, C, H, W):
+    mem(y)[: B * C * H * W].copy_(mem(x)[: B * C * H * W].view(B, C, H * W).transpose(1, 2).reshape(-1))
+
+
+def icg_nhwc_to_nchw(x, y, B, C, H, W):
+    mem(y)[: B * C * H * W].copy_(mem(x)[: B * C * H * W].view(B, H * W, C).transpose(1, 2).reshape(-1))
+
+
+def icg_tanh_fwd(x, y, n):
+    mem(y)[:n].copy_(torch.tanh(mem(x)[:n]))
+
+
+def icg_tanh_bwd(y, dy, dx, n):
+    yy = mem(y)[:n]
+    mem(dx)[:n].copy_(mem(dy)[:n] * (1 - yy * yy))
+
+
+def icg_relu_fwd(x, y, n):
+    mem(y)[:n].copy_(F.relu(mem(x)[:n]))
+
+
+def icg_relu_bwd(x, dy, dx, n):
+    mem(dx)[:n].copy_(mem(dy)[:n] * (mem(x)[:n] > 0))
+
+
+def icg_add(a, b, y, n):
+    mem(y)[:n].copy_(mem(a)[:n] + mem(b)[:n])
+
+
+def _pool_view(t, B, H, W, C):
+    return _nhwc(t, B, H, W, C).view(B, H // 2, 2, W // 2, 2, C)
+
+
+def icg_avgpool2_fwd(x, add, y, B, H, W, C):
+    v = _pool_view(x, B, H, W, C).sum((2, 4)) * 0.25
+    if add is not None:
+        v = v + _nhwc(add, B, H // 2, W // 2, C)
+    mem(y)[: B * H * W * C // 4].copy_(v.reshape(-1))
+
+
+def icg_sumpool2_fwd(x, y, B, H, W, C):
+    mem(y)[: B * H * W * C // 4].copy_(_pool_view(x, B, H, W, C).sum((2, 4)).reshape(-1))
+
+
+def icg_avgpool2_bwd(dy, dx, B, H, W, C):
+    g = _nhwc(dy, B, H // 2, W // 2, C) * 0.25
+    mem(dx)[: B * H * W * C].copy_(g.view(B, H // 2, 1, W // 2, 1, C).expand(B, H // 2, 2, W // 2, 2, C).reshape(-1))
+
+
+def icg_maxpool2_fwd(x, y, B, H, W, C):
+    xn = _nhwc(x, B, H, W, C).permute(0, 3, 1, 2)
+    mem(y)[: B * H * W * C // 4].copy_(F.max_pool2d(xn, 2).permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_maxpool2_bwd(x, dy, dx, B, H, W, C):
+    with torch.enable_grad():
+        xn = _nhwc(x, B, H, W, C).permute(0, 3, 1, 2).detach().clone().requires_grad_(True)
+        out = F.max_pool2d(xn, 2)
+        g = _nhwc(dy, B, H // 2, W // 2, C).permute(0, 3, 1, 2)
+        (gx,) = torch.autograd.grad(out, xn, g)
+    mem(dx)[: B * H * W * C].copy_(gx.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_softmax_fwd(x, y, rows, cols):
+    mem(y)[: rows * cols].copy_(F.softmax(mem(x)[: rows * cols].view(rows, cols), -1).reshape(-1))
+
+
+def icg_softmax_bwd(y, dy, dx, rows, cols):
+    yy = mem(y)[: rows * cols].view(rows, cols)
+    g = mem(dy)[: rows * cols].view(rows, cols)
+    mem(dx)[: rows * cols].copy_((yy * (g - (yy * g).sum(-1, keepdim=True))).reshape(-1))
+
+
+def icg_relu_sumpool_fwd(x, y, B, HW, C):
+    mem(y)[: B * C].copy_(F.relu(mem(x)[: B * HW * C].view(B, HW, C)).sum(1).reshape(-1))
+
+
+def icg_relu_sumpool_bwd(x, dy, dx, B, HW, C):
+    xv = mem(x)[: B * HW * C].view(B, HW, C)
+    mem(dx)[: B * HW * C].copy_(((xv > 0) * mem(dy)[: B * C].view(B, 1, C)).reshape(-1))
+
+
+def icg_scale_add_fwd(gamma, o, x, out, n):
+    mem(out)[:n].copy_(gamma.view(-1)[0] * mem(o)[:n] + mem(x)[:n])
+
+
+def icg_scale_add_bwd(gamma, o, dout, d_o, dgamma, n, scratch, scratch_bytes):
+    mem(d_o)[:n].copy_(gamma.view(-1)[0] * mem(dout)[:n])
+    dgamma.fill_(float((mem(dout)[:n].double() * mem(o)[:n].double()).sum()))
+
+
+def icg_colsum_workspace_bytes(rows, C):
+    return 16
+
+
+def icg_colsum(x, rows, C, out, workspace, workspace_bytes):
+    mem(out)[:C].copy_(mem(x)[: rows * C].view(rows, C).double().sum(0).float())
+
+
+# ---------------------------------------------------------------- optimiser / EMA (tensor-level references of
+# icg_adam_multi / icg_ema_multi; the C entry points take descriptor arrays of raw pointers)
+def adam_multi_ref(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step):
+    """torch.optim.Adam single-tensor rule (weight_decay=0, amsgrad=False)."""
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    for p, g, m, v in zip(params, grads, exp_avgs, exp_avg_sqs):
+        m.lerp_(g, 1 - beta1)
+        v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
+
+
+def ema_multi_ref(targets, sources, decay):
+    for t, s in zip(targets, sources):
+        t.copy_(t * decay + s * (1 - decay))
+
+
+# ---------------------------------------------------------------- StyleGAN2 ops
+_ACTS = {1: lambda x, a: x, 2: lambda x, a: F.relu(x), 3: lambda x, a: F.leaky_relu(x, a), 4: lambda x, a: torch.tanh(x),
+         5: lambda x, a: torch.sigmoid(x), 6: lambda x, a: F.elu(x), 7: lambda x, a: F.selu(x),
+         8: lambda x, a: F.softplus(x), 9: lambda x, a: torch.sigmoid(x) * x}
+
+
+def icg_bias_act(x, b, xref, yref, dy, y, n, step_b, size_b, grad, act, alpha, gain, clamp):
+    """grad 0 only follows _bias_act_ref (bias_act.py:177-207); grad 1/2 are derived by autograd from it."""
+    xv = mem(x)[:n]
+    idx = (torch.arange(n) // step_b) % size_b if b is not None else None
+    bias = mem(b)[idx] if b is not None else 0.0
+    up = mem(dy)[:n] if dy is not None else 1.0
+
+    def fwd(inp):
+        o = _ACTS[act](inp + bias, alpha) * gain
+        return o.clamp(-clamp, clamp) if clamp >= 0 else o
+
+    if grad == 0:
+        mem(y)[:n].copy_(fwd(xv) * up if dy is not None else fwd(xv))
+        return
+    xr = mem(xref)[:n].detach().clone().double().requires_grad_(True) if xref is not None else None
+    if xr is None:       # activations whose derivative is expressed through y: rebuild an input that maps to yref
+        raise NotImplementedError("kernel_ref.icg_bias_act(grad>0) needs xref")
+    bias = bias.double() if b is not None else 0.0
+    with torch.enable_grad():
+        o = fwd(xr)
+        (g1,) = torch.autograd.grad(o.sum(), xr, create_graph=True)
+        if grad == 1:
+            mem(y)[:n].copy_((xv.double() * g1 * up).detach().float())
+        else:
+            g2 = None
+            if g1.requires_grad:
+                (g2,) = torch.autograd.grad(g1.sum(), xr, allow_unused=True)
+            g2 = torch.zeros_like(xr) if g2 is None else g2
+            mem(y)[:n].copy_((xv.double() * g2 * up).detach().float())
+
+
+def icg_upfirdn2d(x, f, y, N, C, H, W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, outH, outW):
+    """_upfirdn2d_ref (upfirdn2d.py:199-246) restated for a 2-D filter."""
+    xv = mem(x)[: N * C * H * W].view(N, C, H, 1, W, 1)
+    xv = F.pad(xv, [0, upx - 1, 0, 0, 0, upy - 1]).reshape(N, C, H * upy, W * upx)
+    xv = F.pad(xv, [max(padx0, 0), max(padx1, 0), max(pady0, 0), max(pady1, 0)])
+    xv = xv[:, :, max(-pady0, 0): xv.shape[2] - max(-pady1, 0), max(-padx0, 0): xv.shape[3] - max(-padx1, 0)]
+    ff = mem(f)[: fh * fw].view(fh, fw) * gain
+    if not flip:
+        ff = ff.flip([0, 1])
+    out = F.conv2d(xv, ff[None, None].repeat(C, 1, 1, 1), groups=C)[:, :, ::downy, ::downx]
+    assert out.shape[2] == outH and out.shape[3] == outW, (out.shape, outH, outW)
+    mem(y)[: N * C * outH * outW].copy_(out.reshape(-1))
+
+
+# ---------------------------------------------------------------- host-logic test harness
+def install(monkeypatch):
+    """Route ic_gan_amd._lib.call / query to this module (CPU host-logic tests only)."""
+    import ic_gan_amd._lib as L
+    import ic_gan_amd.ops as ops
+    g = globals()
+
+    def call(name, *args):
+        g[name](*args)
+
+    def query(name, *args):
+        return int(g[name](*args))
+
+    monkeypatch.setattr(L, "call", call)
+    monkeypatch.setattr(L, "query", query)
+    monkeypatch.setattr(ops, "_require_gpu", lambda t: None)
+    monkeypatch.setattr(ops, "adam_multi", adam_multi_ref)
+    monkeypatch.setattr(ops, "ema_multi", ema_multi_ref)

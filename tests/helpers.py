@@ -29,21 +29,40 @@ def fingerprint(t):
     return float(t.sum()), float((t * t).sum()), samp
 
 
-def check_group(gold, prefix, tensors, rtol, atol, what=""):
-    """Compare a dict name->tensor with the packed fingerprints stored under `prefix`."""
+def noise_grad_names(gold, prefix, rel=1e-3):
+    """Parameters whose golden gradient is rounding noise (mathematically zero, e.g. a conv bias feeding a
+    BatchNorm).  Adam with beta1 = 0 turns that noise into +-lr updates, so their post-step values are only
+    defined up to ~lr per step; callers pass them to check_group(extra_atol=...)."""
+    names = json.loads(str(gold[prefix + "names"]))
+    sq, samp = gold[prefix + "sq"], gold[prefix + "samp"]
+    rms = [float(np.sqrt(sq[i] / max(np.count_nonzero(samp[i]), 1))) for i in range(len(names))]
+    top = max(rms) if rms else 0.0
+    return {n for n, r in zip(names, rms) if r < rel * top}
+
+
+def check_group(gold, prefix, tensors, rtol, atol, what="", noise_floor=2e-3, extra_atol=None):
+    """Compare a dict name->tensor with the packed fingerprints stored under `prefix`.
+
+    Per tensor the tolerance is  atol + rtol * max(rms(golden), noise_floor * max rms in the group):
+    tensors that are pure rounding noise relative to their siblings (e.g. the gradient of a conv bias
+    that feeds a BatchNorm, mathematically zero) are compared on the group's scale, not their own."""
     names = json.loads(str(gold[prefix + "names"]))
     assert set(names) == set(tensors.keys()), (what, sorted(set(names) ^ set(tensors.keys()))[:8])
+    scales = []
+    for i, n in enumerate(names):
+        scales.append(float(np.sqrt(gold[prefix + "sq"][i] / max(tensors[n].numel(), 1))))
+    floor = noise_floor * (max(scales) if scales else 0.0)
     worst = (0.0, None)
     for i, n in enumerate(names):
         s, q, samp = fingerprint(tensors[n])
         gs, gq, gsamp = gold[prefix + "sum"][i], gold[prefix + "sq"][i], gold[prefix + "samp"][i]
-        scale = float(np.sqrt(gq / max(tensors[n].numel(), 1))) + 1e-12     # rms of the golden tensor
-        err = float(np.max(np.abs(samp - gsamp))) / (scale + atol / max(rtol, 1e-30))
-        if err > worst[0]:
-            worst = (err, n)
-        assert np.allclose(samp, gsamp, rtol=rtol, atol=atol + rtol * scale), \
-            f"{what}{n}: samples differ, max abs {np.max(np.abs(samp - gsamp)):.3e} (rms {scale:.3e})"
-        assert abs(q - gq) <= 4 * rtol * abs(gq) + atol, f"{what}{n}: sumsq {q} vs {gq}"
         n_el = max(tensors[n].numel(), 1)
-        assert abs(s - gs) <= 4 * rtol * scale * n_el ** 0.5 * 8 + atol * n_el, f"{what}{n}: sum {s} vs {gs}"
+        scale = max(scales[i], floor)
+        tol = atol + rtol * scale + (extra_atol or {}).get(n, 0.0)
+        err = float(np.max(np.abs(samp - gsamp)))
+        if err / tol > worst[0]:
+            worst = (err / tol, n)
+        assert err <= tol, f"{what}{n}: samples differ, max abs {err:.3e} > tol {tol:.3e} (rms {scales[i]:.3e})"
+        assert abs(np.sqrt(q / n_el) - np.sqrt(gq / n_el)) <= 4 * tol, f"{what}{n}: rms {q} vs {gq}"
+        assert abs(s - gs) <= 32 * tol * n_el ** 0.5 + atol * n_el, f"{what}{n}: sum {s} vs {gs}"
     return worst
