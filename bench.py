@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the IC-GAN BigGAN G+D training step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A "step" is one call of ic_gan_amd.train_fns.GAN_training_function.train on one synthetic batch that is already
+resident in HBM: 1 D update (G forward no-grad on B, D forward/backward on fake++real 2B, Adam) + 1 G update
+(G forward, D forward, backward through D and G, Adam) + EMA — exactly reference train_fns.py:40-191 with
+num_D_steps = num_D_accumulations = num_G_accumulations = 1.  Workload = BASELINE.json configs[2] ("cfg3"): class +
+instance conditional BigGAN 256x256, ch 96, B = 64 per GPU (the configuration the metric is quoted on; it fits one
+288 GB MI355X).  Weights: the reference's orthogonal init; data: synthetic.
+
+Output: ONE JSON line on rank 0 (see the driver contract) with two extra objects:
+  roofline     — for the dominant kernel (the fp32-MFMA implicit-GEMM convolution): algorithmic FLOPs (2*M*N*K per
+                 launch, the reference op graph's count) / HIP-event time of those launches inside the timed region
+  cpu_baseline — the CPU oracle ("port") timed on this box's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+WORKLOADS = {
+    # name: (config overrides, per-GPU batch)
+    "cfg3": (dict(resolution=256, G_ch=96, D_ch=96, class_cond=True, instance_cond=True, G_attn="64", D_attn="64"), 64),
+    "cfg2": (dict(resolution=128, G_ch=96, D_ch=96, class_cond=False, instance_cond=True, G_attn="64", D_attn="64"), 64),
+    "cfg1": (dict(resolution=64, G_ch=64, D_ch=64, class_cond=False, instance_cond=True, G_attn="32", D_attn="32"), 8),
+}
+BASE_CFG = dict(dim_z=120, shared_dim=128, shared_dim_feat=512, G_shared=True, G_shared_feat=True, hier=True,
+                n_classes=1000, SN_eps=1e-6, BN_eps=1e-5, adam_eps=1e-6, G_lr=4e-5, D_lr=1e-4, G_B1=0.0, G_B2=0.999,
+                D_B1=0.0, D_B2=0.999, ema=True, ema_decay=0.9999, ema_start=20000, toggle_grads=True, num_D_steps=1,
+                num_D_accumulations=1, num_G_accumulations=1, split_D=False, DiffAugment="", DA=False, D_ortho=0.0,
+                G_ortho=0.0, G_init="ortho", D_init="ortho")
+
+
+def pick_tn(n):
+    """mirror of pick_tn() in ic_gan_amd/csrc/gemm_conv.hip: N-tile (in units of 32) of the launched kernel."""
+    if n <= 32:
+        return 1
+    if n <= 64:
+        return 2
+    if n % 128 == 0:
+        return 4
+    if n % 96 == 0 or n <= 96:
+        return 3
+    return 4
+
+
+class KernelTimer:
+    """HIP-event timing of every convolution launch (fprop and dgrad go through icg_conv2d_fprop, wgrad through
+    icg_conv2d_wgrad) on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []      # (variant, flops, start_event, end_event)
+        self.enabled = False
+
+    def install(self):
+        import ic_gan_amd._lib as L
+        raw = L.call
+        timer = self
+
+        def timed_call(name, *args):
+            if not timer.enabled or name not in ("icg_conv2d_fprop", "icg_conv2d_wgrad"):
+                return raw(name, *args)
+            if name == "icg_conv2d_fprop":
+                B, H, W, Cin, Cout, R = args[8:14]
+                variant = f"icg_gemm_kernel<A_K,B_K,TN={pick_tn(Cout)}>"
+            else:
+                B, H, W, Cin, Cout, R = args[6:12]
+                variant = f"icg_gemm_kernel<A_M,B_N,TN={pick_tn(Cout)}>"
+            flops = 2.0 * B * H * W * Cout * Cin * R * R
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            raw(name, *args)
+            e.record()
+            timer.records.append((variant, flops, s, e))
+
+        L.call = timed_call
+
+    def summary(self):
+        agg = {}
+        for variant, flops, s, e in self.records:
+            a = agg.setdefault(variant, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += s.elapsed_time(e) * 1e-3
+            a[2] += 1
+        return agg
+
+
+def build_models(cfg, device):
+    import ic_gan_amd.BigGAN as M
+    from ic_gan_amd import utils
+    from ic_gan_amd.optim import FusedAdam
+    G = M.Generator(**{**cfg, "skip_init": True, "embedded_optimizers": False}).to(device)
+    D = M.Discriminator(**{**cfg, "skip_init": True, "embedded_optimizers": False}).to(device)
+    try:                       # reference init (orthogonal) on the device: QR of up to 1536 x 13824 matrices
+        G.init_weights(); D.init_weights()
+        init = "ortho"
+    except Exception as exc:   # noqa: BLE001  (rocSOLVER unavailable -> documented fall back to N(0, 0.02))
+        print(f"[bench] orthogonal init unavailable ({exc}); using N02", file=sys.stderr)
+        G.init, D.init = "N02", "N02"
+        G.init_weights(); D.init_weights()
+        init = "N02"
+    G_ema = M.Generator(**{**cfg, "skip_init": True, "no_optim": True}).to(device)
+    ema = utils.ema(G, G_ema, cfg["ema_decay"], cfg["ema_start"])
+    opt_d = FusedAdam(D.parameters(), lr=cfg["D_lr"], betas=(cfg["D_B1"], cfg["D_B2"]), eps=cfg["adam_eps"])
+    opt_g = FusedAdam(G.parameters(), lr=cfg["G_lr"], betas=(cfg["G_B1"], cfg["G_B2"]), eps=cfg["adam_eps"])
+    return M, G, D, G_ema, ema, opt_g, opt_d, init
+
+
+def cpu_baseline(cfg, name):
+    """CPU oracle (restatement of the reference step, pinned to reference goldens) on this box's host cores."""
+    from oracle import biggan_oracle as O, synth
+    import ic_gan_amd.BigGAN as M
+    torch.set_num_threads(os.cpu_count() or 1)
+    b = 2 if cfg["resolution"] >= 128 else 8
+    G = M.Generator(**{**cfg, "skip_init": True, "embedded_optimizers": False})
+    D = M.Discriminator(**{**cfg, "skip_init": True, "embedded_optimizers": False})
+    gsd = synth.synth_state(synth.spec_of(G.state_dict()), 11)
+    dsd = synth.synth_state(synth.spec_of(D.state_dict()), 22)
+    dim_z = G.dim_z
+    del G, D
+    ema_sd = {k: v.clone() for k, v in gsd.items()}
+    og = O.AdamState(O.param_names(gsd), cfg["G_lr"], 0.0, 0.999, 1e-6)
+    od = O.AdamState(O.param_names(dsd), cfg["D_lr"], 0.0, 0.999, 1e-6)
+    samp = synth.CondSampler(cfg, dim_z, b, 3)
+    x, y, f = synth.synth_batch(cfg, b, seed=4)
+    times = []
+    t_end = time.time() + 25.0
+    while len(times) < 3 and (not times or time.time() + times[-1] < t_end):
+        t0 = time.time()
+        O.train_step(gsd, dsd, ema_sd, cfg, og, od, x, y, f, samp, len(times) + 1, b)
+        times.append(time.time() - t0)
+    t = min(times)
+    return {"value": round(b / t, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{name} shape, batch {b}, best of {len(times)} step(s) of oracle.biggan_oracle.train_step "
+                      f"(PyTorch CPU fp32), {t:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (invalidates the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="cross-replica BN statistics over RCCL (cfg3 variant)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")          # RCCL on ROCm
+    assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+
+    over, batch = WORKLOADS[args.workload]
+    batch = args.batch or batch
+    cfg = dict(BASE_CFG)
+    cfg.update(over)
+    if args.sync_bn:
+        cfg["sync_bn"] = True
+    from ic_gan_amd import train_fns, utils
+    from oracle import synth          # synthetic inputs only (data generation, not compute)
+    utils.seed_rng(0 + rank)
+    M, G, D, G_ema, ema, opt_g, opt_d, init = build_models(cfg, device)
+    dim_z = G.dim_z
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        # reference wiring: trainer.py:196-210 (separate wrappers, find_unused_parameters, buffer broadcast on)
+        G = DDP(G, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True)
+        D = DDP(D, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True)
+    GD = M.G_D(G, D, optimizer_G=opt_g, optimizer_D=opt_d)
+    state = {"itr": 0}
+    sampler = synth.CondSampler(cfg, dim_z, batch, seed=1000 + rank)
+    train = train_fns.GAN_training_function(G, D, GD, ema, state, cfg, sampler, embedded_optimizers=False,
+                                            device=device, batch_size=batch)
+    x, y, f = synth.synth_batch(cfg, batch, seed=7 + rank)
+    x, y, f = x.to(device), (y.to(device) if y is not None else None), (f.to(device) if f is not None else None)
+
+    timer = KernelTimer()
+    timer.install()
+
+    def one_step():
+        state["itr"] += 1
+        G.train(); D.train(); G_ema.train()
+        return train(x, y, f)
+
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        metrics = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        agg = timer.summary()
+        roof = None
+        if agg:
+            variant, (flops, secs, n) = max(agg.items(), key=lambda kv: kv[1][1])
+            ach = flops / secs / 1e12
+            roof = {"bound": "mfma", "kernel": variant, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
+                    "flops_per_launch_avg": round(flops / n / 1e9, 3),
+                    "all_conv_variants": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(
+                        v[1] / args.steps * 1e3, 2), "launches_per_step": v[2] // args.steps} for k, v in agg.items()}}
+        out = {
+            "metric": "images/sec G+D train step, IC-GAN BigGAN 256^2 bs=64/GPU" if args.workload == "cfg3"
+            else f"images/sec G+D train step, IC-GAN BigGAN ({args.workload})",
+            "value": round(batch * world * args.steps / elapsed, 3), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: IC-GAN BigGAN {cfg['resolution']}x{cfg['resolution']} ch={cfg['G_ch']}"
+                                   f" class_cond={cfg['class_cond']} instance_cond={cfg['instance_cond']} hier attn@64,"
+                                   f" 1 D step + 1 G step + Adam x2 + EMA, fp32 exact MFMA",
+                       "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
+                       "init": init, "sync_bn": bool(args.sync_bn), "losses_last_step": metrics},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, args.workload)
+            except Exception as exc:   # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "error": str(exc)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

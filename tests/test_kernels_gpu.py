@@ -1,0 +1,460 @@
+"""GPU parity, kernel by kernel: every C-ABI entry point of libicgan_hip.so is run on the MI355X through the
+product's binding (ic_gan_amd._lib.call) and compared with its plain-PyTorch fp32 CPU reference
+(oracle/kernel_ref.py) on the same seeded inputs.  Tolerances are fp32-roundoff class and written per test
+(north_star: generated samples within 1e-3 rel L2; kernels are held to ~1e-5)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernel_ref as R
+
+pytestmark = pytest.mark.gpu
+
+PRE_RELU, PRE_AFFINE, UP, RES_UP = 1, 2, 4, 8
+
+
+def _L():
+    import ic_gan_amd._lib as L
+    return L
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def cl(b, c, h, w, seed=0, scale=1.0):
+    return rnd(b, c, h, w, seed=seed, scale=scale).contiguous(memory_format=torch.channels_last)
+
+
+def dev(t):
+    return None if t is None else t.cuda()
+
+
+def close(got, ref, rtol=2e-5, atol_rel=2e-5, what=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite values"
+    scale = float(ref.abs().max()) + 1e-30
+    err = (got - ref).abs()
+    tol = atol_rel * scale + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        idx = int(torch.argmax(err - tol))
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} mismatches; worst at flat {idx}: got "
+                             f"{got.flatten()[idx]:.7g} ref {ref.flatten()[idx]:.7g} (max|ref| {scale:.4g}); "
+                             f"rel L2 {float((got - ref).norm() / (ref.norm() + 1e-30)):.3e}")
+
+
+def run_pair(name, args, outs):
+    """args: list of CPU tensors / scalars / None.  outs: indices of output tensors.  Runs the HIP kernel on
+    device copies and the reference on the CPU tensors; returns [(gpu_out, ref_out), ...]."""
+    L = _L()
+    dargs = [a.cuda() if isinstance(a, torch.Tensor) else a for a in args]
+    L.call(name, *dargs)
+    torch.cuda.synchronize()
+    getattr(R, name)(*args)
+    return [(dargs[i], args[i]) for i in outs]
+
+
+# ------------------------------------------------------------------------------------------------ conv / linear
+CONV_CASES = [
+    # B, H, W, Cin, Cout, R, flags, residual(0 none / 1 same / 2 half-res), bias
+    (2, 8, 8, 32, 32, 3, 0, 0, True),
+    (2, 8, 8, 8, 16, 3, PRE_RELU, 1, True),              # K-tile straddles taps (Cin = 8)
+    (1, 16, 16, 3, 96, 3, 0, 0, True),                   # RGB stem: scalar gather path
+    (2, 16, 16, 96, 96, 3, PRE_AFFINE | PRE_RELU | UP, 2, True),   # GBlock conv1-like + half-res residual
+    (2, 16, 16, 96, 96, 3, PRE_AFFINE | PRE_RELU, 2, True),
+    (3, 6, 10, 16, 40, 3, PRE_AFFINE | PRE_RELU | UP, 0, False),  # non-square, ragged N
+    (1, 4, 4, 256, 384, 3, PRE_RELU, 1, True),
+    (2, 8, 8, 64, 48, 1, 0, 0, False),                   # attention theta
+    (2, 8, 8, 192, 24, 1, 0, 0, False),
+    (2, 16, 16, 96, 3, 3, PRE_AFFINE | PRE_RELU, 0, True),        # generator RGB tail (N = 3)
+    (64, 1, 1, 657, 96, 1, 0, 0, False),                 # ccbn gain linear (K = 657: scalar path)
+    (64, 1, 1, 17, 256, 1, 0, 0, True),                  # z-chunk linear
+    (4, 1, 1, 2048, 512, 1, 0, 0, True),                 # shared_feat
+    (8, 1, 1, 128, 1, 1, 0, 0, True),                    # D output linear (N = 1)
+    (1, 32, 32, 32, 160, 3, 0, 0, True),                 # N = 160 -> TN = 4 with ragged last tile
+    (5, 2, 2, 20, 20, 3, PRE_AFFINE, 0, True),           # tiny spatial, affine without relu
+]
+
+
+def _conv_inputs(case, seed):
+    B, H, W, Cin, Cout, R, flags, res, bias = case
+    up = 1 if flags & UP else 0
+    x = cl(B, Cin, H >> up, W >> up, seed=seed)
+    w = rnd(Cout, R, R, Cin, seed=seed + 1, scale=1.0 / np.sqrt(R * R * Cin))
+    bvec = rnd(Cout, seed=seed + 2) if bias else None
+    rflags = flags
+    r = None
+    if res == 1:
+        r = cl(B, Cout, H, W, seed=seed + 3)
+    elif res == 2:
+        r = cl(B, Cout, H // 2, W // 2, seed=seed + 3)
+        rflags |= RES_UP
+    sc = sh = None
+    ssb = 0
+    if flags & PRE_AFFINE:
+        sc = (1.0 + 0.3 * rnd(B, Cin, seed=seed + 4)).contiguous()
+        sh = (0.3 * rnd(B, Cin, seed=seed + 5)).contiguous()
+        ssb = Cin
+    return x, w, bvec, r, sc, sh, ssb, rflags
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fprop(case):
+    B, H, W, Cin, Cout, R, flags, res, bias = case
+    x, w, bvec, r, sc, sh, ssb, rflags = _conv_inputs(case, 10)
+    out = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
+    (pair,) = run_pair("icg_conv2d_fprop", [x, w, bvec, r, out, sc, sh, ssb, B, H, W, Cin, Cout, R, rflags, 1.0], [4])
+    close(*pair, what=f"fprop {case}")
+
+
+def test_conv2d_fprop_shared_affine_row():
+    """scale/shift with a single row (plain bn: ss_bstride = 0)."""
+    B, H, W, Cin, Cout, R = 3, 8, 8, 32, 32, 3
+    x, w = cl(B, Cin, H, W, seed=1), rnd(Cout, R, R, Cin, seed=2, scale=0.06)
+    sc, sh = 1 + 0.2 * rnd(Cin, seed=3), 0.2 * rnd(Cin, seed=4)
+    out = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
+    (pair,) = run_pair("icg_conv2d_fprop", [x, w, None, None, out, sc, sh, 0, B, H, W, Cin, Cout, R,
+                                            PRE_AFFINE | PRE_RELU, 1.0], [4])
+    close(*pair, what="fprop shared affine")
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_dgrad_as_fprop(case):
+    """data gradient = fprop on dy with the tap-flipped, transposed weight (no prologue)."""
+    B, H, W, Cin, Cout, R, flags, res, bias = case
+    w4 = rnd(Cout, Cin, R, R, seed=3, scale=1.0 / np.sqrt(R * R * Cin))
+    wd = w4.flip(2, 3).permute(1, 2, 3, 0).contiguous()          # [Cin][R][R][Cout]
+    dy = cl(B, Cout, H, W, seed=4)
+    da = torch.empty(B, Cin, H, W).contiguous(memory_format=torch.channels_last)
+    L = _L()
+    ddy, dwd, dda = dy.cuda(), wd.cuda(), da.cuda()
+    L.call("icg_conv2d_fprop", ddy, dwd, None, None, dda, None, None, 0, B, H, W, Cout, Cin, R, 0, 1.0)
+    ref = torch.nn.grad.conv2d_input((B, Cin, H, W), w4, dy.contiguous(), padding=R // 2)
+    close(dda, ref.contiguous(memory_format=torch.channels_last), what=f"dgrad {case}")
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_wgrad(case):
+    B, H, W, Cin, Cout, R, flags, res, bias = case
+    x, w, bvec, r, sc, sh, ssb, rflags = _conv_inputs(case, 20)
+    dy = cl(B, Cout, H, W, seed=31)
+    dw = torch.empty(R * R * Cin * Cout)
+    L = _L()
+    nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, Cin, Cout, R)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8)
+    (pair,) = run_pair("icg_conv2d_wgrad", [x, dy, dw, sc, sh, ssb, B, H, W, Cin, Cout, R, flags, ws, nb], [2])
+    close(*pair, rtol=5e-5, atol_rel=5e-5, what=f"wgrad {case}")
+
+
+def test_conv2d_wgrad_split_k_large():
+    """many pixels, few channels: exercises split-K + the deterministic slab reduction."""
+    B, H, W, Cin, Cout, R = 4, 64, 64, 16, 24, 3
+    x, dy = cl(B, Cin, H, W, seed=1), cl(B, Cout, H, W, seed=2)
+    dw = torch.empty(R * R * Cin * Cout)
+    L = _L()
+    nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, Cin, Cout, R)
+    assert nb > 16, "expected a split-K plan"
+    ws = torch.empty(nb, dtype=torch.uint8)
+    (pair,) = run_pair("icg_conv2d_wgrad", [x, dy, dw, None, None, 0, B, H, W, Cin, Cout, R, PRE_RELU, ws, nb], [2])
+    close(*pair, rtol=1e-4, atol_rel=1e-4, what="wgrad split-K")
+    # determinism: two launches give bit-identical results
+    a, b = torch.empty_like(dw).cuda(), torch.empty_like(dw).cuda()
+    for o in (a, b):
+        L.call("icg_conv2d_wgrad", x.cuda(), dy.cuda(), o, None, None, 0, B, H, W, Cin, Cout, R, PRE_RELU,
+               ws.cuda(), nb)
+    assert torch.equal(a, b)
+
+
+GEMM_CASES = [
+    # M, N, K, transA, transB, batch
+    (256, 64, 4, 0, 1, 3), (256, 16, 64, 0, 0, 3), (64, 16, 256, 1, 0, 3), (64, 4, 256, 1, 0, 2),
+    (1024, 256, 48, 0, 1, 2), (1024, 192, 256, 0, 0, 2), (256, 192, 1024, 1, 0, 2), (256, 24, 1024, 1, 0, 2),
+    (130, 70, 24, 0, 1, 1), (100, 36, 52, 0, 0, 1), (36, 20, 100, 1, 0, 2),
+]
+
+
+@pytest.mark.parametrize("case", GEMM_CASES)
+def test_gemm_batched(case):
+    M, N, K, ta, tb, batch = case
+    A = rnd(batch, M * K, seed=1, scale=1 / np.sqrt(K))
+    Bm = rnd(batch, N * K, seed=2)
+    C = torch.empty(batch, M * N)
+    (pair,) = run_pair("icg_gemm_batched", [A, Bm, C, M, N, K, ta, tb, M * K, N * K, M * N, batch, 0.5], [2])
+    close(*pair, what=f"gemm {case}")
+
+
+# ------------------------------------------------------------------------------------------------ batch norm
+BN_SHAPES = [(128, 8), (4096, 96), (70001, 192), (64, 1536), (100, 384), (3, 4), (20000, 32)]
+
+
+@pytest.mark.parametrize("rows,C", BN_SHAPES)
+def test_bn_forward_chain(rows, C):
+    """partial stats -> reduce -> finalize vs the fp64 reference; running stats, scale/shift."""
+    L = _L()
+    B = 4
+    x = rnd(rows, C, seed=3) * (1 + torch.arange(C).float() / C) + 3.0 * rnd(C, seed=4)   # non-trivial means
+    rm, rv = 0.1 * rnd(C, seed=5), 1 + 0.2 * torch.rand(C, generator=torch.Generator().manual_seed(6))
+    gain, beta = 0.3 * rnd(B, C, seed=7), 0.3 * rnd(B, C, seed=8)
+    outs = {}
+    for tag, to in (("gpu", lambda t: t.cuda()), ("ref", lambda t: t.clone())):
+        xx, rmm, rvv = to(x), to(rm), to(rv)
+        nb = L.query("icg_bn_workspace_bytes", rows, C)
+        ws = to(torch.empty(max(nb, 2 * C * 4, 16), dtype=torch.uint8))
+        sums = to(torch.empty(2 * C, dtype=torch.float64))
+        mean, invstd = to(torch.empty(C)), to(torch.empty(C))
+        scale, shift = to(torch.empty(B, C)), to(torch.empty(B, C))
+        fn = (lambda n, *a: L.call(n, *a)) if tag == "gpu" else (lambda n, *a: getattr(R, n)(*a))
+        fn("icg_bn_partial_stats", xx, rmm, rows, C, ws, ws.numel())
+        fn("icg_bn_reduce_partials", ws, rows, C, sums)
+        fn("icg_bn_finalize", sums, rmm, float(rows), rmm, rvv, 0.1, 1e-5, 1, to(gain), to(beta), B, 1.0, C, mean,
+           invstd, scale, shift)
+        outs[tag] = dict(sums=sums, mean=mean, invstd=invstd, scale=scale, shift=shift, rm=rmm, rv=rvv)
+    for k in outs["gpu"]:
+        close(outs["gpu"][k], outs["ref"][k], rtol=3e-5, atol_rel=3e-5, what=f"bn fwd {k} {rows}x{C}")
+    # against torch's own batch_norm statistics
+    ref_mean, ref_var = x.double().mean(0), x.double().var(0, unbiased=False)
+    close(outs["gpu"]["mean"], ref_mean.float(), rtol=1e-5, atol_rel=1e-5, what="bn mean vs torch")
+    close(outs["gpu"]["invstd"], (1 / torch.sqrt(ref_var + 1e-5)).float(), rtol=1e-4, atol_rel=1e-5, what="bn invstd")
+
+
+def test_bn_finalize_eval_mode():
+    L = _L()
+    C, B = 96, 3
+    rm, rv = rnd(C, seed=1), 1 + torch.rand(C, generator=torch.Generator().manual_seed(2))
+    gain = rnd(1, C, seed=3)
+    res = {}
+    for tag, to in (("gpu", lambda t: t.cuda()), ("ref", lambda t: t.clone())):
+        mean, invstd, scale, shift = (to(torch.empty(C)) for _ in range(4))
+        rmm, rvv = to(rm), to(rv)
+        fn = (lambda n, *a: L.call(n, *a)) if tag == "gpu" else (lambda n, *a: getattr(R, n)(*a))
+        fn("icg_bn_finalize", None, None, 0.0, rmm, rvv, 0.1, 1e-5, 0, to(gain), None, 1, 0.0, C, mean, invstd, scale,
+           shift)
+        res[tag] = (mean, invstd, scale, shift, rmm, rvv)
+    for a, b in zip(res["gpu"], res["ref"]):
+        close(a, b, what="bn finalize eval")
+
+
+BNB_CASES = [(2, 8, 8, 16, PRE_AFFINE | PRE_RELU, 2), (2, 8, 8, 96, PRE_AFFINE | PRE_RELU | UP, 2),
+             (3, 5, 7, 32, PRE_AFFINE | PRE_RELU, 3), (4, 4, 4, 1536, PRE_AFFINE | PRE_RELU | UP, 4),
+             (2, 16, 16, 192, PRE_AFFINE, 1), (2, 32, 32, 24, PRE_AFFINE | PRE_RELU | UP, 1)]
+
+
+@pytest.mark.parametrize("B,Hs,Ws,C,flags,gb_rows", BNB_CASES)
+def test_bn_backward_chain(B, Hs, Ws, C, flags, gb_rows):
+    L = _L()
+    up = 2 if flags & UP else 1
+    x = cl(B, C, Hs, Ws, seed=1)
+    da = cl(B, C, Hs * up, Ws * up, seed=2)
+    rows = gb_rows if gb_rows > 1 else 1
+    gb = B if gb_rows > 1 else 1
+    gain = 0.3 * rnd(gb, C, seed=3)
+    mean, invstd = 0.2 * rnd(C, seed=4), 1 + 0.3 * torch.rand(C, generator=torch.Generator().manual_seed(5))
+    scale = (invstd.view(1, C) * (1.0 + gain)).contiguous()
+    shift = (0.2 * rnd(gb, C, seed=6) - mean.view(1, C) * scale).contiguous()
+    ssb = C if gb > 1 else 0
+    res = {}
+    for tag, to in (("gpu", lambda t: t.cuda()), ("ref", lambda t: t.clone())):
+        fn = (lambda n, *a: L.call(n, *a)) if tag == "gpu" else (lambda n, *a: getattr(R, n)(*a))
+        nb = L.query("icg_bn_bwd_workspace_bytes", B, Hs, Ws, C)
+        ws = to(torch.empty(max(nb, 16), dtype=torch.uint8))
+        sd, sx = to(torch.empty(B, C)), to(torch.empty(B, C))
+        xx, dd, sc, sh, mu, istd, gg = to(x), to(da), to(scale), to(shift), to(mean), to(invstd), to(gain)
+        fn("icg_bn_bwd_reduce", xx, dd, sc, sh, ssb, mu, B, Hs, Ws, C, flags, ws, ws.numel(), sd, sx)
+        chan = to(torch.empty(2 * C, dtype=torch.float64))
+        fn("icg_bn_bwd_channel_sums", sd, sx, gg, gb, 1.0, istd, B, C, chan)
+        dgain, dbeta = to(torch.empty(gb, C)), to(torch.empty(gb, C))
+        ca, cb = to(torch.empty(C)), to(torch.empty(C))
+        fn("icg_bn_bwd_coefs", sd, sx, chan, istd, float(B * Hs * Ws), 1, gb, B, C, dgain, dbeta, ca, cb)
+        dx = to(torch.empty(B, C, Hs, Ws).contiguous(memory_format=torch.channels_last))
+        fn("icg_bn_bwd_apply", xx, dd, sc, sh, ssb, mu, ca, cb, B, Hs, Ws, C, flags, dx)
+        res[tag] = dict(sd=sd, sx=sx, chan=chan, dgain=dgain, dbeta=dbeta, ca=ca, cb=cb, dx=dx)
+    for k in res["gpu"]:
+        close(res["gpu"][k], res["ref"][k], rtol=5e-5, atol_rel=5e-5, what=f"bn bwd {k}")
+
+
+def test_bn_backward_matches_autograd():
+    """the four-stage backward equals autograd through  relu(batch_norm(x)*(1+g)+b)  followed by nearest x2."""
+    L = _L()
+    B, C, Hs, Ws = 3, 32, 6, 6
+    x = cl(B, C, Hs, Ws, seed=1)
+    g, be = 0.3 * rnd(B, C, seed=2), 0.3 * rnd(B, C, seed=3)
+    da = cl(B, C, 2 * Hs, 2 * Ws, seed=4)
+    xr, gr, br = x.clone().double().requires_grad_(True), g.clone().double().requires_grad_(True), \
+        be.clone().double().requires_grad_(True)
+    y = torch.nn.functional.batch_norm(xr, None, None, None, None, True, 0.1, 1e-5)
+    a = torch.relu(y * (1 + gr).view(B, C, 1, 1) + br.view(B, C, 1, 1))
+    a = torch.nn.functional.interpolate(a, scale_factor=2)
+    a.backward(da.double())
+    import ic_gan_amd.ops as ops
+    bn = ops.BNOpt(torch.zeros(C).cuda(), torch.ones(C).cuda(), 1e-5, 0.1, True, 1.0, None)
+    xc = x.cuda().requires_grad_(True)
+    gc, bc = g.cuda().requires_grad_(True), be.cuda().requires_grad_(True)
+    out = ops.norm_act(xc, bn, gc, bc, relu=True)
+    ref_fwd = torch.relu(torch.nn.functional.batch_norm(x.double(), None, None, None, None, True, 0.1, 1e-5)
+                         * (1 + g.double()).view(B, C, 1, 1) + be.double().view(B, C, 1, 1))
+    close(out, ref_fwd.float(), rtol=1e-4, atol_rel=1e-5, what="norm_act fwd")
+    # backward with the upsample adjoint folded (sum-pool da first, then stand-alone backward)
+    dsum = da.view(B, C, Hs, 2, Ws, 2).sum((3, 5)).contiguous(memory_format=torch.channels_last)
+    out.backward(dsum.cuda())
+    close(xc.grad, xr.grad.float(), rtol=2e-4, atol_rel=2e-5, what="bn dx vs autograd")
+    close(gc.grad, gr.grad.float(), rtol=2e-4, atol_rel=2e-5, what="bn dgain vs autograd")
+    close(bc.grad, br.grad.float(), rtol=2e-4, atol_rel=2e-5, what="bn dbias vs autograd")
+
+
+# ------------------------------------------------------------------------------------------------ spectral norm
+SN_CASES = [(32, 32, 3), (3, 96, 3), (96, 3, 3), (10, 16, 1), (1000, 64, 1), (384, 384, 3), (24, 192, 1), (1, 128, 1),
+            (512, 30, 1)]
+
+
+@pytest.mark.parametrize("rows,Cin,taps", SN_CASES)
+def test_sn_forward_backward(rows, Cin, taps):
+    L = _L()
+    w = rnd(rows, Cin, taps, taps, seed=1, scale=1 / np.sqrt(Cin * taps * taps))
+    u = rnd(1, rows, seed=2)
+    dw_hwio = rnd(taps * taps * Cin * rows, seed=3)
+    n = rows * Cin * taps * taps
+    res = {}
+    for tag, to in (("gpu", lambda t: t.cuda()), ("ref", lambda t: t.clone())):
+        fn = (lambda nm, *a: L.call(nm, *a)) if tag == "gpu" else (lambda nm, *a: getattr(R, nm)(*a))
+        ww, uu, sv = to(w), to(u), to(torch.ones(1))
+        v, uo, sg = to(torch.empty(Cin * taps * taps)), to(torch.empty(rows)), to(torch.empty(1))
+        wo, wd = to(torch.empty(n)), to(torch.empty(n))
+        nb = L.query("icg_sn_scratch_bytes", rows, Cin, taps)
+        sc = to(torch.empty(max(nb, 4096), dtype=torch.uint8))
+        fn("icg_sn_forward", ww, uu, sv, rows, Cin, taps, 1e-6, 1, v, uo, sg, wo, wd, sc, sc.numel())
+        dw = to(torch.empty(rows, Cin, taps, taps))
+        fn("icg_sn_backward", to(dw_hwio), None, wo, uo, v, sg, rows, Cin, taps, dw, 0, sc, sc.numel())
+        res[tag] = dict(u=uu, sv=sv, v=v, uo=uo, sigma=sg, w_ohwi=wo, w_dgrad=wd, dw=dw)
+    for k in res["gpu"]:
+        close(res["gpu"][k], res["ref"][k], rtol=5e-5, atol_rel=5e-5, what=f"sn {k} {rows}x{Cin}x{taps}")
+
+
+# ------------------------------------------------------------------------------------------------ pointwise / pooling
+@pytest.mark.parametrize("B,C,H,W", [(2, 3, 8, 8), (2, 96, 16, 16), (1, 5, 6, 10), (3, 48, 4, 4)])
+def test_layout_pool_pointwise(B, C, H, W):
+    x = cl(B, C, H, W, seed=1)
+    n = x.numel()
+    # layout
+    xn = rnd(B, C, H, W, seed=2)
+    y = torch.empty(B * C * H * W)
+    (p,) = run_pair("icg_nchw_to_nhwc", [xn, y, B, C, H, W], [1]); close(*p, what="nchw->nhwc")
+    (p,) = run_pair("icg_nhwc_to_nchw", [y.clone(), torch.empty(n), B, C, H, W], [1]); close(*p, what="nhwc->nchw")
+    # pooling
+    add = cl(B, C, H // 2, W // 2, seed=3)
+    yp = torch.empty_like(add)
+    (p,) = run_pair("icg_avgpool2_fwd", [x, add, yp, B, H, W, C], [2]); close(*p, what="avgpool+add")
+    (p,) = run_pair("icg_avgpool2_fwd", [x, None, yp.clone(), B, H, W, C], [2]); close(*p, what="avgpool")
+    (p,) = run_pair("icg_sumpool2_fwd", [x, yp.clone(), B, H, W, C], [1]); close(*p, what="sumpool")
+    (p,) = run_pair("icg_avgpool2_bwd", [add, torch.empty_like(x), B, H, W, C], [1]); close(*p, what="avgpool bwd")
+    (p,) = run_pair("icg_maxpool2_fwd", [x, yp.clone(), B, H, W, C], [1]); close(*p, what="maxpool")
+    (p,) = run_pair("icg_maxpool2_bwd", [x, add, torch.empty_like(x), B, H, W, C], [2]); close(*p, what="maxpool bwd")
+    # pointwise
+    (p,) = run_pair("icg_tanh_fwd", [x, torch.empty_like(x), n], [1]); close(*p, what="tanh")
+    (p,) = run_pair("icg_tanh_bwd", [torch.tanh(x), cl(B, C, H, W, seed=5), torch.empty_like(x), n], [2])
+    close(*p, what="tanh bwd")
+    (p,) = run_pair("icg_relu_fwd", [x, torch.empty_like(x), n], [1]); close(*p, what="relu")
+    (p,) = run_pair("icg_relu_bwd", [x, cl(B, C, H, W, seed=6), torch.empty_like(x), n], [2]); close(*p, what="relu bwd")
+    (p,) = run_pair("icg_add", [x, cl(B, C, H, W, seed=7), torch.empty_like(x), n], [2]); close(*p, what="add")
+    # relu + sum pool
+    (p,) = run_pair("icg_relu_sumpool_fwd", [x, torch.empty(B, C), B, H * W, C], [1]); close(*p, what="relu sumpool")
+    (p,) = run_pair("icg_relu_sumpool_bwd", [x, rnd(B, C, seed=8), torch.empty_like(x), B, H * W, C], [2])
+    close(*p, what="relu sumpool bwd")
+    # gamma * o + x
+    gamma = torch.tensor([0.37])
+    (p,) = run_pair("icg_scale_add_fwd", [gamma, x, cl(B, C, H, W, seed=9), torch.empty_like(x), n], [3])
+    close(*p, what="scale_add")
+    sc = torch.empty(4096, dtype=torch.uint8)
+    ps = run_pair("icg_scale_add_bwd", [gamma, x, cl(B, C, H, W, seed=10), torch.empty_like(x), torch.empty(1), n, sc,
+                                        4096], [3, 4])
+    close(*ps[0], what="scale_add d_o"); close(*ps[1], rtol=1e-4, atol_rel=1e-5, what="scale_add dgamma")
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 16), (1000, 64), (4096, 256), (333, 1024), (7, 1000)])
+def test_softmax(rows, cols):
+    x = rnd(rows, cols, seed=1, scale=3.0)
+    (p,) = run_pair("icg_softmax_fwd", [x, torch.empty_like(x), rows, cols], [1]); close(*p, what="softmax")
+    y = torch.softmax(x, -1)
+    (p,) = run_pair("icg_softmax_bwd", [y, rnd(rows, cols, seed=2), torch.empty_like(x), rows, cols], [2])
+    close(*p, what="softmax bwd")
+
+
+@pytest.mark.parametrize("rows,C", [(4096, 96), (128, 1536), (70000, 3), (64, 1), (5000, 48), (33, 657), (16, 384)])
+def test_colsum(rows, C):
+    L = _L()
+    x = rnd(rows, C, seed=1) + 0.5
+    nb = L.query("icg_colsum_workspace_bytes", rows, C)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8)
+    (p,) = run_pair("icg_colsum", [x, rows, C, torch.empty(C), ws, ws.numel()], [3])
+    close(*p, rtol=1e-4, atol_rel=1e-5, what=f"colsum {rows}x{C}")
+
+
+# ------------------------------------------------------------------------------------------------ optimiser / EMA
+def test_adam_and_ema_multi():
+    import ic_gan_amd.ops as ops
+    sizes = [1, 3, 17, 4096, 4097, 100000, 5, 64 * 64 * 9] + [7 + i for i in range(60)]   # > 48 tensors: 2 launches
+    ps = [rnd(n, seed=i) for i, n in enumerate(sizes)]
+    gs = [rnd(n, seed=100 + i, scale=0.1) for i, n in enumerate(sizes)]
+    ms = [0.01 * rnd(n, seed=200 + i) for i, n in enumerate(sizes)]
+    vs = [(0.01 * rnd(n, seed=300 + i)) ** 2 for i, n in enumerate(sizes)]
+    for (b1, step) in [(0.0, 1), (0.0, 7), (0.5, 3)]:
+        dp, dg, dm, dv = ([t.cuda() for t in l] for l in (ps, gs, ms, vs))
+        cp, cg, cm, cv = ([t.clone() for t in l] for l in (ps, gs, ms, vs))
+        ops.adam_multi(dp, dg, dm, dv, 2e-4, b1, 0.999, 1e-6, step)
+        R.adam_multi_ref(cp, cg, cm, cv, 2e-4, b1, 0.999, 1e-6, step)
+        for a, b in zip(dp + dm + dv, cp + cm + cv):
+            close(a, b, rtol=1e-5, atol_rel=1e-6, what=f"adam b1={b1} step={step}")
+    tg, sr = [t.cuda() for t in ps], [t.cuda() for t in gs]
+    ct, cs = [t.clone() for t in ps], [t.clone() for t in gs]
+    ops.ema_multi(tg, sr, 0.9999)
+    R.ema_multi_ref(ct, cs, 0.9999)
+    for a, b in zip(tg, ct):
+        close(a, b, rtol=1e-6, atol_rel=1e-7, what="ema")
+
+
+# ------------------------------------------------------------------------------------------------ StyleGAN2 ops
+ACT = dict(linear=1, relu=2, lrelu=3, tanh=4, sigmoid=5, elu=6, selu=7, softplus=8, swish=9)
+DEF_GAIN = dict(linear=1, relu=np.sqrt(2), lrelu=np.sqrt(2), tanh=1, sigmoid=1, elu=1, selu=1, softplus=1, swish=np.sqrt(2))
+
+
+@pytest.mark.parametrize("act", list(ACT))
+@pytest.mark.parametrize("clamp", [-1.0, 0.7])
+def test_bias_act(act, clamp):
+    N, C, H, W = 3, 6, 5, 5
+    n = N * C * H * W
+    x, b = rnd(n, seed=1, scale=1.5), rnd(C, seed=2, scale=0.5)
+    alpha, gain = 0.2, float(DEF_GAIN[act])
+    y = torch.empty(n)
+    (p,) = run_pair("icg_bias_act", [x, b, None, None, None, y, n, H * W, C, 0, ACT[act], alpha, gain, clamp], [5])
+    close(*p, rtol=1e-5, atol_rel=1e-6, what=f"bias_act fwd {act}")
+    yref = p[1].clone()
+    dy = rnd(n, seed=3)
+    # first-order: kernel(x=dy, xref=x, yref=y)
+    (p1,) = run_pair("icg_bias_act", [dy, b, x, yref, None, torch.empty(n), n, H * W, C, 1, ACT[act], alpha, gain, clamp], [5])
+    close(*p1, rtol=2e-4, atol_rel=2e-5, what=f"bias_act grad1 {act}")
+    d2 = rnd(n, seed=4)
+    (p2,) = run_pair("icg_bias_act", [d2, b, x, yref, dy, torch.empty(n), n, H * W, C, 2, ACT[act], alpha, gain, clamp], [5])
+    close(*p2, rtol=5e-4, atol_rel=5e-5, what=f"bias_act grad2 {act}")
+
+
+UPFIR = [  # N, C, H, W, fh, fw, up, down, (px0, px1, py0, py1), flip
+    (2, 3, 8, 8, 4, 4, 2, 1, (2, 1, 2, 1), 0), (2, 5, 9, 7, 4, 4, 1, 2, (1, 1, 1, 1), 0),
+    (1, 4, 16, 16, 4, 4, 1, 1, (1, 2, 2, 1), 1), (2, 2, 6, 6, 3, 5, 2, 2, (0, 3, -1, 2), 0),
+    (1, 8, 17, 17, 4, 4, 1, 1, (-1, -1, 0, 0), 0), (1, 1, 4, 4, 1, 1, 1, 1, (0, 0, 0, 0), 0),
+    (2, 3, 8, 8, 8, 8, 2, 1, (4, 3, 4, 3), 1),
+]
+
+
+@pytest.mark.parametrize("case", UPFIR)
+def test_upfirdn2d(case):
+    N, C, H, W, fh, fw, up, down, pad, flip = case
+    px0, px1, py0, py1 = pad
+    outW = (W * up + px0 + px1 - fw + down) // down
+    outH = (H * up + py0 + py1 - fh + down) // down
+    x, f = rnd(N, C, H, W, seed=1), rnd(fh, fw, seed=2)
+    y = torch.empty(N, C, outH, outW)
+    (p,) = run_pair("icg_upfirdn2d", [x, f, y, N, C, H, W, fh, fw, up, up, down, down, px0, px1, py0, py1, flip, 1.7,
+                                      outH, outW], [2])
+    close(*p, rtol=2e-5, atol_rel=2e-5, what=f"upfirdn2d {case}")
