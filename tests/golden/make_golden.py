@@ -51,9 +51,9 @@ CASES = {
     "cc_r32_flat": (dict(resolution=32, class_cond=True, instance_cond=False, hier=False,
                          G_attn="16", D_attn="16", shared_dim=0, dim_z=24), 4, 1, True),
     "cc_ic_r128": (dict(resolution=128, class_cond=True, instance_cond=True, G_attn="64", D_attn="64"),
-                   2, 1, False),
+                   4, 1, False),
     "cc_ic_r256": (dict(resolution=256, class_cond=True, instance_cond=True, G_attn="64", D_attn="64",
-                        G_ch=8, D_ch=8), 2, 1, False),
+                        G_ch=8, D_ch=8), 4, 1, False),
 }
 NS = 64
 

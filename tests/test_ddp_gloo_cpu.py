@@ -1,0 +1,142 @@
+"""CPU, world_size = 2 over gloo: the data-parallel wiring of the hot path.
+
+The HIP kernels cannot run here, so every C-ABI call is routed to oracle/kernel_ref.py inside the spawned
+workers (test-only); what is under test is the distributed *host* logic:
+  * DDP gradient averaging + buffer broadcast keep G/D replicas bit-identical after a full G+D step
+  * sync_bn=True: 2 ranks on half batches == 1 process on the concatenated batch (outputs, running statistics,
+    DDP-averaged gradients) — the oracle for cross-replica BN named in SURVEY F2
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import kernel_ref, synth
+
+CFG = dict(dim_z=24, shared_dim=16, shared_dim_feat=32, G_shared=True, G_shared_feat=True, hier=True, n_classes=10,
+           SN_eps=1e-6, BN_eps=1e-5, adam_eps=1e-6, G_ch=8, D_ch=8, G_attn="16", D_attn="16", resolution=32,
+           class_cond=True, instance_cond=True, toggle_grads=True, num_D_steps=1, num_D_accumulations=1,
+           num_G_accumulations=1, split_D=False, DiffAugment="", DA=False, D_ortho=0.0, G_ortho=0.0, ema=True,
+           ema_decay=0.9, ema_start=0)
+
+
+class _Patch:
+    def setattr(self, obj, name, val):
+        setattr(obj, name, val)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kernel_ref.install(_Patch())
+    torch.set_num_threads(2)
+
+
+def _models(cfg):
+    import ic_gan_amd.BigGAN as M
+    G = M.Generator(**{**cfg, "skip_init": True, "embedded_optimizers": False})
+    D = M.Discriminator(**{**cfg, "skip_init": True, "embedded_optimizers": False})
+    G.load_state_dict(synth.synth_state(synth.spec_of(G.state_dict()), 11))
+    D.load_state_dict(synth.synth_state(synth.spec_of(D.state_dict()), 22))
+    return M, G, D
+
+
+def _worker_step(rank, world, port, out):
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from ic_gan_amd import train_fns, utils
+    from ic_gan_amd.optim import FusedAdam
+    _init(rank, world, port)
+    M, G, D = _models(CFG)
+    if rank == 1:                       # perturb rank 1's buffers: the per-forward broadcast must overwrite them (F3)
+        with torch.no_grad():
+            G.linear.u0.add_(1.0)
+    G_ema = M.Generator(**{**CFG, "skip_init": True, "no_optim": True})
+    ema = utils.ema(G, G_ema, 0.9, 0)
+    opt_d = FusedAdam(D.parameters(), lr=2e-3, betas=(0.0, 0.999), eps=1e-6)
+    opt_g = FusedAdam(G.parameters(), lr=1e-3, betas=(0.0, 0.999), eps=1e-6)
+    Gd, Dd = DDP(G, find_unused_parameters=True), DDP(D, find_unused_parameters=True)
+    GD = M.G_D(Gd, Dd, optimizer_G=opt_g, optimizer_D=opt_d)
+    gb = 2
+    train = train_fns.GAN_training_function(Gd, Dd, GD, ema, {"itr": 1}, CFG, synth.CondSampler(CFG, G.dim_z, gb, 50 + rank),
+                                            embedded_optimizers=False, device="cpu", batch_size=gb)
+    x, y, f = synth.synth_batch(CFG, gb, seed=70 + rank)
+    Gd.train(); Dd.train()
+    m = train(x, y, f)
+    flat = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        out["identical"] = bool(torch.equal(gathered[0], gathered[1]))
+        out["finite"] = bool(torch.isfinite(flat).all())
+        out["loss"] = m
+    dist.destroy_process_group()
+
+
+def _worker_syncbn(rank, world, port, out):
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    _init(rank, world, port)
+    cfg = dict(CFG, sync_bn=True)
+    _, G, _ = _models(cfg)
+    Gd = DDP(G)
+    B = 4
+    c = synth.CondSampler(cfg, G.dim_z, B, 9)()
+    z, lab, fg = c
+    wts = torch.from_numpy(__import__("numpy").random.RandomState(3).standard_normal((B, 3, 32, 32))).float()
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+    Gd.train()
+    img = Gd(z[sl], lab[sl], fg[sl])
+    (img * wts[sl]).sum().backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in G.parameters()])
+    imgs = [torch.empty_like(img) for _ in range(world)]
+    dist.all_gather(imgs, img.detach().contiguous())
+    if rank == 0:
+        out["img"] = torch.cat(imgs, 0)
+        out["grads"] = grads.clone()
+        out["rm"] = G.blocks[0][0].bn1.stored_mean.clone()
+        out["rv"] = G.output_layer[0].stored_var.clone()
+    dist.destroy_process_group()
+
+
+def _spawn(fn):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(fn, args=(2, _free_port(), out), nprocs=2, join=True)
+    return dict(out)
+
+
+@pytest.mark.timeout(600)
+def test_ddp_step_keeps_replicas_identical():
+    out = _spawn(_worker_step)
+    assert out["finite"] and out["identical"], out
+
+
+@pytest.mark.timeout(600)
+def test_syncbn_two_ranks_equal_one_process_on_full_batch(monkeypatch):
+    out = _spawn(_worker_syncbn)
+    kernel_ref.install(monkeypatch)
+    cfg = dict(CFG, sync_bn=False)
+    _, G, _ = _models(cfg)
+    B = 4
+    z, lab, fg = synth.CondSampler(cfg, G.dim_z, B, 9)()
+    import numpy as np
+    wts = torch.from_numpy(np.random.RandomState(3).standard_normal((B, 3, 32, 32))).float()
+    G.train()
+    img = G(z, lab, fg)
+    ((img * wts).sum() / 2).backward()          # DDP averages the two ranks' gradients
+    grads = torch.cat([p.grad.reshape(-1) for p in G.parameters()])
+    assert torch.allclose(out["img"], img.detach(), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(out["rm"], G.blocks[0][0].bn1.stored_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out["rv"], G.output_layer[0].stored_var, rtol=1e-5, atol=1e-6)
+    rel = float((out["grads"] - grads).norm() / grads.norm())
+    assert rel < 1e-4, rel

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import kernel_ref, synth
-from tests.helpers import CASES, check_group, load_golden, noise_grad_names
+from tests.helpers import CASES, GRAD_RTOL, STATE_RTOL, adam_slack, check_group, load_golden
 
 
 @pytest.fixture
@@ -86,11 +86,11 @@ def test_train_step_host_logic(case, emu):
                                    rtol=5e-4, atol=5e-4)
         if s == 0:
             check_group(g, "step1/G_grad/", {n: p.grad for n, p in G.named_parameters() if p.grad is not None},
-                        5e-3, 1e-6, "G grad ")
+                        GRAD_RTOL, 1e-6, "G grad ")
             check_group(g, "step1/D_grad/", {n: p.grad for n, p in D.named_parameters() if p.grad is not None},
-                        5e-3, 1e-6, "D grad ")
-        gx = {n: 2.2 * cfg["G_lr"] * (s + 1) for n in noise_grad_names(g, "step1/G_grad/")}
-        dx = {n: 2.2 * cfg["D_lr"] * (s + 1) for n in noise_grad_names(g, "step1/D_grad/")}
-        check_group(g, f"step{s + 1}/G_state/", G.state_dict(), 5e-3, 2e-6, "G ", extra_atol=gx)
-        check_group(g, f"step{s + 1}/D_state/", D.state_dict(), 5e-3, 2e-6, "D ", extra_atol=dx)
-        check_group(g, f"step{s + 1}/EMA_state/", G_ema.state_dict(), 5e-3, 2e-6, "EMA ", extra_atol=gx)
+                        GRAD_RTOL, 1e-6, "D grad ")
+        gx = adam_slack(g, "step1/G_grad/", cfg["G_lr"], s + 1, G.state_dict().keys())
+        dx = adam_slack(g, "step1/D_grad/", cfg["D_lr"], s + 1, D.state_dict().keys())
+        check_group(g, f"step{s + 1}/G_state/", G.state_dict(), STATE_RTOL, 2e-6, "G ", extra_atol=gx)
+        check_group(g, f"step{s + 1}/D_state/", D.state_dict(), STATE_RTOL, 2e-6, "D ", extra_atol=dx)
+        check_group(g, f"step{s + 1}/EMA_state/", G_ema.state_dict(), STATE_RTOL, 2e-6, "EMA ", extra_atol=gx)
