@@ -124,7 +124,9 @@ def cpu_baseline(cfg, name):
     """CPU oracle (restatement of the reference step, pinned to reference goldens) on this box's host cores."""
     from oracle import biggan_oracle as O, synth
     import ic_gan_amd.BigGAN as M
-    torch.set_num_threads(os.cpu_count() or 1)
+    # Thread count: with all 256 hardware threads of the GPU box PyTorch's CPU convolutions oversubscribe (measured
+    # 375 s/step); 8 threads in the build container gave 7.6 s/step.  We cap at 32 and report that as `cores`.
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     b = 2 if cfg["resolution"] >= 128 else 8
     G = M.Generator(**{**cfg, "skip_init": True, "embedded_optimizers": False})
     D = M.Discriminator(**{**cfg, "skip_init": True, "embedded_optimizers": False})
@@ -157,8 +159,15 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sync-bn", action="store_true", help="cross-replica BN statistics over RCCL (cfg3 variant)")
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:          # child process of the N=1 run: bounded CPU sample, prints one JSON object
+        cfg = dict(BASE_CFG)
+        cfg.update(WORKLOADS[args.workload][0])
+        print("CPU_BASELINE " + json.dumps(cpu_baseline(cfg, args.workload)), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -248,10 +257,16 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(cfg, args.workload)
+            import subprocess
+            try:     # separate process with a hard wall-clock bound: the default bench run must finish in minutes
+                res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload",
+                                      args.workload], capture_output=True, text=True, timeout=180,
+                                     env={**os.environ, "HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+                line = [l for l in res.stdout.splitlines() if l.startswith("CPU_BASELINE ")][-1]
+                out["cpu_baseline"] = json.loads(line[len("CPU_BASELINE "):])
             except Exception as exc:   # noqa: BLE001
-                out["cpu_baseline"] = {"value": None, "error": str(exc)}
+                out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": min(32, os.cpu_count() or 1),
+                                       "kind": "port", "sample": f"not completed within 180 s ({type(exc).__name__})"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -40,18 +40,28 @@ struct GemmP {
   long strideA, strideB, strideC;  // per blockIdx.z
   int kchunk;                      // >0: split-K, z selects the K range
   int ntiles_n;
+  int lw, lh;                      // log2(W), log2(H) (fast path: H, W powers of two)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-template <int AMODE, int BMODE, int TN, bool VEC>
+// PATH 0: element-wise gather (any Cin); 1: 16-byte loads, generic index decode; 2: 16-byte loads, 32-bit offsets,
+// branch-free loads (clamped address + select), scalar tap tracking (A_K: Cin % 16 == 0) / shift-mask pixel decode
+// (A_M: H, W powers of two).  PATH 2 cuts the per-K-tile address section from ~330 to ~90 instructions.
+template <int AMODE, int BMODE, int TN, int PATH>
 __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
+  // PATH 3 = PATH 2 with the BN/ccbn affine prologue compiled in (PATH 2 itself has none): keeps the hot loop
+  // free of uniform branches so that the scheduler can interleave the staging work with the MFMAs
+  constexpr bool VEC = PATH >= 1;
+  constexpr bool FAST = PATH >= 2;
+  constexpr bool FAST_AFFINE = PATH == 3;
   constexpr int BM = 128, BN = 32 * TN, BK = 16;
   constexpr int LDA = (AMODE == A_K) ? BM + 1 : BM + 4;
   constexpr int LDB = (BMODE == B_K) ? BN + 1 : BN + 4;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+  constexpr int NBUF = 3;   // 3-deep LDS ring: lets the single barrier per K-tile sit mid-tile (see main loop)
+  __shared__ __attribute__((aligned(16))) float As[NBUF][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF][BK * LDB];
 
   const int tid = threadIdx.x;
   const int nt = blockIdx.x % p.ntiles_n;
@@ -101,6 +111,101 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
       am_tap_s[j] = tap - am_tap_r[j] * p.R;
     }
   }
+
+  // ---- PATH 2 state -------------------------------------------------------------------------------------
+  unsigned f_img[2], f_ss[2], f_boff[2];
+  int f_h[2], f_w[2];
+  bool f_rowok[2], f_ok[2];
+  int f_tr = 0, f_ts = 0, f_c0 = 0;          // wave-uniform tap tracking (A_K)
+  unsigned f_mtap_c = 0;                      // A_M: channel of this thread's 4 columns
+  int f_mr = 0, f_ms = 0;
+  bool f_mok = false;
+  if (FAST) {
+    if (AMODE == A_K) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f_rowok[i] = amv[i];
+        f_h[i] = ah[i];
+        f_w[i] = aw[i];
+        f_img[i] = (unsigned)ab[i] * (unsigned)(p.Hs * p.Ws);
+        f_ss[i] = (unsigned)ab[i] * (unsigned)p.ss_bstride;
+      }
+    } else {
+      f_mok = am_mv[0];
+      f_mtap_c = (unsigned)am_c[0];
+      f_mr = am_tap_r[0];
+      f_ms = am_tap_s[0];
+    }
+    if (BMODE == B_K) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int nl = arow + 64 * i;
+        const int n = n0 + nl;
+        f_boff[i] = (nl < BN && n < p.N) ? (unsigned)n * (unsigned)p.ldb : 0u;
+      }
+    }
+  }
+
+  // one row (i = 0 / 1) of this thread's A staging; `last` advances the tap tracker
+  auto load_A_fast = [&](int k0, int i, bool last) {
+    if (AMODE == A_K) {
+      const unsigned c = (unsigned)(f_c0 + 4 * kq);
+      {
+        const int hi = f_h[i] + f_tr - pad, wi = f_w[i] + f_ts - pad;
+        const bool ok = f_rowok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+        const unsigned idx = (f_img[i] + (unsigned)(hi >> p.up) * (unsigned)p.Ws + (unsigned)(wi >> p.up)) *
+                                 (unsigned)Cin + c;
+        f_ok[i] = ok;
+        ra[i] = ld4(Ag + (ok ? idx : 0u));
+        if (FAST_AFFINE) {
+          rsc[i] = ld4(p.scale + (f_ss[i] + c));
+          rsh[i] = ld4(p.shift + (f_ss[i] + c));
+        }
+      }
+      if (last) {
+        f_c0 += BK;                             // K-tiles never straddle a tap: Cin % BK == 0
+        if (f_c0 >= Cin) {
+          f_c0 = 0;
+          if (++f_ts == p.R) { f_ts = 0; ++f_tr; }
+        }
+      }
+    } else {
+      {
+        const int kp = k0 + krow + 8 * i;
+        const int w = kp & (p.W - 1);
+        const int h = (kp >> p.lw) & (p.H - 1);
+        const int b = kp >> (p.lw + p.lh);
+        const int hi = h + f_mr - pad, wi = w + f_ms - pad;
+        const bool ok = f_mok & (kp < kend) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+        const unsigned idx = (((unsigned)b * (unsigned)p.Hs + (unsigned)(hi >> p.up)) * (unsigned)p.Ws +
+                              (unsigned)(wi >> p.up)) * (unsigned)Cin + f_mtap_c;
+        f_ok[i] = ok;
+        ra[i] = ld4(Ag + (ok ? idx : 0u));
+        if (FAST_AFFINE) {
+          const unsigned so = ok ? (unsigned)b * (unsigned)p.ss_bstride + f_mtap_c : 0u;
+          rsc[i] = ld4(p.scale + so);
+          rsh[i] = ld4(p.shift + so);
+        }
+      }
+    }
+  };
+
+  auto load_B_fast = [&](int k0) {
+    if (BMODE == B_K) {
+      const unsigned kg = (unsigned)(min(k0, kend - BK) + 4 * kq);   // clamp: the pipeline over-fetches past the last tile
+#pragma unroll
+      for (int i = 0; i < 2; ++i) rb[i] = ld4(Bg + (f_boff[i] + kg));   // rows >= N only feed masked outputs
+    } else {
+      const int n = n0 + 4 * mq;
+      const bool nok = (4 * mq < BN) && n < p.N;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kp = k0 + krow + 8 * i;
+        const unsigned idx = (nok & (kp < kend)) ? (unsigned)kp * (unsigned)p.ldb + (unsigned)n : 0u;
+        rb[i] = ld4(Bg + idx);                                          // A is zero for kp >= kend
+      }
+    }
+  };
 
   auto src_index = [&](int b, int hi, int wi, int c) -> long {
     return (((long)b * p.Hs + (hi >> p.up)) * p.Ws + (wi >> p.up)) * Cin + c;
@@ -200,7 +305,21 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
     }
   };
 
+  const float relu_floor = p.pre_relu ? 0.f : -INFINITY;
   auto act4 = [&](float4 v, float4 sc, float4 sh) -> float4 {
+    if (FAST) {
+      if (FAST_AFFINE) {
+        v.x = fmaf(v.x, sc.x, sh.x);
+        v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z);
+        v.w = fmaf(v.w, sc.w, sh.w);
+      }
+      v.x = fmaxf(v.x, relu_floor);
+      v.y = fmaxf(v.y, relu_floor);
+      v.z = fmaxf(v.z, relu_floor);
+      v.w = fmaxf(v.w, relu_floor);
+      return v;
+    }
     if (p.pre_affine) {
       v.x = fmaf(v.x, sc.x, sh.x);
       v.y = fmaf(v.y, sc.y, sh.y);
@@ -221,7 +340,8 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
     if (AMODE == A_K) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const float4 v = act4(ra[i], rsc[i], rsh[i]);
+        float4 v = act4(ra[i], rsc[i], rsh[i]);
+        if (FAST && !f_ok[i]) v = zero4();
         const int row = arow + 64 * i;
         as[(4 * kq + 0) * LDA + row] = v.x;
         as[(4 * kq + 1) * LDA + row] = v.y;
@@ -231,7 +351,8 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const float4 v = act4(ra[i], rsc[i], rsh[i]);
+        float4 v = act4(ra[i], rsc[i], rsh[i]);
+        if (FAST && !f_ok[i]) v = zero4();
         *reinterpret_cast<float4*>(&as[(krow + 8 * i) * LDA + 4 * mq]) = v;
       }
     }
@@ -285,7 +406,7 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int nl = arow + 64 * i;
-        if (nl < BN) {
+        if (BN == 128 || nl < BN) {
           bs[(4 * kq + 0) * LDB + nl] = rb[i].x;
           bs[(4 * kq + 1) * LDB + nl] = rb[i].y;
           bs[(4 * kq + 2) * LDB + nl] = rb[i].z;
@@ -293,7 +414,7 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
         }
       }
     } else {
-      if (4 * mq < BN) {
+      if (BN == 128 || 4 * mq < BN) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
           *reinterpret_cast<float4*>(&bs[(krow + 8 * i) * LDB + 4 * mq]) = rb[i];
@@ -312,30 +433,72 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
   const int li = lane & 31, lh = lane >> 5;
   const int nk = (kend - kbeg + BK - 1) / BK;
 
+  auto load_A_any = [&](int k0, int half) {      // half 0 / 1: first / second staged row of this thread
+    if (FAST) load_A_fast(k0, half, half == 1);
+    else if (half == 0) load_A(k0);               // generic paths stage both rows at once
+  };
+  auto load_B_any = [&](int k0) {
+    if (FAST) load_B_fast(k0); else load_B(k0);
+  };
+
+  // Software pipeline over K-tiles, ONE barrier per tile, 3-deep LDS ring (tile kt lives in buffer kt % 3):
+  //   on loop entry the registers hold tile kt+1 (global loads issued one tile earlier) and the MFMA operand
+  //   fragments of k-step 0 of tile kt are already in registers.
+  //   k-step 0-1 : MFMAs  ||  write tile kt+1 into ring slot (kt+1)%3
+  //   barrier    : tile kt+1 is complete in LDS (and every wave is done with tile kt-1, whose slot is reused next)
+  //   k-step 2-4 : MFMAs  ||  issue the global loads of tile kt+2 (row 0, row 1, B)
+  //   k-step 7   : MFMAs  ||  fetch the k-step-0 fragments of tile kt+1  -> the MFMA stream never drains at a
+  //                tile boundary; all staging work sits in the 64-cycle shadows of the MFMAs.
+  // Past the last tile the staging work is harmless (idle ring slot / clamped or masked addresses).
+  float fa[2], fb[2][TN];
   if (nk > 0) {
-    load_A(kbeg);
-    load_B(kbeg);
-  }
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    store_A(buf);
-    store_B(buf);
+    load_A_any(kbeg, 0);
+    load_A_any(kbeg, 1);
+    load_B_any(kbeg);
+    store_A(0);
+    store_B(0);
+    load_A_any(kbeg + BK, 0);
+    load_A_any(kbeg + BK, 1);
+    load_B_any(kbeg + BK);
     __syncthreads();
-    if (kt + 1 < nk) {
-      load_A(kbeg + (kt + 1) * BK);
-      load_B(kbeg + (kt + 1) * BK);
-    }
-    const float* as = As[buf] + 32 * wv + li;
-    const float* bs = Bs[buf] + li;
+    fa[0] = As[0][32 * wv + li + lh * LDA];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = Bs[0][li + lh * LDB + 32 * j];
+  }
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int nxt = (cur == NBUF - 1) ? 0 : cur + 1;
+    const float* as = As[cur] + 32 * wv + li + lh * LDA;
+    const float* bs = Bs[cur] + li + lh * LDB;
+    const float* asn = As[nxt] + 32 * wv + li + lh * LDA;
+    const float* bsn = Bs[nxt] + li + lh * LDB;
+    const int k2 = kbeg + (kt + 2) * BK;
 #pragma unroll
     for (int t = 0; t < BK / 2; ++t) {
-      const float a = as[(2 * t + lh) * LDA];
+      if (t + 1 < BK / 2) {
+        fa[(t + 1) & 1] = as[(2 * t + 2) * LDA];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const float b = bs[(2 * t + lh) * LDB + 32 * j];
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) fb[(t + 1) & 1][j] = bs[(2 * t + 2) * LDB + 32 * j];
+      } else {
+        fa[0] = asn[0];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = bsn[32 * j];
       }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1], fb[t & 1][j], acc[j], 0, 0, 0);
+      if (t == 0) store_A(nxt);
+      if (t == 1) {
+        store_B(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+      }
+      if (t == 2) load_A_any(k2, 0);
+      if (t == 3) load_A_any(k2, 1);
+      if (t == 4) load_B_any(k2);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    cur = nxt;
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -388,32 +551,42 @@ static int pick_tn(int N) {
   return 4;
 }
 
+static int ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
 template <int AMODE, int BMODE>
-static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st) {
+static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool fast_ok = false) {
   GemmP p = p0;
+  p.lw = ilog2_exact(p.W);
+  p.lh = ilog2_exact(p.H);
+  int path = vec ? 1 : 0;
+  if (vec && fast_ok) {
+    if (AMODE == A_K && (p.Cin % 16 == 0) && p.kchunk == 0) path = 2;
+    if (AMODE == A_M && p.lw >= 0 && p.lh >= 0) path = 2;
+  }
   const int tn = pick_tn(p.N);
   const int bn = 32 * tn;
   p.ntiles_n = (int)icg_cdiv(p.N, bn);
   const long tiles = icg_cdiv(p.M, 128) * p.ntiles_n;
   if (tiles <= 0 || tiles > 0x7fffffffL || zdim <= 0 || zdim > 65535) return ICG_ERR_ARG;
   dim3 grid((unsigned)tiles, 1, (unsigned)zdim), block(256);
-#define ICG_LAUNCH(TN_, VEC_) \
-  hipLaunchKernelGGL((icg_gemm_kernel<AMODE, BMODE, TN_, VEC_>), grid, block, 0, st, p)
-  if (vec) {
-    switch (tn) {
-      case 1: ICG_LAUNCH(1, true); break;
-      case 2: ICG_LAUNCH(2, true); break;
-      case 3: ICG_LAUNCH(3, true); break;
-      default: ICG_LAUNCH(4, true); break;
-    }
-  } else {
-    switch (tn) {
-      case 1: ICG_LAUNCH(1, false); break;
-      case 2: ICG_LAUNCH(2, false); break;
-      case 3: ICG_LAUNCH(3, false); break;
-      default: ICG_LAUNCH(4, false); break;
-    }
+#define ICG_LAUNCH(TN_, PATH_) \
+  hipLaunchKernelGGL((icg_gemm_kernel<AMODE, BMODE, TN_, PATH_>), grid, block, 0, st, p)
+#define ICG_LAUNCH_TN(PATH_)             \
+  switch (tn) {                          \
+    case 1: ICG_LAUNCH(1, PATH_); break; \
+    case 2: ICG_LAUNCH(2, PATH_); break; \
+    case 3: ICG_LAUNCH(3, PATH_); break; \
+    default: ICG_LAUNCH(4, PATH_); break; \
   }
+  if (path == 2 && p.pre_affine) path = 3;
+  if (path == 3) { ICG_LAUNCH_TN(3) } else if (path == 2) { ICG_LAUNCH_TN(2) } else if (path == 1) { ICG_LAUNCH_TN(1) }
+  else { ICG_LAUNCH_TN(0) }
+#undef ICG_LAUNCH_TN
 #undef ICG_LAUNCH
   return icg_check_launch();
 }
@@ -445,7 +618,9 @@ extern "C" int icg_conv2d_fprop(const float* x, const float* w, const float* bia
   p.kchunk = 0;
   bool vec = (Cin % 4 == 0) && aligned16(x) && aligned16(w);
   if (p.pre_affine) vec = vec && (ss_bstride % 4 == 0) && aligned16(scale) && aligned16(shift);
-  return launch_gemm<A_K, B_K>(p, vec, 1, (hipStream_t)stream);
+  const bool small = ((long)B * p.Hs * p.Ws * Cin < 0x7fffffffL) && ((long)Cout * p.K < 0x7fffffffL) &&
+                     ((long)B * (ss_bstride > 0 ? ss_bstride : 0) + Cin < 0x7fffffffL);
+  return launch_gemm<A_K, B_K>(p, vec, 1, (hipStream_t)stream, small);
 }
 
 struct WgradPlan {
@@ -505,7 +680,9 @@ extern "C" int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
   p.strideA = 0; p.strideB = 0; p.strideC = (long)M * Cout;
   bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && aligned16(x) && aligned16(dy);
   if (p.pre_affine) vec = vec && (ss_bstride % 4 == 0) && aligned16(scale) && aligned16(shift);
-  int rc = launch_gemm<A_M, B_N>(p, vec, pl.splits, (hipStream_t)stream);
+  const bool small = ((long)B * p.Hs * p.Ws * Cin < 0x7fffffffL) && (K * (long)Cout < 0x7fffffffL) &&
+                     ((long)B * (ss_bstride > 0 ? ss_bstride : 0) + Cin < 0x7fffffffL);
+  int rc = launch_gemm<A_M, B_N>(p, vec, pl.splits, (hipStream_t)stream, small);
   if (rc != ICG_OK) return rc;
   if (pl.splits > 1) {
     const long n = (long)M * Cout;
@@ -531,15 +708,16 @@ extern "C" int icg_gemm_batched(const float* A, const float* B, float* C, int M,
   p.strideA = strideA; p.strideB = strideB; p.strideC = strideC;
   const bool al = aligned16(A) && aligned16(B) && (strideA % 4 == 0) && (strideB % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
+  const bool small = ((long)M * K < 0x7fffffffL) && ((long)N * K < 0x7fffffffL);
   if (transA == 0 && transB == 1) {        // A [M][K], B [N][K]
     p.Cin = K; p.ldb = K;
-    return launch_gemm<A_K, B_K>(p, al && (K % 4 == 0), batch, st);
+    return launch_gemm<A_K, B_K>(p, al && (K % 4 == 0), batch, st, small);
   } else if (transA == 0 && transB == 0) { // A [M][K], B [K][N]
     p.Cin = K; p.ldb = N;
-    return launch_gemm<A_K, B_N>(p, al && (K % 4 == 0) && (N % 4 == 0), batch, st);
+    return launch_gemm<A_K, B_N>(p, al && (K % 4 == 0) && (N % 4 == 0), batch, st, small);
   } else if (transA == 1 && transB == 0) { // A [K][M], B [K][N]
     p.Cin = M; p.ldb = N;
-    return launch_gemm<A_M, B_N>(p, al && (M % 4 == 0) && (N % 4 == 0), batch, st);
+    return launch_gemm<A_M, B_N>(p, al && (M % 4 == 0) && (N % 4 == 0), batch, st, small);
   }
   return ICG_ERR_ARG;
 }
