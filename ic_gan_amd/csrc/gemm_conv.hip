@@ -147,21 +147,19 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
   }
 
   // one row (i = 0 / 1) of this thread's A staging; `last` advances the tap tracker
-  auto load_A_fast = [&](int k0, int i, bool last) {
+  // staging row i (0/1) of this thread's A data, split into an address piece and a load piece so that each fits
+  // into one MFMA shadow; `last` advances the tap tracker
+  unsigned f_idx[2], f_so[2];
+  auto addr_A_fast = [&](int k0, int i, bool last) {
     if (AMODE == A_K) {
       const unsigned c = (unsigned)(f_c0 + 4 * kq);
-      {
-        const int hi = f_h[i] + f_tr - pad, wi = f_w[i] + f_ts - pad;
-        const bool ok = f_rowok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-        const unsigned idx = (f_img[i] + (unsigned)(hi >> p.up) * (unsigned)p.Ws + (unsigned)(wi >> p.up)) *
-                                 (unsigned)Cin + c;
-        f_ok[i] = ok;
-        ra[i] = ld4(Ag + (ok ? idx : 0u));
-        if (FAST_AFFINE) {
-          rsc[i] = ld4(p.scale + (f_ss[i] + c));
-          rsh[i] = ld4(p.shift + (f_ss[i] + c));
-        }
-      }
+      const int hi = f_h[i] + f_tr - pad, wi = f_w[i] + f_ts - pad;
+      const bool ok = f_rowok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+      const unsigned idx =
+          (f_img[i] + (unsigned)(hi >> p.up) * (unsigned)p.Ws + (unsigned)(wi >> p.up)) * (unsigned)Cin + c;
+      f_ok[i] = ok;
+      f_idx[i] = ok ? idx : 0u;
+      f_so[i] = f_ss[i] + c;
       if (last) {
         f_c0 += BK;                             // K-tiles never straddle a tap: Cin % BK == 0
         if (f_c0 >= Cin) {
@@ -170,31 +168,50 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
         }
       }
     } else {
-      {
-        const int kp = k0 + krow + 8 * i;
-        const int w = kp & (p.W - 1);
-        const int h = (kp >> p.lw) & (p.H - 1);
-        const int b = kp >> (p.lw + p.lh);
-        const int hi = h + f_mr - pad, wi = w + f_ms - pad;
-        const bool ok = f_mok & (kp < kend) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
-        const unsigned idx = (((unsigned)b * (unsigned)p.Hs + (unsigned)(hi >> p.up)) * (unsigned)p.Ws +
-                              (unsigned)(wi >> p.up)) * (unsigned)Cin + f_mtap_c;
-        f_ok[i] = ok;
-        ra[i] = ld4(Ag + (ok ? idx : 0u));
-        if (FAST_AFFINE) {
-          const unsigned so = ok ? (unsigned)b * (unsigned)p.ss_bstride + f_mtap_c : 0u;
-          rsc[i] = ld4(p.scale + so);
-          rsh[i] = ld4(p.shift + so);
-        }
-      }
+      const int kp = k0 + krow + 8 * i;
+      const int w = kp & (p.W - 1);
+      const int h = (kp >> p.lw) & (p.H - 1);
+      const int b = kp >> (p.lw + p.lh);
+      const int hi = h + f_mr - pad, wi = w + f_ms - pad;
+      const bool ok = f_mok & (kp < kend) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+      const unsigned idx = (((unsigned)b * (unsigned)p.Hs + (unsigned)(hi >> p.up)) * (unsigned)p.Ws +
+                            (unsigned)(wi >> p.up)) * (unsigned)Cin + f_mtap_c;
+      f_ok[i] = ok;
+      f_idx[i] = ok ? idx : 0u;
+      f_so[i] = ok ? (unsigned)b * (unsigned)p.ss_bstride + f_mtap_c : 0u;
     }
+  };
+  auto issue_A_fast = [&](int i) {
+#if defined(ICG_DBG_LOAD_FIXED)
+    ra[i] = ld4(Ag + ((tid * 4) & 1023));
+#elif defined(ICG_DBG_ADDR_ONLY)
+    { unsigned keep = f_idx[i]; asm volatile("" ::"v"(keep)); ra[i] = zero4(); }
+#else
+    ra[i] = ld4(Ag + f_idx[i]);
+#endif
+    if (FAST_AFFINE) {
+      rsc[i] = ld4(p.scale + f_so[i]);
+      rsh[i] = ld4(p.shift + f_so[i]);
+    }
+  };
+  auto load_A_fast = [&](int k0, int i, bool last) {
+    addr_A_fast(k0, i, last);
+    issue_A_fast(i);
   };
 
   auto load_B_fast = [&](int k0) {
     if (BMODE == B_K) {
       const unsigned kg = (unsigned)(min(k0, kend - BK) + 4 * kq);   // clamp: the pipeline over-fetches past the last tile
 #pragma unroll
-      for (int i = 0; i < 2; ++i) rb[i] = ld4(Bg + (f_boff[i] + kg));   // rows >= N only feed masked outputs
+      for (int i = 0; i < 2; ++i) {
+#if defined(ICG_DBG_LOAD_FIXED)
+        rb[i] = ld4(Bg + ((tid * 4) & 1023));
+#elif defined(ICG_DBG_ADDR_ONLY)
+        { unsigned keep = f_boff[i] + kg; asm volatile("" ::"v"(keep)); rb[i] = zero4(); }
+#else
+        rb[i] = ld4(Bg + (f_boff[i] + kg));   // rows >= N only feed masked outputs
+#endif
+      }
     } else {
       const int n = n0 + 4 * mq;
       const bool nok = (4 * mq < BN) && n < p.N;
@@ -335,27 +352,42 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
     return v;
   };
 
-  auto store_A = [&](int buf) {
+  float4 sv[2];
+  auto prep_A_row = [&](int i) {
+    float4 v = act4(ra[i], rsc[i], rsh[i]);
+    if (FAST && !f_ok[i]) v = zero4();
+    sv[i] = v;
+  };
+  auto write_A_row = [&](int buf, int i) {
     float* as = As[buf];
+    const float4 v = sv[i];
     if (AMODE == A_K) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float4 v = act4(ra[i], rsc[i], rsh[i]);
-        if (FAST && !f_ok[i]) v = zero4();
-        const int row = arow + 64 * i;
-        as[(4 * kq + 0) * LDA + row] = v.x;
-        as[(4 * kq + 1) * LDA + row] = v.y;
-        as[(4 * kq + 2) * LDA + row] = v.z;
-        as[(4 * kq + 3) * LDA + row] = v.w;
-      }
+      const int row = arow + 64 * i;
+      as[(4 * kq + 0) * LDA + row] = v.x;
+      as[(4 * kq + 1) * LDA + row] = v.y;
+      as[(4 * kq + 2) * LDA + row] = v.z;
+      as[(4 * kq + 3) * LDA + row] = v.w;
     } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float4 v = act4(ra[i], rsc[i], rsh[i]);
-        if (FAST && !f_ok[i]) v = zero4();
-        *reinterpret_cast<float4*>(&as[(krow + 8 * i) * LDA + 4 * mq]) = v;
-      }
+      *reinterpret_cast<float4*>(&as[(krow + 8 * i) * LDA + 4 * mq]) = v;
     }
+  };
+  auto store_A_row = [&](int buf, int i) {
+    float* as = As[buf];
+    float4 v = act4(ra[i], rsc[i], rsh[i]);
+    if (FAST && !f_ok[i]) v = zero4();
+    if (AMODE == A_K) {
+      const int row = arow + 64 * i;
+      as[(4 * kq + 0) * LDA + row] = v.x;
+      as[(4 * kq + 1) * LDA + row] = v.y;
+      as[(4 * kq + 2) * LDA + row] = v.z;
+      as[(4 * kq + 3) * LDA + row] = v.w;
+    } else {
+      *reinterpret_cast<float4*>(&as[(krow + 8 * i) * LDA + 4 * mq]) = v;
+    }
+  };
+  auto store_A = [&](int buf) {
+    store_A_row(buf, 0);
+    store_A_row(buf, 1);
   };
 
   auto load_B = [&](int k0) {
@@ -400,26 +432,23 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
     }
   };
 
-  auto store_B = [&](int buf) {
+  auto store_B_row = [&](int buf, int i) {
     float* bs = Bs[buf];
     if (BMODE == B_K) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int nl = arow + 64 * i;
-        if (BN == 128 || nl < BN) {
-          bs[(4 * kq + 0) * LDB + nl] = rb[i].x;
-          bs[(4 * kq + 1) * LDB + nl] = rb[i].y;
-          bs[(4 * kq + 2) * LDB + nl] = rb[i].z;
-          bs[(4 * kq + 3) * LDB + nl] = rb[i].w;
-        }
+      const int nl = arow + 64 * i;
+      if (BN == 128 || nl < BN) {
+        bs[(4 * kq + 0) * LDB + nl] = rb[i].x;
+        bs[(4 * kq + 1) * LDB + nl] = rb[i].y;
+        bs[(4 * kq + 2) * LDB + nl] = rb[i].z;
+        bs[(4 * kq + 3) * LDB + nl] = rb[i].w;
       }
     } else {
-      if (BN == 128 || 4 * mq < BN) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          *reinterpret_cast<float4*>(&bs[(krow + 8 * i) * LDB + 4 * mq]) = rb[i];
-      }
+      if (BN == 128 || 4 * mq < BN) *reinterpret_cast<float4*>(&bs[(krow + 8 * i) * LDB + 4 * mq]) = rb[i];
     }
+  };
+  auto store_B = [&](int buf) {
+    store_B_row(buf, 0);
+    store_B_row(buf, 1);
   };
 
   // ------------------------------------------------------------------ main loop
@@ -473,30 +502,54 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
     const float* asn = As[nxt] + 32 * wv + li + lh * LDA;
     const float* bsn = Bs[nxt] + li + lh * LDB;
     const int k2 = kbeg + (kt + 2) * BK;
+    // 8*TN micro-slices: MFMA m = (k-step t, column tile j) is followed by ONE small piece of staging work, pinned
+    // there with sched_barrier.  A wave issues in order and an MFMA only shadows what sits between it and the next
+    // MFMA (~64 cycles), so the staging instructions must be spread evenly over the MFMA gaps, not clumped.
+    //   pieces 0-3: tile kt+1 A rows (activation math | LDS write)   4,5: B rows -> LDS   6: barrier
+    //   pieces 7-10: tile kt+2 A rows (address math | global loads)   11: B loads
+    //   every gap also fetches one operand fragment of the next k-step (after step 7: of tile kt+1)
 #pragma unroll
     for (int t = 0; t < BK / 2; ++t) {
-      if (t + 1 < BK / 2) {
-        fa[(t + 1) & 1] = as[(2 * t + 2) * LDA];
+      const int pn = (t + 1) & 1;
+      const bool wrap = (t + 1 == BK / 2);
+      const float* fas = wrap ? asn : as + (2 * t + 2) * LDA;
+      const float* fbs = wrap ? bsn : bs + (2 * t + 2) * LDB;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[(t + 1) & 1][j] = bs[(2 * t + 2) * LDB + 32 * j];
-      } else {
-        fa[0] = asn[0];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[0][j] = bsn[32 * j];
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j) {
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1], fb[t & 1][j], acc[j], 0, 0, 0);
-      if (t == 0) store_A(nxt);
-      if (t == 1) {
-        store_B(nxt);
+        if (j == 0) fa[wrap ? 0 : pn] = fas[0];
+        fb[wrap ? 0 : pn][j] = fbs[32 * j];
+        // 12 staging pieces over the 8*TN MFMA gaps (PPG pieces per gap; 1 for TN >= 2)
+        constexpr int PPG = (8 * TN >= 12) ? 1 : 2;
+        const int m = t * TN + j;
+#pragma unroll
+        for (int q = m * PPG; q < (m + 1) * PPG; ++q) {
+#ifndef ICG_DBG_SKIP_LDSW     // (ablation builds of tools/conv_bench.py; never defined in the product)
+          if (q == 0) prep_A_row(0);
+          if (q == 1) write_A_row(nxt, 0);
+          if (q == 2) prep_A_row(1);
+          if (q == 3) write_A_row(nxt, 1);
+          if (q == 4) store_B_row(nxt, 0);
+          if (q == 5) store_B_row(nxt, 1);
+#endif
+          if (q == 6) {
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+          }
+#ifndef ICG_DBG_SKIP_GLOAD
+          if (FAST) {
+            if (q == 7) addr_A_fast(k2, 0, false);
+            if (q == 8) issue_A_fast(0);
+            if (q == 9) addr_A_fast(k2, 1, true);
+            if (q == 10) issue_A_fast(1);
+          } else {
+            if (q == 7) load_A(k2);
+          }
+          if (q == 11) load_B_any(k2);
+#endif
+        }
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
       }
-      if (t == 2) load_A_any(k2, 0);
-      if (t == 3) load_A_any(k2, 1);
-      if (t == 4) load_B_any(k2);
-      __builtin_amdgcn_sched_barrier(0);
     }
     cur = nxt;
   }

@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import ic_gan_amd._lib as L
+if os.environ.get('ICG_LIB'):
+    L.LIB_PATH = os.environ['ICG_LIB']
 
 def ev_time(fn, iters=5, warm=2):
     for _ in range(warm): fn()
@@ -22,7 +24,7 @@ def mfma_peak():
                                os.path.join(ROOT, "tools", "mfma_peak.hip"), "-o", so])
     lib = ctypes.CDLL(so)
     res = {}
-    for blocks in (1024, 2048, 3072):
+    for blocks in (256, 2048):
         out = torch.empty(blocks * 256, device="cuda")
         iters = 4000
         t = ev_time(lambda: lib.mfma_peak_launch(ctypes.c_void_p(out.data_ptr()), blocks, iters,
