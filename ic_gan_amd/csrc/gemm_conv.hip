@@ -41,6 +41,12 @@ struct GemmP {
   int kchunk;                      // >0: split-K, z selects the K range
   int ntiles_n;
   int lw, lh;                      // log2(W), log2(H) (fast path: H, W powers of two)
+  // generalised gather geometry: source coordinate = pixel*gs + tap - pad, valid inside [0,Hb) x [0,Wb)
+  int pad_h, pad_w, gs, Hb, Wb;
+  // phase decomposition of the nearest-x2-upsample-fused 3x3 convolution (4 phases of 2x2 taps at source resolution):
+  //   1: fprop  - blockIdx.z = phase (al, be); pad = (1-al, 1-be); C rows scatter to (2h+al, 2w+be); B += z*strideB
+  //   2: wgrad  - blockIdx.z = phase*nsplit + split; pad as above; B rows gather from (2h+al, 2w+be)
+  int phase_mode, nsplit;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -72,12 +78,30 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
   const float* __restrict__ Bg = p.B + (long)z * p.strideB;
   float* __restrict__ Cg = p.C + (long)z * p.strideC;
   int kbeg = 0, kend = p.K;
+  int ksplit = z, ph_a = 0, ph_b = 0;
+  int pad_h = p.pad_h, pad_w = p.pad_w;
+  if (p.phase_mode) {
+    const int phase = (p.phase_mode == 2) ? z / p.nsplit : z;
+    ksplit = (p.phase_mode == 2) ? z - phase * p.nsplit : 0;
+    ph_a = phase >> 1;
+    ph_b = phase & 1;
+    pad_h = 1 - ph_a;
+    pad_w = 1 - ph_b;
+  }
   if (p.kchunk > 0) {
-    kbeg = z * p.kchunk;
+    kbeg = ksplit * p.kchunk;
     kend = min(p.K, kbeg + p.kchunk);
   }
-  const int pad = p.R >> 1;
+  const int gs = p.gs;
   const int Cin = p.Cin;
+  // row of the (2H x 2W) grid that phase (ph_a, ph_b) of source pixel index q = (b, h, w) maps to
+  auto phase_row = [&](int q) -> long {
+    const int w = q % p.W;
+    const int t = q / p.W;
+    const int h = t % p.H;
+    const int b = t / p.H;
+    return ((long)b * (2 * p.H) + (2 * h + ph_a)) * (2 * p.W) + (2 * w + ph_b);
+  };
 
   // ------------------------------------------------------------------ loader state
   float4 ra[2], rsc[2], rsh[2], rb[2];
@@ -153,8 +177,8 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
   auto addr_A_fast = [&](int k0, int i, bool last) {
     if (AMODE == A_K) {
       const unsigned c = (unsigned)(f_c0 + 4 * kq);
-      const int hi = f_h[i] + f_tr - pad, wi = f_w[i] + f_ts - pad;
-      const bool ok = f_rowok[i] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+      const int hi = f_h[i] * gs + f_tr - pad_h, wi = f_w[i] * gs + f_ts - pad_w;
+      const bool ok = f_rowok[i] & ((unsigned)hi < (unsigned)p.Hb) & ((unsigned)wi < (unsigned)p.Wb);
       const unsigned idx =
           (f_img[i] + (unsigned)(hi >> p.up) * (unsigned)p.Ws + (unsigned)(wi >> p.up)) * (unsigned)Cin + c;
       f_ok[i] = ok;
@@ -172,8 +196,8 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
       const int w = kp & (p.W - 1);
       const int h = (kp >> p.lw) & (p.H - 1);
       const int b = kp >> (p.lw + p.lh);
-      const int hi = h + f_mr - pad, wi = w + f_ms - pad;
-      const bool ok = f_mok & (kp < kend) & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+      const int hi = h * gs + f_mr - pad_h, wi = w * gs + f_ms - pad_w;
+      const bool ok = f_mok & (kp < kend) & ((unsigned)hi < (unsigned)p.Hb) & ((unsigned)wi < (unsigned)p.Wb);
       const unsigned idx = (((unsigned)b * (unsigned)p.Hs + (unsigned)(hi >> p.up)) * (unsigned)p.Ws +
                             (unsigned)(wi >> p.up)) * (unsigned)Cin + f_mtap_c;
       f_ok[i] = ok;
@@ -218,7 +242,9 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int kp = k0 + krow + 8 * i;
-        const unsigned idx = (nok & (kp < kend)) ? (unsigned)kp * (unsigned)p.ldb + (unsigned)n : 0u;
+        const bool kok = nok & (kp < kend);
+        const unsigned brow = (p.phase_mode == 2) ? (unsigned)phase_row(kok ? kp : 0) : (unsigned)kp;
+        const unsigned idx = kok ? brow * (unsigned)p.ldb + (unsigned)n : 0u;
         rb[i] = ld4(Bg + idx);                                          // A is zero for kp >= kend
       }
     }
@@ -238,8 +264,8 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
         const int r = tap / p.R, s = tap - r * p.R;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int hi = ah[i] + r - pad, wi = aw[i] + s - pad;
-          const bool ok = kv && amv[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+          const int hi = ah[i] * gs + r - pad_h, wi = aw[i] * gs + s - pad_w;
+          const bool ok = kv && amv[i] && hi >= 0 && hi < p.Hb && wi >= 0 && wi < p.Wb;
           ra[i] = zero4();
           rsc[i] = zero4();
           rsh[i] = zero4();
@@ -263,8 +289,8 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
               const int tap = kj / Cin;
               const int c = kj - tap * Cin;
               const int r = tap / p.R, s = tap - r * p.R;
-              const int hi = ah[i] + r - pad, wi = aw[i] + s - pad;
-              if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
+              const int hi = ah[i] * gs + r - pad_h, wi = aw[i] * gs + s - pad_w;
+              if (hi >= 0 && hi < p.Hb && wi >= 0 && wi < p.Wb) {
                 v[j] = Ag[src_index(ab[i], hi, wi, c)];
                 if (p.pre_affine) {
                   sc[j] = p.scale[(long)ab[i] * p.ss_bstride + c];
@@ -291,8 +317,8 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
           const int h = t % p.H;
           const int b = t / p.H;
           if (VEC) {
-            const int hi = h + am_tap_r[0] - pad, wi = w + am_tap_s[0] - pad;
-            if (am_mv[0] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
+            const int hi = h * gs + am_tap_r[0] - pad_h, wi = w * gs + am_tap_s[0] - pad_w;
+            if (am_mv[0] && hi >= 0 && hi < p.Hb && wi >= 0 && wi < p.Wb) {
               ra[i] = ld4(Ag + src_index(b, hi, wi, am_c[0]));
               if (p.pre_affine) {
                 rsc[i] = ld4(p.scale + (long)b * p.ss_bstride + am_c[0]);
@@ -304,8 +330,8 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               v[j] = 0.f; sc[j] = 0.f; sh[j] = 0.f;
-              const int hi = h + am_tap_r[j] - pad, wi = w + am_tap_s[j] - pad;
-              if (am_mv[j] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
+              const int hi = h * gs + am_tap_r[j] - pad_h, wi = w * gs + am_tap_s[j] - pad_w;
+              if (am_mv[j] && hi >= 0 && hi < p.Hb && wi >= 0 && wi < p.Wb) {
                 v[j] = Ag[src_index(b, hi, wi, am_c[j])];
                 if (p.pre_affine) {
                   sc[j] = p.scale[(long)b * p.ss_bstride + am_c[j]];
@@ -418,7 +444,8 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
         const int kp = k0 + krow + 8 * i;
         rb[i] = zero4();
         if (nl < BN && kp < kend) {
-          const float* src = Bg + (long)kp * p.ldb + n;
+          const long brow = (p.phase_mode == 2) ? phase_row(kp) : (long)kp;
+          const float* src = Bg + brow * p.ldb + n;
           if (VEC) {
             if (n < p.N) rb[i] = ld4(src);
           } else {
@@ -561,7 +588,8 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
     const int m = m0 + 32 * wv + row;
     if (m >= p.M) continue;
-    long res_row = (long)m;
+    const long out_row = (p.phase_mode == 1) ? phase_row(m) : (long)m;
+    long res_row = out_row;
     if (p.res != nullptr && p.res_up) {
       const int w = m % p.W;
       const int t = m / p.W;
@@ -576,7 +604,7 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
         float v = p.alpha * acc[j][r];
         if (p.bias != nullptr) v += p.bias[n];
         if (p.res != nullptr) v += p.res[res_row * p.ldc + n];
-        Cg[(long)m * p.ldc + n] = v;
+        Cg[out_row * p.ldc + n] = v;
       }
     }
   }
@@ -662,6 +690,7 @@ extern "C" int icg_conv2d_fprop(const float* x, const float* w, const float* bia
   p.A = x; p.B = w; p.C = out;
   p.M = (int)M; p.N = Cout; p.K = R * R * Cin;
   p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.up = up; p.Hs = H >> up; p.Ws = W >> up;
+  p.pad_h = R >> 1; p.pad_w = R >> 1; p.gs = 1; p.Hb = H; p.Wb = W;
   p.scale = scale; p.shift = shift; p.ss_bstride = ss_bstride;
   p.pre_affine = (flags & ICG_PRE_AFFINE) ? 1 : 0;
   p.pre_relu = (flags & ICG_PRE_RELU) ? 1 : 0;
@@ -724,6 +753,7 @@ extern "C" int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
   p.C = (pl.splits <= 1) ? dw : (float*)workspace;
   p.M = M; p.N = Cout; p.K = (int)K;
   p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.up = up; p.Hs = H >> up; p.Ws = W >> up;
+  p.pad_h = R >> 1; p.pad_w = R >> 1; p.gs = 1; p.Hb = H; p.Wb = W;
   p.scale = scale; p.shift = shift; p.ss_bstride = ss_bstride;
   p.pre_affine = (flags & ICG_PRE_AFFINE) ? 1 : 0;
   p.pre_relu = (flags & ICG_PRE_RELU) ? 1 : 0;
@@ -747,6 +777,119 @@ extern "C" int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
   return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Nearest-x2-upsample-fused 3x3 convolution as 4 phases of 2x2 taps at SOURCE resolution (2.25x fewer MACs than
+// convolving the upsampled tensor, which is what the reference does: layers.py:545-548, BigGAN.py:260).
+//   out[b, 2h+al, 2w+be, co] = sum_{u,v,ci} act(x)[b, h+al-1+u, w+be-1+v, ci] * wp[al][be][co][u][v][ci] + bias[co]
+// wp = phase weights emitted by icg_sn_forward (sums of the 3x3 taps that land on the same source pixel).
+extern "C" int icg_conv2d_up_fprop(const float* x, const float* wp, const float* bias, float* out, const float* scale,
+                                   const float* shift, int64_t ss_bstride, int B, int Hs, int Ws, int Cin, int Cout,
+                                   unsigned flags, void* stream) {
+  ICG_REQUIRE(x && wp && out && B > 0 && Hs > 0 && Ws > 0 && Cin > 0 && Cout > 0);
+  if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift);
+  const long M = (long)B * Hs * Ws;
+  ICG_REQUIRE(M * 4 < 0x7fffffffL);
+  GemmP p{};
+  p.A = x; p.B = wp; p.C = out;
+  p.M = (int)M; p.N = Cout; p.K = 4 * Cin;
+  p.H = Hs; p.W = Ws; p.Cin = Cin; p.R = 2; p.up = 0; p.Hs = Hs; p.Ws = Ws;
+  p.pad_h = 1; p.pad_w = 1; p.gs = 1; p.Hb = Hs; p.Wb = Ws;
+  p.scale = scale; p.shift = shift; p.ss_bstride = ss_bstride;
+  p.pre_affine = (flags & ICG_PRE_AFFINE) ? 1 : 0;
+  p.pre_relu = (flags & ICG_PRE_RELU) ? 1 : 0;
+  p.ldb = p.K; p.ldc = Cout;
+  p.bias = bias; p.alpha = 1.f;
+  p.kchunk = 0; p.phase_mode = 1; p.nsplit = 1;
+  p.strideA = 0; p.strideB = (long)Cout * p.K; p.strideC = 0;
+  bool vec = (Cin % 4 == 0) && aligned16(x) && aligned16(wp);
+  if (p.pre_affine) vec = vec && (ss_bstride % 4 == 0) && aligned16(scale) && aligned16(shift);
+  const bool small = (M * Cin < 0x7fffffffL) && ((long)Cout * p.K < 0x7fffffffL) &&
+                     ((long)B * (ss_bstride > 0 ? ss_bstride : 0) + Cin < 0x7fffffffL);
+  return launch_gemm<A_K, B_K>(p, vec, 4, (hipStream_t)stream, small);
+}
+
+// Data gradient of the same layer, produced directly at SOURCE resolution (the 2x2 adjoint of the upsample is part of
+// the contraction): a 4x4 / stride-2 / pad-1 gather over dy with K = 16*Cout.
+//   da[b,h,w,ci] = sum_{P,Q,co} dy[b, 2h-1+P, 2w-1+Q, co] * vd[ci][P][Q][co]
+extern "C" int icg_conv2d_up_dgrad(const float* dy, const float* vd, float* da, int B, int Hs, int Ws, int Cin,
+                                   int Cout, void* stream) {
+  ICG_REQUIRE(dy && vd && da && B > 0 && Hs > 0 && Ws > 0 && Cin > 0 && Cout > 0);
+  const long M = (long)B * Hs * Ws;
+  ICG_REQUIRE(M * 4 < 0x7fffffffL);
+  GemmP p{};
+  p.A = dy; p.B = vd; p.C = da;
+  p.M = (int)M; p.N = Cin; p.K = 16 * Cout;
+  p.H = Hs; p.W = Ws; p.Cin = Cout; p.R = 4; p.up = 0; p.Hs = 2 * Hs; p.Ws = 2 * Ws;
+  p.pad_h = 1; p.pad_w = 1; p.gs = 2; p.Hb = 2 * Hs; p.Wb = 2 * Ws;
+  p.ldb = p.K; p.ldc = Cin;
+  p.alpha = 1.f;
+  p.kchunk = 0; p.phase_mode = 0; p.nsplit = 1;
+  const bool vec = (Cout % 4 == 0) && aligned16(dy) && aligned16(vd);
+  const bool small = (M * 4 * Cout < 0x7fffffffL) && ((long)Cin * p.K < 0x7fffffffL);
+  return launch_gemm<A_K, B_K>(p, vec, 1, (hipStream_t)stream, small);
+}
+
+// Weight gradient in phase form: dwp[al][be][u][v][ci][co] = sum_{b,h,w} act(x)[b,h+al-1+u,w+be-1+v,ci] *
+// dy[b,2h+al,2w+be,co]; icg_sn_backward folds the 16 phase taps back onto the 3x3 parameter.
+static WgradPlan up_wgrad_plan(long K, int M, int N) {
+  WgradPlan pl = wgrad_plan(K, M, N);
+  int s = pl.splits / 4;            // four phases share the grid
+  if (s < 1) s = 1;
+  long kchunk = icg_cdiv(icg_cdiv(K, s), 16) * 16;
+  pl.splits = (int)icg_cdiv(K, kchunk);
+  pl.kchunk = (int)kchunk;
+  return pl;
+}
+
+extern "C" size_t icg_conv2d_up_wgrad_workspace_bytes(int B, int Hs, int Ws, int Cin, int Cout) {
+  WgradPlan pl = up_wgrad_plan((long)B * Hs * Ws, 4 * Cin, Cout);
+  if (pl.splits <= 1) return 16;
+  return (size_t)4 * pl.splits * (size_t)(4 * Cin) * (size_t)Cout * sizeof(float);
+}
+
+extern "C" int icg_conv2d_up_wgrad(const float* x, const float* dy, float* dwp, const float* scale, const float* shift,
+                                   int64_t ss_bstride, int B, int Hs, int Ws, int Cin, int Cout, unsigned flags,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(x && dy && dwp && B > 0 && Hs > 0 && Ws > 0 && Cin > 0 && Cout > 0);
+  if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift);
+  const long K = (long)B * Hs * Ws;
+  ICG_REQUIRE(K * 4 < 0x7fffffffL);
+  const int M = 4 * Cin;
+  WgradPlan pl = up_wgrad_plan(K, M, Cout);
+  const size_t need = (pl.splits <= 1) ? 0 : (size_t)4 * pl.splits * M * Cout * sizeof(float);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) return ICG_ERR_WORKSPACE;
+  GemmP p{};
+  p.A = x; p.B = dy;
+  p.C = (pl.splits <= 1) ? dwp : (float*)workspace;
+  p.M = M; p.N = Cout; p.K = (int)K;
+  p.H = Hs; p.W = Ws; p.Cin = Cin; p.R = 2; p.up = 0; p.Hs = Hs; p.Ws = Ws;
+  p.pad_h = 1; p.pad_w = 1; p.gs = 1; p.Hb = Hs; p.Wb = Ws;
+  p.scale = scale; p.shift = shift; p.ss_bstride = ss_bstride;
+  p.pre_affine = (flags & ICG_PRE_AFFINE) ? 1 : 0;
+  p.pre_relu = (flags & ICG_PRE_RELU) ? 1 : 0;
+  p.ldb = Cout; p.ldc = Cout;
+  p.alpha = 1.f;
+  p.kchunk = pl.kchunk; p.phase_mode = 2; p.nsplit = pl.splits;
+  p.strideA = 0; p.strideB = 0; p.strideC = (long)M * Cout;
+  bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && aligned16(x) && aligned16(dy);
+  if (p.pre_affine) vec = vec && (ss_bstride % 4 == 0) && aligned16(scale) && aligned16(shift);
+  const bool small = (K * Cin < 0x7fffffffL) && (4 * K * (long)Cout < 0x7fffffffL) &&
+                     ((long)B * (ss_bstride > 0 ? ss_bstride : 0) + Cin < 0x7fffffffL);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_gemm<A_M, B_N>(p, vec, 4 * pl.splits, st, small);
+  if (rc != ICG_OK) return rc;
+  if (pl.splits > 1) {
+    const long n = (long)M * Cout;
+    int blocks = (int)(icg_cdiv(n, 256) > 2048 ? 2048 : icg_cdiv(n, 256));
+    for (int ph = 0; ph < 4; ++ph) {
+      hipLaunchKernelGGL(icg_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st,
+                         (const float*)workspace + (long)ph * pl.splits * n, dwp + (long)ph * n, n, pl.splits);
+    }
+    rc = icg_check_launch();
+  }
+  return rc;
+}
+
 extern "C" int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int transA,
                                 int transB, int64_t strideA, int64_t strideB, int64_t strideC, int batch,
                                 float alpha, void* stream) {
@@ -755,6 +898,7 @@ extern "C" int icg_gemm_batched(const float* A, const float* B, float* C, int M,
   p.A = A; p.B = B; p.C = C;
   p.M = M; p.N = N; p.K = K;
   p.H = 1; p.W = 1; p.R = 1; p.up = 0; p.Hs = 1; p.Ws = 1;
+  p.pad_h = 0; p.pad_w = 0; p.gs = 1; p.Hb = 1; p.Wb = 1;
   p.ldc = N;
   p.alpha = alpha;
   p.kchunk = 0;

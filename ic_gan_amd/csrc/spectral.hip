@@ -116,6 +116,53 @@ __global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__
   }
 }
 
+// phase weights of the upsample-fused 3x3 conv (gemm_conv.hip, icg_conv2d_up_*), one thread per (co, ci):
+//   wp[al][be][co][u][v][ci] = sum_{r in S(al,u), s in S(be,v)} w[co][ci][r][s]/sigma
+//        S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}
+//   vd[ci][P][Q][co]         = sum_{r in T(P), s in T(Q)} w[co][ci][r][s]/sigma,   T = {2}, {1,2}, {0,1}, {0}
+__global__ __launch_bounds__(256) void sn_up_layouts_kernel(const float* __restrict__ w, const float* __restrict__ sigma,
+                                                            int rows, int Cin, float* __restrict__ wp,
+                                                            float* __restrict__ vd) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * Cin) return;
+  const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
+  const float inv = 1.0f / sigma[0];
+  float k[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) k[r][s] = w[((long)co * Cin + ci) * 9 + r * 3 + s];
+  // row / column partial sums over the tap sets  {0}, {1,2}, {0,1}, {2}
+  auto rowsum = [&](int set, int s) -> float {
+    return set == 0 ? k[0][s] : set == 1 ? k[1][s] + k[2][s] : set == 2 ? k[0][s] + k[1][s] : k[2][s];
+  };
+  auto both = [&](int rset, int cset) -> float {
+    const float c0 = rowsum(rset, 0), c1 = rowsum(rset, 1), c2 = rowsum(rset, 2);
+    return cset == 0 ? c0 : cset == 1 ? c1 + c2 : cset == 2 ? c0 + c1 : c2;
+  };
+  // S(al,u): (0,0)->set0 {0}, (0,1)->set1 {1,2}, (1,0)->set2 {0,1}, (1,1)->set3 {2}   => set = 2*al + u
+  if (wp) {
+#pragma unroll
+    for (int al = 0; al < 2; ++al)
+#pragma unroll
+      for (int be = 0; be < 2; ++be)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+            wp[((((long)(al * 2 + be) * rows + co) * 2 + u) * 2 + v) * Cin + ci] = both(2 * al + u, 2 * be + v) * inv;
+  }
+  // T(P): P=0 {2} = set3, P=1 {1,2} = set1, P=2 {0,1} = set2, P=3 {0} = set0
+  if (vd) {
+    const int tset[4] = {3, 1, 2, 0};
+#pragma unroll
+    for (int P = 0; P < 4; ++P)
+#pragma unroll
+      for (int Q = 0; Q < 4; ++Q)
+        vd[(((long)ci * 4 + P) * 4 + Q) * rows + co] = both(tset[P], tset[Q]) * inv;
+  }
+}
+
 extern "C" size_t icg_sn_scratch_bytes(int rows, int Cin, int R) {
   const long cols = (long)Cin * R * R;
   return (size_t)(16 * cols + rows + 512) * sizeof(float);
@@ -123,7 +170,8 @@ extern "C" size_t icg_sn_scratch_bytes(int rows, int Cin, int R) {
 
 extern "C" int icg_sn_forward(const float* w, float* u, float* sv, int rows, int Cin, int R, float eps, int training,
                               float* v_out, float* u_out, float* sigma_out, float* w_ohwi, float* w_dgrad,
-                              void* scratch, size_t scratch_bytes, void* stream) {
+                              float* w_up_fprop, float* w_up_dgrad, void* scratch, size_t scratch_bytes,
+                              void* stream) {
   ICG_REQUIRE(w && u && v_out && u_out && sigma_out && w_ohwi && scratch);
   ICG_REQUIRE(rows > 0 && Cin > 0 && R >= 1);
   if (scratch_bytes < icg_sn_scratch_bytes(rows, Cin, R)) return ICG_ERR_WORKSPACE;
@@ -147,21 +195,42 @@ extern "C" int icg_sn_forward(const float* w, float* u, float* sv, int rows, int
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(sn_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, (const float*)sigma_out, rows, Cin,
                      R, w_ohwi, w_dgrad);
+  if (w_up_fprop || w_up_dgrad) {
+    if (R != 3) return ICG_ERR_ARG;
+    hipLaunchKernelGGL(sn_up_layouts_kernel, dim3((unsigned)icg_cdiv((long)rows * Cin, 256)), dim3(256), 0, st, w,
+                       (const float*)sigma_out, rows, Cin, w_up_fprop, w_up_dgrad);
+  }
   return icg_check_launch();
 }
 
 // ---------------------------------------------------------------- backward
 // element idx of the PARAMETER layout [co][ci][tap]  ->  g = dw_hwio[tap][ci][co] + dw_ohwi[co][tap][ci]
+// dw_up: phase-form weight gradient [al][be][u][v][ci][co] of the upsample-fused conv; tap r receives the phase taps
+// (al,u) with r in S(al,u):  r=0: (0,0),(1,0)   r=1: (0,1),(1,0)   r=2: (0,1),(1,1)
 __device__ __forceinline__ float sn_gather_g(const float* __restrict__ dw_hwio, const float* __restrict__ dw_ohwi,
-                                              int co, int ci, int tap, int rows, int Cin, int RR) {
+                                              const float* __restrict__ dw_up, int co, int ci, int tap, int rows,
+                                              int Cin, int RR) {
   float g = 0.f;
   if (dw_hwio) g += dw_hwio[((long)tap * Cin + ci) * rows + co];
   if (dw_ohwi) g += dw_ohwi[((long)co * RR + tap) * Cin + ci];
+  if (dw_up) {
+    const int r = tap / 3, s = tap - 3 * r;
+    const int ru[2] = {r == 0 ? 0 : 1, r == 2 ? 1 : 0};     // u of the pair contributed by phase al = 0 / 1
+    const int su[2] = {s == 0 ? 0 : 1, s == 2 ? 1 : 0};     // v of the pair contributed by phase be = 0 / 1
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int al = a, u = ru[a], be = b, v = su[b];
+        g += dw_up[(((((long)(al * 2 + be)) * 2 + u) * 2 + v) * Cin + ci) * rows + co];
+      }
+  }
   return g;
 }
 
 __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ dw_hwio,
                                                          const float* __restrict__ dw_ohwi,
+                                                         const float* __restrict__ dw_up,
                                                          const float* __restrict__ w_ohwi, int rows, int Cin, int RR,
                                                          double* __restrict__ part) {
   __shared__ double red[4];
@@ -174,7 +243,7 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict
     long t = idx / Cin;
     const int tap = (int)(t % RR);
     const int co = (int)(t / RR);
-    const float g = sn_gather_g(dw_hwio, dw_ohwi, co, ci, tap, rows, Cin, RR);
+    const float g = sn_gather_g(dw_hwio, dw_ohwi, dw_up, co, ci, tap, rows, Cin, RR);
     acc += (double)g * (double)w_ohwi[idx];
   }
   acc = wave_sum_d(acc);
@@ -185,6 +254,7 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dw_hwio,
                                                            const float* __restrict__ dw_ohwi,
+                                                           const float* __restrict__ dw_up,
                                                            const float* __restrict__ u, const float* __restrict__ v,
                                                            const float* __restrict__ sigma,
                                                            const double* __restrict__ part, int nparts, int rows,
@@ -205,28 +275,30 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
     const int j = (int)(idx % ((long)Cin * RR));
     const int co = (int)(idx / ((long)Cin * RR));
     const int ci = j / RR, tap = j - ci * RR;
-    const float g = sn_gather_g(dw_hwio, dw_ohwi, co, ci, tap, rows, Cin, RR);
+    const float g = sn_gather_g(dw_hwio, dw_ohwi, dw_up, co, ci, tap, rows, Cin, RR);
     const float corr = (u != nullptr && v != nullptr) ? dot * u[co] * v[j] : 0.f;
     const float val = (g - corr) * inv_sigma;
     dw[idx] = accumulate ? dw[idx] + val : val;
   }
 }
 
-extern "C" int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* w_ohwi, const float* u_saved,
+extern "C" int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* dw_up, const float* w_ohwi,
+                               const float* u_saved,
                                const float* v_saved, const float* sigma, int rows, int Cin, int R, float* dw,
                                int accumulate, void* scratch, size_t scratch_bytes, void* stream) {
-  ICG_REQUIRE((dw_hwio || dw_ohwi) && w_ohwi && sigma && dw && scratch);
+  ICG_REQUIRE((dw_hwio || dw_ohwi || dw_up) && w_ohwi && sigma && dw && scratch);
+  if (dw_up) ICG_REQUIRE(R == 3);
   ICG_REQUIRE(rows > 0 && Cin > 0 && R >= 1);
   if (scratch_bytes < 256 * sizeof(double)) return ICG_ERR_WORKSPACE;
   const int RR = R * R;
   const long total = (long)rows * Cin * RR;
   int nparts = (int)(icg_cdiv(total, 1024) > 256 ? 256 : icg_cdiv(total, 1024));
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(nparts), dim3(256), 0, st, dw_hwio, dw_ohwi, w_ohwi, rows, Cin, RR,
+  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(nparts), dim3(256), 0, st, dw_hwio, dw_ohwi, dw_up, w_ohwi, rows, Cin, RR,
                      (double*)scratch);
   long blocks = icg_cdiv(total, 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dw_hwio, dw_ohwi, u_saved,
+  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dw_hwio, dw_ohwi, dw_up, u_saved,
                      v_saved, sigma, (const double*)scratch, nparts, rows, Cin, RR, dw, accumulate);
   return icg_check_launch();
 }

@@ -47,11 +47,11 @@ class SN(object):
     def sv(self):
         return [self.sv0]
 
-    def sn_state(self, need_dgrad=None) -> ops.SNState:
+    def sn_state(self, need_dgrad=None, upsample=False) -> ops.SNState:
         """One power-iteration step (in place on u0/sv0 in training mode) + W/sigma in kernel layouts."""
         if need_dgrad is None:
             need_dgrad = torch.is_grad_enabled()
-        return ops.sn_prepare(self.weight, self.u0, self.sv0, self.eps, self.training, need_dgrad)
+        return ops.sn_prepare(self.weight, self.u0, self.sv0, self.eps, self.training, need_dgrad, upsample)
 
     def W_(self):
         """Spectrally normalised weight in the parameter layout (debug / API parity; not on the hot path)."""
@@ -73,7 +73,10 @@ class SNConv2d(nn.Conv2d, SN):
         self._sn_init(num_svs, num_itrs, out_channels, eps=eps)
 
     def forward(self, x, **fuse):
-        return ops.fused_conv(x, self.weight, self.bias, self.sn_state(), **fuse)
+        # a 3x3 conv fed by a nearest x2 upsample runs in 4-phase form (needs channel counts the vector loader takes)
+        phase = bool(fuse.get("upsample")) and self.kernel_size == (3, 3) and self.in_channels % 4 == 0 \
+            and self.out_channels % 4 == 0 and fuse.get("residual") is None
+        return ops.fused_conv(x, self.weight, self.bias, self.sn_state(upsample=phase), **fuse)
 
 
 class SNLinear(nn.Linear, SN):

@@ -70,6 +70,24 @@ int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* sc
                      int R, unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Nearest-x2-upsample-fused 3x3 convolution in PHASE form (GBlock conv1: F.interpolate(scale_factor=2) followed by
+ * SNConv2d, layers.py:545-548): each of the 4 output phases (al, be) is a 2x2-tap convolution of the SOURCE-resolution
+ * tensor, 2.25x fewer multiply-adds than convolving the upsampled tensor.  x is [B][Hs][Ws][Cin]; out / dy are
+ * [B][2Hs][2Ws][Cout].  wp = [4][Cout][2][2][Cin] and vd = [Cin][4][4][Cout] come from icg_sn_forward; the weight
+ * gradient dwp = [4][2][2][Cin][Cout] goes to icg_sn_backward (dw_up), which folds it onto the 3x3 parameter.
+ * up_dgrad returns the gradient w.r.t. act(x) at SOURCE resolution (upsample adjoint included).
+ */
+int icg_conv2d_up_fprop(const float* x, const float* wp, const float* bias, float* out, const float* scale,
+                        const float* shift, int64_t ss_bstride, int B, int Hs, int Ws, int Cin, int Cout,
+                        unsigned flags, void* stream);
+int icg_conv2d_up_dgrad(const float* dy, const float* vd, float* da, int B, int Hs, int Ws, int Cin, int Cout,
+                        void* stream);
+size_t icg_conv2d_up_wgrad_workspace_bytes(int B, int Hs, int Ws, int Cin, int Cout);
+int icg_conv2d_up_wgrad(const float* x, const float* dy, float* dwp, const float* scale, const float* shift,
+                        int64_t ss_bstride, int B, int Hs, int Ws, int Cin, int Cout, unsigned flags,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Batched fp32 GEMM  C[z] = alpha * op(A[z]) * op(B[z]) for the attention
  * contractions (layers.py:237-243: theta^T phi, g beta^T and their gradients).
  *   transA = 0: A is [M][K] row-major;  1: A is [K][M]
@@ -141,19 +159,21 @@ int icg_bn_bwd_apply(const float* x, const float* da, const float* scale, const 
  * PyTorch layout [rows = Cout][Cin][R][R]; u is [rows] (updated in place when training);
  * sv (1 float, optional) receives sigma when training; v_out [Cin*R*R], u_out [rows] and
  * sigma_out[1] are saved for backward.  w_ohwi = w/sigma as [Cout][R][R][Cin]; w_dgrad (optional)
- * = w/sigma as [Cin][R][R][Cout] with taps flipped.  scratch: icg_sn_scratch_bytes().
+ * = w/sigma as [Cin][R][R][Cout] with taps flipped.  w_up_fprop / w_up_dgrad (optional, R = 3 only): the phase
+ * layouts of icg_conv2d_up_*.  scratch: icg_sn_scratch_bytes().
  */
 size_t icg_sn_scratch_bytes(int rows, int Cin, int R);
 int icg_sn_forward(const float* w, float* u, float* sv, int rows, int Cin, int R, float eps,
                    int training, float* v_out, float* u_out, float* sigma_out, float* w_ohwi,
-                   float* w_dgrad, void* scratch, size_t scratch_bytes, void* stream);
+                   float* w_dgrad, float* w_up_fprop, float* w_up_dgrad, void* scratch,
+                   size_t scratch_bytes, void* stream);
 /*
  * Backward of w_ = w/sigma with u,v constant:  dw = (dw_ - <dw_, w_> u^T v) / sigma.
- * dw_ is given in HWIO ([R][R][Cin][Cout], layout=1) or OHWI (layout=0) or both summed
- * (dw_hwio and dw_ohwi may each be NULL); dw is written/accumulated (accumulate != 0) in the
- * parameter layout.
+ * dw_ is the sum of the given pieces: HWIO ([R][R][Cin][Cout]), OHWI, and the phase form dw_up
+ * ([4][2][2][Cin][Cout], R = 3) — each may be NULL; dw is written / accumulated (accumulate != 0) in
+ * the parameter layout.
  */
-int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* w_ohwi,
+int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* dw_up, const float* w_ohwi,
                     const float* u_saved, const float* v_saved, const float* sigma, int rows, int Cin,
                     int R, float* dw, int accumulate, void* scratch, size_t scratch_bytes, void* stream);
 

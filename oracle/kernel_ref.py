@@ -77,6 +77,47 @@ def icg_conv2d_wgrad(x, dy, dw, scale, shift, ss_bstride, B, H, W, Cin, Cout, R,
     mem(dw)[: R * R * Cin * Cout].copy_(gw.permute(2, 3, 1, 0).reshape(-1))       # HWIO
 
 
+# tap sets of the 4-phase form of (nearest x2 upsample -> 3x3 conv): phase al, source tap u  ->  3x3 taps r
+_S = {(0, 0): [0], (0, 1): [1, 2], (1, 0): [0, 1], (1, 1): [2]}
+_T = {0: [2], 1: [1, 2], 2: [0, 1], 3: [0]}          # 4x4 stride-2 data-gradient taps
+
+
+def icg_conv2d_up_fprop(x, wp, bias, out, scale, shift, ss_bstride, B, Hs, Ws, Cin, Cout, flags):
+    a = _act(x, scale, shift, ss_bstride, flags, B, Hs, Ws, Cin)               # [B,Cin,Hs,Ws]
+    w = mem(wp)[: 16 * Cout * Cin].view(4, Cout, 2, 2, Cin)
+    y = torch.empty(B, Cout, 2 * Hs, 2 * Ws)
+    for al in range(2):
+        for be in range(2):
+            ap = F.pad(a, (1 - be, be, 1 - al, al))
+            y[:, :, al::2, be::2] = F.conv2d(ap, w[al * 2 + be].permute(0, 3, 1, 2))
+    if bias is not None:
+        y = y + mem(bias)[:Cout].view(1, -1, 1, 1)
+    mem(out)[: B * 4 * Hs * Ws * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_conv2d_up_dgrad(dy, vd, da, B, Hs, Ws, Cin, Cout):
+    g = _nhwc(dy, B, 2 * Hs, 2 * Ws, Cout).permute(0, 3, 1, 2)
+    w = mem(vd)[: 16 * Cout * Cin].view(Cin, 4, 4, Cout).permute(0, 3, 1, 2)     # [Cin][Cout][4][4]
+    r = F.conv2d(g, w, None, stride=2, padding=1)
+    mem(da)[: B * Hs * Ws * Cin].copy_(r.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_conv2d_up_wgrad_workspace_bytes(B, Hs, Ws, Cin, Cout):
+    return 16
+
+
+def icg_conv2d_up_wgrad(x, dy, dwp, scale, shift, ss_bstride, B, Hs, Ws, Cin, Cout, flags, workspace, workspace_bytes):
+    a = _act(x, scale, shift, ss_bstride, flags, B, Hs, Ws, Cin)
+    g = _nhwc(dy, B, 2 * Hs, 2 * Ws, Cout).permute(0, 3, 1, 2)
+    o = torch.empty(4, 2, 2, Cin, Cout)
+    for al in range(2):
+        for be in range(2):
+            ap = F.pad(a, (1 - be, be, 1 - al, al)).contiguous()
+            gw = torch.nn.grad.conv2d_weight(ap, (Cout, Cin, 2, 2), g[:, :, al::2, be::2].contiguous())
+            o[al * 2 + be] = gw.permute(2, 3, 1, 0)
+    mem(dwp)[: 16 * Cin * Cout].copy_(o.reshape(-1))
+
+
 def icg_gemm_batched(A, Bm, C, M, N, K, transA, transB, strideA, strideB, strideC, batch, alpha):
     a, b, c = mem(A), mem(Bm), mem(C)
     for z in range(batch):
@@ -205,8 +246,8 @@ def icg_sn_scratch_bytes(rows, Cin, R):
     return 16
 
 
-def icg_sn_forward(w, u, sv, rows, Cin, R, eps, training, v_out, u_out, sigma_out, w_ohwi, w_dgrad, scratch,
-                   scratch_bytes):
+def icg_sn_forward(w, u, sv, rows, Cin, R, eps, training, v_out, u_out, sigma_out, w_ohwi, w_dgrad, w_up_fprop,
+                   w_up_dgrad, scratch, scratch_bytes):
     wm = mem(w)[: rows * Cin * R * R].view(rows, -1)
     uu = mem(u)[:rows].view(1, rows)
     v = F.normalize(uu @ wm, eps=eps)
@@ -224,15 +265,47 @@ def icg_sn_forward(w, u, sv, rows, Cin, R, eps, training, v_out, u_out, sigma_ou
     w_ohwi.copy_(w4.permute(0, 2, 3, 1).reshape(-1))
     if w_dgrad is not None:
         w_dgrad.copy_(w4.flip(2, 3).permute(1, 2, 3, 0).reshape(-1))
+    if w_up_fprop is not None:
+        wp = torch.zeros(4, rows, 2, 2, Cin)
+        for al in range(2):
+            for be in range(2):
+                for uu in range(2):
+                    for vv in range(2):
+                        acc = 0
+                        for r in _S[(al, uu)]:
+                            for c in _S[(be, vv)]:
+                                acc = acc + w4[:, :, r, c]
+                        wp[al * 2 + be, :, uu, vv, :] = acc
+        w_up_fprop.copy_(wp.reshape(-1))
+    if w_up_dgrad is not None:
+        vd = torch.zeros(Cin, 4, 4, rows)
+        for P in range(4):
+            for Q in range(4):
+                acc = 0
+                for r in _T[P]:
+                    for c in _T[Q]:
+                        acc = acc + w4[:, :, r, c]
+                vd[:, P, Q, :] = acc.t()
+        w_up_dgrad.copy_(vd.reshape(-1))
 
 
-def icg_sn_backward(dw_hwio, dw_ohwi, w_ohwi, u_saved, v_saved, sigma, rows, Cin, R, dw, accumulate, scratch,
+def icg_sn_backward(dw_hwio, dw_ohwi, dw_up, w_ohwi, u_saved, v_saved, sigma, rows, Cin, R, dw, accumulate, scratch,
                     scratch_bytes):
     g = torch.zeros(rows, Cin, R, R)
     if dw_hwio is not None:
         g = g + mem(dw_hwio)[: rows * Cin * R * R].view(R, R, Cin, rows).permute(3, 2, 0, 1)
     if dw_ohwi is not None:
         g = g + mem(dw_ohwi)[: rows * Cin * R * R].view(rows, R, R, Cin).permute(0, 3, 1, 2)
+    if dw_up is not None:       # adjoint of the phase-weight construction in icg_sn_forward
+        d = mem(dw_up)[: 16 * rows * Cin].view(4, 2, 2, Cin, rows)
+        g = g.clone()
+        for al in range(2):
+            for be in range(2):
+                for uu in range(2):
+                    for vv in range(2):
+                        for r in _S[(al, uu)]:
+                            for c in _S[(be, vv)]:
+                                g[:, :, r, c] += d[al * 2 + be, uu, vv].t()
     w_ = w_ohwi.view(rows, R, R, Cin).permute(0, 3, 1, 2)
     dot = (g.double() * w_.double()).sum().float()
     corr = 0.0

@@ -168,6 +168,72 @@ def test_conv2d_wgrad_split_k_large():
     assert torch.equal(a, b)
 
 
+UP_CASES = [  # B, Hs, Ws, Cin, Cout, flags
+    (2, 8, 8, 32, 32, PRE_AFFINE | PRE_RELU), (2, 16, 16, 96, 96, PRE_AFFINE | PRE_RELU), (3, 3, 5, 16, 40, PRE_RELU),
+    (1, 4, 4, 256, 128, PRE_AFFINE | PRE_RELU), (2, 8, 8, 8, 12, 0), (4, 4, 4, 64, 192, PRE_AFFINE | PRE_RELU),
+]
+
+
+def _phase_weights(w4):
+    """[Cout,Cin,3,3] -> (wp [4][Cout][2][2][Cin], vd [Cin][4][4][Cout]) through the SN reference (sigma ~ 1 path)."""
+    Cout, Cin = w4.shape[:2]
+    n = Cout * Cin * 9
+    v, uo, sg = torch.empty(Cin * 9), torch.empty(Cout), torch.empty(1)
+    wo, wd, wp, vd = torch.empty(n), torch.empty(n), torch.empty(16 * Cout * Cin), torch.empty(16 * Cout * Cin)
+    R.icg_sn_forward(w4.clone(), rnd(1, Cout, seed=77), torch.ones(1), Cout, Cin, 3, 1e-6, 0, v, uo, sg, wo, wd, wp, vd,
+                     torch.empty(16, dtype=torch.uint8), 16)
+    return wo, wp, vd
+
+
+@pytest.mark.parametrize("case", UP_CASES)
+def test_conv2d_up_phase_triplet(case):
+    """4-phase upsample-fused conv: fprop / dgrad / wgrad vs their references AND vs the direct formulation."""
+    B, Hs, Ws, Cin, Cout, flags = case
+    L = _L()
+    w4 = rnd(Cout, Cin, 3, 3, seed=5, scale=1 / np.sqrt(9 * Cin))
+    w_ohwi, wp, vd = _phase_weights(w4)
+    x = cl(B, Cin, Hs, Ws, seed=6)
+    bias = rnd(Cout, seed=7)
+    sc = sh = None
+    ssb = 0
+    if flags & PRE_AFFINE:
+        sc, sh, ssb = (1 + 0.3 * rnd(B, Cin, seed=8)).contiguous(), (0.3 * rnd(B, Cin, seed=9)).contiguous(), Cin
+    out = torch.empty(B, Cout, 2 * Hs, 2 * Ws).contiguous(memory_format=torch.channels_last)
+    (p,) = run_pair("icg_conv2d_up_fprop", [x, wp, bias, out, sc, sh, ssb, B, Hs, Ws, Cin, Cout, flags], [3])
+    close(*p, what=f"up_fprop {case}")
+    # equals the direct (upsampled-tensor) convolution
+    direct = torch.empty_like(out)
+    R.icg_conv2d_fprop(x, w_ohwi, bias, None, direct, sc, sh, ssb, B, 2 * Hs, 2 * Ws, Cin, Cout, 3, flags | UP, 1.0)
+    close(p[0], direct, rtol=1e-4, atol_rel=2e-5, what=f"up_fprop vs direct {case}")
+    # dgrad at source resolution == 2x2 sum of the direct data gradient
+    dy = cl(B, Cout, 2 * Hs, 2 * Ws, seed=11)
+    da = torch.empty(B, Cin, Hs, Ws).contiguous(memory_format=torch.channels_last)
+    (p,) = run_pair("icg_conv2d_up_dgrad", [dy, vd, da, B, Hs, Ws, Cin, Cout], [2])
+    close(*p, what=f"up_dgrad {case}")
+    sigma_w = w_ohwi.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).contiguous()
+    full = torch.nn.grad.conv2d_input((B, Cin, 2 * Hs, 2 * Ws), sigma_w, dy.contiguous(), padding=1)
+    ref = full.view(B, Cin, Hs, 2, Ws, 2).sum((3, 5)).contiguous(memory_format=torch.channels_last)
+    close(p[0], ref, rtol=1e-4, atol_rel=2e-5, what=f"up_dgrad vs direct {case}")
+    # wgrad in phase form
+    nb = L.query("icg_conv2d_up_wgrad_workspace_bytes", B, Hs, Ws, Cin, Cout)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8)
+    dwp = torch.empty(16 * Cin * Cout)
+    (p,) = run_pair("icg_conv2d_up_wgrad", [x, dy, dwp, sc, sh, ssb, B, Hs, Ws, Cin, Cout, flags, ws, nb], [2])
+    close(*p, rtol=5e-5, atol_rel=5e-5, what=f"up_wgrad {case}")
+
+
+def test_conv2d_up_wgrad_split_k():
+    B, Hs, Ws, Cin, Cout = 4, 32, 32, 16, 24
+    L = _L()
+    x, dy = cl(B, Cin, Hs, Ws, seed=1), cl(B, Cout, 2 * Hs, 2 * Ws, seed=2)
+    nb = L.query("icg_conv2d_up_wgrad_workspace_bytes", B, Hs, Ws, Cin, Cout)
+    assert nb > 16
+    ws = torch.empty(nb, dtype=torch.uint8)
+    (p,) = run_pair("icg_conv2d_up_wgrad", [x, dy, torch.empty(16 * Cin * Cout), None, None, 0, B, Hs, Ws, Cin, Cout,
+                                            PRE_RELU, ws, nb], [2])
+    close(*p, rtol=1e-4, atol_rel=1e-4, what="up_wgrad split-K")
+
+
 GEMM_CASES = [
     # M, N, K, transA, transB, batch
     (256, 64, 4, 0, 1, 3), (256, 16, 64, 0, 0, 3), (64, 16, 256, 1, 0, 3), (64, 4, 256, 1, 0, 2),
@@ -322,12 +388,19 @@ def test_sn_forward_backward(rows, Cin, taps):
         ww, uu, sv = to(w), to(u), to(torch.ones(1))
         v, uo, sg = to(torch.empty(Cin * taps * taps)), to(torch.empty(rows)), to(torch.empty(1))
         wo, wd = to(torch.empty(n)), to(torch.empty(n))
+        wup = to(torch.empty(16 * rows * Cin)) if taps == 3 else None
+        wupd = to(torch.empty(16 * rows * Cin)) if taps == 3 else None
         nb = L.query("icg_sn_scratch_bytes", rows, Cin, taps)
         sc = to(torch.empty(max(nb, 4096), dtype=torch.uint8))
-        fn("icg_sn_forward", ww, uu, sv, rows, Cin, taps, 1e-6, 1, v, uo, sg, wo, wd, sc, sc.numel())
+        fn("icg_sn_forward", ww, uu, sv, rows, Cin, taps, 1e-6, 1, v, uo, sg, wo, wd, wup, wupd, sc, sc.numel())
         dw = to(torch.empty(rows, Cin, taps, taps))
-        fn("icg_sn_backward", to(dw_hwio), None, wo, uo, v, sg, rows, Cin, taps, dw, 0, sc, sc.numel())
+        fn("icg_sn_backward", to(dw_hwio), None, None, wo, uo, v, sg, rows, Cin, taps, dw, 0, sc, sc.numel())
         res[tag] = dict(u=uu, sv=sv, v=v, uo=uo, sigma=sg, w_ohwi=wo, w_dgrad=wd, dw=dw)
+        if taps == 3:
+            dw2 = to(torch.empty(rows, Cin, taps, taps))
+            fn("icg_sn_backward", None, None, to(rnd(16 * rows * Cin, seed=9)), wo, uo, v, sg, rows, Cin, taps, dw2, 0,
+               sc, sc.numel())
+            res[tag].update(w_up=wup, w_up_dgrad=wupd, dw_from_up=dw2)
     for k in res["gpu"]:
         close(res["gpu"][k], res["ref"][k], rtol=5e-5, atol_rel=5e-5, what=f"sn {k} {rows}x{Cin}x{taps}")
 
