@@ -64,7 +64,8 @@ class KernelTimer:
 
     # entry point -> (index of B in the argument list, kind)
     SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_wgrad": (6, "conv"), "icg_conv2d_up_fprop": (7, "up"),
-            "icg_conv2d_up_dgrad": (3, "up"), "icg_conv2d_up_wgrad": (6, "up")}
+            "icg_conv2d_up_dgrad": (3, "up"), "icg_conv2d_up_wgrad": (6, "up"), "icg_conv2d_down_fprop": (5, "up"),
+            "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_wgrad": (3, "up")}
 
     def __init__(self):
         self.records = []      # (variant, algorithmic flops, executed flops, start_event, end_event)
@@ -83,11 +84,12 @@ class KernelTimer:
                 B, H, W, Cin, Cout, R = args[sl:sl + 6]
                 alg = exe = 2.0 * B * H * W * Cout * Cin * R * R
                 n_tile = Cout
-            else:       # 4-phase upsample-fused conv: executed MACs are 16/36 of the reference op graph's
+            else:       # upsample- / avgpool-fused conv (2x2-phase or 4x4-stride-2 form): executed MACs are 16/36 of the
+                        # reference op graph's (3x3 at the HIGH resolution)
                 B, Hs, Ws, Cin, Cout = args[sl:sl + 5]
                 alg = 2.0 * B * (4 * Hs * Ws) * Cout * Cin * 9
                 exe = 2.0 * B * Hs * Ws * Cout * Cin * 16
-                n_tile = Cin if name == "icg_conv2d_up_dgrad" else Cout
+                n_tile = Cin if name.endswith("dgrad") else Cout
             fam = "A_M,B_N" if name.endswith("wgrad") else "A_K,B_K"
             variant = f"icg_gemm_kernel<{fam},TN={pick_tn(n_tile)}>"
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -890,6 +890,97 @@ extern "C" int icg_conv2d_up_wgrad(const float* x, const float* dy, float* dwp, 
   return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 convolution followed by 2x2 average pooling (DBlock conv2 -> nn.AvgPool2d(2): layers.py:603-606, BigGAN.py:528)
+// as ONE 4x4 / stride-2 / pad-1 convolution at the pooled resolution (2.25x fewer MACs, no full-resolution output):
+//   out[b,hp,wp,co] = sum_{P,Q,ci} act(x)[b, 2hp-1+P, 2wp-1+Q, ci] * vdn[co][P][Q][ci] + bias[co] + residual[b,hp,wp,co]
+// x is [B][2Hp][2Wp][Cin]; vdn = [Cout][4][4][Cin] from icg_sn_forward (0.25 * sums of the 3x3 taps).
+extern "C" int icg_conv2d_down_fprop(const float* x, const float* vdn, const float* bias, const float* residual,
+                                     float* out, int B, int Hp, int Wp, int Cin, int Cout, unsigned flags,
+                                     void* stream) {
+  ICG_REQUIRE(x && vdn && out && B > 0 && Hp > 0 && Wp > 0 && Cin > 0 && Cout > 0);
+  ICG_REQUIRE(!(flags & (ICG_PRE_AFFINE | ICG_UPSAMPLE2X | ICG_RES_UPSAMPLE2X)));
+  const long M = (long)B * Hp * Wp;
+  ICG_REQUIRE(M * 4 < 0x7fffffffL);
+  GemmP p{};
+  p.A = x; p.B = vdn; p.C = out;
+  p.M = (int)M; p.N = Cout; p.K = 16 * Cin;
+  p.H = Hp; p.W = Wp; p.Cin = Cin; p.R = 4; p.up = 0; p.Hs = 2 * Hp; p.Ws = 2 * Wp;
+  p.pad_h = 1; p.pad_w = 1; p.gs = 2; p.Hb = 2 * Hp; p.Wb = 2 * Wp;
+  p.pre_relu = (flags & ICG_PRE_RELU) ? 1 : 0;
+  p.ldb = p.K; p.ldc = Cout;
+  p.bias = bias; p.res = residual; p.alpha = 1.f;
+  p.kchunk = 0; p.phase_mode = 0; p.nsplit = 1;
+  const bool vec = (Cin % 4 == 0) && aligned16(x) && aligned16(vdn);
+  const bool small = (M * 4 * Cin < 0x7fffffffL) && ((long)Cout * p.K < 0x7fffffffL);
+  return launch_gemm<A_K, B_K>(p, vec, 1, (hipStream_t)stream, small);
+}
+
+// data gradient of the same layer: 4 phases of 2x2 taps scattering from the pooled gradient to full resolution
+//   da[b, 2hp+al, 2wp+be, ci] = sum_{u,v,co} dy[b, hp+al-1+u, wp+be-1+v, co] * wq[al][be][ci][u][v][co]
+extern "C" int icg_conv2d_down_dgrad(const float* dy, const float* wq, float* da, int B, int Hp, int Wp, int Cin,
+                                     int Cout, void* stream) {
+  ICG_REQUIRE(dy && wq && da && B > 0 && Hp > 0 && Wp > 0 && Cin > 0 && Cout > 0);
+  const long M = (long)B * Hp * Wp;
+  ICG_REQUIRE(M * 4 < 0x7fffffffL);
+  GemmP p{};
+  p.A = dy; p.B = wq; p.C = da;
+  p.M = (int)M; p.N = Cin; p.K = 4 * Cout;
+  p.H = Hp; p.W = Wp; p.Cin = Cout; p.R = 2; p.up = 0; p.Hs = Hp; p.Ws = Wp;
+  p.pad_h = 1; p.pad_w = 1; p.gs = 1; p.Hb = Hp; p.Wb = Wp;
+  p.ldb = p.K; p.ldc = Cin;
+  p.alpha = 1.f;
+  p.kchunk = 0; p.phase_mode = 1; p.nsplit = 1;
+  p.strideA = 0; p.strideB = (long)Cin * p.K; p.strideC = 0;
+  const bool vec = (Cout % 4 == 0) && aligned16(dy) && aligned16(wq);
+  const bool small = (M * Cout < 0x7fffffffL) && ((long)Cin * p.K < 0x7fffffffL);
+  return launch_gemm<A_K, B_K>(p, vec, 4, (hipStream_t)stream, small);
+}
+
+// weight gradient w.r.t. the 4x4 kernel, HWIO: dvdn[P][Q][ci][co] = sum act(x)[b,2hp-1+P,2wp-1+Q,ci] * dy[b,hp,wp,co]
+extern "C" size_t icg_conv2d_down_wgrad_workspace_bytes(int B, int Hp, int Wp, int Cin, int Cout) {
+  WgradPlan pl = wgrad_plan((long)B * Hp * Wp, 16 * Cin, Cout);
+  if (pl.splits <= 1) return 16;
+  return (size_t)pl.splits * (size_t)(16 * Cin) * (size_t)Cout * sizeof(float);
+}
+
+extern "C" int icg_conv2d_down_wgrad(const float* x, const float* dy, float* dvdn, int B, int Hp, int Wp, int Cin,
+                                     int Cout, unsigned flags, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  ICG_REQUIRE(x && dy && dvdn && B > 0 && Hp > 0 && Wp > 0 && Cin > 0 && Cout > 0);
+  ICG_REQUIRE(!(flags & (ICG_PRE_AFFINE | ICG_UPSAMPLE2X)));
+  const long K = (long)B * Hp * Wp;
+  ICG_REQUIRE(K * 4 < 0x7fffffffL);
+  const int M = 16 * Cin;
+  WgradPlan pl = wgrad_plan(K, M, Cout);
+  const size_t need = (pl.splits <= 1) ? 0 : (size_t)pl.splits * M * Cout * sizeof(float);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) return ICG_ERR_WORKSPACE;
+  GemmP p{};
+  p.A = x; p.B = dy;
+  p.C = (pl.splits <= 1) ? dvdn : (float*)workspace;
+  p.M = M; p.N = Cout; p.K = (int)K;
+  p.H = Hp; p.W = Wp; p.Cin = Cin; p.R = 4; p.up = 0; p.Hs = 2 * Hp; p.Ws = 2 * Wp;
+  p.pad_h = 1; p.pad_w = 1; p.gs = 2; p.Hb = 2 * Hp; p.Wb = 2 * Wp;
+  p.pre_relu = (flags & ICG_PRE_RELU) ? 1 : 0;
+  p.ldb = Cout; p.ldc = Cout;
+  p.alpha = 1.f;
+  p.kchunk = pl.kchunk; p.phase_mode = 0; p.nsplit = 1;
+  p.strideA = 0; p.strideB = 0; p.strideC = (long)M * Cout;
+  const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && aligned16(x) && aligned16(dy);
+  const bool small = (K * 4 * Cin < 0x7fffffffL) && (K * (long)Cout < 0x7fffffffL);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_gemm<A_M, B_N>(p, vec, pl.splits, st, small);
+  if (rc != ICG_OK) return rc;
+  if (pl.splits > 1) {
+    const long n = (long)M * Cout;
+    int blocks = (int)(icg_cdiv(n, 256) > 2048 ? 2048 : icg_cdiv(n, 256));
+    hipLaunchKernelGGL(icg_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dvdn, n,
+                       pl.splits);
+    rc = icg_check_launch();
+  }
+  return rc;
+}
+
 extern "C" int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int transA,
                                 int transB, int64_t strideA, int64_t strideB, int64_t strideC, int batch,
                                 float alpha, void* stream) {

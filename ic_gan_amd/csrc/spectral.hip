@@ -120,9 +120,14 @@ __global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__
 //   wp[al][be][co][u][v][ci] = sum_{r in S(al,u), s in S(be,v)} w[co][ci][r][s]/sigma
 //        S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}
 //   vd[ci][P][Q][co]         = sum_{r in T(P), s in T(Q)} w[co][ci][r][s]/sigma,   T = {2}, {1,2}, {0,1}, {0}
+// phase / pooled layouts of the downsample-fused conv (icg_conv2d_down_*): with c[P] = sum_{a+r=P} w[r]
+// (c0 = w0, c1 = w0+w1, c2 = w1+w2, c3 = w2) per dimension,
+//   vdn[co][P][Q][ci] = 0.25 * c[P] (x) c[Q] / sigma
+//   wq[al][be][ci][u][v][co] = vdn[co][Pd(al,u)][Pd(be,v)][ci],   Pd(0,0) = 3, Pd(0,1) = 1, Pd(1,0) = 2, Pd(1,1) = 0
 __global__ __launch_bounds__(256) void sn_up_layouts_kernel(const float* __restrict__ w, const float* __restrict__ sigma,
                                                             int rows, int Cin, float* __restrict__ wp,
-                                                            float* __restrict__ vd) {
+                                                            float* __restrict__ vd, float* __restrict__ vdn,
+                                                            float* __restrict__ wq) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)rows * Cin) return;
   const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
@@ -161,6 +166,33 @@ __global__ __launch_bounds__(256) void sn_up_layouts_kernel(const float* __restr
       for (int Q = 0; Q < 4; ++Q)
         vd[(((long)ci * 4 + P) * 4 + Q) * rows + co] = both(tset[P], tset[Q]) * inv;
   }
+  if (vdn || wq) {
+    // c-sets in the numbering of rowsum(): c0 = {0} = set0, c1 = {0,1} = set2, c2 = {1,2} = set1, c3 = {2} = set3
+    const int cset[4] = {0, 2, 1, 3};
+    float vv[4][4];
+#pragma unroll
+    for (int P = 0; P < 4; ++P)
+#pragma unroll
+      for (int Q = 0; Q < 4; ++Q) vv[P][Q] = 0.25f * both(cset[P], cset[Q]) * inv;
+    if (vdn) {
+#pragma unroll
+      for (int P = 0; P < 4; ++P)
+#pragma unroll
+        for (int Q = 0; Q < 4; ++Q) vdn[(((long)co * 4 + P) * 4 + Q) * Cin + ci] = vv[P][Q];
+    }
+    if (wq) {
+      const int pd[2][2] = {{3, 1}, {2, 0}};
+#pragma unroll
+      for (int al = 0; al < 2; ++al)
+#pragma unroll
+        for (int be = 0; be < 2; ++be)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+              wq[((((long)(al * 2 + be) * Cin + ci) * 2 + u) * 2 + v) * rows + co] = vv[pd[al][u]][pd[be][v]];
+    }
+  }
 }
 
 extern "C" size_t icg_sn_scratch_bytes(int rows, int Cin, int R) {
@@ -170,8 +202,8 @@ extern "C" size_t icg_sn_scratch_bytes(int rows, int Cin, int R) {
 
 extern "C" int icg_sn_forward(const float* w, float* u, float* sv, int rows, int Cin, int R, float eps, int training,
                               float* v_out, float* u_out, float* sigma_out, float* w_ohwi, float* w_dgrad,
-                              float* w_up_fprop, float* w_up_dgrad, void* scratch, size_t scratch_bytes,
-                              void* stream) {
+                              float* w_up_fprop, float* w_up_dgrad, float* w_down_fprop, float* w_down_dgrad,
+                              void* scratch, size_t scratch_bytes, void* stream) {
   ICG_REQUIRE(w && u && v_out && u_out && sigma_out && w_ohwi && scratch);
   ICG_REQUIRE(rows > 0 && Cin > 0 && R >= 1);
   if (scratch_bytes < icg_sn_scratch_bytes(rows, Cin, R)) return ICG_ERR_WORKSPACE;
@@ -195,10 +227,10 @@ extern "C" int icg_sn_forward(const float* w, float* u, float* sv, int rows, int
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(sn_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, (const float*)sigma_out, rows, Cin,
                      R, w_ohwi, w_dgrad);
-  if (w_up_fprop || w_up_dgrad) {
+  if (w_up_fprop || w_up_dgrad || w_down_fprop || w_down_dgrad) {
     if (R != 3) return ICG_ERR_ARG;
     hipLaunchKernelGGL(sn_up_layouts_kernel, dim3((unsigned)icg_cdiv((long)rows * Cin, 256)), dim3(256), 0, st, w,
-                       (const float*)sigma_out, rows, Cin, w_up_fprop, w_up_dgrad);
+                       (const float*)sigma_out, rows, Cin, w_up_fprop, w_up_dgrad, w_down_fprop, w_down_dgrad);
   }
   return icg_check_launch();
 }
@@ -207,9 +239,10 @@ extern "C" int icg_sn_forward(const float* w, float* u, float* sv, int rows, int
 // element idx of the PARAMETER layout [co][ci][tap]  ->  g = dw_hwio[tap][ci][co] + dw_ohwi[co][tap][ci]
 // dw_up: phase-form weight gradient [al][be][u][v][ci][co] of the upsample-fused conv; tap r receives the phase taps
 // (al,u) with r in S(al,u):  r=0: (0,0),(1,0)   r=1: (0,1),(1,0)   r=2: (0,1),(1,1)
+// dw_down: gradient w.r.t. the 4x4 pooled kernel [P][Q][ci][co]; tap (r,s) receives 0.25 * sum_{a,b in {0,1}} [r+a][s+b]
 __device__ __forceinline__ float sn_gather_g(const float* __restrict__ dw_hwio, const float* __restrict__ dw_ohwi,
-                                              const float* __restrict__ dw_up, int co, int ci, int tap, int rows,
-                                              int Cin, int RR) {
+                                              const float* __restrict__ dw_up, const float* __restrict__ dw_down,
+                                              int co, int ci, int tap, int rows, int Cin, int RR) {
   float g = 0.f;
   if (dw_hwio) g += dw_hwio[((long)tap * Cin + ci) * rows + co];
   if (dw_ohwi) g += dw_ohwi[((long)co * RR + tap) * Cin + ci];
@@ -225,12 +258,22 @@ __device__ __forceinline__ float sn_gather_g(const float* __restrict__ dw_hwio, 
         g += dw_up[(((((long)(al * 2 + be)) * 2 + u) * 2 + v) * Cin + ci) * rows + co];
       }
   }
+  if (dw_down) {
+    const int r = tap / 3, s = tap - 3 * r;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc += dw_down[((((long)(r + a)) * 4 + (s + b)) * Cin + ci) * rows + co];
+    g += 0.25f * acc;
+  }
   return g;
 }
 
 __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ dw_hwio,
                                                          const float* __restrict__ dw_ohwi,
                                                          const float* __restrict__ dw_up,
+                                                         const float* __restrict__ dw_down,
                                                          const float* __restrict__ w_ohwi, int rows, int Cin, int RR,
                                                          double* __restrict__ part) {
   __shared__ double red[4];
@@ -243,7 +286,7 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict
     long t = idx / Cin;
     const int tap = (int)(t % RR);
     const int co = (int)(t / RR);
-    const float g = sn_gather_g(dw_hwio, dw_ohwi, dw_up, co, ci, tap, rows, Cin, RR);
+    const float g = sn_gather_g(dw_hwio, dw_ohwi, dw_up, dw_down, co, ci, tap, rows, Cin, RR);
     acc += (double)g * (double)w_ohwi[idx];
   }
   acc = wave_sum_d(acc);
@@ -255,6 +298,7 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dw_hwio,
                                                            const float* __restrict__ dw_ohwi,
                                                            const float* __restrict__ dw_up,
+                                                           const float* __restrict__ dw_down,
                                                            const float* __restrict__ u, const float* __restrict__ v,
                                                            const float* __restrict__ sigma,
                                                            const double* __restrict__ part, int nparts, int rows,
@@ -275,30 +319,30 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
     const int j = (int)(idx % ((long)Cin * RR));
     const int co = (int)(idx / ((long)Cin * RR));
     const int ci = j / RR, tap = j - ci * RR;
-    const float g = sn_gather_g(dw_hwio, dw_ohwi, dw_up, co, ci, tap, rows, Cin, RR);
+    const float g = sn_gather_g(dw_hwio, dw_ohwi, dw_up, dw_down, co, ci, tap, rows, Cin, RR);
     const float corr = (u != nullptr && v != nullptr) ? dot * u[co] * v[j] : 0.f;
     const float val = (g - corr) * inv_sigma;
     dw[idx] = accumulate ? dw[idx] + val : val;
   }
 }
 
-extern "C" int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* dw_up, const float* w_ohwi,
-                               const float* u_saved,
+extern "C" int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* dw_up, const float* dw_down,
+                               const float* w_ohwi, const float* u_saved,
                                const float* v_saved, const float* sigma, int rows, int Cin, int R, float* dw,
                                int accumulate, void* scratch, size_t scratch_bytes, void* stream) {
-  ICG_REQUIRE((dw_hwio || dw_ohwi || dw_up) && w_ohwi && sigma && dw && scratch);
-  if (dw_up) ICG_REQUIRE(R == 3);
+  ICG_REQUIRE((dw_hwio || dw_ohwi || dw_up || dw_down) && w_ohwi && sigma && dw && scratch);
+  if (dw_up || dw_down) ICG_REQUIRE(R == 3);
   ICG_REQUIRE(rows > 0 && Cin > 0 && R >= 1);
   if (scratch_bytes < 256 * sizeof(double)) return ICG_ERR_WORKSPACE;
   const int RR = R * R;
   const long total = (long)rows * Cin * RR;
   int nparts = (int)(icg_cdiv(total, 1024) > 256 ? 256 : icg_cdiv(total, 1024));
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(nparts), dim3(256), 0, st, dw_hwio, dw_ohwi, dw_up, w_ohwi, rows, Cin, RR,
+  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(nparts), dim3(256), 0, st, dw_hwio, dw_ohwi, dw_up, dw_down, w_ohwi, rows, Cin, RR,
                      (double*)scratch);
   long blocks = icg_cdiv(total, 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dw_hwio, dw_ohwi, dw_up, u_saved,
+  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dw_hwio, dw_ohwi, dw_up, dw_down, u_saved,
                      v_saved, sigma, (const double*)scratch, nparts, rows, Cin, RR, dw, accumulate);
   return icg_check_launch();
 }

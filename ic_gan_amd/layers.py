@@ -47,11 +47,12 @@ class SN(object):
     def sv(self):
         return [self.sv0]
 
-    def sn_state(self, need_dgrad=None, upsample=False) -> ops.SNState:
+    def sn_state(self, need_dgrad=None, upsample=False, downsample=False) -> ops.SNState:
         """One power-iteration step (in place on u0/sv0 in training mode) + W/sigma in kernel layouts."""
         if need_dgrad is None:
             need_dgrad = torch.is_grad_enabled()
-        return ops.sn_prepare(self.weight, self.u0, self.sv0, self.eps, self.training, need_dgrad, upsample)
+        return ops.sn_prepare(self.weight, self.u0, self.sv0, self.eps, self.training, need_dgrad, upsample,
+                              downsample)
 
     def W_(self):
         """Spectrally normalised weight in the parameter layout (debug / API parity; not on the hot path)."""
@@ -76,7 +77,8 @@ class SNConv2d(nn.Conv2d, SN):
         # a 3x3 conv fed by a nearest x2 upsample runs in 4-phase form (needs channel counts the vector loader takes)
         phase = bool(fuse.get("upsample")) and self.kernel_size == (3, 3) and self.in_channels % 4 == 0 \
             and self.out_channels % 4 == 0 and fuse.get("residual") is None
-        return ops.fused_conv(x, self.weight, self.bias, self.sn_state(upsample=phase), **fuse)
+        down = bool(fuse.get("downsample"))
+        return ops.fused_conv(x, self.weight, self.bias, self.sn_state(upsample=phase, downsample=down), **fuse)
 
 
 class SNLinear(nn.Linear, SN):
@@ -251,6 +253,9 @@ class DBlock(nn.Module):
             s = ops.AvgPool2Fn.apply(x, None)
             if self.learnable_sc:
                 s = self.conv_sc(s)
+            if self.conv2.in_channels % 4 == 0 and self.conv2.out_channels % 4 == 0:
+                # conv2 + AvgPool2d + residual add as ONE 4x4/stride-2 conv at the pooled resolution
+                return self.conv2(h, relu=True, downsample=True, residual=s)
             h = self.conv2(h, relu=True)
             return ops.AvgPool2Fn.apply(h, s)
         s = self.conv_sc(x) if self.learnable_sc else x

@@ -59,10 +59,12 @@ class SNState:
     R: int
     w_up: Optional[torch.Tensor] = None      # phase weights of the upsample-fused conv, [4][Cout][2][2][Cin]
     w_up_dgrad: Optional[torch.Tensor] = None  # [Cin][4][4][Cout]
+    w_down: Optional[torch.Tensor] = None    # 4x4/stride-2 kernel of conv3x3 -> avgpool2, [Cout][4][4][Cin]
+    w_down_dgrad: Optional[torch.Tensor] = None  # [4][Cin][2][2][Cout]
 
 
 def sn_prepare(weight: torch.Tensor, u: torch.Tensor, sv: Optional[torch.Tensor], eps: float, training: bool,
-               need_dgrad: bool, upsample: bool = False) -> SNState:
+               need_dgrad: bool, upsample: bool = False, downsample: bool = False) -> SNState:
     """One power iteration (updates `u`/`sv` in place when training) and W/sigma in kernel layouts.
     upsample=True (3x3 conv that follows a nearest x2 upsample) emits the 4-phase 2x2 layouts instead of OHWI-dgrad."""
     _require_gpu(weight)
@@ -78,22 +80,26 @@ def sn_prepare(weight: torch.Tensor, u: torch.Tensor, sv: Optional[torch.Tensor]
     dev = w.device
     n = rows * cin * R * R
     up = bool(upsample) and R == 3
-    st = SNState(_f32(n, dev), _f32(n, dev) if (need_dgrad and not up) else None, _f32(rows, dev),
+    down = bool(downsample) and R == 3
+    st = SNState(_f32(n, dev), _f32(n, dev) if (need_dgrad and not up and not down) else None, _f32(rows, dev),
                  _f32(cin * R * R, dev), _f32(1, dev), rows, cin, R)
     if up:
         st.w_up = _f32(16 * rows * cin, dev)
         st.w_up_dgrad = _f32(16 * rows * cin, dev) if need_dgrad else None
+    if down:
+        st.w_down = _f32(16 * rows * cin, dev)
+        st.w_down_dgrad = _f32(16 * rows * cin, dev) if need_dgrad else None
     nb = L.query("icg_sn_scratch_bytes", rows, cin, R)
     scratch = _bytes(nb, dev)
     L.call("icg_sn_forward", w, u, sv, rows, cin, R, float(eps), int(bool(training)), st.v, st.u, st.sigma,
-           st.w_ohwi, st.w_dgrad, st.w_up, st.w_up_dgrad, scratch, nb)
+           st.w_ohwi, st.w_dgrad, st.w_up, st.w_up_dgrad, st.w_down, st.w_down_dgrad, scratch, nb)
     return st
 
 
-def _sn_backward(dw_hwio, dw_ohwi, sn: SNState, like: torch.Tensor, dw_up=None) -> torch.Tensor:
+def _sn_backward(dw_hwio, dw_ohwi, sn: SNState, like: torch.Tensor, dw_up=None, dw_down=None) -> torch.Tensor:
     dw = torch.empty_like(like, memory_format=torch.contiguous_format)
     scratch = _bytes(256 * 8, like.device)
-    L.call("icg_sn_backward", dw_hwio, dw_ohwi, dw_up, sn.w_ohwi, sn.u, sn.v, sn.sigma, sn.rows, sn.cin, sn.R, dw, 0,
+    L.call("icg_sn_backward", dw_hwio, dw_ohwi, dw_up, dw_down, sn.w_ohwi, sn.u, sn.v, sn.sigma, sn.rows, sn.cin, sn.R, dw, 0,
            scratch, 256 * 8)
     return dw
 
@@ -120,6 +126,7 @@ class ConvOpt:
     upsample: bool = False
     res_up: bool = False
     bn: Optional[BNOpt] = None
+    downsample: bool = False    # conv3x3 -> 2x2 average pool, run as one 4x4/stride-2 conv (needs sn.w_down)
 
 
 def _sync_enabled(bn: Optional[BNOpt]) -> bool:
@@ -142,6 +149,10 @@ class FusedConvFn(Function):
         up = 1 if opt.upsample else 0
         H, W = Hs << up, Ws << up
         Cout, R = sn.rows, sn.R
+        down = bool(opt.downsample)
+        if down:
+            assert sn.w_down is not None and opt.bn is None and not up and Hs % 2 == 0 and Ws % 2 == 0
+            H, W = Hs // 2, Ws // 2
         dev = x.device
         flags = (L.ICG_PRE_RELU if opt.relu else 0) | (L.ICG_UPSAMPLE2X if up else 0)
         scale = shift = mean = invstd = None
@@ -163,7 +174,10 @@ class FusedConvFn(Function):
                 assert res.shape == (B, Cout, H, W)
         out = _empty_cl(B, Cout, H, W, dev)
         phase = bool(up and sn.w_up is not None)
-        if phase:
+        if down:
+            # conv3x3 + avgpool2 as one 4x4 / stride-2 conv at the pooled resolution (2.25x fewer MACs)
+            L.call("icg_conv2d_down_fprop", x, sn.w_down, bias, res, out, B, H, W, Cin, Cout, flags)
+        elif phase:
             # nearest-x2 + 3x3 as 4 phases of 2x2 taps on the source tensor (2.25x fewer MACs)
             assert res is None, "the phase path has no residual epilogue (GBlock conv1 has none)"
             L.call("icg_conv2d_up_fprop", x, sn.w_up, bias, out, scale, shift, ssb, B, Hs, Ws, Cin, Cout,
@@ -171,7 +185,7 @@ class FusedConvFn(Function):
         else:
             L.call("icg_conv2d_fprop", x, sn.w_ohwi, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, fflags,
                    1.0)
-        ctx.phase = phase
+        ctx.phase, ctx.down = phase, down
         ctx.opt, ctx.flags, ctx.dims = opt, flags, (B, Cin, Hs, Ws, H, W, Cout, R, gb_rows, ssb, count)
         ctx.has = (bias is not None, residual is not None, gain is not None, beta is not None)
         ctx.weight_like = weight
@@ -190,7 +204,12 @@ class FusedConvFn(Function):
         need = ctx.needs_input_grad
         dx = dweight = dbias = dres = dgain = dbeta = None
         if need[0] or (bn is not None and (need[4] or need[5])):
-            if ctx.phase:
+            if ctx.down:
+                if sn.w_down_dgrad is None:
+                    raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
+                da = _empty_cl(B, Cin, Hs, Ws, dev)          # full (input) resolution
+                L.call("icg_conv2d_down_dgrad", dout, sn.w_down_dgrad, da, B, H, W, Cin, Cout)
+            elif ctx.phase:
                 if sn.w_up_dgrad is None:
                     raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
                 da = _empty_cl(B, Cin, Hs, Ws, dev)          # already at source resolution (upsample adjoint folded)
@@ -212,7 +231,13 @@ class FusedConvFn(Function):
                 dx = da
             if not need[0]:
                 dx = None
-        if need[1] and ctx.phase:
+        if need[1] and ctx.down:
+            nb = L.query("icg_conv2d_down_wgrad_workspace_bytes", B, H, W, Cin, Cout)
+            ws = _bytes(nb, dev)
+            dw_down = _f32(16 * Cin * Cout, dev)
+            L.call("icg_conv2d_down_wgrad", x, dout, dw_down, B, H, W, Cin, Cout, ctx.flags, ws, nb)
+            dweight = _sn_backward(None, None, sn, ctx.weight_like, dw_down=dw_down)
+        elif need[1] and ctx.phase:
             nb = L.query("icg_conv2d_up_wgrad_workspace_bytes", B, Hs, Ws, Cin, Cout)
             ws = _bytes(nb, dev)
             dw_up = _f32(16 * Cin * Cout, dev)
@@ -328,9 +353,10 @@ def norm_act(x, bn: BNOpt, gain, beta, relu=False):
 
 
 def fused_conv(x, weight, bias, sn: SNState, *, relu=False, upsample=False, residual=None, res_up=False,
-               bn: Optional[BNOpt] = None, gain=None, beta=None):
-    """conv(act(x)) with act = [BN affine] -> [ReLU] -> [nearest x2]; `gain`/`beta` are [B,C] (ccbn) or [C] (bn)."""
-    opt = ConvOpt(sn=sn, relu=relu, upsample=upsample, res_up=res_up, bn=bn)
+               bn: Optional[BNOpt] = None, gain=None, beta=None, downsample=False):
+    """conv(act(x)) with act = [BN affine] -> [ReLU] -> [nearest x2]; `gain`/`beta` are [B,C] (ccbn) or [C] (bn);
+    downsample=True appends the 2x2 average pool (residual is then at the pooled resolution)."""
+    opt = ConvOpt(sn=sn, relu=relu, upsample=upsample, res_up=res_up, bn=bn, downsample=downsample)
     if bn is not None:
         g2 = gain if gain is None or gain.dim() == 2 else gain.view(1, -1)
         b2 = beta if beta is None or beta.dim() == 2 else beta.view(1, -1)

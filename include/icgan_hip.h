@@ -88,6 +88,21 @@ int icg_conv2d_up_wgrad(const float* x, const float* dy, float* dwp, const float
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * 3x3 convolution followed by 2x2 average pooling (DBlock conv2 + nn.AvgPool2d(2): layers.py:603-606, BigGAN.py:528) as
+ * ONE 4x4 / stride-2 convolution at the pooled resolution (2.25x fewer multiply-adds; the full-resolution conv output
+ * never exists).  x is [B][2Hp][2Wp][Cin], out / dy / residual are [B][Hp][Wp][Cout].  vdn = [Cout][4][4][Cin] and
+ * wq = [4][Cin][2][2][Cout] come from icg_sn_forward; dvdn = [4][4][Cin][Cout] goes to icg_sn_backward (dw_down).
+ * Only ICG_PRE_RELU is accepted in flags.  down_dgrad returns the gradient w.r.t. act(x) at full resolution.
+ */
+int icg_conv2d_down_fprop(const float* x, const float* vdn, const float* bias, const float* residual, float* out,
+                          int B, int Hp, int Wp, int Cin, int Cout, unsigned flags, void* stream);
+int icg_conv2d_down_dgrad(const float* dy, const float* wq, float* da, int B, int Hp, int Wp, int Cin, int Cout,
+                          void* stream);
+size_t icg_conv2d_down_wgrad_workspace_bytes(int B, int Hp, int Wp, int Cin, int Cout);
+int icg_conv2d_down_wgrad(const float* x, const float* dy, float* dvdn, int B, int Hp, int Wp, int Cin, int Cout,
+                          unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Batched fp32 GEMM  C[z] = alpha * op(A[z]) * op(B[z]) for the attention
  * contractions (layers.py:237-243: theta^T phi, g beta^T and their gradients).
  *   transA = 0: A is [M][K] row-major;  1: A is [K][M]
@@ -160,20 +175,22 @@ int icg_bn_bwd_apply(const float* x, const float* da, const float* scale, const 
  * sv (1 float, optional) receives sigma when training; v_out [Cin*R*R], u_out [rows] and
  * sigma_out[1] are saved for backward.  w_ohwi = w/sigma as [Cout][R][R][Cin]; w_dgrad (optional)
  * = w/sigma as [Cin][R][R][Cout] with taps flipped.  w_up_fprop / w_up_dgrad (optional, R = 3 only): the phase
- * layouts of icg_conv2d_up_*.  scratch: icg_sn_scratch_bytes().
+ * layouts of icg_conv2d_up_*; w_down_fprop / w_down_dgrad likewise for icg_conv2d_down_*.
+ * scratch: icg_sn_scratch_bytes().
  */
 size_t icg_sn_scratch_bytes(int rows, int Cin, int R);
 int icg_sn_forward(const float* w, float* u, float* sv, int rows, int Cin, int R, float eps,
                    int training, float* v_out, float* u_out, float* sigma_out, float* w_ohwi,
-                   float* w_dgrad, float* w_up_fprop, float* w_up_dgrad, void* scratch,
-                   size_t scratch_bytes, void* stream);
+                   float* w_dgrad, float* w_up_fprop, float* w_up_dgrad, float* w_down_fprop,
+                   float* w_down_dgrad, void* scratch, size_t scratch_bytes, void* stream);
 /*
  * Backward of w_ = w/sigma with u,v constant:  dw = (dw_ - <dw_, w_> u^T v) / sigma.
  * dw_ is the sum of the given pieces: HWIO ([R][R][Cin][Cout]), OHWI, and the phase form dw_up
- * ([4][2][2][Cin][Cout], R = 3) — each may be NULL; dw is written / accumulated (accumulate != 0) in
+ * ([4][2][2][Cin][Cout], R = 3), the pooled 4x4 form dw_down ([4][4][Cin][Cout], R = 3) — each may be NULL; dw is written / accumulated (accumulate != 0) in
  * the parameter layout.
  */
-int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* dw_up, const float* w_ohwi,
+int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* dw_up, const float* dw_down,
+                    const float* w_ohwi,
                     const float* u_saved, const float* v_saved, const float* sigma, int rows, int Cin,
                     int R, float* dw, int accumulate, void* scratch, size_t scratch_bytes, void* stream);
 

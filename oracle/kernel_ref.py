@@ -118,6 +118,39 @@ def icg_conv2d_up_wgrad(x, dy, dwp, scale, shift, ss_bstride, B, Hs, Ws, Cin, Co
     mem(dwp)[: 16 * Cin * Cout].copy_(o.reshape(-1))
 
 
+def icg_conv2d_down_fprop(x, vdn, bias, residual, out, B, Hp, Wp, Cin, Cout, flags):
+    a = _act(x, None, None, 0, flags, B, 2 * Hp, 2 * Wp, Cin)
+    w = mem(vdn)[: 16 * Cout * Cin].view(Cout, 4, 4, Cin).permute(0, 3, 1, 2)
+    y = F.conv2d(a, w, None, stride=2, padding=1)
+    if bias is not None:
+        y = y + mem(bias)[:Cout].view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + _nhwc(residual, B, Hp, Wp, Cout).permute(0, 3, 1, 2)
+    mem(out)[: B * Hp * Wp * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_conv2d_down_dgrad(dy, wq, da, B, Hp, Wp, Cin, Cout):
+    g = _nhwc(dy, B, Hp, Wp, Cout).permute(0, 3, 1, 2)
+    w = mem(wq)[: 16 * Cout * Cin].view(4, Cin, 2, 2, Cout)
+    r = torch.empty(B, Cin, 2 * Hp, 2 * Wp)
+    for al in range(2):
+        for be in range(2):
+            gp = F.pad(g, (1 - be, be, 1 - al, al))
+            r[:, :, al::2, be::2] = F.conv2d(gp, w[al * 2 + be].permute(0, 3, 1, 2))
+    mem(da)[: B * 4 * Hp * Wp * Cin].copy_(r.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_conv2d_down_wgrad_workspace_bytes(B, Hp, Wp, Cin, Cout):
+    return 16
+
+
+def icg_conv2d_down_wgrad(x, dy, dvdn, B, Hp, Wp, Cin, Cout, flags, workspace, workspace_bytes):
+    a = _act(x, None, None, 0, flags, B, 2 * Hp, 2 * Wp, Cin)
+    g = _nhwc(dy, B, Hp, Wp, Cout).permute(0, 3, 1, 2)
+    gw = torch.nn.grad.conv2d_weight(a.contiguous(), (Cout, Cin, 4, 4), g.contiguous(), stride=2, padding=1)
+    mem(dvdn)[: 16 * Cin * Cout].copy_(gw.permute(2, 3, 1, 0).reshape(-1))       # [P][Q][ci][co]
+
+
 def icg_gemm_batched(A, Bm, C, M, N, K, transA, transB, strideA, strideB, strideC, batch, alpha):
     a, b, c = mem(A), mem(Bm), mem(C)
     for z in range(batch):
@@ -246,8 +279,12 @@ def icg_sn_scratch_bytes(rows, Cin, R):
     return 16
 
 
+_C = {0: [0], 1: [0, 1], 2: [1, 2], 3: [2]}          # 4x4 pooled-kernel taps:  c[P] = sum_{a+r=P} w[r]
+_PD = {(0, 0): 3, (0, 1): 1, (1, 0): 2, (1, 1): 0}    # down-dgrad phase (al,u) -> P
+
+
 def icg_sn_forward(w, u, sv, rows, Cin, R, eps, training, v_out, u_out, sigma_out, w_ohwi, w_dgrad, w_up_fprop,
-                   w_up_dgrad, scratch, scratch_bytes):
+                   w_up_dgrad, w_down_fprop, w_down_dgrad, scratch, scratch_bytes):
     wm = mem(w)[: rows * Cin * R * R].view(rows, -1)
     uu = mem(u)[:rows].view(1, rows)
     v = F.normalize(uu @ wm, eps=eps)
@@ -287,10 +324,27 @@ def icg_sn_forward(w, u, sv, rows, Cin, R, eps, training, v_out, u_out, sigma_ou
                         acc = acc + w4[:, :, r, c]
                 vd[:, P, Q, :] = acc.t()
         w_up_dgrad.copy_(vd.reshape(-1))
+    if w_down_fprop is not None or w_down_dgrad is not None:
+        vdn = torch.zeros(rows, 4, 4, Cin)
+        for P in range(4):
+            for Q in range(4):
+                acc = 0
+                for r in _C[P]:
+                    for c in _C[Q]:
+                        acc = acc + w4[:, :, r, c]
+                vdn[:, P, Q, :] = 0.25 * acc
+        if w_down_fprop is not None:
+            w_down_fprop.copy_(vdn.reshape(-1))
+        if w_down_dgrad is not None:
+            wq = torch.zeros(4, Cin, 2, 2, rows)
+            for (al, uu), P in _PD.items():
+                for (be, vv), Q in _PD.items():
+                    wq[al * 2 + be, :, uu, vv, :] = vdn[:, P, Q, :].t()
+            w_down_dgrad.copy_(wq.reshape(-1))
 
 
-def icg_sn_backward(dw_hwio, dw_ohwi, dw_up, w_ohwi, u_saved, v_saved, sigma, rows, Cin, R, dw, accumulate, scratch,
-                    scratch_bytes):
+def icg_sn_backward(dw_hwio, dw_ohwi, dw_up, dw_down, w_ohwi, u_saved, v_saved, sigma, rows, Cin, R, dw, accumulate,
+                    scratch, scratch_bytes):
     g = torch.zeros(rows, Cin, R, R)
     if dw_hwio is not None:
         g = g + mem(dw_hwio)[: rows * Cin * R * R].view(R, R, Cin, rows).permute(3, 2, 0, 1)
@@ -306,6 +360,14 @@ def icg_sn_backward(dw_hwio, dw_ohwi, dw_up, w_ohwi, u_saved, v_saved, sigma, ro
                         for r in _S[(al, uu)]:
                             for c in _S[(be, vv)]:
                                 g[:, :, r, c] += d[al * 2 + be, uu, vv].t()
+    if dw_down is not None:     # adjoint of vdn = 0.25 * c (x) c
+        d = mem(dw_down)[: 16 * rows * Cin].view(4, 4, Cin, rows)
+        g = g.clone()
+        for P in range(4):
+            for Q in range(4):
+                for r in _C[P]:
+                    for c in _C[Q]:
+                        g[:, :, r, c] += 0.25 * d[P, Q].t()
     w_ = w_ohwi.view(rows, R, R, Cin).permute(0, 3, 1, 2)
     dot = (g.double() * w_.double()).sum().float()
     corr = 0.0

@@ -174,14 +174,17 @@ UP_CASES = [  # B, Hs, Ws, Cin, Cout, flags
 ]
 
 
-def _phase_weights(w4):
+def _phase_weights(w4, down=False):
     """[Cout,Cin,3,3] -> (wp [4][Cout][2][2][Cin], vd [Cin][4][4][Cout]) through the SN reference (sigma ~ 1 path)."""
     Cout, Cin = w4.shape[:2]
     n = Cout * Cin * 9
     v, uo, sg = torch.empty(Cin * 9), torch.empty(Cout), torch.empty(1)
     wo, wd, wp, vd = torch.empty(n), torch.empty(n), torch.empty(16 * Cout * Cin), torch.empty(16 * Cout * Cin)
+    vdn, wq = torch.empty(16 * Cout * Cin), torch.empty(16 * Cout * Cin)
     R.icg_sn_forward(w4.clone(), rnd(1, Cout, seed=77), torch.ones(1), Cout, Cin, 3, 1e-6, 0, v, uo, sg, wo, wd, wp, vd,
-                     torch.empty(16, dtype=torch.uint8), 16)
+                     vdn, wq, torch.empty(16, dtype=torch.uint8), 16)
+    if down:
+        return wo, vdn, wq
     return wo, wp, vd
 
 
@@ -232,6 +235,49 @@ def test_conv2d_up_wgrad_split_k():
     (p,) = run_pair("icg_conv2d_up_wgrad", [x, dy, torch.empty(16 * Cin * Cout), None, None, 0, B, Hs, Ws, Cin, Cout,
                                             PRE_RELU, ws, nb], [2])
     close(*p, rtol=1e-4, atol_rel=1e-4, what="up_wgrad split-K")
+
+
+DOWN_CASES = [  # B, Hp, Wp, Cin, Cout, relu, residual
+    (2, 8, 8, 32, 32, 1, 1), (2, 16, 16, 96, 96, 1, 1), (3, 3, 5, 16, 40, 0, 0), (1, 2, 2, 256, 128, 1, 1),
+    (2, 4, 4, 8, 12, 1, 0), (4, 8, 8, 64, 192, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", DOWN_CASES)
+def test_conv2d_down_fused_triplet(case):
+    """conv3x3 -> avgpool2 as one 4x4/stride-2 conv: fprop / dgrad / wgrad vs references AND vs conv-then-pool."""
+    B, Hp, Wp, Cin, Cout, relu, has_res = case
+    L = _L()
+    H, W = 2 * Hp, 2 * Wp
+    flags = PRE_RELU if relu else 0
+    w4 = rnd(Cout, Cin, 3, 3, seed=5, scale=1 / np.sqrt(9 * Cin))
+    w_ohwi, vdn, wq = _phase_weights(w4, down=True)
+    x = cl(B, Cin, H, W, seed=6)
+    bias = rnd(Cout, seed=7)
+    res = cl(B, Cout, Hp, Wp, seed=8) if has_res else None
+    out = torch.empty(B, Cout, Hp, Wp).contiguous(memory_format=torch.channels_last)
+    (p,) = run_pair("icg_conv2d_down_fprop", [x, vdn, bias, res, out, B, Hp, Wp, Cin, Cout, flags], [4])
+    close(*p, what=f"down_fprop {case}")
+    wn = w_ohwi.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).contiguous()
+    a = torch.relu(x) if relu else x
+    direct = torch.nn.functional.avg_pool2d(torch.nn.functional.conv2d(a, wn, bias, padding=1), 2)
+    if has_res:
+        direct = direct + res
+    close(p[0], direct.contiguous(memory_format=torch.channels_last), rtol=1e-4, atol_rel=2e-5,
+          what=f"down_fprop vs conv+pool {case}")
+    dy = cl(B, Cout, Hp, Wp, seed=11)
+    da = torch.empty(B, Cin, H, W).contiguous(memory_format=torch.channels_last)
+    (p,) = run_pair("icg_conv2d_down_dgrad", [dy, wq, da, B, Hp, Wp, Cin, Cout], [2])
+    close(*p, what=f"down_dgrad {case}")
+    up_dy = (0.25 * dy).repeat_interleave(2, 2).repeat_interleave(2, 3).contiguous()
+    ref = torch.nn.grad.conv2d_input((B, Cin, H, W), wn, up_dy, padding=1)
+    close(p[0], ref.contiguous(memory_format=torch.channels_last), rtol=1e-4, atol_rel=2e-5,
+          what=f"down_dgrad vs direct {case}")
+    nb = L.query("icg_conv2d_down_wgrad_workspace_bytes", B, Hp, Wp, Cin, Cout)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8)
+    (p,) = run_pair("icg_conv2d_down_wgrad", [x, dy, torch.empty(16 * Cin * Cout), B, Hp, Wp, Cin, Cout, flags, ws, nb],
+                    [2])
+    close(*p, rtol=5e-5, atol_rel=5e-5, what=f"down_wgrad {case}")
 
 
 GEMM_CASES = [
@@ -390,17 +436,23 @@ def test_sn_forward_backward(rows, Cin, taps):
         wo, wd = to(torch.empty(n)), to(torch.empty(n))
         wup = to(torch.empty(16 * rows * Cin)) if taps == 3 else None
         wupd = to(torch.empty(16 * rows * Cin)) if taps == 3 else None
+        wdn = to(torch.empty(16 * rows * Cin)) if taps == 3 else None
+        wdnd = to(torch.empty(16 * rows * Cin)) if taps == 3 else None
         nb = L.query("icg_sn_scratch_bytes", rows, Cin, taps)
         sc = to(torch.empty(max(nb, 4096), dtype=torch.uint8))
-        fn("icg_sn_forward", ww, uu, sv, rows, Cin, taps, 1e-6, 1, v, uo, sg, wo, wd, wup, wupd, sc, sc.numel())
+        fn("icg_sn_forward", ww, uu, sv, rows, Cin, taps, 1e-6, 1, v, uo, sg, wo, wd, wup, wupd, wdn, wdnd, sc,
+           sc.numel())
         dw = to(torch.empty(rows, Cin, taps, taps))
-        fn("icg_sn_backward", to(dw_hwio), None, None, wo, uo, v, sg, rows, Cin, taps, dw, 0, sc, sc.numel())
+        fn("icg_sn_backward", to(dw_hwio), None, None, None, wo, uo, v, sg, rows, Cin, taps, dw, 0, sc, sc.numel())
         res[tag] = dict(u=uu, sv=sv, v=v, uo=uo, sigma=sg, w_ohwi=wo, w_dgrad=wd, dw=dw)
         if taps == 3:
             dw2 = to(torch.empty(rows, Cin, taps, taps))
-            fn("icg_sn_backward", None, None, to(rnd(16 * rows * Cin, seed=9)), wo, uo, v, sg, rows, Cin, taps, dw2, 0,
-               sc, sc.numel())
-            res[tag].update(w_up=wup, w_up_dgrad=wupd, dw_from_up=dw2)
+            fn("icg_sn_backward", None, None, to(rnd(16 * rows * Cin, seed=9)), None, wo, uo, v, sg, rows, Cin, taps,
+               dw2, 0, sc, sc.numel())
+            dw3 = to(torch.empty(rows, Cin, taps, taps))
+            fn("icg_sn_backward", None, None, None, to(rnd(16 * rows * Cin, seed=10)), wo, uo, v, sg, rows, Cin, taps,
+               dw3, 0, sc, sc.numel())
+            res[tag].update(w_up=wup, w_up_dgrad=wupd, dw_from_up=dw2, w_down=wdn, w_down_dgrad=wdnd, dw_from_down=dw3)
     for k in res["gpu"]:
         close(res["gpu"][k], res["ref"][k], rtol=5e-5, atol_rel=5e-5, what=f"sn {k} {rows}x{Cin}x{taps}")
 
