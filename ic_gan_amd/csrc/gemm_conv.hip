@@ -47,6 +47,7 @@ struct GemmP {
   //   1: fprop  - blockIdx.z = phase (al, be); pad = (1-al, 1-be); C rows scatter to (2h+al, 2w+be); B += z*strideB
   //   2: wgrad  - blockIdx.z = phase*nsplit + split; pad as above; B rows gather from (2h+al, 2w+be)
   int phase_mode, nsplit;
+  int vec_b;                       // PATH 1 only: 16-byte loads allowed on the B operand (A is vectorised)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
         rb[i] = zero4();
         if (nl < BN && n < p.N) {
           const float* src = Bg + (long)n * p.ldb + kg;
-          if (VEC) {
+          if (VEC && p.vec_b) {
             if (kg < kend) rb[i] = ld4(src);
           } else {
             float v[4];
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
         if (nl < BN && kp < kend) {
           const long brow = (p.phase_mode == 2) ? phase_row(kp) : (long)kp;
           const float* src = Bg + brow * p.ldb + n;
-          if (VEC) {
+          if (VEC && p.vec_b) {
             if (n < p.N) rb[i] = ld4(src);
           } else {
             float v[4];
@@ -640,10 +641,17 @@ static int ilog2_exact(int v) {
 }
 
 template <int AMODE, int BMODE>
-static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool fast_ok = false) {
+static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool fast_ok = false,
+                       bool vec_a_only = false) {
   GemmP p = p0;
   p.lw = ilog2_exact(p.W);
   p.lh = ilog2_exact(p.H);
+  p.vec_b = 1;
+  if (!vec && vec_a_only) {     // A operand vectorisable, B not (e.g. weight gradient of a 3-channel output)
+    vec = true;
+    fast_ok = false;
+    p.vec_b = 0;
+  }
   int path = vec ? 1 : 0;
   if (vec && fast_ok) {
     if (AMODE == A_K && (p.Cin % 16 == 0) && p.kchunk == 0) path = 2;
@@ -761,11 +769,12 @@ extern "C" int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
   p.alpha = 1.f;
   p.kchunk = pl.kchunk;
   p.strideA = 0; p.strideB = 0; p.strideC = (long)M * Cout;
-  bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && aligned16(x) && aligned16(dy);
-  if (p.pre_affine) vec = vec && (ss_bstride % 4 == 0) && aligned16(scale) && aligned16(shift);
+  bool vec_a = (Cin % 4 == 0) && aligned16(x);
+  if (p.pre_affine) vec_a = vec_a && (ss_bstride % 4 == 0) && aligned16(scale) && aligned16(shift);
+  const bool vec = vec_a && (Cout % 4 == 0) && aligned16(dy);
   const bool small = ((long)B * p.Hs * p.Ws * Cin < 0x7fffffffL) && (K * (long)Cout < 0x7fffffffL) &&
                      ((long)B * (ss_bstride > 0 ? ss_bstride : 0) + Cin < 0x7fffffffL);
-  int rc = launch_gemm<A_M, B_N>(p, vec, pl.splits, (hipStream_t)stream, small);
+  int rc = launch_gemm<A_M, B_N>(p, vec, pl.splits, (hipStream_t)stream, small, vec_a);
   if (rc != ICG_OK) return rc;
   if (pl.splits > 1) {
     const long n = (long)M * Cout;
