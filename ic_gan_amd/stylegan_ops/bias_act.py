@@ -1,0 +1,101 @@
+"""bias_act on the HIP kernel `icg_bias_act` — API of stylegan2_ada_pytorch/torch_utils/ops/bias_act.py:131-171.
+
+    y = clamp(gain * act(x + b[dim]))        act in {linear, relu, lrelu, tanh, sigmoid, elu, selu, softplus, swish}
+
+Autograd mirrors the reference plugin's scheme (bias_act.py:231-317): the first-order gradient is the same kernel
+with grad=1 fed by the saved input/output, the second-order gradient (R1 / path-length regularisers,
+training/loss.py:126-131,182-187) is grad=2.  fp32, contiguous tensors; no fallback implementation."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+# name -> (plugin id, default alpha, default gain, what the backward needs: 'x', 'y' or '', has 2nd-order term)
+activation_funcs = {
+    "linear": (1, 0.0, 1.0, "", False),
+    "relu": (2, 0.0, float(np.sqrt(2)), "y", False),
+    "lrelu": (3, 0.2, float(np.sqrt(2)), "y", False),
+    "tanh": (4, 0.0, 1.0, "y", True),
+    "sigmoid": (5, 0.0, 1.0, "y", True),
+    "elu": (6, 0.0, 1.0, "y", True),
+    "selu": (7, 0.0, 1.0, "y", True),
+    "softplus": (8, 0.0, 1.0, "y", True),
+    "swish": (9, 0.0, float(np.sqrt(2)), "x", True),
+}
+
+
+def _kernel(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
+    if not x.is_cuda:
+        raise RuntimeError("ic_gan_amd.stylegan_ops.bias_act runs on an AMD GPU only; there is no CPU path")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    n = x.numel()
+    if n == 0:
+        return y
+    step_b = int(np.prod(x.shape[dim + 1:])) if b is not None else 1
+    size_b = b.numel() if b is not None else 1
+    L.call("icg_bias_act", x, b, xref, yref, dy, y, n, step_b, size_b, grad, act_id, float(alpha), float(gain),
+           float(clamp))
+    return y
+
+
+def bias_act(x, b=None, dim=1, act="linear", alpha=None, gain=None, clamp=None, impl="hip"):
+    assert isinstance(x, torch.Tensor) and x.dtype == torch.float32, "fp32 only"
+    act_id, def_alpha, def_gain, ref, has2 = activation_funcs[act]
+    alpha = float(alpha if alpha is not None else def_alpha)
+    gain = float(gain if gain is not None else def_gain)
+    clamp = float(clamp if clamp is not None else -1)
+    if b is not None:
+        assert b.ndim == 1 and 0 <= dim < x.ndim and b.shape[0] == x.shape[dim]
+        b = b.contiguous().float()
+    return _BiasAct.apply(x, b, dim, act_id, alpha, gain, clamp, ref, has2)
+
+
+class _BiasAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, b, dim, act_id, alpha, gain, clamp, ref, has2):
+        x = x.contiguous()
+        y = _kernel(x, b, None, None, None, 0, dim, act_id, alpha, gain, clamp)
+        ctx.cfg = (dim, act_id, alpha, gain, clamp, ref, has2)
+        ctx.save_for_backward(x if ("x" in ref or has2) else None, b if ("x" in ref or has2) else None,
+                              y if "y" in ref else None)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, b, y = ctx.saved_tensors
+        dim, act_id, alpha, gain, clamp, ref, has2 = ctx.cfg
+        dx = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dx = dy
+            if act_id != 1 or gain != 1 or clamp >= 0:
+                dx = _BiasActGrad.apply(dy.contiguous(), x, b, y, ctx.cfg)
+        if ctx.has_b and ctx.needs_input_grad[1]:
+            db = dx.sum([i for i in range(dx.ndim) if i != dim])
+        return dx, db, None, None, None, None, None, None, None
+
+
+class _BiasActGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, x, b, y, cfg):
+        dim, act_id, alpha, gain, clamp, ref, has2 = cfg
+        dx = _kernel(dy, b, x, y, None, 1, dim, act_id, alpha, gain, clamp)
+        ctx.cfg = cfg
+        ctx.save_for_backward(dy if has2 else None, x, b, y)
+        return dx
+
+    @staticmethod
+    def backward(ctx, d_dx):
+        dy, x, b, y = ctx.saved_tensors
+        dim, act_id, alpha, gain, clamp, ref, has2 = ctx.cfg
+        d_dy = d_x = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_dy = _BiasActGrad.apply(d_dx.contiguous(), x, b, y, ctx.cfg)
+        if has2 and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            d_x = _kernel(d_dx.contiguous(), b, x, y, dy, 2, dim, act_id, alpha, gain, clamp)
+        if has2 and ctx.needs_input_grad[2] and d_x is not None:
+            d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
+        return d_dy, d_x, d_b, None, None

@@ -1,0 +1,92 @@
+"""StyleGAN2 custom ops: parity with goldens produced by the reference's own `impl='ref'`
+implementations (tests/golden/make_golden_stylegan_ops.py), forward + first- and second-order gradients.
+CPU part pins the per-kernel oracle (oracle/kernel_ref.py); GPU part checks the HIP kernels through the product's
+`ic_gan_amd.stylegan_ops` wrappers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernel_ref as R
+from tests.stylegan_cases import ACTS, UPFIR, rnd
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "stylegan_ops.npz"))
+ACT_ID = {a: i + 1 for i, a in enumerate(ACTS)}
+DEF_GAIN = dict(linear=1, relu=np.sqrt(2), lrelu=np.sqrt(2), tanh=1, sigmoid=1, elu=1, selu=1, softplus=1, swish=np.sqrt(2))
+
+
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("ci", [0, 1])
+def test_kernel_ref_bias_act_pinned_to_reference(act, ci):
+    ai = ACTS.index(act)
+    clamp = -1.0 if ci == 0 else 0.7
+    x, b, dy = rnd((3, 6, 5, 5), 10 + ai, 1.5), rnd((6,), 20 + ai, 0.5), rnd((3, 6, 5, 5), 30 + ai)
+    n = x.numel()
+    alpha, gain = (0.2 if act == "lrelu" else 0.0), float(DEF_GAIN[act])
+    y = torch.empty(n)
+    R.icg_bias_act(x, b, None, None, None, y, n, 25, 6, 0, ACT_ID[act], alpha, gain, clamp)
+    np.testing.assert_allclose(y.view(3, 6, 5, 5).numpy(), G[f"ba/{act}/{ci}/y"], rtol=1e-5, atol=1e-6)
+    dx = torch.empty(n)
+    R.icg_bias_act(dy, b, x, y.view_as(x), None, dx, n, 25, 6, 1, ACT_ID[act], alpha, gain, clamp)
+    np.testing.assert_allclose(dx.view(3, 6, 5, 5).numpy(), G[f"ba/{act}/{ci}/dx"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("i", range(len(UPFIR)))
+def test_kernel_ref_upfirdn2d_pinned_to_reference(i):
+    n, c, h, w, taps, up, down, pad, flip, gain = UPFIR[i]
+    x = rnd((n, c, h, w), 50 + i)
+    f = torch.from_numpy(G[f"up/{i}/f"])
+    f2 = f.ger(f) if f.ndim == 1 else f
+    yg = G[f"up/{i}/y"]
+    y = torch.empty(yg.shape)
+    R.icg_upfirdn2d(x, f2.contiguous(), y, n, c, h, w, f2.shape[0], f2.shape[1], up, up, down, down, pad[0], pad[1],
+                    pad[2], pad[3], int(flip), gain, yg.shape[2], yg.shape[3])
+    np.testing.assert_allclose(y.numpy(), yg, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("ci", [0, 1])
+def test_bias_act_hip_matches_reference(act, ci):
+    from ic_gan_amd.stylegan_ops import bias_act
+    ai = ACTS.index(act)
+    clamp = None if ci == 0 else 0.7
+    x = rnd((3, 6, 5, 5), 10 + ai, 1.5).cuda().requires_grad_(True)
+    b = rnd((6,), 20 + ai, 0.5).cuda().requires_grad_(True)
+    dy = rnd((3, 6, 5, 5), 30 + ai).cuda().requires_grad_(True)
+    d2 = rnd((3, 6, 5, 5), 40 + ai).cuda()
+    y = bias_act.bias_act(x, b, act=act, clamp=clamp)
+    k = f"ba/{act}/{ci}/"
+    np.testing.assert_allclose(y.detach().cpu().numpy(), G[k + "y"], rtol=1e-5, atol=1e-6)
+    dx, db = torch.autograd.grad(y, (x, b), dy, create_graph=True)
+    np.testing.assert_allclose(dx.detach().cpu().numpy(), G[k + "dx"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(db.detach().cpu().numpy(), G[k + "db"], rtol=1e-4, atol=1e-4)
+    ddx, ddy = torch.autograd.grad((dx * d2).sum(), (x, dy), allow_unused=True)
+    ddx = torch.zeros_like(x) if ddx is None else ddx
+    np.testing.assert_allclose(ddy.detach().cpu().numpy(), G[k + "ddy"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ddx.detach().cpu().numpy(), G[k + "ddx"], rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(UPFIR)))
+def test_upfirdn2d_hip_matches_reference(i):
+    from ic_gan_amd.stylegan_ops import upfirdn2d as U
+    n, c, h, w, taps, up, down, pad, flip, gain = UPFIR[i]
+    x = rnd((n, c, h, w), 50 + i).cuda().requires_grad_(True)
+    f = U.setup_filter(taps, device="cuda")
+    np.testing.assert_allclose(f.cpu().numpy(), G[f"up/{i}/f"], rtol=1e-6, atol=1e-7)
+    y = U.upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=flip, gain=gain)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), G[f"up/{i}/y"], rtol=1e-4, atol=1e-5)
+    dy = rnd(tuple(y.shape), 60 + i).cuda()
+    (dx,) = torch.autograd.grad(y, x, dy)
+    np.testing.assert_allclose(dx.cpu().numpy(), G[f"up/{i}/dx"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_upfirdn2d_wrappers_hip():
+    from ic_gan_amd.stylegan_ops import upfirdn2d as U
+    x = rnd((2, 3, 8, 8), 70).cuda()
+    f = U.setup_filter([1, 3, 3, 1], device="cuda")
+    for name in ("upsample2d", "downsample2d", "filter2d"):
+        np.testing.assert_allclose(getattr(U, name)(x, f).cpu().numpy(), G["wrap/" + name], rtol=1e-4, atol=1e-5)
