@@ -184,8 +184,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_ddp = world > 1 or os.environ.get("ICG_FORCE_DDP") == "1"   # (the override exercises the RCCL/DDP wiring on 1 GPU)
+    if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl")          # RCCL on ROCm
     assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
@@ -202,7 +206,7 @@ def main():
     utils.seed_rng(0 + rank)
     M, G, D, G_ema, ema, opt_g, opt_d, init = build_models(cfg, device)
     dim_z = G.dim_z
-    if world > 1:
+    if use_ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
         # reference wiring: trainer.py:196-210 (separate wrappers, find_unused_parameters, buffer broadcast on)
         G = DDP(G, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True)
@@ -225,7 +229,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    if world > 1:
+    if use_ddp:
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
@@ -233,12 +237,12 @@ def main():
     for _ in range(args.steps):
         metrics = one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_ddp:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
+    if use_ddp:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -287,7 +291,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": min(32, os.cpu_count() or 1),
                                        "kind": "port", "sample": f"not completed within 180 s ({type(exc).__name__})"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_ddp:
         dist.destroy_process_group()
 
 

@@ -59,8 +59,11 @@ class _BiasAct(torch.autograd.Function):
         x = x.contiguous()
         y = _kernel(x, b, None, None, None, 0, dim, act_id, alpha, gain, clamp)
         ctx.cfg = (dim, act_id, alpha, gain, clamp, ref, has2)
+        # y is also kept whenever a clamp is active: the clamp mask of the gradient needs it.  (The reference's CUDA
+        # plugin drops y for act='linear' (bias_act.py:262-266) and therefore does not mask the gradient of a clamped
+        # linear bias_act — e.g. ToRGB with conv_clamp; we follow its own `impl='ref'` semantics, the true gradient.)
         ctx.save_for_backward(x if ("x" in ref or has2) else None, b if ("x" in ref or has2) else None,
-                              y if "y" in ref else None)
+                              y if ("y" in ref or clamp >= 0) else None)
         ctx.has_b = b is not None
         return y
 
