@@ -132,6 +132,38 @@ def build_models(cfg, device):
     return M, G, D, G_ema, ema, opt_g, opt_d, init
 
 
+def synthetic_batch(cfg, batch, seed):
+    """Real-side batch of the step: x uint8 uniform -> ((u8/255)-0.5)*2 (datasets_common.py:505-507),
+    labels uniform, unit-L2 2048-d features (datasets_common.py:662,678)."""
+    rs = np.random.RandomState(seed)
+    r = cfg["resolution"]
+    x = torch.from_numpy(rs.randint(0, 256, size=(batch, 3, r, r)).astype(np.float32)).div_(255.0).sub_(0.5).mul_(2.0)
+    y = torch.from_numpy(rs.randint(0, cfg["n_classes"], size=(batch,)).astype(np.int64))
+    f = rs.standard_normal((batch, 2048))
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    return x, (y if cfg["class_cond"] else None), (torch.from_numpy(f).float() if cfg["instance_cond"] else None)
+
+
+def conditioning_sampler(cfg, dim_z, batch, device, seed, n_table=10000, k_nn=50):
+    """`sample_conditionings()` of train_fns.py:70,135 = functools.partial(sample_conditioning_values, ...) exactly as
+    trainer.py:373-385 builds it, over a synthetic conditioning table (N=10 000 unit-norm 2048-d rows,
+    labels, exact L2 k=50 neighbourhoods) held resident in HBM by ic_gan_amd.data_utils.ConditioningStore."""
+    import functools
+    from ic_gan_amd import data_utils
+    rs = np.random.RandomState(seed)
+    feats = rs.standard_normal((n_table, 2048)).astype(np.float32)
+    labels = rs.randint(0, cfg["n_classes"], size=n_table).astype(np.int64)
+    store = data_utils.ConditioningStore(labels=labels, feats=feats, load_in_mem_feats=True, k_nn=k_nn,
+                                         load_labels=cfg["class_cond"], load_features=cfg["instance_cond"],
+                                         device=device)
+    np.random.seed(seed)                       # the sampler draws from numpy's global state, like the reference
+    z_, y_ = data_utils.prepare_z_y(batch, dim_z, cfg["n_classes"], device=device)
+    return functools.partial(data_utils.sample_conditioning_values, z_=z_, y_=y_, dataset=store, batch_size=batch,
+                             weights_sampling=None, ddp=True, constant_conditioning=False,
+                             class_cond=cfg["class_cond"], instance_cond=cfg["instance_cond"],
+                             nn_sampling_strategy="instance_balance")
+
+
 def cpu_baseline(cfg, name):
     """CPU oracle (restatement of the reference step, pinned to reference goldens) on this box's host cores."""
     from oracle import biggan_oracle as O, synth
@@ -202,7 +234,6 @@ def main():
     if args.sync_bn:
         cfg["sync_bn"] = True
     from ic_gan_amd import train_fns, utils
-    from oracle import synth          # synthetic inputs only (data generation, not compute)
     utils.seed_rng(0 + rank)
     M, G, D, G_ema, ema, opt_g, opt_d, init = build_models(cfg, device)
     dim_z = G.dim_z
@@ -213,10 +244,10 @@ def main():
         D = DDP(D, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True)
     GD = M.G_D(G, D, optimizer_G=opt_g, optimizer_D=opt_d)
     state = {"itr": 0}
-    sampler = synth.CondSampler(cfg, dim_z, batch, seed=1000 + rank)
+    sampler = conditioning_sampler(cfg, dim_z, batch, device, seed=1000 + rank)
     train = train_fns.GAN_training_function(G, D, GD, ema, state, cfg, sampler, embedded_optimizers=False,
                                             device=device, batch_size=batch)
-    x, y, f = synth.synth_batch(cfg, batch, seed=7 + rank)
+    x, y, f = synthetic_batch(cfg, batch, seed=7 + rank)
     x, y, f = x.to(device), (y.to(device) if y is not None else None), (f.to(device) if f is not None else None)
 
     timer = KernelTimer()

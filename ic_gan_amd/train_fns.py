@@ -46,7 +46,8 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
             z_ = z_[:batch_size]
             labels_g = labels_g[:batch_size] if labels_g is not None else None
             f_g = f_g[:batch_size] if f_g is not None else None
-        z_ = z_.to(device, non_blocking=True)
+        # a `Distribution` (Tensor subclass) would otherwise propagate its type through every op of the step
+        z_ = z_.to(device, non_blocking=True).as_subclass(torch.Tensor)
         if labels_g is not None:
             labels_g = labels_g.to(device, non_blocking=True).long()
         if f_g is not None:
