@@ -45,22 +45,11 @@ BASE_CFG = dict(dim_z=120, shared_dim=128, shared_dim_feat=512, G_shared=True, G
                 G_ortho=0.0, G_init="ortho", D_init="ortho")
 
 
-def pick_tn(n):
-    """mirror of pick_tn() in ic_gan_amd/csrc/gemm_conv.hip: N-tile (in units of 32) of the launched kernel."""
-    if n <= 32:
-        return 1
-    if n <= 64:
-        return 2
-    if n % 128 == 0:
-        return 4
-    if n % 96 == 0 or n <= 96:
-        return 3
-    return 4
-
-
 class KernelTimer:
     """HIP-event timing of every convolution launch (fprop and dgrad go through icg_conv2d_fprop, wgrad through
-    icg_conv2d_wgrad) on the stream the kernels are launched on (torch's current stream)."""
+    icg_conv2d_wgrad, the resample-fused forms through icg_conv2d_up_* / icg_conv2d_down_*) on the stream the kernels
+    are launched on (torch's current stream).  Records are keyed by the kernel's rocprofv3 name, obtained from the
+    library (icg_gemm_last_variant), so they can be compared line by line with profiles/*_kernel_stats.csv."""
 
     # entry point -> (index of B in the argument list, kind)
     SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_wgrad": (6, "conv"), "icg_conv2d_up_fprop": (7, "up"),
@@ -68,13 +57,16 @@ class KernelTimer:
             "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_wgrad": (3, "up")}
 
     def __init__(self):
-        self.records = []      # (variant, algorithmic flops, executed flops, start_event, end_event)
+        self.records = []      # (kernel name, algorithmic flops, executed flops, algorithmic bytes, start, end)
         self.enabled = False
 
     def install(self):
+        import ctypes
         import ic_gan_amd._lib as L
         raw = L.call
         timer = self
+        last = (ctypes.c_int * 4)()
+        query = L.lib().icg_gemm_last_variant
 
         def timed_call(name, *args):
             if not timer.enabled or name not in timer.SPEC:
@@ -83,32 +75,47 @@ class KernelTimer:
             if mode == "conv":
                 B, H, W, Cin, Cout, R = args[sl:sl + 6]
                 alg = exe = 2.0 * B * H * W * Cout * Cin * R * R
-                n_tile = Cout
+                byt = 4.0 * (B * H * W * (Cin + Cout) + Cout * Cin * R * R)
             else:       # upsample- / avgpool-fused conv (2x2-phase or 4x4-stride-2 form): executed MACs are 16/36 of the
-                        # reference op graph's (3x3 at the HIGH resolution)
+                        # reference op graph's (3x3 at the HIGH resolution); tensors: low-res one side, high-res the other
                 B, Hs, Ws, Cin, Cout = args[sl:sl + 5]
                 alg = 2.0 * B * (4 * Hs * Ws) * Cout * Cin * 9
                 exe = 2.0 * B * Hs * Ws * Cout * Cin * 16
-                n_tile = Cin if name.endswith("dgrad") else Cout
-            fam = "A_M,B_N" if name.endswith("wgrad") else "A_K,B_K"
-            variant = f"icg_gemm_kernel<{fam},TN={pick_tn(n_tile)}>"
+                lo, hi = (Cin, Cout) if "_up_" in name else (Cout, Cin)
+                byt = 4.0 * (B * Hs * Ws * (lo + 4 * hi) + 16 * Cout * Cin)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             raw(name, *args)
             e.record()
-            timer.records.append((variant, alg, exe, s, e))
+            query(last)
+            kname = "void icg_gemm_kernel<%d, %d, %d, %d>(GemmP)" % tuple(last)
+            timer.records.append((kname, alg, exe, byt, s, e))
 
         L.call = timed_call
 
     def summary(self):
         agg = {}
-        for variant, alg, exe, s, e in self.records:
-            a = agg.setdefault(variant, [0.0, 0.0, 0, 0.0])
+        for kname, alg, exe, byt, s, e in self.records:
+            a = agg.setdefault(kname, [0.0, 0.0, 0, 0.0, 0.0])
             a[0] += alg
             a[1] += s.elapsed_time(e) * 1e-3
             a[2] += 1
             a[3] += exe
+            a[4] += byt
         return agg
+
+
+def measured_traffic(kname):
+    """HBM bytes per launch of `kname` from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE
+    / --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction; tools/pmc_hbm.py writes the
+    summary).  PMC collection cannot run inside the timed process, hence the file; None when it is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        return table["kernels"][kname]["hbm_bytes_per_launch"], table.get("source")
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def build_models(cfg, device):
@@ -282,21 +289,24 @@ def main():
         agg = timer.summary()
         roof = None
         if agg:
-            variant, (flops, secs, n, exe) = max(agg.items(), key=lambda kv: kv[1][1])
+            variant, (flops, secs, n, exe, byt) = max(agg.items(), key=lambda kv: kv[1][1])
             ach = flops / secs / 1e12
+            traffic, traffic_src = measured_traffic(variant)
             # `achieved` counts ALGORITHMIC FLOPs (the reference op graph: the 3x3 conv that follows a nearest x2
             # upsample is counted on the upsampled tensor); `executed_tflops` is what the MFMA pipe really ran (the
             # 4-phase form of those layers executes 16/36 of the algorithmic MACs), i.e. the hardware utilisation.
             roof = {"bound": "mfma", "kernel": variant, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(byt / n),
                     "executed_tflops": round(exe / secs / 1e12, 2),
                     "executed_frac": round(exe / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                     "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
                     "flops_per_launch_avg": round(flops / n / 1e9, 3),
-                    "all_conv_variants": {k: {"algorithmic_tflops": round(v[0] / v[1] / 1e12, 2),
-                                              "executed_tflops": round(v[3] / v[1] / 1e12, 2),
-                                              "ms_per_step": round(v[1] / args.steps * 1e3, 2),
-                                              "launches_per_step": v[2] // args.steps} for k, v in agg.items()}}
+                    "all_conv_kernels": {k: {"algorithmic_tflops": round(v[0] / v[1] / 1e12, 2),
+                                             "executed_tflops": round(v[3] / v[1] / 1e12, 2),
+                                             "ms_per_step": round(v[1] / args.steps * 1e3, 2),
+                                             "avg_launch_ms": round(v[1] / v[2] * 1e3, 4),
+                                             "launches_per_step": v[2] // args.steps} for k, v in agg.items()}}
         out = {
             "metric": "images/sec G+D train step, IC-GAN BigGAN 256^2 bs=64/GPU" if args.workload == "cfg3"
             else f"images/sec G+D train step, IC-GAN BigGAN ({args.workload})",

@@ -640,6 +640,16 @@ static int ilog2_exact(int v) {
   return l;
 }
 
+// template arguments of the last icg_gemm_kernel this host thread launched (measurement support: lets a profiler
+// harness name its HIP-event timings exactly like rocprofv3 names the kernel)
+static thread_local int g_last_variant[4] = {-1, -1, -1, -1};
+
+extern "C" int icg_gemm_last_variant(int* out4) {
+  ICG_REQUIRE(out4);
+  for (int i = 0; i < 4; ++i) out4[i] = g_last_variant[i];
+  return ICG_OK;
+}
+
 template <int AMODE, int BMODE>
 static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool fast_ok = false,
                        bool vec_a_only = false) {
@@ -673,6 +683,7 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
     default: ICG_LAUNCH(4, PATH_); break; \
   }
   if (path == 2 && p.pre_affine) path = 3;
+  g_last_variant[0] = AMODE; g_last_variant[1] = BMODE; g_last_variant[2] = tn; g_last_variant[3] = path;
   if (path == 3) { ICG_LAUNCH_TN(3) } else if (path == 2) { ICG_LAUNCH_TN(2) } else if (path == 1) { ICG_LAUNCH_TN(1) }
   else { ICG_LAUNCH_TN(0) }
 #undef ICG_LAUNCH_TN

@@ -112,6 +112,14 @@ int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int
                      int transB, int64_t strideA, int64_t strideB, int64_t strideC, int batch,
                      float alpha, void* stream);
 
+/*
+ * Measurement support (no reference counterpart): template arguments {AMODE, BMODE, TN, PATH} of the last
+ * icg_gemm_kernel<AMODE, BMODE, TN, PATH> launched by the calling host thread through any of the conv / GEMM
+ * entry points above ({-1,...} before the first launch).  bench.py uses it to label its HIP-event timings with
+ * exactly the kernel name rocprofv3 reports.
+ */
+int icg_gemm_last_variant(int* out4);
+
 /* ---- BatchNorm / ccbn statistics  (layers.py:398-437 ccbn.forward, 485-503 bn.forward,
  *      sync_batchnorm/batchnorm.py:61-193 for the cross-replica variant) ---------------- */
 /* number of float partial slots per channel pair produced by icg_bn_partial_stats */
