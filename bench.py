@@ -109,22 +109,25 @@ def measured_traffic(kname):
     """HBM bytes per launch of `kname` from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE
     / --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction; tools/pmc_hbm.py writes the
     summary).  PMC collection cannot run inside the timed process, hence the file; None when it is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    import glob
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_hbm_traffic.json")))
     try:
-        with open(path) as f:
+        with open(paths[-1]) as f:
             table = json.load(f)
         return table["kernels"][kname]["hbm_bytes_per_launch"], table.get("source")
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, IndexError):
         return None, None
 
 
-def build_models(cfg, device):
+def build_models(cfg, device, init_mode="ortho"):
     import ic_gan_amd.BigGAN as M
     from ic_gan_amd import utils
     from ic_gan_amd.optim import FusedAdam
     G = M.Generator(**{**cfg, "skip_init": True, "embedded_optimizers": False}).to(device)
     D = M.Discriminator(**{**cfg, "skip_init": True, "embedded_optimizers": False}).to(device)
     try:                       # reference init (orthogonal) on the device: QR of up to 1536 x 13824 matrices
+        if init_mode != "ortho":
+            raise RuntimeError("--init %s requested" % init_mode)
         G.init_weights(); D.init_weights()
         init = "ortho"
     except Exception as exc:   # noqa: BLE001  (rocSOLVER unavailable -> documented fall back to N(0, 0.02))
@@ -211,6 +214,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--init", default="ortho", choices=["ortho", "N02"],
+                    help="weight init; N02 skips the rocSOLVER QR (which crashes under rocprofv3 --pmc); timings are init-independent")
     ap.add_argument("--sync-bn", action="store_true", help="cross-replica BN statistics over RCCL (cfg3 variant)")
     args = ap.parse_args()
 
@@ -242,7 +247,7 @@ def main():
         cfg["sync_bn"] = True
     from ic_gan_amd import train_fns, utils
     utils.seed_rng(0 + rank)
-    M, G, D, G_ema, ema, opt_g, opt_d, init = build_models(cfg, device)
+    M, G, D, G_ema, ema, opt_g, opt_d, init = build_models(cfg, device, args.init)
     dim_z = G.dim_z
     if use_ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP

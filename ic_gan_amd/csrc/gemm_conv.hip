@@ -47,6 +47,7 @@ struct GemmP {
   //   1: fprop  - blockIdx.z = phase (al, be); pad = (1-al, 1-be); C rows scatter to (2h+al, 2w+be); B += z*strideB
   //   2: wgrad  - blockIdx.z = phase*nsplit + split; pad as above; B rows gather from (2h+al, 2w+be)
   int phase_mode, nsplit;
+  int swz;                         // XCD-aware tile order (see kernel head)
   int vec_b;                       // PATH 1 only: 16-byte loads allowed on the B operand (A is vectorised)
 };
 
@@ -71,9 +72,22 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
   __shared__ __attribute__((aligned(16))) float Bs[NBUF][BK * LDB];
 
   const int tid = threadIdx.x;
-  const int nt = blockIdx.x % p.ntiles_n;
-  const int mt = blockIdx.x / p.ntiles_n;
-  const int z = blockIdx.z;
+  // XCD-aware tile order.  The dispatcher places workgroup `lin` on XCD lin % 8, each XCD with a private 4 MiB L2.
+  // Giving every XCD one CONTIGUOUS range of the (z, m-tile, n-tile) order keeps the tiles that share operand panels
+  // (all n-tiles of an m-tile, neighbouring pixel rows and their 3x3 halos, all tiles of one split-K / phase plane) on one
+  // L2 instead of fetching each panel into all eight.  Bijective for any grid size (cdna_hip_programming.md T1);
+  // placement is a speed choice only — results do not depend on it.
+  unsigned tile = blockIdx.x, zz = blockIdx.z;
+  if (p.swz) {
+    const unsigned nwg = gridDim.x, lin = blockIdx.x + blockIdx.z * nwg, tot = nwg * gridDim.z;
+    const unsigned q = tot >> 3, r = tot & 7u, xcd = lin & 7u;
+    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    zz = t / nwg;
+    tile = t - zz * nwg;
+  }
+  const int nt = tile % p.ntiles_n;
+  const int mt = tile / p.ntiles_n;
+  const int z = (int)zz;
   const int m0 = mt * BM, n0 = nt * BN;
   const float* __restrict__ Ag = p.A + (long)z * p.strideA;
   const float* __restrict__ Bg = p.B + (long)z * p.strideB;
@@ -142,6 +156,7 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
   int f_h[2], f_w[2];
   bool f_rowok[2], f_ok[2];
   int f_tr = 0, f_ts = 0, f_c0 = 0;          // wave-uniform tap tracking (A_K)
+  int f_btap = 0, f_bc0 = 0;                 // the same position, for the B operand (advanced by load_B_fast)
   unsigned f_mtap_c = 0;                      // A_M: channel of this thread's 4 columns
   int f_mr = 0, f_ms = 0;
   bool f_mok = false;
@@ -179,17 +194,21 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
     if (AMODE == A_K) {
       const unsigned c = (unsigned)(f_c0 + 4 * kq);
       const int hi = f_h[i] * gs + f_tr - pad_h, wi = f_w[i] * gs + f_ts - pad_w;
-      const bool ok = f_rowok[i] & ((unsigned)hi < (unsigned)p.Hb) & ((unsigned)wi < (unsigned)p.Wb);
+      // (f_c0 < Cin fails only on the tile the pipeline over-fetches past the end of K)
+      const bool ok = f_rowok[i] & (f_c0 < Cin) & ((unsigned)hi < (unsigned)p.Hb) & ((unsigned)wi < (unsigned)p.Wb);
       const unsigned idx =
           (f_img[i] + (unsigned)(hi >> p.up) * (unsigned)p.Ws + (unsigned)(wi >> p.up)) * (unsigned)Cin + c;
       f_ok[i] = ok;
       f_idx[i] = ok ? idx : 0u;
-      f_so[i] = f_ss[i] + c;
+      f_so[i] = ok ? f_ss[i] + c : 0u;
       if (last) {
-        f_c0 += BK;                             // K-tiles never straddle a tap: Cin % BK == 0
-        if (f_c0 >= Cin) {
-          f_c0 = 0;
-          if (++f_ts == p.R) { f_ts = 0; ++f_tr; }
+        // K order of the fast path: TAP-MINOR — all R*R taps of one 16-channel slice, then the next slice (a K-tile never
+        // straddles a tap: Cin % BK == 0).  The R*R shifted re-reads of an activation element are then ~R*R K-tiles apart
+        // (a few KB of footprint per workgroup) instead of a full Cin sweep apart (hundreds of KB), so they hit L1/L2
+        // instead of going back to HBM: measured fetch traffic of the 3x3 layers drops accordingly.
+        if (++f_ts == p.R) {
+          f_ts = 0;
+          if (++f_tr == p.R) { f_tr = 0; f_c0 += BK; }
         }
       }
     } else {
@@ -226,7 +245,16 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
 
   auto load_B_fast = [&](int k0) {
     if (BMODE == B_K) {
-      const unsigned kg = (unsigned)(min(k0, kend - BK) + 4 * kq);   // clamp: the pipeline over-fetches past the last tile
+      // tap-minor K order (see addr_A_fast): tile -> (16-channel slice f_bc0, tap f_btap); the weight matrix keeps its
+      // [N][tap][Cin] layout, only the order in which its K-tiles are visited changes.  Clamp: the pipeline over-fetches
+      // one tile past the end.
+      unsigned kg;
+      if (AMODE == A_K) {
+        kg = (unsigned)(min(f_btap * Cin + f_bc0, kend - BK) + 4 * kq);
+        if (++f_btap == p.R * p.R) { f_btap = 0; f_bc0 += BK; }
+      } else {
+        kg = (unsigned)(min(k0, kend - BK) + 4 * kq);
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
 #if defined(ICG_DBG_LOAD_FIXED)
@@ -640,6 +668,11 @@ static int ilog2_exact(int v) {
   return l;
 }
 
+static bool getenv_flag(const char* name) {   // measurement switch, read once per process
+  static const bool v = [](const char* n) { const char* e = getenv(n); return e && e[0] == '1'; }(name);
+  return v;
+}
+
 // template arguments of the last icg_gemm_kernel this host thread launched (measurement support: lets a profiler
 // harness name its HIP-event timings exactly like rocprofv3 names the kernel)
 static thread_local int g_last_variant[4] = {-1, -1, -1, -1};
@@ -672,6 +705,7 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
   p.ntiles_n = (int)icg_cdiv(p.N, bn);
   const long tiles = icg_cdiv(p.M, 128) * p.ntiles_n;
   if (tiles <= 0 || tiles > 0x7fffffffL || zdim <= 0 || zdim > 65535) return ICG_ERR_ARG;
+  p.swz = (tiles * zdim >= 16 && tiles * zdim < 0x7fffffffL && !getenv_flag("ICG_NO_XCD_SWIZZLE")) ? 1 : 0;
   dim3 grid((unsigned)tiles, 1, (unsigned)zdim), block(256);
 #define ICG_LAUNCH(TN_, PATH_) \
   hipLaunchKernelGGL((icg_gemm_kernel<AMODE, BMODE, TN_, PATH_>), grid, block, 0, st, p)

@@ -32,7 +32,7 @@ def main():
     ft, fc, ff = load(fdir, "FETCH_SIZE")
     wt, wc, wf = load(wdir, "WRITE_SIZE")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 2 "
-                     "--warmup 1 --no-cpu-baseline`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+                     "--warmup 1 --no-cpu-baseline --init N02`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                      "MI355X_MICROARCH.md HBM section; tools/pmc_hbm.py",
            "kernels": {}}
     for k in sorted(ft, key=lambda k: -ft[k]):
