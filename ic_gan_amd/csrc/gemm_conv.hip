@@ -48,6 +48,7 @@ struct GemmP {
   //   2: wgrad  - blockIdx.z = phase*nsplit + split; pad as above; B rows gather from (2h+al, 2w+be)
   int phase_mode, nsplit;
   int swz;                         // XCD-aware tile order (see kernel head)
+  int zmask;                       // generic A_K paths only: source is zero-inserted by (zmask+1): hi, wi must be multiples
   int vec_b;                       // PATH 1 only: 16-byte loads allowed on the B operand (A is vectorised)
 };
 
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int hi = ah[i] * gs + r - pad_h, wi = aw[i] * gs + s - pad_w;
-          const bool ok = kv && amv[i] && hi >= 0 && hi < p.Hb && wi >= 0 && wi < p.Wb;
+          const bool ok = kv && amv[i] && hi >= 0 && hi < p.Hb && wi >= 0 && wi < p.Wb && (((hi | wi) & p.zmask) == 0);
           ra[i] = zero4();
           rsc[i] = zero4();
           rsh[i] = zero4();
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
               const int c = kj - tap * Cin;
               const int r = tap / p.R, s = tap - r * p.R;
               const int hi = ah[i] * gs + r - pad_h, wi = aw[i] * gs + s - pad_w;
-              if (hi >= 0 && hi < p.Hb && wi >= 0 && wi < p.Wb) {
+              if (hi >= 0 && hi < p.Hb && wi >= 0 && wi < p.Wb && (((hi | wi) & p.zmask) == 0)) {
                 v[j] = Ag[src_index(ab[i], hi, wi, c)];
                 if (p.pre_affine) {
                   sc[j] = p.scale[(long)ab[i] * p.ss_bstride + c];
@@ -696,7 +697,7 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
     p.vec_b = 0;
   }
   int path = vec ? 1 : 0;
-  if (vec && fast_ok) {
+  if (vec && fast_ok && p.zmask == 0) {
     if (AMODE == A_K && (p.Cin % 16 == 0) && p.kchunk == 0) path = 2;
     if (AMODE == A_M && p.lw >= 0 && p.lh >= 0) path = 2;
   }
@@ -1029,6 +1030,84 @@ extern "C" int icg_conv2d_down_wgrad(const float* x, const float* dy, float* dvd
     const long n = (long)M * Cout;
     int blocks = (int)(icg_cdiv(n, 256) > 2048 ? 2048 : icg_cdiv(n, 256));
     hipLaunchKernelGGL(icg_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dvdn, n,
+                       pl.splits);
+    rc = icg_check_launch();
+  }
+  return rc;
+}
+
+// ---- general strided / zero-inserted convolution (StyleGAN2 conv2d_gradfix: conv2d, conv_transpose2d and all their
+// first- and second-order gradients are parameterisations of these two gathers) --------------------------------------
+//   out[b,oy,ox,co] = bias[co] + sum_{r,s,ci} src(b, oy*stride + r - pad, ox*stride + s - pad, ci) * w[co][r][s][ci]
+//   src = x inside [0,Hin)x[0,Win), zero outside                                         (zero_insert = 0)
+//   src = x[(h/z, w/z)] where h, w are multiples of z = zero_insert's factor inside the zero-inserted extent
+//         [(Hin-1)*z+1] x [(Win-1)*z+1], zero elsewhere; stride must be 1                (zero_insert = z in {2, 4})
+extern "C" int icg_conv2d_g_fprop(const float* x, const float* w, const float* bias, float* out, int B, int Hin, int Win,
+                                  int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, int zero_insert,
+                                  void* stream) {
+  ICG_REQUIRE(x && w && out && B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Hout > 0 && Wout > 0 && Cout > 0);
+  ICG_REQUIRE(R >= 1 && R <= 7 && stride >= 1 && stride <= 4 && pad >= 0 && pad <= 8);
+  ICG_REQUIRE(zero_insert == 0 || ((zero_insert == 2 || zero_insert == 4) && stride == 1));
+  const long M = (long)B * Hout * Wout;
+  ICG_REQUIRE(M < 0x7fffffffL);
+  GemmP p{};
+  p.A = x; p.B = w; p.C = out;
+  p.M = (int)M; p.N = Cout; p.K = R * R * Cin;
+  p.H = Hout; p.W = Wout; p.Cin = Cin; p.R = R; p.Hs = Hin; p.Ws = Win;
+  p.pad_h = pad; p.pad_w = pad; p.gs = stride;
+  if (zero_insert) {
+    p.up = (zero_insert == 2) ? 1 : 2;
+    p.zmask = zero_insert - 1;
+    p.Hb = (Hin - 1) * zero_insert + 1; p.Wb = (Win - 1) * zero_insert + 1;
+  } else {
+    p.up = 0; p.zmask = 0; p.Hb = Hin; p.Wb = Win;
+  }
+  p.ldb = p.K; p.ldc = Cout;
+  p.bias = bias; p.alpha = 1.f;
+  p.kchunk = 0; p.phase_mode = 0; p.nsplit = 1;
+  const bool vec = (Cin % 4 == 0) && aligned16(x) && aligned16(w);
+  // the fast path decodes pixels with shifts: needs power-of-two OUTPUT grid only in A_M mode; A_K needs Cin % 16 == 0
+  const bool small = ((long)B * Hin * Win * Cin < 0x7fffffffL) && ((long)Cout * p.K < 0x7fffffffL);
+  return launch_gemm<A_K, B_K>(p, vec, 1, (hipStream_t)stream, small);
+}
+
+//   dw[r][s][ci][co] = sum_{b,oy,ox} x[b, oy*stride + r - pad, ox*stride + s - pad, ci] * dy[b,oy,ox,co]      (HWIO)
+extern "C" size_t icg_conv2d_g_wgrad_workspace_bytes(int B, int Hout, int Wout, int Cin, int Cout, int R) {
+  WgradPlan pl = wgrad_plan((long)B * Hout * Wout, R * R * Cin, Cout);
+  if (pl.splits <= 1) return 16;
+  return (size_t)pl.splits * (size_t)(R * R * Cin) * (size_t)Cout * sizeof(float);
+}
+
+extern "C" int icg_conv2d_g_wgrad(const float* x, const float* dy, float* dw, int B, int Hin, int Win, int Cin, int Hout,
+                                  int Wout, int Cout, int R, int stride, int pad, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(x && dy && dw && B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Hout > 0 && Wout > 0 && Cout > 0);
+  ICG_REQUIRE(R >= 1 && R <= 7 && stride >= 1 && stride <= 4 && pad >= 0 && pad <= 8);
+  const long K = (long)B * Hout * Wout;
+  ICG_REQUIRE(K < 0x7fffffffL);
+  const int M = R * R * Cin;
+  WgradPlan pl = wgrad_plan(K, M, Cout);
+  const size_t need = (pl.splits <= 1) ? 0 : (size_t)pl.splits * M * Cout * sizeof(float);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need)) return ICG_ERR_WORKSPACE;
+  GemmP p{};
+  p.A = x; p.B = dy;
+  p.C = (pl.splits <= 1) ? dw : (float*)workspace;
+  p.M = M; p.N = Cout; p.K = (int)K;
+  p.H = Hout; p.W = Wout; p.Cin = Cin; p.R = R; p.up = 0; p.Hs = Hin; p.Ws = Win;
+  p.pad_h = pad; p.pad_w = pad; p.gs = stride; p.Hb = Hin; p.Wb = Win;
+  p.ldb = Cout; p.ldc = Cout;
+  p.alpha = 1.f;
+  p.kchunk = pl.kchunk; p.phase_mode = 0; p.nsplit = 1;
+  p.strideA = 0; p.strideB = 0; p.strideC = (long)M * Cout;
+  const bool vec = (Cin % 4 == 0) && (Cout % 4 == 0) && aligned16(x) && aligned16(dy);
+  const bool small = ((long)B * Hin * Win * Cin < 0x7fffffffL) && (K * (long)Cout < 0x7fffffffL);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_gemm<A_M, B_N>(p, vec, pl.splits, st, small);
+  if (rc != ICG_OK) return rc;
+  if (pl.splits > 1) {
+    const long n = (long)M * Cout;
+    int blocks = (int)(icg_cdiv(n, 256) > 2048 ? 2048 : icg_cdiv(n, 256));
+    hipLaunchKernelGGL(icg_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, n,
                        pl.splits);
     rc = icg_check_launch();
   }

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
+from .. import ops as _ops
 
 # name -> (plugin id, default alpha, default gain, what the backward needs: 'x', 'y' or '', has 2nd-order term)
 activation_funcs = {
@@ -27,8 +28,7 @@ activation_funcs = {
 
 
 def _kernel(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
-    if not x.is_cuda:
-        raise RuntimeError("ic_gan_amd.stylegan_ops.bias_act runs on an AMD GPU only; there is no CPU path")
+    _ops._require_gpu(x)          # fails loudly off-GPU: there is no CPU path
     x = x.contiguous()
     y = torch.empty_like(x)
     n = x.numel()

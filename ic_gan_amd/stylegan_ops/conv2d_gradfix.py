@@ -1,0 +1,180 @@
+"""conv2d / conv_transpose2d with arbitrary-order gradients on the HIP implicit-GEMM kernel.
+
+API of stylegan2_ada_pytorch/torch_utils/ops/conv2d_gradfix.py (conv2d 43-64, conv_transpose2d 67-99,
+no_weight_gradients 31-37); the reference builds it from cudnn_convolution / cudnn_convolution_transpose /
+cudnn_convolution_backward_weight (139-272) so that R1 and path-length regularisation can differentiate twice.
+
+Here every one of those contractions is one of two gathers of the C-ABI (include/icgan_hip.h):
+
+    gather conv   G[geo](x, w)  = icg_conv2d_g_fprop   out[o] = sum_r src(o*stride + r - pad) w[r]
+    gather wgrad  W[geo](x, dy) = icg_conv2d_g_wgrad   dw[r]  = sum_o x[o*stride + r - pad] dy[o]
+
+and the family is closed under differentiation:
+    d/dx  G[s, p, zins=0] = G[1, R-1-p, zins=s] with the flipped, transposed weight  (and back)
+    d/dw  G               = W  (roles of x and dy swapped for the zero-inserted direction)
+    d/dx  W(x, dy)        = adjoint gather of dy with the incoming cotangent as the weight;  d/ddy W = G(x, cotangent)
+so both autograd Functions below express their backward with each other and gradients of any order exist.
+
+Tensors are logical NCHW fp32 stored channels-last (NHWC in memory), weights are handed to the kernel as
+[Cout][R][R][Cin].  groups > 1, dilation > 1 and non-square stride/padding are not supported (StyleGAN2 training uses
+none of them: `fused_modconv` — the only groups>1 user — is off in training mode, networks.py:440-444).
+"""
+import contextlib
+from dataclasses import dataclass
+
+import torch
+
+from .. import _lib as L
+from .. import ops as _ops
+
+enabled = True                       # kept for API parity; the HIP path is the only path
+weight_gradients_disabled = False    # conv2d_gradfix.py:26-37
+
+
+@contextlib.contextmanager
+def no_weight_gradients():
+    global weight_gradients_disabled
+    old = weight_gradients_disabled
+    weight_gradients_disabled = True
+    try:
+        yield
+    finally:
+        weight_gradients_disabled = old
+
+
+@dataclass(frozen=True)
+class _Geo:
+    R: int
+    stride: int      # gather stride over the source (1 when zins > 0)
+    pad: int
+    zins: int        # 0, or the zero-insertion factor of the source
+    src: tuple       # (H, W) of the gathered tensor
+    out: tuple       # (H, W) of the result
+
+    def adjoint(self):
+        """geometry of the data gradient (which gathers from `out`-shaped dy and produces `src`-shaped dx)."""
+        p = self.R - 1 - self.pad
+        if p < 0:
+            raise NotImplementedError("padding larger than kernel_size - 1 is not supported")
+        if self.zins:
+            return _Geo(self.R, self.zins, p, 0, self.out, self.src)
+        return _Geo(self.R, 1, p, self.stride if self.stride > 1 else 0, self.out, self.src)
+
+
+def _adjoint_weight(w):
+    """[Cout][R][R][Cin] -> the weight of the adjoint gather: [Cin][R][R][Cout], taps flipped."""
+    return w.permute(3, 1, 2, 0).flip(1, 2).contiguous()
+
+
+class _GatherConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, geo):
+        _ops._require_gpu(x)
+        # the autograd inputs themselves are saved (not their re-laid-out copies): the backward differentiates through them
+        ctx.geo = geo
+        ctx.save_for_backward(x, w)
+        x = _ops._cl(x)
+        w = w.contiguous()
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        assert (H, W) == geo.src and w.shape == (Cout, geo.R, geo.R, Cin), (x.shape, w.shape, geo)
+        y = _ops._empty_cl(B, Cout, geo.out[0], geo.out[1], x.device)
+        L.call("icg_conv2d_g_fprop", x, w, None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout, geo.R, geo.stride,
+               geo.pad, geo.zins)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        geo = ctx.geo
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _GatherConv.apply(dy, _adjoint_weight(w), geo.adjoint())
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            dw = _GatherWgrad.apply(x, dy, geo)
+        return dx, dw, None
+
+
+class _GatherWgrad(torch.autograd.Function):
+    """dw[Cout][R][R][Cin] of y = G[geo](x, w) given dy."""
+
+    @staticmethod
+    def forward(ctx, x, dy, geo):
+        _ops._require_gpu(x)
+        ctx.geo = geo
+        ctx.save_for_backward(x, dy)
+        x, dy = _ops._cl(x), _ops._cl(dy)
+        B, Cin, H, W = x.shape
+        Cout = dy.shape[1]
+        assert (H, W) == geo.src and tuple(dy.shape[2:]) == geo.out, (x.shape, dy.shape, geo)
+        R = geo.R
+        if geo.zins:      # zero-inserted direction: dy is the gathered tensor, x lives on the pixel grid
+            adj = geo.adjoint()
+            ws_bytes = L.query("icg_conv2d_g_wgrad_workspace_bytes", B, H, W, Cout, Cin, R)
+            t = torch.empty(R, R, Cout, Cin, device=x.device, dtype=torch.float32)
+            L.call("icg_conv2d_g_wgrad", dy, x, t, B, geo.out[0], geo.out[1], Cout, H, W, Cin, R, adj.stride, adj.pad,
+                   _ops._bytes(ws_bytes, x.device), ws_bytes)
+            dw = t.flip(0, 1).permute(2, 0, 1, 3).contiguous()
+        else:
+            ws_bytes = L.query("icg_conv2d_g_wgrad_workspace_bytes", B, geo.out[0], geo.out[1], Cin, Cout, R)
+            t = torch.empty(R, R, Cin, Cout, device=x.device, dtype=torch.float32)
+            L.call("icg_conv2d_g_wgrad", x, dy, t, B, H, W, Cin, geo.out[0], geo.out[1], Cout, R, geo.stride, geo.pad,
+                   _ops._bytes(ws_bytes, x.device), ws_bytes)
+            dw = t.permute(3, 0, 1, 2).contiguous()
+        return dw
+
+    @staticmethod
+    def backward(ctx, ddw):
+        x, dy = ctx.saved_tensors
+        geo = ctx.geo
+        gx = gdy = None
+        if ctx.needs_input_grad[0]:
+            gx = _GatherConv.apply(dy, _adjoint_weight(ddw), geo.adjoint())
+        if ctx.needs_input_grad[1]:
+            gdy = _GatherConv.apply(x, ddw.contiguous(), geo)
+        return gx, gdy, None
+
+
+def _one(v, what):
+    if isinstance(v, (tuple, list)):
+        if len(v) != 2 or v[0] != v[1]:
+            raise NotImplementedError("%s must be the same in both dimensions (got %r)" % (what, v))
+        v = v[0]
+    return int(v)
+
+
+def _check(input, weight, dilation, groups):
+    assert isinstance(input, torch.Tensor) and input.ndim == 4 and weight.ndim == 4
+    if _one(dilation, "dilation") != 1 or groups != 1:
+        raise NotImplementedError("conv2d_gradfix on HIP supports dilation=1, groups=1 (got %r, %r)" % (dilation, groups))
+    if weight.shape[2] != weight.shape[3]:
+        raise NotImplementedError("square kernels only")
+
+
+def _with_bias(y, bias):
+    return y if bias is None else y + bias.to(y.dtype).reshape(1, -1, 1, 1)
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    """F.conv2d semantics; weight [Cout][Cin][R][R]  (conv2d_gradfix.py:43-64)."""
+    _check(input, weight, dilation, groups)
+    s, p, R = _one(stride, "stride"), _one(padding, "padding"), int(weight.shape[2])
+    H, W = int(input.shape[2]), int(input.shape[3])
+    out = ((H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1)
+    if min(out) < 1 or p < 0:
+        raise ValueError("conv2d: empty output / negative padding")
+    geo = _Geo(R, s, p, 0, (H, W), out)
+    return _with_bias(_GatherConv.apply(input, weight.permute(0, 2, 3, 1), geo), bias)
+
+
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+    """F.conv_transpose2d semantics; weight [Cin][Cout][R][R]  (conv2d_gradfix.py:67-99)."""
+    _check(input, weight, dilation, groups)
+    s, p, op, R = _one(stride, "stride"), _one(padding, "padding"), _one(output_padding, "output_padding"), int(weight.shape[2])
+    H, W = int(input.shape[2]), int(input.shape[3])
+    out = ((H - 1) * s - 2 * p + R + op, (W - 1) * s - 2 * p + R + op)
+    if min(out) < 1 or p < 0 or p > R - 1:
+        raise ValueError("conv_transpose2d: unsupported padding / empty output")
+    geo = _Geo(R, 1, R - 1 - p, s if s > 1 else 0, (H, W), out)
+    w = weight.permute(1, 2, 3, 0).flip(1, 2)               # -> [Cout][R][R][Cin], taps flipped
+    return _with_bias(_GatherConv.apply(input, w, geo), bias)

@@ -1,0 +1,36 @@
+"""modulated_conv2d  (stylegan2_ada_pytorch/training/networks.py:37-117).
+
+Style modulation, convolution (with optional resampling), demodulation and noise.  Executed as "scale the activations
+before and after the convolution" (the reference's fused_modconv=False branch, networks.py:78-97, which is what training
+uses); `fused_modconv=True` — a grouped convolution over per-sample weights in the reference, used in eval mode — is
+computed through the same branch: x*s -> conv(w) -> *d equals conv(w*s*d) exactly in real arithmetic and to fp32 rounding
+here, and needs no per-sample weight tensor [N, O, I, k, k] in HBM."""
+import torch
+
+from . import conv2d_resample, fma
+
+
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
+                     flip_weight=True, fused_modconv=True):
+    batch_size = int(x.shape[0])
+    out_channels, in_channels, kh, kw = (int(s) for s in weight.shape)
+    assert x.shape[1] == in_channels and tuple(styles.shape) == (batch_size, in_channels)
+    if x.dtype != torch.float32:
+        raise NotImplementedError("fp16 activations are not part of the fp32 hot path (use num_fp16_res=0)")
+
+    dcoefs = None
+    if demodulate:
+        # d[n, o] = rsqrt(sum_{i,k} (w[o,i,k] s[n,i])^2 + 1e-8)  (networks.py:70-75) without materialising [N,O,I,k,k]
+        wsq = weight.square().sum(dim=[2, 3])                              # [O, I]
+        dcoefs = (styles.square() @ wsq.t() + 1e-8).rsqrt()                # [N, O]
+
+    x = x * styles.reshape(batch_size, -1, 1, 1)
+    x = conv2d_resample.conv2d_resample(x=x, w=weight, f=resample_filter, up=up, down=down, padding=padding,
+                                        flip_weight=flip_weight)
+    if demodulate and noise is not None:
+        x = fma.fma(x, dcoefs.reshape(batch_size, -1, 1, 1), noise)
+    elif demodulate:
+        x = x * dcoefs.reshape(batch_size, -1, 1, 1)
+    elif noise is not None:
+        x = x + noise
+    return x

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
+from .. import ops as _ops
 
 
 def _parse_scaling(scaling):
@@ -66,8 +67,7 @@ def _filter2d(f, device):
 
 
 def _run(x, f2, up, down, padding, flip, gain):
-    if not x.is_cuda:
-        raise RuntimeError("ic_gan_amd.stylegan_ops.upfirdn2d runs on an AMD GPU only; there is no CPU path")
+    _ops._require_gpu(x)          # fails loudly off-GPU: there is no CPU path
     upx, upy = up
     downx, downy = down
     px0, px1, py0, py1 = padding

@@ -103,6 +103,30 @@ int icg_conv2d_down_wgrad(const float* x, const float* dy, float* dvdn, int B, i
                           unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * General strided / zero-inserted convolution, NHWC fp32 — the contraction behind StyleGAN2's
+ * conv2d_gradfix.conv2d / conv_transpose2d (stylegan2_ada_pytorch/torch_utils/ops/conv2d_gradfix.py:43-99), their
+ * data / weight gradients (conv2d_gradfix.py:139-272) and, through those, conv2d_resample (conv2d_resample.py:79-216)
+ * and modulated_conv2d (training/networks.py:37-117).  Replaces cudnn_convolution(_transpose) and
+ * cudnn_convolution_backward_weight.
+ *
+ *   out[b,oy,ox,co] = bias[co] + sum_{r,s,ci} src(b, oy*stride + r - pad, ox*stride + s - pad, ci) * w[co][r][s][ci]
+ *   zero_insert = 0: src = x (zero outside [0,Hin) x [0,Win))               -> F.conv2d(stride, padding=pad)
+ *   zero_insert = z: src = x zero-inserted by z (extent (Hin-1)*z+1), stride must be 1
+ *                    -> F.conv_transpose2d(stride=z, padding=R-1-pad) with w = flipped, transposed weight
+ * Hout/Wout are free (positions beyond the source read zeros): output_padding needs no separate argument.
+ * w is [Cout][R][R][Cin]; bias may be NULL.
+ */
+int icg_conv2d_g_fprop(const float* x, const float* w, const float* bias, float* out, int B, int Hin, int Win,
+                       int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, int zero_insert,
+                       void* stream);
+/*   dw[r][s][ci][co] = sum_{b,oy,ox} x[b, oy*stride + r - pad, ox*stride + s - pad, ci] * dy[b,oy,ox,co]
+ * (weight gradient of either direction: for the transposed convolution swap the roles of x and dy). */
+size_t icg_conv2d_g_wgrad_workspace_bytes(int B, int Hout, int Wout, int Cin, int Cout, int R);
+int icg_conv2d_g_wgrad(const float* x, const float* dy, float* dw, int B, int Hin, int Win, int Cin, int Hout,
+                       int Wout, int Cout, int R, int stride, int pad, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/*
  * Batched fp32 GEMM  C[z] = alpha * op(A[z]) * op(B[z]) for the attention
  * contractions (layers.py:237-243: theta^T phi, g beta^T and their gradients).
  *   transA = 0: A is [M][K] row-major;  1: A is [K][M]

@@ -545,6 +545,53 @@ def icg_upfirdn2d(x, f, y, N, C, H, W, fh, fw, upx, upy, downx, downy, padx0, pa
     mem(y)[: N * C * outH * outW].copy_(out.reshape(-1))
 
 
+def _gather_src(x, B, Hin, Win, Cin, zero_insert):
+    a = _nhwc(x, B, Hin, Win, Cin).permute(0, 3, 1, 2)
+    if zero_insert:
+        z = zero_insert
+        up = torch.zeros(B, Cin, (Hin - 1) * z + 1, (Win - 1) * z + 1, dtype=a.dtype)
+        up[:, :, ::z, ::z] = a
+        a = up
+    return a
+
+
+def _fit(y, Hout, Wout):
+    """crop / zero-extend the conv output to the requested grid (positions beyond the source read zeros)."""
+    y = y[:, :, :Hout, :Wout]
+    return F.pad(y, (0, Wout - y.shape[3], 0, Hout - y.shape[2]))
+
+
+def icg_conv2d_g_fprop(x, w, bias, out, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, zero_insert):
+    a = _gather_src(x, B, Hin, Win, Cin, zero_insert)
+    wt = mem(w)[: Cout * R * R * Cin].view(Cout, R, R, Cin).permute(0, 3, 1, 2)
+    # enough trailing zeros that every requested output position exists
+    need_h = (Hout - 1) * stride + R - pad - a.shape[2]
+    need_w = (Wout - 1) * stride + R - pad - a.shape[3]
+    a = F.pad(a, (pad, max(need_w, 0), pad, max(need_h, 0)))
+    y = _fit(F.conv2d(a, wt, None, stride, 0), Hout, Wout)
+    if bias is not None:
+        y = y + mem(bias)[:Cout].view(1, -1, 1, 1)
+    mem(out)[: B * Hout * Wout * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_conv2d_g_wgrad_workspace_bytes(B, Hout, Wout, Cin, Cout, R):
+    return 16
+
+
+def icg_conv2d_g_wgrad(x, dy, dw, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, workspace, workspace_bytes):
+    a = _nhwc(x, B, Hin, Win, Cin).double()
+    g = _nhwc(dy, B, Hout, Wout, Cout).double()
+    need_h = (Hout - 1) * stride + R - pad - Hin
+    need_w = (Wout - 1) * stride + R - pad - Win
+    ap = F.pad(a, (0, 0, pad, max(need_w, 0), pad, max(need_h, 0)))
+    o = torch.empty(R, R, Cin, Cout, dtype=torch.float64)
+    for r in range(R):
+        for s_ in range(R):
+            win = ap[:, r: r + (Hout - 1) * stride + 1: stride, s_: s_ + (Wout - 1) * stride + 1: stride, :]
+            o[r, s_] = torch.einsum("bhwi,bhwo->io", win, g)
+    mem(dw)[: R * R * Cin * Cout].copy_(o.float().reshape(-1))
+
+
 # ---------------------------------------------------------------- host-logic test harness
 def install(monkeypatch):
     """Route ic_gan_amd._lib.call / query to this module (CPU host-logic tests only)."""

@@ -1,0 +1,130 @@
+"""conv2d_gradfix / conv2d_resample / modulated_conv2d against outputs and first- and second-order
+gradients of the reference itself (tests/golden/stylegan_conv.npz, made by make_golden_stylegan_conv.py).
+
+fp32 tolerance: 2e-4 of the tensor's rms for outputs and first-order gradients, 1e-3 for second-order ones (two chained
+fp32 contractions in a different summation order than the CPU reference); measured errors are ~1e-6 / ~1e-5.
+CPU variants route the C-ABI to oracle/kernel_ref.py (host logic: geometry algebra, adjoint weights, autograd wiring);
+GPU variants run the HIP kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernel_ref
+from tests.helpers import GOLDEN_DIR
+from tests.stylegan_cases import CONV, MODCONV, RESAMPLE, rnd
+
+GOLD = np.load(os.path.join(GOLDEN_DIR, "stylegan_conv.npz"))
+TOL1, TOL2 = 2e-4, 1e-3
+
+
+@pytest.fixture
+def emu(monkeypatch):
+    kernel_ref.install(monkeypatch)
+
+
+def _close(got, key, tol):
+    ref = GOLD[key]
+    got = got.detach().cpu().numpy()
+    assert got.shape == ref.shape, (key, got.shape, ref.shape)
+    scale = max(float(np.sqrt((ref.astype(np.float64) ** 2).mean())), 1e-6)
+    err = float(np.abs(got - ref).max())
+    assert err <= tol * scale + 1e-6, "%s: max abs err %.3e vs rms %.3e (tol %.1e)" % (key, err, scale, tol)
+
+
+def _second_order(key, y, inputs, names, seed, dev):
+    dy = rnd(tuple(y.shape), seed).to(dev).requires_grad_(True)
+    g1 = torch.autograd.grad(y, inputs, dy, create_graph=True)
+    for n, g in zip(names, g1):
+        _close(g, f"{key}d{n}", TOL1)
+    scalar = sum((g * rnd(tuple(g.shape), seed + 1 + i).to(dev)).sum() for i, g in enumerate(g1))
+    g2 = torch.autograd.grad(scalar, list(inputs) + [dy], allow_unused=True)
+    for n, g, ref in zip(list(names) + ["y"], g2, list(inputs) + [dy]):
+        _close(g if g is not None else torch.zeros_like(ref), f"{key}dd{n}", TOL2)
+
+
+def _conv_case(i, dev):
+    from ic_gan_amd.stylegan_ops import conv2d_gradfix as cg
+    n, ci, h, w, co, r, s, p, tr, op = CONV[i]
+    x = rnd((n, ci, h, w), 100 + i).to(dev).requires_grad_(True)
+    wt = (rnd((ci, co, r, r) if tr else (co, ci, r, r), 200 + i) * (ci * r * r) ** -0.5).to(dev).requires_grad_(True)
+    if tr:
+        y = cg.conv_transpose2d(x, wt, stride=s, padding=p, output_padding=op)
+    else:
+        y = cg.conv2d(x, wt, stride=s, padding=p)
+    _close(y, f"conv/{i}/y", TOL1)
+    _second_order(f"conv/{i}/", y, (x, wt), ("x", "w"), 300 + 10 * i, dev)
+
+
+def _resample_case(i, dev):
+    from ic_gan_amd.stylegan_ops import conv2d_resample as cr, upfirdn2d as up_
+    n, ci, h, w, co, k, up, down, pad, fw, ff, taps = RESAMPLE[i]
+    x = rnd((n, ci, h, w), 400 + i).to(dev).requires_grad_(True)
+    wt = (rnd((co, ci, k, k), 500 + i) * (ci * k * k) ** -0.5).to(dev).requires_grad_(True)
+    f = up_.setup_filter(taps, device=dev) if taps is not None else None
+    y = cr.conv2d_resample(x, wt, f=f, up=up, down=down, padding=pad, flip_weight=fw, flip_filter=ff)
+    _close(y, f"rs/{i}/y", TOL1)
+    _second_order(f"rs/{i}/", y, (x, wt), ("x", "w"), 600 + 10 * i, dev)
+
+
+def _modconv_case(i, dev):
+    from ic_gan_amd.stylegan_ops import modulated_conv2d, upfirdn2d as up_
+    n, ci, h, w, co, k, up, demod, noise, fused = MODCONV[i]
+    x = rnd((n, ci, h, w), 700 + i).to(dev).requires_grad_(True)
+    wt = rnd((co, ci, k, k), 800 + i).to(dev).requires_grad_(True)
+    st = (rnd((n, ci), 900 + i) * 0.5 + 1.0).to(dev).requires_grad_(True)
+    nz = (rnd((n, 1, h * up, w * up), 950 + i) * 0.1).to(dev) if noise else None
+    f = up_.setup_filter([1, 3, 3, 1], device=dev)
+    y = modulated_conv2d(x=x, weight=wt, styles=st, noise=nz, up=up, padding=k // 2, resample_filter=f,
+                         demodulate=demod, flip_weight=(up == 1), fused_modconv=fused)
+    _close(y, f"mc/{i}/y", TOL1)
+    _second_order(f"mc/{i}/", y, (x, wt, st), ("x", "w", "s"), 1000 + 10 * i, dev)
+
+
+@pytest.mark.parametrize("i", range(len(CONV)))
+def test_conv2d_gradfix_host_logic(i, emu):
+    _conv_case(i, "cpu")
+
+
+@pytest.mark.parametrize("i", range(len(RESAMPLE)))
+def test_conv2d_resample_host_logic(i, emu):
+    _resample_case(i, "cpu")
+
+
+@pytest.mark.parametrize("i", range(len(MODCONV)))
+def test_modulated_conv2d_host_logic(i, emu):
+    _modconv_case(i, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(CONV)))
+def test_conv2d_gradfix_hip(i):
+    _conv_case(i, "cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(RESAMPLE)))
+def test_conv2d_resample_hip(i):
+    _resample_case(i, "cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(len(MODCONV)))
+def test_modulated_conv2d_hip(i):
+    _modconv_case(i, "cuda:0")
+
+
+def test_no_weight_gradients_context(emu):
+    from ic_gan_amd.stylegan_ops import conv2d_gradfix as cg
+    x = rnd((1, 4, 6, 6), 1).requires_grad_(True)
+    w = rnd((4, 4, 3, 3), 2).requires_grad_(True)
+    with cg.no_weight_gradients():
+        y = cg.conv2d(x, w, padding=1)
+        gx, gw = torch.autograd.grad(y.sum(), (x, w), allow_unused=True)
+    assert gx is not None and gw is None
+    assert cg.weight_gradients_disabled is False
+    with pytest.raises(NotImplementedError):
+        cg.conv2d(x, w, padding=1, groups=2)
+    with pytest.raises(NotImplementedError):
+        cg.conv2d(x, w, padding=1, dilation=2)
