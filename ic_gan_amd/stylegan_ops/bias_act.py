@@ -27,14 +27,29 @@ activation_funcs = {
 }
 
 
+def _is_cl(t, dim):
+    """4-D tensor stored channels-last (NHWC in memory) with the bias on the channel dim: handled in place, the kernel's
+    (step_b, size_b) addressing covers it with step_b = 1 — no NCHW round trip between the NHWC convolutions."""
+    return (t.ndim == 4 and dim == 1 and not t.is_contiguous()
+            and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def _lay(t, cl):
+    if t is None:
+        return None
+    return t.contiguous(memory_format=torch.channels_last) if cl else t.contiguous()
+
+
 def _kernel(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
     _ops._require_gpu(x)          # fails loudly off-GPU: there is no CPU path
-    x = x.contiguous()
+    lead = next(t for t in (xref, yref, x) if t is not None)     # saved tensors fix the layout of a gradient pass
+    cl = _is_cl(lead, dim)
+    x, xref, yref, dy = _lay(x, cl), _lay(xref, cl), _lay(yref, cl), _lay(dy, cl)
     y = torch.empty_like(x)
     n = x.numel()
     if n == 0:
         return y
-    step_b = int(np.prod(x.shape[dim + 1:])) if b is not None else 1
+    step_b = (1 if cl else int(np.prod(x.shape[dim + 1:]))) if b is not None else 1
     size_b = b.numel() if b is not None else 1
     L.call("icg_bias_act", x, b, xref, yref, dy, y, n, step_b, size_b, grad, act_id, float(alpha), float(gain),
            float(clamp))
@@ -56,7 +71,7 @@ def bias_act(x, b=None, dim=1, act="linear", alpha=None, gain=None, clamp=None, 
 class _BiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, b, dim, act_id, alpha, gain, clamp, ref, has2):
-        x = x.contiguous()
+        x = _lay(x, _is_cl(x, dim))
         y = _kernel(x, b, None, None, None, 0, dim, act_id, alpha, gain, clamp)
         ctx.cfg = (dim, act_id, alpha, gain, clamp, ref, has2)
         # y is also kept whenever a clamp is active: the clamp mask of the gradient needs it.  (The reference's CUDA
@@ -75,7 +90,7 @@ class _BiasAct(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dx = dy
             if act_id != 1 or gain != 1 or clamp >= 0:
-                dx = _BiasActGrad.apply(dy.contiguous(), x, b, y, ctx.cfg)
+                dx = _BiasActGrad.apply(dy, x, b, y, ctx.cfg)
         if ctx.has_b and ctx.needs_input_grad[1]:
             db = dx.sum([i for i in range(dx.ndim) if i != dim])
         return dx, db, None, None, None, None, None, None, None
@@ -96,9 +111,9 @@ class _BiasActGrad(torch.autograd.Function):
         dim, act_id, alpha, gain, clamp, ref, has2 = ctx.cfg
         d_dy = d_x = d_b = None
         if ctx.needs_input_grad[0]:
-            d_dy = _BiasActGrad.apply(d_dx.contiguous(), x, b, y, ctx.cfg)
+            d_dy = _BiasActGrad.apply(d_dx, x, b, y, ctx.cfg)
         if has2 and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
-            d_x = _kernel(d_dx.contiguous(), b, x, y, dy, 2, dim, act_id, alpha, gain, clamp)
+            d_x = _kernel(d_dx, b, x, y, dy, 2, dim, act_id, alpha, gain, clamp)
         if has2 and ctx.needs_input_grad[2] and d_x is not None:
             d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
         return d_dy, d_x, d_b, None, None

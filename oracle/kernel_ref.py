@@ -515,8 +515,20 @@ def icg_bias_act(x, b, xref, yref, dy, y, n, step_b, size_b, grad, act, alpha, g
         mem(y)[:n].copy_(fwd(xv) * up if dy is not None else fwd(xv))
         return
     xr = mem(xref)[:n].detach().clone().double().requires_grad_(True) if xref is not None else None
-    if xr is None:       # activations whose derivative is expressed through y: rebuild an input that maps to yref
-        raise NotImplementedError("kernel_ref.icg_bias_act(grad>0) needs xref")
+    if xr is None:       # piecewise-linear activations: the derivative is a function of the sign of y (bias_act.cu)
+        names = {1: "linear", 2: "relu", 3: "lrelu"}
+        if act not in names or yref is None and (act != 1 or clamp >= 0):
+            raise NotImplementedError("kernel_ref.icg_bias_act(grad>0) without xref: linear / relu / lrelu only")
+        if grad == 2:
+            mem(y)[:n].zero_()
+            return
+        yv = mem(yref)[:n] if yref is not None else None
+        slope = torch.ones(n) if act == 1 else torch.where(yv > 0, torch.ones(n), torch.full((n,), alpha if act == 3 else 0.0))
+        g = xv * slope * gain
+        if clamp >= 0:
+            g = torch.where(yv.abs() < clamp, g, torch.zeros_like(g))
+        mem(y)[:n].copy_(g)
+        return
     bias = bias.double() if b is not None else 0.0
     with torch.enable_grad():
         o = fwd(xr)

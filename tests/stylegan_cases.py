@@ -50,3 +50,65 @@ MODCONV = [  # N, Cin, H, W, Cout, k, up, demodulate, noise, fused_modconv
     (2, 8, 4, 4, 8, 3, 1, True, False, True),        # eval-mode fused request
     (2, 8, 4, 4, 8, 3, 2, True, True, True),
 ]
+
+
+# ---- N1: StyleGAN2 networks / loss / training iteration -------------------------------------------------------------
+SG2_NETS = {
+    # name: dict(G kwargs, D kwargs, batch)
+    "ic_r32": dict(
+        G=dict(z_dim=32, c_dim=0, h_dim=24, w_dim=32, img_resolution=32, img_channels=3,
+               mapping_kwargs=dict(num_layers=2), synthesis_kwargs=dict(channel_base=512, channel_max=64)),
+        D=dict(c_dim=0, h_dim=24, img_resolution=32, img_channels=3, channel_base=512, channel_max=64,
+               mapping_kwargs=dict(num_layers=2), epilogue_kwargs=dict(mbstd_group_size=2)),
+        batch=4),
+    "cc_ic_r16_resnetG": dict(
+        G=dict(z_dim=16, c_dim=5, h_dim=12, w_dim=24, img_resolution=16, img_channels=3,
+               mapping_kwargs=dict(num_layers=3), synthesis_kwargs=dict(channel_base=256, channel_max=32,
+                                                                       architecture="resnet", conv_clamp=256)),
+        D=dict(c_dim=5, h_dim=12, img_resolution=16, img_channels=3, channel_base=256, channel_max=32,
+               architecture="skip", conv_clamp=256, mapping_kwargs=dict(num_layers=2),
+               epilogue_kwargs=dict(mbstd_group_size=4)),
+        batch=4),
+}
+SG2_LOSS = dict(style_mixing_prob=0, r1_gamma=1.0, pl_batch_shrink=2, pl_decay=0.01, pl_weight=2)
+SG2_OPT = dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)
+
+
+def sg2_state(spec, seed):
+    """Deterministic values for every state_dict entry (name -> tensor): N(0,1) weights like the reference's init,
+    non-trivial biases / noise strengths / running averages so that every term of the networks is exercised."""
+    out = {}
+    for i, (name, shape) in enumerate(spec):
+        rs = np.random.RandomState(seed * 100003 + i)
+        if name.endswith("resample_filter"):
+            out[name] = None                      # keep the constructor's value
+            continue
+        a = rs.standard_normal(shape).astype(np.float32)
+        if name.endswith(".bias"):
+            a = 0.2 * a + (1.0 if ".affine." in name else 0.0)
+        elif name.endswith("noise_strength"):
+            a = np.float32(0.1) * a
+        elif name.endswith("w_avg"):
+            a = 0.1 * a
+        out[name] = torch.from_numpy(np.asarray(a, dtype=np.float32).reshape(shape))
+    return out
+
+
+def sg2_inputs(cfg, seed, n_sets):
+    """n_sets batches of (z, c, h) plus one real batch (img in [-1,1], c, h)."""
+    g, b = cfg["G"], cfg["batch"]
+    rs = np.random.RandomState(seed)
+
+    def cond(n):
+        c = np.zeros((n, g["c_dim"]), dtype=np.float32)
+        if g["c_dim"]:
+            c[np.arange(n), rs.randint(0, g["c_dim"], size=n)] = 1
+        h = rs.standard_normal((n, g["h_dim"])).astype(np.float32)
+        h /= np.linalg.norm(h, axis=1, keepdims=True)
+        return torch.from_numpy(c), torch.from_numpy(h)
+
+    z = torch.from_numpy(rs.standard_normal((n_sets * b, g["z_dim"])).astype(np.float32))
+    gc, gh = cond(n_sets * b)
+    img = torch.from_numpy((rs.randint(0, 256, size=(b, 3, g["img_resolution"], g["img_resolution"])) / 127.5 - 1).astype(np.float32))
+    rc, rh = cond(b)
+    return z, gc, gh, img, rc, rh

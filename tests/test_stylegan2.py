@@ -1,0 +1,171 @@
+"""IC-GAN StyleGAN2 backbone: networks, loss phases (incl. the second-order R1 / path-length terms) and
+whole training iterations against the reference's own outputs (tests/golden/stylegan2_*.npz from
+make_golden_stylegan2.py).  CPU variants route the C-ABI to oracle/kernel_ref.py; GPU variants run the HIP kernels.
+
+Random numbers: the reference draws per-layer noise and the path-length probe from torch's global CPU generator; the
+tests point the two RNG entry points of the product (networks._randn, loss._randn_like) at the same generator so that
+both sides see identical draws."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernel_ref
+from tests.helpers import GOLDEN_DIR, check_group
+from tests.stylegan_cases import SG2_LOSS, SG2_NETS, SG2_OPT, sg2_inputs, sg2_state
+
+CASES = sorted(SG2_NETS)
+
+
+@pytest.fixture
+def emu(monkeypatch):
+    kernel_ref.install(monkeypatch)
+
+
+def _gold(name):
+    z = np.load(os.path.join(GOLDEN_DIR, f"stylegan2_{name}.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def _spec(m):
+    return [[k, list(v.shape)] for k, v in m.state_dict().items()]
+
+
+def _load(m, seed, dev):
+    sd = sg2_state(_spec(m), seed)
+    cur = m.state_dict()
+    m.load_state_dict({k: (cur[k] if v is None else v.to(dev)) for k, v in sd.items()})
+
+
+def _build(name, dev, monkeypatch):
+    from ic_gan_amd.stylegan2 import loss as L, networks as N
+    monkeypatch.setattr(N, "_randn", lambda shape, device: torch.randn(shape).to(device))
+    monkeypatch.setattr(L, "_randn_like", lambda t: torch.randn(t.shape).to(t.device))
+    cfg = SG2_NETS[name]
+    G = N.Generator(**cfg["G"]).train().requires_grad_(False).to(dev)
+    D = N.Discriminator(**cfg["D"]).train().requires_grad_(False).to(dev)
+    _load(G, 1, dev)
+    _load(D, 2, dev)
+    return cfg, G, D
+
+
+def _close(got, ref, rtol, what):
+    got = got.detach().cpu().numpy()
+    scale = max(float(np.sqrt((ref.astype(np.float64) ** 2).mean())), 1e-6)
+    err = float(np.abs(got - ref).max())
+    assert got.shape == ref.shape and err <= rtol * scale + 1e-6, "%s: err %.3e rms %.3e" % (what, err, scale)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_state_dict_contract(name):
+    from ic_gan_amd.stylegan2 import networks as N
+    g = _gold(name)
+    cfg = SG2_NETS[name]
+    assert _spec(N.Generator(**cfg["G"])) == json.loads(str(g["gspec"]))
+    assert _spec(N.Discriminator(**cfg["D"])) == json.loads(str(g["dspec"]))
+    with pytest.raises(NotImplementedError):
+        N.Generator(**{**cfg["G"], "synthesis_kwargs": {**cfg["G"]["synthesis_kwargs"], "num_fp16_res": 2}})
+
+
+def _forward(name, dev, monkeypatch):
+    g = _gold(name)
+    cfg, G, D = _build(name, dev, monkeypatch)
+    b = cfg["batch"]
+    z, gc, gh, img, rc, rh = (t.to(dev) for t in sg2_inputs(cfg, 7, 4))
+    with torch.no_grad():
+        fake = G(z[:b], gc[:b], gh[:b], noise_mode="const")
+        _close(fake, g["fwd/img"], 2e-4, "G img")
+        _close(D(fake, gc[:b], gh[:b]), g["fwd/logits_fake"], 5e-4, "D(fake)")
+        _close(D(img, rc, rh), g["fwd/logits_real"], 5e-4, "D(real)")
+        _close(G.mapping.w_avg, g["fwd/w_avg"], 1e-4, "w_avg")
+        G.eval()
+        samp = G(z[:b], gc[:b], gh[:b], truncation_psi=0.7, noise_mode="const")
+        ref = g["sample/img"].astype(np.float64)
+        rel = np.linalg.norm(samp.cpu().numpy() - ref) / np.linalg.norm(ref)
+        assert rel < 1e-3, rel                     # north_star: generated samples within 1e-3 relative L2
+
+
+def _phase_grads(name, dev, monkeypatch):
+    from ic_gan_amd.stylegan2.loss import StyleGAN2Loss
+    g = _gold(name)
+    cfg, G, D = _build(name, dev, monkeypatch)
+    b = cfg["batch"]
+    z, gc, gh, img, rc, rh = (t.to(dev) for t in sg2_inputs(cfg, 7, 4))
+    for pi, phase in enumerate(["Gmain", "Greg", "Dmain", "Dreg"]):
+        L = StyleGAN2Loss(device=dev, G_mapping=G.mapping, G_synthesis=G.synthesis, D=D, **SG2_LOSS)
+        mod = G if phase[0] == "G" else D
+        _load(G, 1, dev)
+        mod.requires_grad_(True)
+        for p in mod.parameters():
+            p.grad = None
+        torch.manual_seed(100 + pi)
+        L.accumulate_gradients(phase=phase, real_img=img, real_c=rc, real_h=rh, gen_z=z[:b], gen_c=gc[:b], gen_h=gh[:b],
+                               sync=True, gain=1)
+        mod.requires_grad_(False)
+        grads = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in mod.named_parameters()}
+        # second-order phases chain two fp32 contractions: 1e-2 of the tensor rms (measured <= 2e-3); first-order 2e-3
+        rtol = 1e-2 if phase.endswith("reg") else 2e-3
+        check_group(g, f"grad/{phase}/", grads, rtol=rtol, atol=1e-7, what=phase + " ")
+        assert abs(float(L.pl_mean) - float(g[f"grad/{phase}/pl_mean"])) <= 1e-3 * max(abs(float(g[f"grad/{phase}/pl_mean"])), 1e-3)
+        for p in mod.parameters():
+            p.grad = None
+
+
+def _iterations(name, dev, monkeypatch):
+    from ic_gan_amd.stylegan2.training_step import TrainingStep
+    g = _gold(name)
+    cfg, G, D = _build(name, dev, monkeypatch)
+    G_ema = copy.deepcopy(G).eval()
+    b = cfg["batch"]
+    step = TrainingStep(G, D, G_ema, dev, batch_size=b, batch_gpu=b, loss_kwargs=SG2_LOSS, G_opt_kwargs=SG2_OPT,
+                        D_opt_kwargs=SG2_OPT, G_reg_interval=4, D_reg_interval=16, ema_kimg=0.02)
+    lr = SG2_OPT["lr"]
+    for it in range(2):
+        z, gc, gh, img, rc, rh = (t.to(dev) for t in sg2_inputs(cfg, 20 + it, 4))
+        torch.manual_seed(500 + it)
+        ran = step(img, rc, rh, z, gc, gh)
+        assert ran == (["Gmain", "Greg", "Dmain", "Dreg"] if it == 0 else ["Gmain", "Dmain"])
+        # Adam with beta1 = 0 moves every parameter by ~lr per update whatever the gradient's size; a rounding-level
+        # difference in a near-zero gradient component can flip that sign: allow 2.2 lr per optimiser step taken
+        steps = 2 * (it + 1) + (2 if it == 0 else 2)
+        for tag, m in (("G", G), ("D", D), ("G_ema", G_ema)):
+            slack = {n: 1.1 * lr * steps for n in m.state_dict()}
+            check_group(g, f"iter{it + 1}/{tag}/", m.state_dict(), rtol=5e-3, atol=1e-6, what=f"it{it + 1} {tag} ",
+                        extra_atol=slack)
+        assert abs(float(step.loss.pl_mean) - float(g[f"iter{it + 1}/pl_mean"])) <= 2e-3 * abs(float(g[f"iter{it + 1}/pl_mean"])) + 1e-6
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_host_logic(name, emu, monkeypatch):
+    _forward(name, "cpu", monkeypatch)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_phase_gradients_host_logic(name, emu, monkeypatch):
+    _phase_grads(name, "cpu", monkeypatch)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_training_iterations_host_logic(name, emu, monkeypatch):
+    _iterations(name, "cpu", monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_forward_hip(name, monkeypatch):
+    _forward(name, "cuda:0", monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_phase_gradients_hip(name, monkeypatch):
+    _phase_grads(name, "cuda:0", monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_training_iterations_hip(name, monkeypatch):
+    _iterations(name, "cuda:0", monkeypatch)
