@@ -174,6 +174,80 @@ def conditioning_sampler(cfg, dim_z, batch, device, seed, n_table=10000, k_nn=50
                              nn_sampling_strategy="instance_balance")
 
 
+def bench_stylegan2(args, device, rank, world, local_rank, use_ddp):
+    """Secondary workload (BASELINE.json configs[3]): IC-GAN StyleGAN2 256x256 `cfg=auto` on 1 GPU
+    (stylegan2_ada_pytorch/train.py:291-372 for res 256, 1 GPU: batch 16, fmaps 0.5, 2 mapping layers, lr 0.0025,
+    gamma 0.8192, mbstd 4, ema 5 kimg), instance-conditioned (h_dim 2048), fp32 (num_fp16_res = 0).  A step is one
+    training iteration; the timed region must span whole lazy-regularisation cycles (16 iterations) to be an average."""
+    import copy
+    from ic_gan_amd.stylegan2 import networks as N
+    from ic_gan_amd.stylegan2.training_step import TrainingStep
+    res, b = 256, (args.batch or 16)
+    torch.manual_seed(rank)
+    np.random.seed(rank)
+    common = dict(channel_base=16384, channel_max=512, num_fp16_res=0, conv_clamp=None)
+    G = N.Generator(z_dim=512, c_dim=0, h_dim=2048, w_dim=512, img_resolution=res, img_channels=3,
+                    mapping_kwargs=dict(num_layers=2), synthesis_kwargs=common).train().requires_grad_(False).to(device)
+    D = N.Discriminator(c_dim=0, h_dim=2048, img_resolution=res, img_channels=3, mapping_kwargs=dict(num_layers=2),
+                        epilogue_kwargs=dict(mbstd_group_size=4), **common).train().requires_grad_(False).to(device)
+    G_ema = copy.deepcopy(G).eval()
+    mods = None
+    if use_ddp:      # training_loop.py:293-310: mapping, synthesis and D are wrapped separately, no buffer broadcast
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        mods = {}
+        for name, m in (("G_mapping", G.mapping), ("G_synthesis", G.synthesis), ("D", D)):
+            m.requires_grad_(True)
+            mods[name] = DDP(m, device_ids=[local_rank], broadcast_buffers=False)
+            m.requires_grad_(False)
+    adam = dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)
+    step = TrainingStep(G, D, G_ema, device, batch_size=b * world, batch_gpu=b, num_gpus=world,
+                        loss_kwargs=dict(r1_gamma=0.0002 * res ** 2 / (b * world)), G_opt_kwargs=adam, D_opt_kwargs=adam,
+                        ema_kimg=b * world * 10 / 32, ema_rampup=0.05, ddp_modules=mods)
+    rs = np.random.RandomState(7 + rank)
+    img = torch.from_numpy((rs.randint(0, 256, size=(b, 3, res, res)) / 127.5 - 1).astype(np.float32)).to(device)
+
+    def unit(n):
+        h = rs.standard_normal((n, 2048)).astype(np.float32)
+        return torch.from_numpy(h / np.linalg.norm(h, axis=1, keepdims=True)).to(device)
+
+    real_h, real_c = unit(b), torch.empty([b, 0], device=device)
+    n_ph = len(step.phases)
+    gen_h, gen_c = unit(n_ph * b), torch.empty([n_ph * b, 0], device=device)
+
+    def one_step():
+        return step(img, real_c, real_h, torch.randn([n_ph * b, 512], device=device), gen_c, gen_h)
+
+    for _ in range(args.warmup):
+        one_step()
+    step.batch_idx = 0                        # the timed region starts at a cycle boundary
+    if use_ddp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if use_ddp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if use_ddp:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec training iteration, IC-GAN StyleGAN2 256^2 (cfg4, secondary workload)",
+            "value": round(b * world * args.steps / elapsed, 3), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg4: IC-GAN StyleGAN2 256x256 cfg=auto, h_dim 2048, fp32; Gmain+Dmain every iteration, "
+                                   "Greg every 4, Dreg every 16 (steps should be a multiple of 16)",
+                       "batch_per_gpu": b, "global_batch": b * world, "parallelism": f"dp{world}"},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+
+
 def cpu_baseline(cfg, name):
     """CPU oracle (restatement of the reference step, pinned to reference goldens) on this box's host cores."""
     from oracle import biggan_oracle as O, synth
@@ -210,7 +284,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS) + ["cfg4"])
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -239,6 +313,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
 
+    if args.workload == "cfg4":
+        return bench_stylegan2(args, device, rank, world, local_rank, use_ddp)
     over, batch = WORKLOADS[args.workload]
     batch = args.batch or batch
     cfg = dict(BASE_CFG)
