@@ -95,11 +95,102 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__
   }
 }
 
+// 16-byte version: one float4 per thread and iteration.  BMODE 0: no bias; 1: plane-major (NCHW, step_b % 4 == 0: the four
+// elements share one bias); 2: channel-minor (NHWC, step_b == 1, size_b % 4 == 0: four consecutive biases).  ACT is a
+// compile-time constant for the activations the networks use (linear / relu / lrelu), 0 = decided at run time.
+template <int ACT, int GRAD, int BMODE>
+__global__ __launch_bounds__(256) void bias_act_vec_kernel(const float4* __restrict__ x, const float* __restrict__ b,
+                                                           const float4* __restrict__ xref,
+                                                           const float4* __restrict__ yref, const float4* __restrict__ dy,
+                                                           float4* __restrict__ y, unsigned n4, unsigned step_b4,
+                                                           unsigned size_b, int act_rt, float alpha, float gain,
+                                                           float clamp) {
+  const int act = ACT ? ACT : act_rt;
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (BMODE == 1) {
+      const float v = b[(i / step_b4) % size_b];
+      bias[0] = bias[1] = bias[2] = bias[3] = v;
+    } else if (BMODE == 2) {
+      const float4 v = *reinterpret_cast<const float4*>(b + (i * 4u) % size_b);
+      bias[0] = v.x; bias[1] = v.y; bias[2] = v.z; bias[3] = v.w;
+    }
+    const float4 xv4 = x[i];
+    const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+    float up[4] = {1.f, 1.f, 1.f, 1.f};
+    if (dy) { const float4 t = dy[i]; up[0] = t.x; up[1] = t.y; up[2] = t.z; up[3] = t.w; }
+    float xr[4] = {0.f, 0.f, 0.f, 0.f}, yr[4] = {0.f, 0.f, 0.f, 0.f};
+    if (GRAD != 0) {
+      if (xref) { const float4 t = xref[i]; xr[0] = t.x; xr[1] = t.y; xr[2] = t.z; xr[3] = t.w; }
+      if (yref) { const float4 t = yref[i]; yr[0] = t.x; yr[1] = t.y; yr[2] = t.z; yr[3] = t.w; }
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (GRAD == 0) {
+        float out = act_value(act, xv[j] + bias[j], alpha) * (gain * up[j]);
+        if (clamp >= 0.f) out = (out > -clamp && out < clamp) ? out : (out >= 0.f ? clamp : -clamp);
+        o[j] = out;
+      } else {
+        const float xrj = xr[j] + bias[j];
+        float yrj = yr[j];
+        const float yy = gain != 0.f ? yrj / gain : 0.f;
+        const float d = (GRAD == 1) ? act_d1(act, yy, xrj, alpha) : act_d2(act, yy, xrj);
+        float out = xv[j] * d * (gain * up[j]);
+        if (act == ACT_SWISH) yrj = act_value(ACT_SWISH, xrj, alpha) * gain;
+        if (clamp >= 0.f) out = (yrj > -clamp && yrj < clamp) ? out : 0.f;
+        o[j] = out;
+      }
+    }
+    y[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+template <int ACT, int GRAD>
+static void launch_bias_act_vec(int bmode, dim3 grid, hipStream_t st, const float* x, const float* b, const float* xref,
+                                const float* yref, const float* dy, float* y, unsigned n4, unsigned step_b4,
+                                unsigned size_b, int act, float alpha, float gain, float clamp) {
+#define ICG_BA(BM)                                                                                                  \
+  hipLaunchKernelGGL((bias_act_vec_kernel<ACT, GRAD, BM>), grid, dim3(256), 0, st, (const float4*)x, b,               \
+                     (const float4*)xref, (const float4*)yref, (const float4*)dy, (float4*)y, n4, step_b4, size_b, act, \
+                     alpha, gain, clamp)
+  if (bmode == 0) ICG_BA(0); else if (bmode == 1) ICG_BA(1); else ICG_BA(2);
+#undef ICG_BA
+}
+
+static bool al16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 extern "C" int icg_bias_act(const float* x, const float* b, const float* xref, const float* yref, const float* dy,
                             float* y, int64_t n, int64_t step_b, int size_b, int grad, int act, float alpha, float gain,
                             float clamp, void* stream) {
   ICG_REQUIRE(x && y && n > 0 && grad >= 0 && grad <= 2 && act >= ACT_LINEAR && act <= ACT_SWISH);
   if (b) ICG_REQUIRE(step_b > 0 && size_b > 0);
+  // 16-byte path: whole tensor in float4s, a float4 never straddles a bias boundary (or lies across 4 channels, NHWC)
+  int bmode = -1;
+  if (!b) bmode = 0;
+  else if (step_b % 4 == 0) bmode = 1;
+  else if (step_b == 1 && size_b % 4 == 0 && al16(b)) bmode = 2;
+  if (bmode >= 0 && n % 4 == 0 && n < 0xffffffffL && al16(x) && al16(y) && al16(xref) && al16(yref) && al16(dy)) {
+    const unsigned n4 = (unsigned)(n / 4);
+    long vb = icg_cdiv((long)n4, 256);
+    if (vb > 256 * 16) vb = 256 * 16;
+    const dim3 grid((unsigned)vb);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned sb4 = (unsigned)(bmode == 1 ? step_b / 4 : 1), sz = (unsigned)size_b;
+#define ICG_BA_ACT(A)                                                                                               \
+  do {                                                                                                              \
+    if (grad == 0) launch_bias_act_vec<A, 0>(bmode, grid, st, x, b, xref, yref, dy, y, n4, sb4, sz, act, alpha, gain, clamp); \
+    else if (grad == 1) launch_bias_act_vec<A, 1>(bmode, grid, st, x, b, xref, yref, dy, y, n4, sb4, sz, act, alpha, gain, clamp); \
+    else launch_bias_act_vec<A, 2>(bmode, grid, st, x, b, xref, yref, dy, y, n4, sb4, sz, act, alpha, gain, clamp);   \
+  } while (0)
+    if (act == ACT_LINEAR) ICG_BA_ACT(ACT_LINEAR);
+    else if (act == ACT_LRELU) ICG_BA_ACT(ACT_LRELU);
+    else if (act == ACT_RELU) ICG_BA_ACT(ACT_RELU);
+    else ICG_BA_ACT(0);
+#undef ICG_BA_ACT
+    return icg_check_launch();
+  }
   long blocks = icg_cdiv(n, 1024);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, b, xref, yref, dy,
@@ -142,6 +233,154 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const float* __restrict_
     }
     y[i] = acc * gain;
   }
+}
+
+// Channels-last version: x is [N][H][W][C], y is [N][outH][outW][C], C % 4 == 0.  One thread produces a vertical strip of
+// TY output pixels for 4 consecutive channels: lanes run over channels first (16-byte coalesced loads/stores), every
+// loaded input row is reused by all outputs of the strip that it contributes to, the filter sits in LDS.
+template <int TY>
+__global__ __launch_bounds__(256) void upfirdn2d_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ f,
+                                                             float* __restrict__ y, int N, int H, int W, int C4, int fh,
+                                                             int fw, int upx, int upy, int downx, int downy, int padx0,
+                                                             int pady0, int flip, float gain, int outH, int outW) {
+  __shared__ float fs[256];
+  for (int i = threadIdx.x; i < fh * fw; i += blockDim.x) {
+    const int ty = i / fw, tx = i - ty * fw;
+    fs[i] = f[(flip ? ty : fh - 1 - ty) * fw + (flip ? tx : fw - 1 - tx)] * gain;   // fs[ty][tx]: plain correlation taps
+  }
+  __syncthreads();
+  const int strips = (outH + TY - 1) / TY;
+  const long total = (long)N * strips * outW * C4;
+  const long gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const int c4 = (int)(i % C4);
+    long t = i / C4;
+    const int ox = (int)(t % outW);
+    t /= outW;
+    const int ys = (int)(t % strips);
+    const int n = (int)(t / strips);
+    const int oy0 = ys * TY;
+    const int bx = ox * downx - padx0;
+    int ix0 = ceil_div_i(bx, upx), ix1 = ceil_div_i(bx + fw, upx);
+    ix0 = max(ix0, 0); ix1 = min(ix1, W);
+    const int by0 = oy0 * downy - pady0;                         // Z row of tap 0 of the strip's first output
+    const int byl = (min(oy0 + TY, outH) - 1) * downy - pady0;   // ... of its last output
+    int iy0 = ceil_div_i(by0, upy), iy1 = ceil_div_i(byl + fh, upy);
+    iy0 = max(iy0, 0); iy1 = min(iy1, H);
+    float4 acc[TY];
+#pragma unroll
+    for (int j = 0; j < TY; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* xp = reinterpret_cast<const float4*>(x) + (long)n * H * W * C4 + c4;
+    for (int iy = iy0; iy < iy1; ++iy) {
+      const int zy = iy * upy - by0;                             // tap row seen by output j: zy - j*downy
+      for (int ix = ix0; ix < ix1; ++ix) {
+        const int tx = ix * upx - bx;
+        const float4 v = xp[((long)iy * W + ix) * C4];
+#pragma unroll
+        for (int j = 0; j < TY; ++j) {
+          const int ty = zy - j * downy;
+          if (ty >= 0 && ty < fh) {
+            const float w = fs[ty * fw + tx];
+            acc[j].x = fmaf(v.x, w, acc[j].x); acc[j].y = fmaf(v.y, w, acc[j].y);
+            acc[j].z = fmaf(v.z, w, acc[j].z); acc[j].w = fmaf(v.w, w, acc[j].w);
+          }
+        }
+      }
+    }
+    float4* yp = reinterpret_cast<float4*>(y) + (((long)n * outH + oy0) * outW + ox) * C4 + c4;
+#pragma unroll
+    for (int j = 0; j < TY; ++j)
+      if (oy0 + j < outH) yp[(long)j * outW * C4] = acc[j];
+  }
+}
+
+// The case the networks run all the time — a 4x4 filter ([1,3,3,1] (x) [1,3,3,1]), no zero insertion, decimation 1 or 2 —
+// fully unrolled: taps in registers, no predicates in the accumulation, (TY-1)*DOWN + 4 input rows x 4 columns per strip.
+template <int DOWN, int TY>
+__global__ __launch_bounds__(256) void upfirdn2d_nhwc_f4_kernel(const float* __restrict__ x, const float* __restrict__ f,
+                                                                float* __restrict__ y, int N, int H, int W, int C4,
+                                                                int padx0, int pady0, int flip, float gain, int outH,
+                                                                int outW) {
+  __shared__ float fs[16];
+  if (threadIdx.x < 16) {
+    const int ty = threadIdx.x >> 2, tx = threadIdx.x & 3;
+    fs[threadIdx.x] = f[(flip ? ty : 3 - ty) * 4 + (flip ? tx : 3 - tx)] * gain;
+  }
+  __syncthreads();
+  float w[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[a][c] = fs[a * 4 + c];
+  constexpr int NR = (TY - 1) * DOWN + 4;
+  const int strips = (outH + TY - 1) / TY;
+  const long total = (long)N * strips * outW * C4;
+  const long gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const int c4 = (int)(i % C4);
+    long t = i / C4;
+    const int ox = (int)(t % outW);
+    t /= outW;
+    const int ys = (int)(t % strips);
+    const int n = (int)(t / strips);
+    const int oy0 = ys * TY;
+    const int bx = ox * DOWN - padx0, by = oy0 * DOWN - pady0;
+    float4 acc[TY];
+#pragma unroll
+    for (int j = 0; j < TY; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* xp = reinterpret_cast<const float4*>(x) + (long)n * H * W * C4 + c4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ix = bx + c;
+      const bool cok = (unsigned)ix < (unsigned)W;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int iy = by + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cok && (unsigned)iy < (unsigned)H) v = xp[((long)iy * W + ix) * C4];
+#pragma unroll
+        for (int j = 0; j < TY; ++j) {
+          const int ty = r - j * DOWN;          // compile-time after unrolling
+          if (ty >= 0 && ty < 4) {
+            const float ww = w[ty][c];
+            acc[j].x = fmaf(v.x, ww, acc[j].x); acc[j].y = fmaf(v.y, ww, acc[j].y);
+            acc[j].z = fmaf(v.z, ww, acc[j].z); acc[j].w = fmaf(v.w, ww, acc[j].w);
+          }
+        }
+      }
+    }
+    float4* yp = reinterpret_cast<float4*>(y) + (((long)n * outH + oy0) * outW + ox) * C4 + c4;
+#pragma unroll
+    for (int j = 0; j < TY; ++j)
+      if (oy0 + j < outH) yp[(long)j * outW * C4] = acc[j];
+  }
+}
+
+extern "C" int icg_upfirdn2d_nhwc(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw,
+                                  int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1,
+                                  int flip, float gain, int outH, int outW, void* stream) {
+  ICG_REQUIRE(x && f && y && N > 0 && C > 0 && (C % 4 == 0) && H > 0 && W > 0 && fh >= 1 && fw >= 1 && fh * fw <= 256);
+  ICG_REQUIRE(upx >= 1 && upy >= 1 && downx >= 1 && downy >= 1);
+  ICG_REQUIRE(outW == (W * upx + padx0 + padx1 - fw + downx) / downx);
+  ICG_REQUIRE(outH == (H * upy + pady0 + pady1 - fh + downy) / downy);
+  ICG_REQUIRE(outW >= 1 && outH >= 1);
+  ICG_REQUIRE(al16(x) && al16(y));
+  constexpr int TY = 4;
+  const long total = (long)N * ((outH + TY - 1) / TY) * outW * (C / 4);
+  long blocks = icg_cdiv(total, 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (fh == 4 && fw == 4 && upx == 1 && upy == 1 && downx == downy && (downx == 1 || downx == 2)) {
+    if (downx == 1)
+      hipLaunchKernelGGL((upfirdn2d_nhwc_f4_kernel<1, TY>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, f,
+                         y, N, H, W, C / 4, padx0, pady0, flip, gain, outH, outW);
+    else
+      hipLaunchKernelGGL((upfirdn2d_nhwc_f4_kernel<2, TY>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, f,
+                         y, N, H, W, C / 4, padx0, pady0, flip, gain, outH, outW);
+    return icg_check_launch();
+  }
+  hipLaunchKernelGGL(upfirdn2d_nhwc_kernel<TY>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, f, y, N, H,
+                     W, C / 4, fh, fw, upx, upy, downx, downy, padx0, pady0, flip, gain, outH, outW);
+  return icg_check_launch();
 }
 
 extern "C" int icg_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw,

@@ -66,6 +66,16 @@ def _adjoint_weight(w):
     return w.permute(3, 1, 2, 0).flip(1, 2).contiguous()
 
 
+def _phase_weights(w):
+    """[Cout][3][3][Cin] (gather form) -> wp[al][be][Cout][2][2][Cin] of icg_conv2d_tr2_fprop: an even output coordinate
+    meets taps {0, 2}, an odd one tap {1} (second slot zero)."""
+    w4 = torch.nn.functional.pad(w, (0, 0, 0, 1, 0, 1))                  # tap index 3 = zero
+    idx = torch.tensor([0, 2, 1, 3], device=w.device)                    # (al, u) -> tap: (0,0)->0 (0,1)->2 (1,0)->1 (1,1)->zero
+    g = w4.index_select(1, idx).index_select(2, idx)                     # [Cout][al,u][be,v][Cin]
+    Cout, Cin = w.shape[0], w.shape[3]
+    return g.view(Cout, 2, 2, 2, 2, Cin).permute(1, 3, 0, 2, 4, 5).contiguous()
+
+
 class _GatherConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, geo):
@@ -79,6 +89,10 @@ class _GatherConv(torch.autograd.Function):
         Cout = w.shape[0]
         assert (H, W) == geo.src and w.shape == (Cout, geo.R, geo.R, Cin), (x.shape, w.shape, geo)
         y = _ops._empty_cl(B, Cout, geo.out[0], geo.out[1], x.device)
+        if geo.zins == 2 and geo.R == 3 and geo.pad == 2 and geo.out[0] <= 2 * H + 2 and geo.out[1] <= 2 * W + 2:
+            # stride-2 transposed 3x3 convolution: 4 phases of 2x2 taps instead of a gather over the zero-inserted source
+            L.call("icg_conv2d_tr2_fprop", x, _phase_weights(w), None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout)
+            return y
         L.call("icg_conv2d_g_fprop", x, w, None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout, geo.R, geo.stride,
                geo.pad, geo.zins)
         return y

@@ -76,6 +76,12 @@ def _run(x, f2, up, down, padding, flip, gain):
     out_w = (w * upx + px0 + px1 - fw + downx) // downx
     out_h = (h * upy + py0 + py1 - fh + downy) // downy
     assert out_w >= 1 and out_h >= 1
+    if c % 4 == 0 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):
+        # channels-last in, channels-last out: no layout change between the NHWC convolutions and the FIR resampling
+        y = torch.empty((n, c, out_h, out_w), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        L.call("icg_upfirdn2d_nhwc", x, f2, y, n, c, h, w, fh, fw, upx, upy, downx, downy, px0, px1, py0, py1,
+               int(bool(flip)), float(gain), out_h, out_w)
+        return y
     y = torch.empty(n, c, out_h, out_w, device=x.device, dtype=torch.float32)
     L.call("icg_upfirdn2d", x.contiguous(), f2, y, n, c, h, w, fh, fw, upx, upy, downx, downy, px0, px1, py0, py1,
            int(bool(flip)), float(gain), out_h, out_w)

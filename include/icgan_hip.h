@@ -119,6 +119,15 @@ int icg_conv2d_down_wgrad(const float* x, const float* dy, float* dvdn, int B, i
 int icg_conv2d_g_fprop(const float* x, const float* w, const float* bias, float* out, int B, int Hin, int Win,
                        int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, int zero_insert,
                        void* stream);
+/*
+ * The zero_insert = 2, R = 3, pad = 2 case of the above (conv_transpose2d(stride=2, padding=0) of the up-sampling
+ * synthesis layers, conv2d_resample.py:163-186, and the data gradient of the discriminator's stride-2 convolutions) in
+ * phase form: 4 launches-in-one of 2x2 taps at source resolution, 16 instead of 36 tap slots per 4 outputs.
+ *   wp[al][be][co][u][v][ci]  (u, v in {0,1}; even coordinate: taps {0,2}, odd: {1, zero})
+ *   out[b, 2m+al, 2n+be, co] = bias[co] + sum x[b, m-1+al+u, n-1+be+v, ci] * wp[al][be][co][u][v][ci],  rows/cols >= Hout/Wout dropped
+ */
+int icg_conv2d_tr2_fprop(const float* x, const float* wp, const float* bias, float* out, int B, int Hin, int Win,
+                         int Cin, int Hout, int Wout, int Cout, void* stream);
 /*   dw[r][s][ci][co] = sum_{b,oy,ox} x[b, oy*stride + r - pad, ox*stride + s - pad, ci] * dy[b,oy,ox,co]
  * (weight gradient of either direction: for the transposed convolution swap the roles of x and dy). */
 size_t icg_conv2d_g_wgrad_workspace_bytes(int B, int Hout, int Wout, int Cin, int Cout, int R);
@@ -296,6 +305,12 @@ int icg_bias_act(const float* x, const float* b, const float* xref, const float*
 int icg_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw,
                   int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1,
                   int flip, float gain, int outH, int outW, void* stream);
+
+/* the same operation on channels-last data: x [N][H][W][C], y [N][outH][outW][C], C % 4 == 0 (what the NHWC
+ * convolutions produce and consume: no layout change between conv, FIR resampling and bias_act) */
+int icg_upfirdn2d_nhwc(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw,
+                       int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1,
+                       int flip, float gain, int outH, int outW, void* stream);
 
 #ifdef __cplusplus
 }

@@ -557,6 +557,13 @@ def icg_upfirdn2d(x, f, y, N, C, H, W, fh, fw, upx, upy, downx, downy, padx0, pa
     mem(y)[: N * C * outH * outW].copy_(out.reshape(-1))
 
 
+def icg_upfirdn2d_nhwc(x, f, y, N, C, H, W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, outH, outW):
+    xn = _nhwc(x, N, H, W, C).permute(0, 3, 1, 2).contiguous()
+    yn = torch.empty(N, C, outH, outW)
+    icg_upfirdn2d(xn, f, yn, N, C, H, W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, outH, outW)
+    mem(y)[: N * C * outH * outW].copy_(yn.permute(0, 2, 3, 1).reshape(-1))
+
+
 def _gather_src(x, B, Hin, Win, Cin, zero_insert):
     a = _nhwc(x, B, Hin, Win, Cin).permute(0, 3, 1, 2)
     if zero_insert:
@@ -581,6 +588,20 @@ def icg_conv2d_g_fprop(x, w, bias, out, B, Hin, Win, Cin, Hout, Wout, Cout, R, s
     need_w = (Wout - 1) * stride + R - pad - a.shape[3]
     a = F.pad(a, (pad, max(need_w, 0), pad, max(need_h, 0)))
     y = _fit(F.conv2d(a, wt, None, stride, 0), Hout, Wout)
+    if bias is not None:
+        y = y + mem(bias)[:Cout].view(1, -1, 1, 1)
+    mem(out)[: B * Hout * Wout * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_conv2d_tr2_fprop(x, wp, bias, out, B, Hin, Win, Cin, Hout, Wout, Cout):
+    a = _nhwc(x, B, Hin, Win, Cin).permute(0, 3, 1, 2)
+    w = mem(wp)[: 16 * Cout * Cin].view(2, 2, Cout, 2, 2, Cin)
+    big = torch.zeros(B, Cout, 2 * Hin + 2, 2 * Win + 2)
+    for al in range(2):
+        for be in range(2):
+            ap = F.pad(a, (1 - be, 1 + be, 1 - al, 1 + al))          # rows m-1+al+u for m in [0, Hin], u in {0,1}
+            big[:, :, al::2, be::2] = F.conv2d(ap, w[al, be].permute(0, 3, 1, 2))
+    y = big[:, :, :Hout, :Wout]
     if bias is not None:
         y = y + mem(bias)[:Cout].view(1, -1, 1, 1)
     mem(out)[: B * Hout * Wout * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))

@@ -90,3 +90,72 @@ def test_upfirdn2d_wrappers_hip():
     f = U.setup_filter([1, 3, 3, 1], device="cuda")
     for name in ("upsample2d", "downsample2d", "filter2d"):
         np.testing.assert_allclose(getattr(U, name)(x, f).cpu().numpy(), G["wrap/" + name], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", [i for i, c in enumerate(UPFIR) if c[1] % 4 == 0])
+def test_upfirdn2d_channels_last_hip(i):
+    """icg_upfirdn2d_nhwc (channels-last in and out) against the same reference goldens."""
+    from ic_gan_amd.stylegan_ops import upfirdn2d as U
+    n, c, h, w, taps, up, down, pad, flip, gain = UPFIR[i]
+    x = rnd((n, c, h, w), 50 + i).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    f = U.setup_filter(taps, device="cuda")
+    y = U.upfirdn2d(x, f, up=up, down=down, padding=pad, flip_filter=flip, gain=gain)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), G[f"up/{i}/y"], rtol=1e-4, atol=1e-5)
+    dy = rnd(tuple(y.shape), 60 + i).cuda().contiguous(memory_format=torch.channels_last)
+    (dx,) = torch.autograd.grad(y, x, dy)
+    np.testing.assert_allclose(dx.cpu().numpy(), G[f"up/{i}/dx"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,up,down,pad", [((2, 8, 9, 7), 1, 1, [2, 1, 1, 2]), ((1, 16, 8, 8), 2, 1, [2, 1, 2, 1]),
+                                                ((2, 4, 13, 13), 1, 2, [1, 1, 1, 1]), ((1, 12, 5, 6), 2, 2, [3, 0, 0, 3]),
+                                                ((3, 8, 33, 17), 1, 1, [0, 0, 0, 0])])
+def test_upfirdn2d_nhwc_equals_nchw_kernel(shape, up, down, pad):
+    """strip / boundary handling of the channels-last kernel at shapes the goldens do not cover."""
+    from ic_gan_amd.stylegan_ops import upfirdn2d as U
+    x = rnd(shape, 7).cuda()
+    f = U.setup_filter([1, 3, 3, 1], device="cuda")
+    a = U.upfirdn2d(x, f, up=up, down=down, padding=pad, gain=1.7)
+    b = U.upfirdn2d(x.contiguous(memory_format=torch.channels_last), f, up=up, down=down, padding=pad, gain=1.7)
+    assert not a.is_contiguous(memory_format=torch.channels_last) or a.shape[1] == 1
+    torch.testing.assert_close(b.contiguous(), a, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act", ACTS)
+@pytest.mark.parametrize("cl", [False, True])
+def test_bias_act_vectorised_paths(act, cl):
+    """the 16-byte kernels (plane-major bias for NCHW, channel-minor for channels-last) against oracle/kernel_ref.py,
+    which test_kernel_ref_bias_act_pinned_to_reference pins to the reference; forward, first and second order."""
+    from ic_gan_amd.stylegan_ops import bias_act as B
+    from oracle import kernel_ref as K
+    shape = (2, 8, 6, 6)
+    x = rnd(shape, 1, 1.5)
+    b = rnd((8,), 2, 0.5)
+    dy, d2 = rnd(shape, 3), rnd(shape, 4)
+    xg = x.cuda()
+    if cl:
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    xg = xg.requires_grad_(True)
+    bg = b.cuda().requires_grad_(True)
+    dyg = dy.cuda().requires_grad_(True)
+    y = B.bias_act(xg, bg, act=act, clamp=0.9)
+    assert y.is_contiguous(memory_format=torch.channels_last) == cl or not cl
+    dx, db = torch.autograd.grad(y, (xg, bg), dyg, create_graph=True)
+    ddx, ddy = torch.autograd.grad((dx * d2.cuda()).sum(), (xg, dyg), allow_unused=True)
+    # CPU reference through the (scalar, pinned) emulation of the same entry point
+    act_id, alpha, gain = B.activation_funcs[act][0], B.activation_funcs[act][1], B.activation_funcs[act][2]
+    n, step = x.numel(), 36
+    yr, g1, g2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    K.icg_bias_act(x, b, None, None, None, yr, n, step, 8, 0, act_id, alpha, gain, 0.9)
+    K.icg_bias_act(dy, b, x, yr, None, g1, n, step, 8, 1, act_id, alpha, gain, 0.9)
+    torch.testing.assert_close(y.detach().cpu().contiguous(), yr, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dx.detach().cpu().contiguous(), g1, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(db.detach().cpu(), g1.sum([0, 2, 3]), rtol=1e-4, atol=1e-4)
+    K.icg_bias_act(d2, b, x, yr, None, g2, n, step, 8, 1, act_id, alpha, gain, 0.9)          # d(dx.d2)/d(dy)
+    torch.testing.assert_close(ddy.detach().cpu().contiguous(), g2, rtol=1e-4, atol=1e-5)
+    if ddx is not None:
+        K.icg_bias_act(d2, b, x, yr, dy, g2, n, step, 8, 2, act_id, alpha, gain, 0.9)
+        torch.testing.assert_close(ddx.detach().cpu().contiguous(), g2, rtol=1e-3, atol=1e-4)

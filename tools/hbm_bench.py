@@ -1,0 +1,130 @@
+#!/usr/bin/env python
+"""Roofline check of the HBM-bound kernels (tools only): algorithmic bytes / HIP-event time at the sizes the step uses,
+against 8 TB/s (spec) — a float4 copy reaches ≈6.3 TB/s on this part.  Prints one line per kernel."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import ic_gan_amd._lib as L
+from ic_gan_amd import ops
+from ic_gan_amd.stylegan_ops import bias_act as BA, upfirdn2d as UF
+
+dev = "cuda:0"
+PEAK = 8000.0
+
+
+def ev(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); s.record()
+    for _ in range(iters):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def report(name, nbytes, t):
+    gbs = nbytes / t / 1e9
+    print(f"{name:58s} {nbytes / 1e9:7.2f} GB  {t * 1e3:8.3f} ms  {gbs:7.0f} GB/s  {gbs / PEAK:5.2f} of 8 TB/s", flush=True)
+
+
+def cl(*shape):
+    return torch.randn(*shape, device=dev).contiguous(memory_format=torch.channels_last)
+
+
+def main():
+    # reference point: device copy
+    a = torch.empty(256 << 20, device=dev); b = torch.empty_like(a)
+    report("copy (torch) 1 GiB", 2 * a.numel() * 4, ev(lambda: b.copy_(a)))
+    del a, b
+
+    # ---- BigGAN cfg3: largest BN layer [64, 96, 256, 256] ----
+    B, C, H, W = 64, 96, 256, 256
+    x = cl(B, C, H, W); n = x.numel(); rows = B * H * W
+    rm = torch.zeros(C, device=dev)
+    nb = L.query("icg_bn_workspace_bytes", rows, C); ws = ops._bytes(nb, dev)
+    report("bn_partial_stats [64,96,256,256]", 4 * n, ev(lambda: L.call("icg_bn_partial_stats", x, rm, rows, C, ws, nb)))
+    da = cl(B, C, H, W); dx = torch.empty_like(x)
+    scale = torch.rand(B, C, device=dev) + 0.5; shift = torch.randn(B, C, device=dev); mean = torch.zeros(C, device=dev)
+    ca = torch.randn(C, device=dev) * 0.01; cb = torch.randn(C, device=dev) * 0.01
+    flags = 1 | 2
+    nbb = L.query("icg_bn_bwd_workspace_bytes", B, H, W, C); wsb = ops._bytes(nbb, dev)
+    sd = torch.empty(B, C, device=dev); sx = torch.empty(B, C, device=dev)
+    report("bn_bwd_reduce  (reads x, da)", 8 * n,
+           ev(lambda: L.call("icg_bn_bwd_reduce", x, da, scale, shift, C, mean, B, H, W, C, flags, wsb, nbb, sd, sx)))
+    report("bn_bwd_apply   (reads x, da; writes dx)", 12 * n,
+           ev(lambda: L.call("icg_bn_bwd_apply", x, da, scale, shift, C, mean, ca, cb, B, H, W, C, flags, dx)))
+    y = torch.empty_like(x)
+    report("bn_apply (stand-alone) r+w", 8 * n, ev(lambda: L.call("icg_bn_apply", x, scale, shift, C, B, H * W, C, flags, y)))
+    report("relu_fwd r+w", 8 * n, ev(lambda: L.call("icg_relu_fwd", x, y, n)))
+    nbc = L.query("icg_colsum_workspace_bytes", rows, C); wsc = ops._bytes(nbc, dev); cs = torch.empty(C, device=dev)
+    report("colsum (bias gradient) [4.2M x 96]", 4 * n, ev(lambda: L.call("icg_colsum", x, rows, C, cs, wsc, nbc)))
+    p = torch.empty(B, C, H // 2, W // 2, device=dev).contiguous(memory_format=torch.channels_last)
+    report("avgpool2_fwd", 5 * n, ev(lambda: L.call("icg_avgpool2_fwd", x, None, p, B, H, W, C)))
+    del da, dx, y, p
+    img = cl(B, 3, H, W); out = torch.empty_like(img)
+    report("tanh_fwd [64,3,256,256]", 8 * img.numel(), ev(lambda: L.call("icg_tanh_fwd", img, out, img.numel())))
+    del x, img, out
+
+    # attention softmax: beta [64*4096, 1024]
+    r, c = 64 * 4096, 1024
+    s_in = torch.randn(r, c, device=dev); s_out = torch.empty_like(s_in)
+    report("softmax_fwd [262144 x 1024]", 8 * r * c, ev(lambda: L.call("icg_softmax_fwd", s_in, s_out, r, c)))
+    g = torch.randn(r, c, device=dev)
+    report("softmax_bwd", 12 * r * c, ev(lambda: L.call("icg_softmax_bwd", s_out, g, s_in, r, c)))
+    del s_in, s_out, g
+
+    # optimiser: 100 M parameters in 60 tensors
+    ps = [torch.randn(1_700_000, device=dev) for _ in range(60)]
+    gs = [torch.randn_like(t) for t in ps]; ms = [torch.zeros_like(t) for t in ps]; vs = [torch.zeros_like(t) for t in ps]
+    tot = sum(t.numel() for t in ps)
+    report("adam_multi 102 M params (28 B/param)", 28 * tot, ev(lambda: ops.adam_multi(ps, gs, ms, vs, 1e-4, 0.0, 0.999, 1e-6, 3)))
+    report("ema_multi  102 M entries (12 B/entry)", 12 * tot, ev(lambda: ops.ema_multi(ms, ps, 0.999)))
+    del ps, gs, ms, vs
+
+    # spectral norm of the largest layer [1536, 1536*9]
+    wgt = torch.randn(1536, 1536, 3, 3, device=dev) * 0.01
+    u = torch.randn(1, 1536, device=dev); sv = torch.ones(1, device=dev)
+    t = ev(lambda: ops.sn_prepare(wgt, u, sv, 1e-6, True, True))
+    report("sn_forward [1536 x 13824] (3 reads + 2 writes of W)", 5 * wgt.numel() * 4, t)
+    del wgt
+
+    # ---- StyleGAN2 cfg4 sizes ----
+    for fmt in ("nchw", "nhwc"):
+        xs = torch.randn(16, 64, 256, 256, device=dev)
+        if fmt == "nhwc":
+            xs = xs.contiguous(memory_format=torch.channels_last)
+        bias = torch.randn(64, device=dev)
+        report(f"bias_act lrelu fwd [16,64,256,256] {fmt}", 8 * xs.numel(), ev(lambda: BA.bias_act(xs, bias, act="lrelu")))
+        xg = xs.clone().requires_grad_(True)
+        yy = BA.bias_act(xg, bias, act="lrelu"); gy = torch.randn_like(yy)
+        report(f"bias_act lrelu bwd (dy, y -> dx) {fmt}", 12 * xs.numel(),
+               ev(lambda: torch.autograd.grad(yy, xg, gy, retain_graph=True)))
+        del xg, yy, gy
+    f = UF.setup_filter([1, 3, 3, 1], device=dev)
+    xs = torch.randn(16, 64, 257, 257, device=dev)
+    report("upfirdn2d blur after up-conv [16,64,257,257]->256 (nchw)", 4 * (xs.numel() + 16 * 64 * 256 * 256),
+           ev(lambda: UF.upfirdn2d(xs, f, padding=[1, 1, 1, 1], gain=4)))
+    xs = torch.randn(16, 64, 256, 256, device=dev)
+    report("upfirdn2d blur before down-conv [16,64,256,256]->257", 4 * (xs.numel() + 16 * 64 * 257 * 257),
+           ev(lambda: UF.upfirdn2d(xs, f, padding=[2, 2, 2, 2])))
+    xs = cl(16, 64, 257, 257)
+    report("upfirdn2d_nhwc blur after up-conv [16,64,257,257]->256", 4 * (xs.numel() + 16 * 64 * 256 * 256),
+           ev(lambda: UF.upfirdn2d(xs, f, padding=[1, 1, 1, 1], gain=4)))
+    xs = cl(16, 64, 256, 256)
+    report("upfirdn2d_nhwc blur before down-conv [16,64,256,256]->257", 4 * (xs.numel() + 16 * 64 * 257 * 257),
+           ev(lambda: UF.upfirdn2d(xs, f, padding=[2, 2, 2, 2])))
+    report("upfirdn2d_nhwc down=2 (1x1 skip) [16,64,256,256]->128", 4 * xs.numel() * 1.25,
+           ev(lambda: UF.upfirdn2d(xs, f, down=2, padding=[1, 1, 1, 1])))
+    xs = cl(16, 512, 16, 16)
+    report("upfirdn2d_nhwc blur [16,512,17,17]-ish small", 4 * 2 * xs.numel(), ev(lambda: UF.upfirdn2d(xs, f, padding=[2, 1, 2, 1])))
+    xs = torch.randn(16, 3, 128, 128, device=dev)
+    report("upsample2d img [16,3,128,128]->256", 4 * xs.numel() * 5, ev(lambda: UF.upsample2d(xs, f)))
+    xs = torch.randn(16, 64, 256, 256, device=dev)
+    report("downsample2d-style 1x1 skip [16,64,256,256]->128", 4 * xs.numel() * 1.25,
+           ev(lambda: UF.upfirdn2d(xs, f, down=2, padding=[1, 1, 1, 1])))
+
+
+if __name__ == "__main__":
+    main()
