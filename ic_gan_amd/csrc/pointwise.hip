@@ -225,10 +225,85 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   }
 }
 
+// Register-resident rows: cols == 256 * NV, one wavefront per row, every element read once and written once with
+// 16-byte accesses; max / sum by wave shuffles (the attention maps of the 64x64 blocks have cols = 1024 -> NV = 4).
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_fwd_reg_kernel(const float4* __restrict__ x, float4* __restrict__ y,
+                                                              long rows) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  for (long r = wave; r < rows; r += nwaves) {
+    const float4* xr = x + r * (64 * NV);
+    float4 v[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      v[k] = xr[k * 64 + lane];
+      m = fmaxf(fmaxf(m, fmaxf(v[k].x, v[k].y)), fmaxf(v[k].z, v[k].w));
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      v[k].x = expf(v[k].x - m); v[k].y = expf(v[k].y - m); v[k].z = expf(v[k].z - m); v[k].w = expf(v[k].w - m);
+      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    float4* yr = y + r * (64 * NV);
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      yr[k * 64 + lane] = make_float4(v[k].x * inv, v[k].y * inv, v[k].z * inv, v[k].w * inv);
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_bwd_reg_kernel(const float4* __restrict__ y, const float4* __restrict__ dy,
+                                                              float4* __restrict__ dx, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  for (long r = wave; r < rows; r += nwaves) {
+    const float4* yr = y + r * (64 * NV);
+    const float4* gr = dy + r * (64 * NV);
+    float4 a[NV], g[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      a[k] = yr[k * 64 + lane];
+      g[k] = gr[k * 64 + lane];
+      s += (a[k].x * g[k].x + a[k].y * g[k].y) + (a[k].z * g[k].z + a[k].w * g[k].w);
+    }
+    s = wave_sum(s);
+    float4* dr = dx + r * (64 * NV);
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      dr[k * 64 + lane] = make_float4(a[k].x * (g[k].x - s), a[k].y * (g[k].y - s), a[k].z * (g[k].z - s),
+                                      a[k].w * (g[k].w - s));
+  }
+}
+
+static bool softmax_reg_ok(const void* a, const void* b, const void* c, int cols) {
+  return cols % 256 == 0 && cols / 256 >= 1 && cols / 256 <= 8 && ((cols / 256) & (cols / 256 - 1)) == 0 &&
+         ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
 extern "C" int icg_softmax_fwd(const float* x, float* y, int64_t rows, int cols, void* stream) {
   ICG_REQUIRE(x && y && rows > 0 && cols > 0);
   long blocks = icg_cdiv(rows, 4);
   if (blocks > 8192) blocks = 8192;
+  if (softmax_reg_ok(x, y, nullptr, cols)) {
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (cols / 256) {
+      case 1: hipLaunchKernelGGL(softmax_fwd_reg_kernel<1>, grid, blk, 0, st, (const float4*)x, (float4*)y, (long)rows); break;
+      case 2: hipLaunchKernelGGL(softmax_fwd_reg_kernel<2>, grid, blk, 0, st, (const float4*)x, (float4*)y, (long)rows); break;
+      case 4: hipLaunchKernelGGL(softmax_fwd_reg_kernel<4>, grid, blk, 0, st, (const float4*)x, (float4*)y, (long)rows); break;
+      default: hipLaunchKernelGGL(softmax_fwd_reg_kernel<8>, grid, blk, 0, st, (const float4*)x, (float4*)y, (long)rows); break;
+    }
+    return icg_check_launch();
+  }
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, (long)rows,
                      cols);
   return icg_check_launch();
@@ -237,6 +312,17 @@ extern "C" int icg_softmax_bwd(const float* y, const float* dy, float* dx, int64
   ICG_REQUIRE(y && dy && dx && rows > 0 && cols > 0);
   long blocks = icg_cdiv(rows, 4);
   if (blocks > 8192) blocks = 8192;
+  if (softmax_reg_ok(y, dy, dx, cols)) {
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (cols / 256) {
+      case 1: hipLaunchKernelGGL(softmax_bwd_reg_kernel<1>, grid, blk, 0, st, (const float4*)y, (const float4*)dy, (float4*)dx, (long)rows); break;
+      case 2: hipLaunchKernelGGL(softmax_bwd_reg_kernel<2>, grid, blk, 0, st, (const float4*)y, (const float4*)dy, (float4*)dx, (long)rows); break;
+      case 4: hipLaunchKernelGGL(softmax_bwd_reg_kernel<4>, grid, blk, 0, st, (const float4*)y, (const float4*)dy, (float4*)dx, (long)rows); break;
+      default: hipLaunchKernelGGL(softmax_bwd_reg_kernel<8>, grid, blk, 0, st, (const float4*)y, (const float4*)dy, (float4*)dx, (long)rows); break;
+    }
+    return icg_check_launch();
+  }
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, dy, dx,
                      (long)rows, cols);
   return icg_check_launch();
@@ -347,6 +433,53 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     part[(long)blockIdx.x * C + c] = acc;
   }
 }
+// 16-byte version (C % 4 == 0): a thread always sees the same channel quad; 4 independent accumulation chains per thread
+// keep enough loads in flight to stream at HBM rate; order of every sum is fixed (deterministic).
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float4* __restrict__ x, long n4, int C4,
+                                                              float* __restrict__ part) {
+  __shared__ float4 buf[256];
+  const long T = (long)gridDim.x * 256;  // host guarantees T % C4 == 0
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  long i = g;
+  for (; i + 3 * T < n4; i += 4 * T) {
+    const float4 v0 = x[i], v1 = x[i + T], v2 = x[i + 2 * T], v3 = x[i + 3 * T];
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+    a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+    a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+  }
+  for (; i < n4; i += T) {
+    const float4 v0 = x[i];
+    a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+  }
+  buf[threadIdx.x] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                                 (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+  __syncthreads();
+  if (threadIdx.x < C4) {
+    const int q = threadIdx.x;           // channel quad; members are threads t with (block*256 + t) % C4 == q
+    const int first = (int)(((long)q - ((long)blockIdx.x * 256) % C4 + C4) % C4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = first; t < 256; t += C4) {
+      const float4 v = buf[t];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(part + (long)blockIdx.x * C4 * 4)[q] = acc;
+  }
+}
+
+static int colsum4_blocks(int64_t rows, int C) {
+  const int C4 = C / 4;
+  long want = icg_cdiv(rows * C4, 256 * 8);
+  if (want > 2048) want = 2048;
+  if (want < 1) want = 1;
+  int a = 256, b = C4;
+  while (b) { int t = a % b; a = b; b = t; }
+  const int q = C4 / a;
+  want = icg_cdiv(want, q) * q;
+  return (int)want;
+}
+
 // out[c] = sum_k part[k][c]; block = 32 channels x 8 slices of k (deterministic order)
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nblocks, int C,
                                                            float* __restrict__ out) {
@@ -399,7 +532,8 @@ static int colsum_wide_chunks(int64_t rows) {
 extern "C" size_t icg_colsum_workspace_bytes(int64_t rows, int C) {
   if (rows <= 0 || C <= 0) return 0;
   if (C > 256) return (size_t)colsum_wide_chunks(rows) * C * sizeof(float);
-  return (size_t)colsum_blocks(rows, C) * C * sizeof(float);
+  const int b4 = (C % 4 == 0) ? colsum4_blocks(rows, C) : 0, b1 = colsum_blocks(rows, C);
+  return (size_t)(b4 > b1 ? b4 : b1) * C * sizeof(float);
 }
 
 extern "C" int icg_colsum(const float* x, int64_t rows, int C, float* out, void* workspace, size_t workspace_bytes,
@@ -415,6 +549,15 @@ extern "C" int icg_colsum(const float* x, int64_t rows, int C, float* out, void*
                        (long)rows, C, rpc, (float*)workspace);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)icg_cdiv(C, 32)), dim3(256), 0, st,
                        (const float*)workspace, chunks, C, out);
+    return icg_check_launch();
+  }
+  if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+    const int blocks = colsum4_blocks(rows, C);
+    if (workspace_bytes < (size_t)blocks * C * sizeof(float)) return ICG_ERR_WORKSPACE;
+    hipLaunchKernelGGL(colsum_partial4_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)x, (long)rows * (C / 4),
+                       C / 4, (float*)workspace);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)icg_cdiv(C, 32)), dim3(256), 0, st, (const float*)workspace,
+                       blocks, C, out);
     return icg_check_launch();
   }
   const int blocks = colsum_blocks(rows, C);

@@ -497,7 +497,7 @@ def test_layout_pool_pointwise(B, C, H, W):
     close(*ps[0], what="scale_add d_o"); close(*ps[1], rtol=1e-4, atol_rel=1e-5, what="scale_add dgamma")
 
 
-@pytest.mark.parametrize("rows,cols", [(64, 16), (1000, 64), (4096, 256), (333, 1024), (7, 1000)])
+@pytest.mark.parametrize("rows,cols", [(64, 16), (1000, 64), (4096, 256), (333, 1024), (7, 1000), (50, 512), (9, 2048), (5, 1280)])
 def test_softmax(rows, cols):
     x = rnd(rows, cols, seed=1, scale=3.0)
     (p,) = run_pair("icg_softmax_fwd", [x, torch.empty_like(x), rows, cols], [1]); close(*p, what="softmax")
@@ -506,7 +506,7 @@ def test_softmax(rows, cols):
     close(*p, what="softmax bwd")
 
 
-@pytest.mark.parametrize("rows,C", [(4096, 96), (128, 1536), (70000, 3), (64, 1), (5000, 48), (33, 657), (16, 384)])
+@pytest.mark.parametrize("rows,C", [(4096, 96), (128, 1536), (70000, 3), (64, 1), (5000, 48), (33, 657), (16, 384), (300000, 192), (1000, 4), (123, 256), (77, 12)])
 def test_colsum(rows, C):
     L = _L()
     x = rnd(rows, C, seed=1) + 0.5
