@@ -187,9 +187,15 @@ class Generator(nn.Module):
             parts.append(self.shared_feat(feat))
         return torch.cat(parts, dim=-1) if parts else parts
 
+    def _sn_layers(self, with_feats):
+        """the spectrally normalised layers this forward is going to call"""
+        skip = set() if with_feats else {id(m) for m in self.shared_feat.modules()}
+        return [m for m in self.modules() if isinstance(m, layers.SN) and id(m) not in skip]
+
     def forward(self, z, label=None, feats=None):
         """z [B,dim_z], label [B] int64 or None, feats [B,2048] or None -> images [B,3,R,R] in [-1,1]
         (BigGAN.py:364-386)."""
+        layers.sn_prefetch(self._sn_layers(feats is not None))
         y = self.get_condition_embeddings(label, feats)
         if self.hier:
             zs = torch.split(z, self.z_chunk_size, 1)
@@ -261,6 +267,12 @@ class Discriminator(nn.Module):
 
     def forward(self, x, y=None, feat=None):
         """x [N,3,R,R], y [N] int64 or None, feat [N,2048] or None -> logits [N,1]  (BigGAN.py:617-642)."""
+        skip = set()
+        if y is None and hasattr(self, "embed"):
+            skip |= {id(m) for m in self.embed.modules()}
+        if feat is None and hasattr(self, "linear_feat"):
+            skip |= {id(m) for m in self.linear_feat.modules()}
+        layers.sn_prefetch([m for m in self.modules() if isinstance(m, layers.SN) and id(m) not in skip])
         h = x
         for stage in self.blocks:
             for block in stage:

@@ -30,6 +30,13 @@ class AdamTensor(ctypes.Structure):
                 ("exp_avg_sq", ctypes.c_void_p), ("numel", ctypes.c_int64)]
 
 
+class SnLayer(ctypes.Structure):          # icg_sn_layer
+    _fields_ = [(n, ctypes.c_void_p) for n in ("w", "u", "sv", "v_out", "u_out", "sigma_out", "w_ohwi", "w_dgrad",
+                                               "w_up_fprop", "w_up_dgrad", "w_down_fprop", "w_down_dgrad", "scratch")] + \
+               [("scratch_bytes", ctypes.c_size_t), ("rows", ctypes.c_int), ("Cin", ctypes.c_int), ("R", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
 class EmaTensor(ctypes.Structure):
     _fields_ = [("target", ctypes.c_void_p), ("source", ctypes.c_void_p), ("numel", ctypes.c_int64)]
 

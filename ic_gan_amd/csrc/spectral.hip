@@ -8,20 +8,25 @@
 #include "icg_common.h"
 
 // part[yc][j] = sum_{i in row chunk yc} u[i] * w[i][j]
-__global__ __launch_bounds__(256) void sn_uw_partial_kernel(const float* __restrict__ w, const float* __restrict__ u,
+__device__ __forceinline__ void sn_uw_partial_body(int bx, int by, int gx, const float* __restrict__ w, const float* __restrict__ u,
                                                             int rows, int cols, int rows_per_chunk,
                                                             float* __restrict__ part) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const int yc = blockIdx.y;
+  const int j = bx * 256 + threadIdx.x;
+  const int yc = by;
   if (j >= cols) return;
   const int i0 = yc * rows_per_chunk, i1 = min(rows, i0 + rows_per_chunk);
   float s = 0.f;
   for (int i = i0; i < i1; ++i) s = fmaf(u[i], w[(long)i * cols + j], s);
   part[(long)yc * cols + j] = s;
 }
+__global__ __launch_bounds__(256) void sn_uw_partial_kernel(const float* __restrict__ w, const float* __restrict__ u,
+                                                            int rows, int cols, int rows_per_chunk,
+                                                            float* __restrict__ part) {
+  sn_uw_partial_body(blockIdx.x, blockIdx.y, gridDim.x, w, u, rows, cols, rows_per_chunk, part);
+}
 
 // single block: t = sum_yc part ; v = t / max(||t||, eps)
-__global__ __launch_bounds__(1024) void sn_v_kernel(const float* __restrict__ part, int ychunks, int cols, float eps,
+__device__ __forceinline__ void sn_v_body(int bx, int by, int gx, const float* __restrict__ part, int ychunks, int cols, float eps,
                                                     float* __restrict__ v) {
   __shared__ double red[16];
   __shared__ float s_inv;
@@ -45,12 +50,16 @@ __global__ __launch_bounds__(1024) void sn_v_kernel(const float* __restrict__ pa
   const float inv = s_inv;
   for (int j = threadIdx.x; j < cols; j += 1024) v[j] *= inv;
 }
+__global__ __launch_bounds__(1024) void sn_v_kernel(const float* __restrict__ part, int ychunks, int cols, float eps,
+                                                    float* __restrict__ v) {
+  sn_v_body(blockIdx.x, blockIdx.y, gridDim.x, part, ychunks, cols, eps, v);
+}
 
 // s[i] = sum_j w[i][j] v[j]; one wavefront per row
-__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ v, int rows,
+__device__ __forceinline__ void sn_wv_body(int bx, int by, int gx, const float* __restrict__ w, const float* __restrict__ v, int rows,
                                                     int cols, float* __restrict__ s) {
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int i = bx * 4 + (threadIdx.x >> 6);
   if (i >= rows) return;
   const float* wr = w + (long)i * cols;
   float acc = 0.f;
@@ -58,9 +67,13 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w,
   acc = wave_sum(acc);
   if (lane == 0) s[i] = acc;
 }
+__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ v, int rows,
+                                                    int cols, float* __restrict__ s) {
+  sn_wv_body(blockIdx.x, blockIdx.y, gridDim.x, w, v, rows, cols, s);
+}
 
 // single block: u' = s / max(||s||, eps); sigma = s . u'
-__global__ __launch_bounds__(1024) void sn_u_kernel(const float* __restrict__ s, int rows, float eps, int training,
+__device__ __forceinline__ void sn_u_body(int bx, int by, int gx, const float* __restrict__ s, int rows, float eps, int training,
                                                     float* __restrict__ u, float* __restrict__ sv,
                                                     float* __restrict__ u_out, float* __restrict__ sigma_out) {
   __shared__ double red[16];
@@ -95,16 +108,21 @@ __global__ __launch_bounds__(1024) void sn_u_kernel(const float* __restrict__ s,
     if (training && sv) sv[0] = (float)tot;
   }
 }
+__global__ __launch_bounds__(1024) void sn_u_kernel(const float* __restrict__ s, int rows, float eps, int training,
+                                                    float* __restrict__ u, float* __restrict__ sv,
+                                                    float* __restrict__ u_out, float* __restrict__ sigma_out) {
+  sn_u_body(blockIdx.x, blockIdx.y, gridDim.x, s, rows, eps, training, u, sv, u_out, sigma_out);
+}
 
 // w_ohwi[co][r][s][ci] = w[co][ci][r][s]/sigma ; w_dgrad[ci][R-1-r][R-1-s][co] = same
-__global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__ w, const float* __restrict__ sigma,
+__device__ __forceinline__ void sn_scale_body(int bx, int by, int gx, const float* __restrict__ w, const float* __restrict__ sigma,
                                                        int rows, int Cin, int R, float* __restrict__ w_ohwi,
                                                        float* __restrict__ w_dgrad) {
   const int RR = R * R;
   const long total = (long)rows * Cin * RR;
   const float sg = sigma[0];
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+  const long stride = (long)gx * blockDim.x;
+  for (long idx = (long)bx * blockDim.x + threadIdx.x; idx < total; idx += stride) {
     // idx enumerates the OHWI destination so that the stores are coalesced
     const int ci = (int)(idx % Cin);
     long t = idx / Cin;
@@ -115,6 +133,11 @@ __global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__
     if (w_dgrad) w_dgrad[((long)ci * RR + (RR - 1 - tap)) * rows + co] = val;
   }
 }
+__global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__ w, const float* __restrict__ sigma,
+                                                       int rows, int Cin, int R, float* __restrict__ w_ohwi,
+                                                       float* __restrict__ w_dgrad) {
+  sn_scale_body(blockIdx.x, blockIdx.y, gridDim.x, w, sigma, rows, Cin, R, w_ohwi, w_dgrad);
+}
 
 // phase weights of the upsample-fused 3x3 conv (gemm_conv.hip, icg_conv2d_up_*), one thread per (co, ci):
 //   wp[al][be][co][u][v][ci] = sum_{r in S(al,u), s in S(be,v)} w[co][ci][r][s]/sigma
@@ -124,11 +147,11 @@ __global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__
 // (c0 = w0, c1 = w0+w1, c2 = w1+w2, c3 = w2) per dimension,
 //   vdn[co][P][Q][ci] = 0.25 * c[P] (x) c[Q] / sigma
 //   wq[al][be][ci][u][v][co] = vdn[co][Pd(al,u)][Pd(be,v)][ci],   Pd(0,0) = 3, Pd(0,1) = 1, Pd(1,0) = 2, Pd(1,1) = 0
-__global__ __launch_bounds__(256) void sn_up_layouts_kernel(const float* __restrict__ w, const float* __restrict__ sigma,
+__device__ __forceinline__ void sn_up_layouts_body(int bx, int by, int gx, const float* __restrict__ w, const float* __restrict__ sigma,
                                                             int rows, int Cin, float* __restrict__ wp,
                                                             float* __restrict__ vd, float* __restrict__ vdn,
                                                             float* __restrict__ wq) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long idx = (long)bx * blockDim.x + threadIdx.x;
   if (idx >= (long)rows * Cin) return;
   const int ci = (int)(idx % Cin), co = (int)(idx / Cin);
   const float inv = 1.0f / sigma[0];
@@ -194,6 +217,12 @@ __global__ __launch_bounds__(256) void sn_up_layouts_kernel(const float* __restr
     }
   }
 }
+__global__ __launch_bounds__(256) void sn_up_layouts_kernel(const float* __restrict__ w, const float* __restrict__ sigma,
+                                                            int rows, int Cin, float* __restrict__ wp,
+                                                            float* __restrict__ vd, float* __restrict__ vdn,
+                                                            float* __restrict__ wq) {
+  sn_up_layouts_body(blockIdx.x, blockIdx.y, gridDim.x, w, sigma, rows, Cin, wp, vd, vdn, wq);
+}
 
 extern "C" size_t icg_sn_scratch_bytes(int rows, int Cin, int R) {
   const long cols = (long)Cin * R * R;
@@ -231,6 +260,95 @@ extern "C" int icg_sn_forward(const float* w, float* u, float* sv, int rows, int
     if (R != 3) return ICG_ERR_ARG;
     hipLaunchKernelGGL(sn_up_layouts_kernel, dim3((unsigned)icg_cdiv((long)rows * Cin, 256)), dim3(256), 0, st, w,
                        (const float*)sigma_out, rows, Cin, w_up_fprop, w_up_dgrad, w_down_fprop, w_down_dgrad);
+  }
+  return icg_check_launch();
+}
+
+// ---------------------------------------------------------------- all layers of a network in one pass
+// The per-layer kernels above are launch-bound (76 layers x 5-6 launches x 4 forwards per training step).  The multi
+// versions run one stage for up to ICG_SN_PACK layers per launch: blockIdx.z selects the layer (descriptors travel in the
+// kernel arguments), blockIdx.x/y index inside the layer and blocks beyond a layer's own extent exit at once.  Same
+// arithmetic in the same order as the single-layer path: results are bit-identical.
+struct SnPack {
+  icg_sn_layer l[ICG_SN_PACK];
+  int ychunks[ICG_SN_PACK], rpc[ICG_SN_PACK];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void sn_uw_partial_multi_kernel(SnPack p) {
+  const icg_sn_layer& L = p.l[blockIdx.z];
+  const int cols = L.Cin * L.R * L.R;
+  if ((int)blockIdx.x * 256 >= cols || (int)blockIdx.y >= p.ychunks[blockIdx.z]) return;
+  sn_uw_partial_body(blockIdx.x, blockIdx.y, 0, L.w, L.u, L.rows, cols, p.rpc[blockIdx.z], (float*)L.scratch);
+}
+__global__ __launch_bounds__(1024) void sn_v_multi_kernel(SnPack p, float eps) {
+  const icg_sn_layer& L = p.l[blockIdx.z];
+  const int cols = L.Cin * L.R * L.R;
+  sn_v_body(0, 0, 1, (const float*)L.scratch, p.ychunks[blockIdx.z], cols, eps, L.v_out);
+}
+__global__ __launch_bounds__(256) void sn_wv_multi_kernel(SnPack p) {
+  const icg_sn_layer& L = p.l[blockIdx.z];
+  const int cols = L.Cin * L.R * L.R;
+  if ((int)blockIdx.x * 4 >= L.rows) return;
+  sn_wv_body(blockIdx.x, 0, 0, L.w, (const float*)L.v_out, L.rows, cols, (float*)L.scratch + 16L * cols);
+}
+__global__ __launch_bounds__(1024) void sn_u_multi_kernel(SnPack p, float eps, int training) {
+  const icg_sn_layer& L = p.l[blockIdx.z];
+  const int cols = L.Cin * L.R * L.R;
+  sn_u_body(0, 0, 1, (const float*)L.scratch + 16L * cols, L.rows, eps, training, L.u, L.sv, L.u_out, L.sigma_out);
+}
+__global__ __launch_bounds__(256) void sn_scale_multi_kernel(SnPack p) {
+  const icg_sn_layer& L = p.l[blockIdx.z];
+  const long total = (long)L.rows * L.Cin * L.R * L.R;
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;                        // the single-layer launch geometry (same element -> thread map)
+  if ((long)blockIdx.x >= blocks) return;
+  sn_scale_body(blockIdx.x, 0, (int)blocks, L.w, (const float*)L.sigma_out, L.rows, L.Cin, L.R, L.w_ohwi, L.w_dgrad);
+}
+__global__ __launch_bounds__(256) void sn_up_layouts_multi_kernel(SnPack p) {
+  const icg_sn_layer& L = p.l[blockIdx.z];
+  if (!(L.w_up_fprop || L.w_up_dgrad || L.w_down_fprop || L.w_down_dgrad)) return;
+  if ((long)blockIdx.x * 256 >= (long)L.rows * L.Cin) return;
+  sn_up_layouts_body(blockIdx.x, 0, 0, L.w, (const float*)L.sigma_out, L.rows, L.Cin, L.w_up_fprop, L.w_up_dgrad,
+                     L.w_down_fprop, L.w_down_dgrad);
+}
+
+extern "C" int icg_sn_forward_multi(const icg_sn_layer* layers, int n, float eps, int training, void* stream) {
+  ICG_REQUIRE(layers && n > 0);
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < n; base += ICG_SN_PACK) {
+    SnPack p{};
+    p.n = (n - base < ICG_SN_PACK) ? n - base : ICG_SN_PACK;
+    unsigned gx_uw = 1, gy_uw = 1, gx_wv = 1, gx_sc = 1, gx_up = 0;
+    for (int i = 0; i < p.n; ++i) {
+      const icg_sn_layer& L = layers[base + i];
+      ICG_REQUIRE(L.w && L.u && L.v_out && L.u_out && L.sigma_out && L.w_ohwi && L.scratch);
+      ICG_REQUIRE(L.rows > 0 && L.Cin > 0 && L.R >= 1);
+      if (L.scratch_bytes < icg_sn_scratch_bytes(L.rows, L.Cin, L.R)) return ICG_ERR_WORKSPACE;
+      const bool lay = L.w_up_fprop || L.w_up_dgrad || L.w_down_fprop || L.w_down_dgrad;
+      if (lay && L.R != 3) return ICG_ERR_ARG;
+      p.l[i] = L;
+      const int cols = L.Cin * L.R * L.R;
+      int ychunks = (int)icg_cdiv(L.rows, 64);
+      if (ychunks > 16) ychunks = 16;
+      const int rpc = (int)icg_cdiv(L.rows, ychunks);
+      ychunks = (int)icg_cdiv(L.rows, rpc);
+      p.ychunks[i] = ychunks; p.rpc[i] = rpc;
+      gx_uw = max(gx_uw, (unsigned)icg_cdiv(cols, 256));
+      gy_uw = max(gy_uw, (unsigned)ychunks);
+      gx_wv = max(gx_wv, (unsigned)icg_cdiv(L.rows, 4));
+      long sb = icg_cdiv((long)L.rows * cols, 256);
+      if (sb > 2048) sb = 2048;
+      gx_sc = max(gx_sc, (unsigned)sb);
+      if (lay) gx_up = max(gx_up, (unsigned)icg_cdiv((long)L.rows * L.Cin, 256));
+    }
+    const unsigned nz = (unsigned)p.n;
+    hipLaunchKernelGGL(sn_uw_partial_multi_kernel, dim3(gx_uw, gy_uw, nz), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(sn_v_multi_kernel, dim3(1, 1, nz), dim3(1024), 0, st, p, eps);
+    hipLaunchKernelGGL(sn_wv_multi_kernel, dim3(gx_wv, 1, nz), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(sn_u_multi_kernel, dim3(1, 1, nz), dim3(1024), 0, st, p, eps, training);
+    hipLaunchKernelGGL(sn_scale_multi_kernel, dim3(gx_sc, 1, nz), dim3(256), 0, st, p);
+    if (gx_up) hipLaunchKernelGGL(sn_up_layouts_multi_kernel, dim3(gx_up, 1, nz), dim3(256), 0, st, p);
   }
   return icg_check_launch();
 }

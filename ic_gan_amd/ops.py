@@ -63,11 +63,8 @@ class SNState:
     w_down_dgrad: Optional[torch.Tensor] = None  # [4][Cin][2][2][Cout]
 
 
-def sn_prepare(weight: torch.Tensor, u: torch.Tensor, sv: Optional[torch.Tensor], eps: float, training: bool,
-               need_dgrad: bool, upsample: bool = False, downsample: bool = False) -> SNState:
-    """One power iteration (updates `u`/`sv` in place when training) and W/sigma in kernel layouts.
-    upsample=True (3x3 conv that follows a nearest x2 upsample) emits the 4-phase 2x2 layouts instead of OHWI-dgrad."""
-    _require_gpu(weight)
+def _sn_alloc(weight, need_dgrad, upsample, downsample):
+    """-> (contiguous weight, SNState with its output buffers, scratch buffer)"""
     w = weight.detach()
     if not w.is_contiguous():
         w = w.contiguous()
@@ -90,10 +87,44 @@ def sn_prepare(weight: torch.Tensor, u: torch.Tensor, sv: Optional[torch.Tensor]
         st.w_down = _f32(16 * rows * cin, dev)
         st.w_down_dgrad = _f32(16 * rows * cin, dev) if need_dgrad else None
     nb = L.query("icg_sn_scratch_bytes", rows, cin, R)
-    scratch = _bytes(nb, dev)
-    L.call("icg_sn_forward", w, u, sv, rows, cin, R, float(eps), int(bool(training)), st.v, st.u, st.sigma,
-           st.w_ohwi, st.w_dgrad, st.w_up, st.w_up_dgrad, st.w_down, st.w_down_dgrad, scratch, nb)
+    return w, st, _bytes(nb, dev)
+
+
+def sn_prepare(weight: torch.Tensor, u: torch.Tensor, sv: Optional[torch.Tensor], eps: float, training: bool,
+               need_dgrad: bool, upsample: bool = False, downsample: bool = False) -> SNState:
+    """One power iteration (updates `u`/`sv` in place when training) and W/sigma in kernel layouts.
+    upsample=True (3x3 conv that follows a nearest x2 upsample) emits the 4-phase 2x2 layouts instead of OHWI-dgrad."""
+    _require_gpu(weight)
+    w, st, scratch = _sn_alloc(weight, need_dgrad, upsample, downsample)
+    L.call("icg_sn_forward", w, u, sv, st.rows, st.cin, st.R, float(eps), int(bool(training)), st.v, st.u, st.sigma,
+           st.w_ohwi, st.w_dgrad, st.w_up, st.w_up_dgrad, st.w_down, st.w_down_dgrad, scratch, scratch.numel())
     return st
+
+
+def sn_prepare_many(items, eps: float, training: bool):
+    """`sn_prepare` for many layers in one batched pass (icg_sn_forward_multi): items = [(weight, u, sv, need_dgrad,
+    upsample, downsample), ...] -> [SNState, ...].  Bit-identical to calling sn_prepare per layer."""
+    import ctypes
+    if not items:
+        return []
+    _require_gpu(items[0][0])
+    arr = (L.SnLayer * len(items))()
+    states, keep = [], []
+    for i, (weight, u, sv, need_dgrad, upsample, downsample) in enumerate(items):
+        w, st, scratch = _sn_alloc(weight, need_dgrad, upsample, downsample)
+        keep.append((w, scratch))
+        d = arr[i]
+        d.w, d.u, d.sv = w.data_ptr(), u.data_ptr(), (sv.data_ptr() if sv is not None else None)
+        d.v_out, d.u_out, d.sigma_out = st.v.data_ptr(), st.u.data_ptr(), st.sigma.data_ptr()
+        d.w_ohwi = st.w_ohwi.data_ptr()
+        for name, t in (("w_dgrad", st.w_dgrad), ("w_up_fprop", st.w_up), ("w_up_dgrad", st.w_up_dgrad),
+                        ("w_down_fprop", st.w_down), ("w_down_dgrad", st.w_down_dgrad)):
+            setattr(d, name, t.data_ptr() if t is not None else None)
+        d.scratch, d.scratch_bytes = scratch.data_ptr(), scratch.numel()
+        d.rows, d.Cin, d.R = st.rows, st.cin, st.R
+        states.append(st)
+    L.call("icg_sn_forward_multi", ctypes.cast(arr, ctypes.c_void_p), len(items), float(eps), int(bool(training)))
+    return states
 
 
 def _sn_backward(dw_hwio, dw_ohwi, sn: SNState, like: torch.Tensor, dw_up=None, dw_down=None) -> torch.Tensor:

@@ -230,6 +230,30 @@ int icg_sn_forward(const float* w, float* u, float* sv, int rows, int Cin, int R
  * ([4][2][2][Cin][Cout], R = 3), the pooled 4x4 form dw_down ([4][4][Cin][Cout], R = 3) — each may be NULL; dw is written / accumulated (accumulate != 0) in
  * the parameter layout.
  */
+/*
+ * The same for many layers at once (all spectrally normalised layers of a network before its forward): one launch per
+ * stage for up to ICG_SN_PACK layers instead of 5-6 launches per layer.  Bit-identical to icg_sn_forward per layer.
+ */
+#define ICG_SN_PACK 16
+typedef struct {
+  const float* w;
+  float* u;
+  float* sv;
+  float* v_out;
+  float* u_out;
+  float* sigma_out;
+  float* w_ohwi;
+  float* w_dgrad;
+  float* w_up_fprop;
+  float* w_up_dgrad;
+  float* w_down_fprop;
+  float* w_down_dgrad;
+  void* scratch;
+  size_t scratch_bytes;
+  int rows, Cin, R, reserved;
+} icg_sn_layer;
+int icg_sn_forward_multi(const icg_sn_layer* layers, int n, float eps, int training, void* stream);
+
 int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* dw_up, const float* dw_down,
                     const float* w_ohwi,
                     const float* u_saved, const float* v_saved, const float* sigma, int rows, int Cin,

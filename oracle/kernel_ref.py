@@ -643,3 +643,5 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "_require_gpu", lambda t: None)
     monkeypatch.setattr(ops, "adam_multi", adam_multi_ref)
     monkeypatch.setattr(ops, "ema_multi", ema_multi_ref)
+    monkeypatch.setattr(ops, "sn_prepare_many", lambda items, eps, training: [
+        ops.sn_prepare(w, u, sv, eps, training, nd, up, dn) for (w, u, sv, nd, up, dn) in items])

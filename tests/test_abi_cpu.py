@@ -22,6 +22,7 @@ def test_library_built_and_exports_every_declared_symbol():
 def test_descriptor_structs_match_header_layout():
     from ic_gan_amd import _lib
     assert ctypes.sizeof(_lib.AdamTensor) == 40 and ctypes.sizeof(_lib.EmaTensor) == 24
+    assert ctypes.sizeof(_lib.SnLayer) == 13 * 8 + 8 + 4 * 4
 
 
 def test_product_fails_loudly_without_gpu():

@@ -94,3 +94,45 @@ def test_train_step_host_logic(case, emu):
         check_group(g, f"step{s + 1}/G_state/", G.state_dict(), STATE_RTOL, 2e-6, "G ", extra_atol=gx)
         check_group(g, f"step{s + 1}/D_state/", D.state_dict(), STATE_RTOL, 2e-6, "D ", extra_atol=dx)
         check_group(g, f"step{s + 1}/EMA_state/", G_ema.state_dict(), STATE_RTOL, 2e-6, "EMA ", extra_atol=gx)
+
+
+def test_sn_prefetch_bookkeeping(emu):
+    """the batched spectral-norm pass is used from the second forward on, gives the same buffers as the per-layer path,
+    and an unconsumed prefetch is reported instead of silently advancing u twice."""
+    import copy
+    from ic_gan_amd import layers
+    g = load_golden("cc_ic_r64")
+    cfg = g["cfg"]
+    _, G, D = _build(g)
+    G.load_state_dict(synth.synth_state(g["gspec"], 11))
+    G2 = copy.deepcopy(G)
+    c = synth.CondSampler(cfg, G.dim_z, 2, seed=5)()
+    z, lab, fg = c
+    calls = []
+    real = layers.ops.sn_prepare_many
+    layers.ops.sn_prepare_many = lambda items, eps, training: (calls.append(len(items)), real(items, eps, training))[1]
+    try:
+        with torch.no_grad():
+            G.train(); G2.train()
+            a1 = G(z, lab, fg)
+            assert calls == []                      # layouts not known yet: per-layer path
+            a2 = G(z, lab, fg)
+            assert calls and sum(calls) == sum(1 for m in G.modules() if isinstance(m, layers.SN))
+    finally:
+        layers.ops.sn_prepare_many = real
+    noop = layers.sn_prefetch
+    layers.sn_prefetch = lambda modules: None
+    try:
+        with torch.no_grad():
+            b1 = G2(z, lab, fg)
+            b2 = G2(z, lab, fg)
+    finally:
+        layers.sn_prefetch = noop
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    for (k, v), (_, v2) in zip(G.state_dict().items(), G2.state_dict().items()):
+        assert torch.equal(v, v2), k
+    # a prefetched layer that is then not called is detected at the next forward
+    with torch.no_grad():
+        layers.sn_prefetch([G.linear])
+        with pytest.raises(RuntimeError):
+            G(z, lab, fg)

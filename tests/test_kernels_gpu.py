@@ -583,3 +583,27 @@ def test_upfirdn2d(case):
     (p,) = run_pair("icg_upfirdn2d", [x, f, y, N, C, H, W, fh, fw, up, up, down, down, px0, px1, py0, py1, flip, 1.7,
                                       outH, outW], [2])
     close(*p, rtol=2e-5, atol_rel=2e-5, what=f"upfirdn2d {case}")
+
+
+def test_sn_forward_multi_bit_identical():
+    """icg_sn_forward_multi (all layers of a network in one pass) == icg_sn_forward per layer, bit for bit, including the
+    in-place u / sv updates; more layers than one descriptor pack holds."""
+    from ic_gan_amd import ops
+    shapes = [(96, 192, 3), (3, 96, 3), (1536, 17, 1), (24, 8, 3), (768, 768, 1), (64, 128, 3), (1000, 128, 1)] * 3
+    flags = [(True, False, False), (False, False, False), (True, False, False), (True, True, False), (True, False, False),
+             (True, False, True), (False, False, False)] * 3
+    items_a, items_b = [], []
+    for i, ((co, ci, r), fl) in enumerate(zip(shapes, flags)):
+        w = rnd(*((co, ci, r, r) if r > 1 else (co, ci)), seed=100 + i).cuda()
+        u = rnd(1, co, seed=200 + i).cuda()
+        items_a.append((w, u.clone(), torch.ones(1, device="cuda")) + fl)
+        items_b.append((w, u.clone(), torch.ones(1, device="cuda")) + fl)
+    many = ops.sn_prepare_many(items_a, 1e-6, True)
+    for (w, u, sv, nd, up, dn), (_, u2, sv2, _, _, _), st in zip(items_b, items_a, many):
+        one = ops.sn_prepare(w, u, sv, 1e-6, True, nd, up, dn)
+        assert torch.equal(u, u2) and torch.equal(sv, sv2)
+        for name in ("w_ohwi", "w_dgrad", "u", "v", "sigma", "w_up", "w_up_dgrad", "w_down", "w_down_dgrad"):
+            a, b = getattr(one, name), getattr(st, name)
+            assert (a is None) == (b is None), name
+            if a is not None:
+                assert torch.equal(a, b), name
