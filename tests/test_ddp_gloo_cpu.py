@@ -140,3 +140,54 @@ def test_syncbn_two_ranks_equal_one_process_on_full_batch(monkeypatch):
     assert torch.allclose(out["rv"], G.output_layer[0].stored_var, rtol=1e-5, atol=1e-6)
     rel = float((out["grads"] - grads).norm() / grads.norm())
     assert rel < 1e-4, rel
+
+
+def _worker_stylegan2(rank, world, port, out):
+    """StyleGAN2 iteration under DDP (mapping / synthesis / D wrapped separately like training_loop.py:293-310), two
+    accumulation rounds per phase so that the no_sync path (loss.py run_G / run_D `sync` argument) is exercised."""
+    import copy
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from ic_gan_amd.stylegan2 import networks as N
+    from ic_gan_amd.stylegan2.training_step import TrainingStep
+    from tests.stylegan_cases import SG2_LOSS, SG2_NETS, SG2_OPT, sg2_inputs, sg2_state
+    _init(rank, world, port)
+    cfg = SG2_NETS["cc_ic_r16_resnetG"]
+
+    def load(m, seed):
+        spec = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+        cur = m.state_dict()
+        m.load_state_dict({k: (cur[k] if v is None else v) for k, v in sg2_state(spec, seed).items()})
+
+    G = N.Generator(**cfg["G"]).train().requires_grad_(False)
+    D = N.Discriminator(**cfg["D"]).train().requires_grad_(False)
+    load(G, 1); load(D, 2)
+    G_ema = copy.deepcopy(G).eval()
+    mods = {}
+    for name, m in (("G_mapping", G.mapping), ("G_synthesis", G.synthesis), ("D", D)):
+        m.requires_grad_(True)
+        mods[name] = DDP(m, broadcast_buffers=False)
+        m.requires_grad_(False)
+    step = TrainingStep(G, D, G_ema, "cpu", batch_size=8, batch_gpu=2, num_gpus=world, loss_kwargs=SG2_LOSS,
+                        G_opt_kwargs=SG2_OPT, D_opt_kwargs=SG2_OPT, G_reg_interval=4, D_reg_interval=16, ema_kimg=0.02,
+                        ddp_modules=mods)
+    torch.manual_seed(1234 + rank)
+    z, gc, gh, img, rc, rh = sg2_inputs({**cfg, "batch": 4}, 40 + rank, 4)
+    ran = step(img, rc, rh, z, gc, gh)
+    flat = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        out["ran"] = ran
+        out["identical"] = bool(torch.equal(gathered[0], gathered[1]))
+        out["finite"] = bool(torch.isfinite(flat).all())
+        start = torch.cat([v.reshape(-1) for k, v in sg2_state([[k, list(v.shape)] for k, v in G.state_dict().items()], 1).items()
+                           if v is not None and k in dict(G.named_parameters())])
+        out["moved"] = bool((flat[: start.numel()] - start).abs().max() > 0)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_stylegan2_ddp_iteration_keeps_replicas_identical():
+    out = _spawn(_worker_stylegan2)
+    assert out["ran"] == ["Gmain", "Greg", "Dmain", "Dreg"]
+    assert out["finite"] and out["identical"] and out["moved"], out
