@@ -88,7 +88,13 @@ class KernelTimer:
             raw(name, *args)
             e.record()
             query(last)
-            kname = "void icg_gemm_kernel<%d, %d, %d, %d>(GemmP)" % tuple(last)
+            if last[0] == -2:      # direct narrow-output kernels (narrow_conv.hip): {-2, fprop/wgrad, Cout, Cin}
+                lp = 1
+                while lp < last[3] // 4:
+                    lp *= 2
+                kname = "void narrow_%s_kernel<%d, %d>" % ("wgrad" if last[1] else "fprop", last[2], lp)
+            else:
+                kname = "void icg_gemm_kernel<%d, %d, %d, %d>(GemmP)" % tuple(last)
             timer.records.append((kname, alg, exe, byt, s, e))
 
         L.call = timed_call

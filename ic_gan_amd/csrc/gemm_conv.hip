@@ -733,6 +733,14 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// direct kernels for 3x3 convolutions with <= 4 output channels (narrow_conv.hip)
+bool icg_narrow_conv_ok(int Cin, int Cout, int R, const void* a, const void* b, const void* c, long ssb);
+int icg_narrow_fprop(const float* x, const float* w, const float* bias, const float* scale, const float* shift, long ssb,
+                     float* out, int B, int H, int W, int Cin, int Cout, int affine, int relu, float alpha, hipStream_t st);
+size_t icg_narrow_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int icg_narrow_wgrad(const float* x, const float* dy, const float* scale, const float* shift, long ssb, float* dw,
+                     void* workspace, int B, int H, int W, int Cin, int Cout, int affine, int relu, hipStream_t st);
+
 extern "C" int icg_conv2d_fprop(const float* x, const float* w, const float* bias, const float* residual,
                                 float* out, const float* scale, const float* shift, int64_t ss_bstride, int B,
                                 int H, int W, int Cin, int Cout, int R, unsigned flags, float alpha,
@@ -745,6 +753,14 @@ extern "C" int icg_conv2d_fprop(const float* x, const float* w, const float* bia
   if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift);
   const long M = (long)B * H * W;
   ICG_REQUIRE(M < 0x7fffffffL);
+  if (!up && !residual && aligned16(x) && M * Cin < 0x7fffffffL &&
+      icg_narrow_conv_ok(Cin, Cout, R, w, (flags & ICG_PRE_AFFINE) ? scale : nullptr,
+                         (flags & ICG_PRE_AFFINE) ? shift : nullptr, (flags & ICG_PRE_AFFINE) ? ss_bstride : 0))
+  {
+    g_last_variant[0] = -2; g_last_variant[1] = 0; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
+    return icg_narrow_fprop(x, w, bias, scale, shift, ss_bstride, out, B, H, W, Cin, Cout,
+                            (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0, alpha, (hipStream_t)stream);
+  }
   GemmP p{};
   p.A = x; p.B = w; p.C = out;
   p.M = (int)M; p.N = Cout; p.K = R * R * Cin;
@@ -789,8 +805,12 @@ extern "C" size_t icg_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin,
   const long K = (long)B * H * W;
   const int M = R * R * Cin;
   WgradPlan pl = wgrad_plan(K, M, Cout);
-  if (pl.splits <= 1) return 16;
-  return (size_t)pl.splits * (size_t)M * (size_t)Cout * sizeof(float);
+  size_t need = (pl.splits <= 1) ? 16 : (size_t)pl.splits * (size_t)M * (size_t)Cout * sizeof(float);
+  if (icg_narrow_conv_ok(Cin, Cout, R, nullptr, nullptr, nullptr, 0)) {      // the direct kernel may be chosen at run time
+    const size_t nn = icg_narrow_wgrad_workspace_bytes(B, H, W, Cin, Cout);
+    if (nn > need) need = nn;
+  }
+  return need;
 }
 
 extern "C" int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* scale,
@@ -804,6 +824,15 @@ extern "C" int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
   const long K = (long)B * H * W;
   ICG_REQUIRE(K < 0x7fffffffL);
   const int M = R * R * Cin;
+  if (!up && aligned16(x) && K * Cin < 0x7fffffffL &&
+      icg_narrow_conv_ok(Cin, Cout, R, (flags & ICG_PRE_AFFINE) ? scale : nullptr,
+                         (flags & ICG_PRE_AFFINE) ? shift : nullptr, nullptr, (flags & ICG_PRE_AFFINE) ? ss_bstride : 0)) {
+    if (workspace == nullptr || workspace_bytes < icg_narrow_wgrad_workspace_bytes(B, H, W, Cin, Cout))
+      return ICG_ERR_WORKSPACE;
+    g_last_variant[0] = -2; g_last_variant[1] = 1; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
+    return icg_narrow_wgrad(x, dy, scale, shift, ss_bstride, dw, workspace, B, H, W, Cin, Cout,
+                            (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0, (hipStream_t)stream);
+  }
   WgradPlan pl = wgrad_plan(K, M, Cout);
   const size_t need = (pl.splits <= 1) ? 0 : (size_t)pl.splits * M * Cout * sizeof(float);
   if (need > 0 && (workspace == nullptr || workspace_bytes < need)) return ICG_ERR_WORKSPACE;

@@ -1,0 +1,263 @@
+// 3x3 convolutions with 1..4 output channels (the generator's to-RGB layer, BigGAN.py:251-262, and the data gradient of
+// the discriminator's from-RGB layer) and their weight gradient.  A GEMM tile would waste >= 29/32 of every MFMA on
+// them; they are HBM-bound (one pass over the wide tensor), so they get direct kernels:
+//   * a group of LP lanes (LP = power of two >= Cin/4, <= 64) owns one pixel, lane q the channel quad q: the 16-byte loads
+//     of a group are contiguous, the 9 x NOUT weight quads of a lane stay in registers for the whole kernel;
+//   * fprop: per-lane partial dot products over the 9 taps, then a log2(LP)-step shuffle reduction per output channel;
+//   * wgrad: per-lane accumulators dw[tap][quad][co] over the block's pixels, combined across pixel groups through LDS
+//     into one slab per block; the slabs are summed by the deterministic split-K reduction kernel.
+// Prologue (per-sample affine + ReLU, zero padding applied AFTER the activation) as in the GEMM loader.
+#include "icg_common.h"
+
+__device__ __forceinline__ float4 nc_act(float4 v, const float4& sc, const float4& sh, bool affine, bool relu) {
+  if (affine) {
+    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+  }
+  if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  return v;
+}
+
+// out[b,h,w,o] = alpha * sum_{tap,c} act(x)[b,h+r-1,w+s-1,c] * wgt[o][tap][c] + bias[o]
+template <int NOUT, int LP>
+__global__ __launch_bounds__(256) void narrow_fprop_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                           const float* __restrict__ bias, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, long ssb,
+                                                           float* __restrict__ out, int B, int H, int W, int Cin,
+                                                           int affine, int relu, float alpha) {
+  constexpr int GPW = 256 / LP;                     // pixel groups per block
+  const int q = threadIdx.x % LP, grp = threadIdx.x / LP;
+  const int Q = Cin >> 2;
+  const bool lane_on = q < Q;
+  const unsigned qa = (unsigned)(lane_on ? q : Q - 1);      // address lane (idle lanes re-read the last quad)
+  float4 wr[NOUT][9];
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      wr[o][t] = lane_on ? *reinterpret_cast<const float4*>(wgt + ((long)o * 9 + t) * Cin + 4 * q)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+  // 32-bit index arithmetic throughout (the host checks that every offset fits)
+  const unsigned npix = (unsigned)B * H * W, HW = (unsigned)H * W;
+  const unsigned gstride = gridDim.x * GPW;
+  for (unsigned p = blockIdx.x * GPW + grp; p < npix; p += gstride) {
+    const unsigned b = p / HW, rem = p - b * HW;
+    const int h0 = (int)(rem / (unsigned)W);
+    const int w0 = (int)(rem - (unsigned)h0 * W);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (affine) {
+      sc = *reinterpret_cast<const float4*>(scale + b * (unsigned)ssb + 4 * qa);
+      sh = *reinterpret_cast<const float4*>(shift + b * (unsigned)ssb + 4 * qa);
+    }
+    float acc[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) acc[o] = 0.f;
+    // all nine loads are issued before the first use (clamped addresses, no branches): one memory latency per pixel
+    float4 v[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int hi = h0 + t / 3 - 1, wi = w0 + t % 3 - 1;
+      ok[t] = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      const unsigned hc = (unsigned)min(max(hi, 0), H - 1), wc = (unsigned)min(max(wi, 0), W - 1);
+      v[t] = *reinterpret_cast<const float4*>(x + ((b * H + hc) * W + wc) * (unsigned)Cin + 4 * qa);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float4 a = nc_act(v[t], sc, sh, affine, relu);
+      if (!ok[t]) a = make_float4(0.f, 0.f, 0.f, 0.f);            // zero padding applies to the activated tensor
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o)
+        acc[o] += (a.x * wr[o][t].x + a.y * wr[o][t].y) + (a.z * wr[o][t].z + a.w * wr[o][t].w);   // wr = 0 on idle lanes
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+#pragma unroll
+      for (int d = LP / 2; d >= 1; d >>= 1) acc[o] += __shfl_xor(acc[o], d, 64);
+    }
+    if (q == 0) {
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) out[(long)p * NOUT + o] = alpha * acc[o] + (bias ? bias[o] : 0.f);
+    }
+  }
+}
+
+// slab[block][tap][c][o] = sum over the block's pixels of act(x)[pix + tap][c] * dy[pix][o]      (HWIO, like the GEMM wgrad)
+template <int NOUT, int LP>
+__global__ __launch_bounds__(256) void narrow_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           long ssb, float* __restrict__ slabs, int B, int H, int W, int Cin,
+                                                           int affine, int relu) {
+  constexpr int GPW = 256 / LP;
+  __shared__ float red[256 * 4];                     // one float4 per thread at a time
+  const int q = threadIdx.x % LP, grp = threadIdx.x / LP;
+  const int Q = Cin >> 2;
+  const bool lane_on = q < Q;
+  const unsigned qa = (unsigned)(lane_on ? q : Q - 1);
+  float4 acc[9][NOUT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) acc[t][o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned npix = (unsigned)B * H * W, HW = (unsigned)H * W;
+  const unsigned gstride = gridDim.x * GPW;
+  for (unsigned p = blockIdx.x * GPW + grp; p < npix; p += gstride) {
+    const unsigned b = p / HW, rem = p - b * HW;
+    const int h0 = (int)(rem / (unsigned)W);
+    const int w0 = (int)(rem - (unsigned)h0 * W);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (affine) {
+      sc = *reinterpret_cast<const float4*>(scale + b * (unsigned)ssb + 4 * qa);
+      sh = *reinterpret_cast<const float4*>(shift + b * (unsigned)ssb + 4 * qa);
+    }
+    float g[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) g[o] = dy[(long)p * NOUT + o];
+    float4 v[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int hi = h0 + t / 3 - 1, wi = w0 + t % 3 - 1;
+      ok[t] = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      const unsigned hc = (unsigned)min(max(hi, 0), H - 1), wc = (unsigned)min(max(wi, 0), W - 1);
+      v[t] = *reinterpret_cast<const float4*>(x + ((b * H + hc) * W + wc) * (unsigned)Cin + 4 * qa);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float4 a = nc_act(v[t], sc, sh, affine, relu);
+      if (!ok[t]) a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {          // idle lanes accumulate garbage that is never written out
+        acc[t][o].x = fmaf(a.x, g[o], acc[t][o].x); acc[t][o].y = fmaf(a.y, g[o], acc[t][o].y);
+        acc[t][o].z = fmaf(a.z, g[o], acc[t][o].z); acc[t][o].w = fmaf(a.w, g[o], acc[t][o].w);
+      }
+    }
+  }
+  // combine the GPW pixel groups of the block (fixed order), lane q of group 0 writes its channel quad
+  float* slab = slabs + (long)blockIdx.x * 9 * Cin * NOUT;
+  float4* red4 = reinterpret_cast<float4*>(red);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      __syncthreads();
+      red4[threadIdx.x] = acc[t][o];
+      __syncthreads();
+      if (grp == 0 && lane_on) {
+        float4 s = red4[q];
+        for (int gI = 1; gI < GPW; ++gI) {
+          const float4 v = red4[gI * LP + q];
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float* dst = slab + ((long)t * Cin + 4 * q) * NOUT + o;
+        dst[0] = s.x; dst[NOUT] = s.y; dst[2 * NOUT] = s.z; dst[3 * NOUT] = s.w;
+      }
+    }
+}
+
+// out[i] = sum_z slab[z][i]; block = 32 outputs x 8 interleaved slices of z, combined in fixed order (deterministic)
+__global__ __launch_bounds__(256) void narrow_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                            long n, int splits) {
+  __shared__ float red[8][32];
+  const int il = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long i = (long)blockIdx.x * 32 + il;
+  float s = 0.f;
+  if (i < n)
+    for (int z = sl; z < splits; z += 8) s += slabs[(long)z * n + i];
+  red[sl][il] = s;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    for (int k = 1; k < 8; ++k) s += red[k][il];
+    out[i] = s;
+  }
+}
+
+static int narrow_lp(int Cin) {
+  const int Q = Cin / 4;
+  int lp = 1;
+  while (lp < Q) lp <<= 1;
+  return lp;
+}
+
+static int narrow_blocks(long npix, int lp, int cap = 4096) {
+  const long groups = 256 / lp;
+  long b = icg_cdiv(npix, groups * 8);
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+bool icg_narrow_conv_ok(int Cin, int Cout, int R, const void* a, const void* b, const void* c, long ssb) {
+  return R == 3 && ssb >= 0 && ssb < (1L << 20) && Cout >= 1 && Cout <= 4 && Cin % 4 == 0 && Cin >= 16 && Cin <= 256 && (ssb % 4 == 0) &&
+         ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
+template <int NOUT>
+static void narrow_fprop_lp(int lp, dim3 grid, hipStream_t st, const float* x, const float* w, const float* bias,
+                            const float* scale, const float* shift, long ssb, float* out, int B, int H, int W, int Cin,
+                            int affine, int relu, float alpha) {
+#define ICG_NF(LP_) \
+  hipLaunchKernelGGL((narrow_fprop_kernel<NOUT, LP_>), grid, dim3(256), 0, st, x, w, bias, scale, shift, ssb, out, B, H, W, \
+                     Cin, affine, relu, alpha)
+  switch (lp) {
+    case 4: ICG_NF(4); break;
+    case 8: ICG_NF(8); break;
+    case 16: ICG_NF(16); break;
+    case 32: ICG_NF(32); break;
+    default: ICG_NF(64); break;
+  }
+#undef ICG_NF
+}
+
+int icg_narrow_fprop(const float* x, const float* w, const float* bias, const float* scale, const float* shift, long ssb,
+                     float* out, int B, int H, int W, int Cin, int Cout, int affine, int relu, float alpha,
+                     hipStream_t st) {
+  const int lp = narrow_lp(Cin);
+  const dim3 grid((unsigned)narrow_blocks((long)B * H * W, lp));
+  switch (Cout) {
+    case 1: narrow_fprop_lp<1>(lp, grid, st, x, w, bias, scale, shift, ssb, out, B, H, W, Cin, affine, relu, alpha); break;
+    case 2: narrow_fprop_lp<2>(lp, grid, st, x, w, bias, scale, shift, ssb, out, B, H, W, Cin, affine, relu, alpha); break;
+    case 3: narrow_fprop_lp<3>(lp, grid, st, x, w, bias, scale, shift, ssb, out, B, H, W, Cin, affine, relu, alpha); break;
+    default: narrow_fprop_lp<4>(lp, grid, st, x, w, bias, scale, shift, ssb, out, B, H, W, Cin, affine, relu, alpha); break;
+  }
+  return icg_check_launch();
+}
+
+size_t icg_narrow_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  const int lp = narrow_lp(Cin);
+  return (size_t)narrow_blocks((long)B * H * W, lp, 768) * 9 * Cin * Cout * sizeof(float);
+}
+
+template <int NOUT>
+static void narrow_wgrad_lp(int lp, dim3 grid, hipStream_t st, const float* x, const float* dy, const float* scale,
+                            const float* shift, long ssb, float* slabs, int B, int H, int W, int Cin, int affine,
+                            int relu) {
+#define ICG_NW(LP_) \
+  hipLaunchKernelGGL((narrow_wgrad_kernel<NOUT, LP_>), grid, dim3(256), 0, st, x, dy, scale, shift, ssb, slabs, B, H, W, Cin, \
+                     affine, relu)
+  switch (lp) {
+    case 4: ICG_NW(4); break;
+    case 8: ICG_NW(8); break;
+    case 16: ICG_NW(16); break;
+    case 32: ICG_NW(32); break;
+    default: ICG_NW(64); break;
+  }
+#undef ICG_NW
+}
+
+int icg_narrow_wgrad(const float* x, const float* dy, const float* scale, const float* shift, long ssb, float* dw,
+                     void* workspace, int B, int H, int W, int Cin, int Cout, int affine, int relu, hipStream_t st) {
+  const int lp = narrow_lp(Cin);
+  const int blocks = narrow_blocks((long)B * H * W, lp, 768);
+  float* slabs = (float*)workspace;
+  const dim3 grid((unsigned)blocks);
+  switch (Cout) {
+    case 1: narrow_wgrad_lp<1>(lp, grid, st, x, dy, scale, shift, ssb, slabs, B, H, W, Cin, affine, relu); break;
+    case 2: narrow_wgrad_lp<2>(lp, grid, st, x, dy, scale, shift, ssb, slabs, B, H, W, Cin, affine, relu); break;
+    case 3: narrow_wgrad_lp<3>(lp, grid, st, x, dy, scale, shift, ssb, slabs, B, H, W, Cin, affine, relu); break;
+    default: narrow_wgrad_lp<4>(lp, grid, st, x, dy, scale, shift, ssb, slabs, B, H, W, Cin, affine, relu); break;
+  }
+  const long n = 9L * Cin * Cout;
+  hipLaunchKernelGGL(narrow_reduce_kernel, dim3((unsigned)icg_cdiv(n, 32)), dim3(256), 0, st, (const float*)slabs, dw, n,
+                     blocks);
+  return icg_check_launch();
+}

@@ -148,7 +148,8 @@ int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int
 /*
  * Measurement support (no reference counterpart): template arguments {AMODE, BMODE, TN, PATH} of the last
  * icg_gemm_kernel<AMODE, BMODE, TN, PATH> launched by the calling host thread through any of the conv / GEMM
- * entry points above ({-1,...} before the first launch).  bench.py uses it to label its HIP-event timings with
+ * entry points above ({-1,...} before the first launch; {-2, 0 fprop / 1 wgrad, Cout, Cin} when the direct
+ * narrow-output kernels of narrow_conv.hip ran instead).  bench.py uses it to label its HIP-event timings with
  * exactly the kernel name rocprofv3 reports.
  */
 int icg_gemm_last_variant(int* out4);

@@ -76,6 +76,10 @@ CONV_CASES = [
     (8, 1, 1, 128, 1, 1, 0, 0, True),                    # D output linear (N = 1)
     (1, 32, 32, 32, 160, 3, 0, 0, True),                 # N = 160 -> TN = 4 with ragged last tile
     (5, 2, 2, 20, 20, 3, PRE_AFFINE, 0, True),           # tiny spatial, affine without relu
+    (3, 7, 5, 16, 1, 3, 0, 0, False),                    # direct narrow-output kernels (narrow_conv.hip): LP = 4
+    (1, 9, 9, 192, 4, 3, PRE_AFFINE | PRE_RELU, 0, True),  # LP = 64 with 48 active lanes, 4 outputs
+    (2, 4, 6, 256, 2, 3, PRE_RELU, 0, True),             # LP = 64 full
+    (2, 8, 8, 64, 3, 3, PRE_AFFINE, 0, False),           # LP = 16, affine without relu
 ]
 
 
