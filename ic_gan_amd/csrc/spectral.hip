@@ -444,6 +444,57 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// Coalesced form of the gather + dot: the HWIO-ordered sources (dw_hwio and the phase / pooled gradients, all with co as
+// the fastest index) are read 32x32 tiles at a time with co across lanes, transposed through LDS and written to
+// g[co][tap][ci] (OHWI, the order of w_ohwi and dw_ohwi) with (tap, ci) across lanes; <g, w_ohwi> is accumulated on the way.
+__global__ __launch_bounds__(256) void sn_bwd_gather_kernel(const float* __restrict__ dw_hwio,
+                                                            const float* __restrict__ dw_ohwi,
+                                                            const float* __restrict__ dw_up,
+                                                            const float* __restrict__ dw_down,
+                                                            const float* __restrict__ w_ohwi, int rows, int Cin, int RR,
+                                                            float* __restrict__ g_out, double* __restrict__ part) {
+  __shared__ float tile[32][33];
+  __shared__ double red[4];
+  const int K = Cin * RR;
+  const int tk = (K + 31) / 32, tc = (rows + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  double acc = 0.0;
+  for (int tno = blockIdx.x; tno < tk * tc; tno += gridDim.x) {
+    const int k0 = (tno % tk) * 32, c0 = (tno / tk) * 32;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kk = k0 + ty + 8 * r, co = c0 + tx;
+      float v = 0.f;
+      if (kk < K && co < rows) {
+        const int tap = kk / Cin, ci = kk - tap * Cin;
+        v = sn_gather_g(dw_hwio, nullptr, dw_up, dw_down, co, ci, tap, rows, Cin, RR);
+      }
+      tile[ty + 8 * r][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = c0 + ty + 8 * r, kk = k0 + tx;
+      if (kk < K && co < rows) {
+        const long o = (long)co * K + kk;
+        float g = tile[tx][ty + 8 * r];
+        if (dw_ohwi) g += dw_ohwi[o];
+        g_out[o] = g;
+        acc += (double)g * (double)w_ohwi[o];
+      }
+    }
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+extern "C" size_t icg_sn_backward_scratch_bytes(int rows, int Cin, int R) {
+  return 256 * sizeof(double) + (size_t)rows * Cin * R * R * sizeof(float);
+}
+
 extern "C" int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* dw_up, const float* dw_down,
                                const float* w_ohwi, const float* u_saved,
                                const float* v_saved, const float* sigma, int rows, int Cin, int R, float* dw,
@@ -456,6 +507,18 @@ extern "C" int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const
   const long total = (long)rows * Cin * RR;
   int nparts = (int)(icg_cdiv(total, 1024) > 256 ? 256 : icg_cdiv(total, 1024));
   hipStream_t st = (hipStream_t)stream;
+  if ((dw_hwio || dw_up || dw_down) && scratch_bytes >= icg_sn_backward_scratch_bytes(rows, Cin, R)) {
+    // two coalesced passes: transpose-gather into OHWI order (+ dot), then the correction in parameter order
+    float* g = reinterpret_cast<float*>(reinterpret_cast<double*>(scratch) + 256);
+    hipLaunchKernelGGL(sn_bwd_gather_kernel, dim3(nparts), dim3(256), 0, st, dw_hwio, dw_ohwi, dw_up, dw_down, w_ohwi, rows,
+                       Cin, RR, g, (double*)scratch);
+    long blocks2 = icg_cdiv(total, 256);
+    if (blocks2 > 2048) blocks2 = 2048;
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)blocks2), dim3(256), 0, st, (const float*)nullptr,
+                       (const float*)g, (const float*)nullptr, (const float*)nullptr, u_saved, v_saved, sigma,
+                       (const double*)scratch, nparts, rows, Cin, RR, dw, accumulate);
+    return icg_check_launch();
+  }
   hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(nparts), dim3(256), 0, st, dw_hwio, dw_ohwi, dw_up, dw_down, w_ohwi, rows, Cin, RR,
                      (double*)scratch);
   long blocks = icg_cdiv(total, 256);

@@ -129,9 +129,10 @@ def sn_prepare_many(items, eps: float, training: bool):
 
 def _sn_backward(dw_hwio, dw_ohwi, sn: SNState, like: torch.Tensor, dw_up=None, dw_down=None) -> torch.Tensor:
     dw = torch.empty_like(like, memory_format=torch.contiguous_format)
-    scratch = _bytes(256 * 8, like.device)
+    nb = L.query("icg_sn_backward_scratch_bytes", sn.rows, sn.cin, sn.R)
+    scratch = _bytes(nb, like.device)
     L.call("icg_sn_backward", dw_hwio, dw_ohwi, dw_up, dw_down, sn.w_ohwi, sn.u, sn.v, sn.sigma, sn.rows, sn.cin, sn.R, dw, 0,
-           scratch, 256 * 8)
+           scratch, nb)
     return dw
 
 

@@ -255,6 +255,8 @@ typedef struct {
 } icg_sn_layer;
 int icg_sn_forward_multi(const icg_sn_layer* layers, int n, float eps, int training, void* stream);
 
+/* scratch for icg_sn_backward: 256 doubles (minimum; uncoalesced gather) or this size (coalesced two-pass form) */
+size_t icg_sn_backward_scratch_bytes(int rows, int Cin, int R);
 int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* dw_up, const float* dw_down,
                     const float* w_ohwi,
                     const float* u_saved, const float* v_saved, const float* sigma, int rows, int Cin,

@@ -343,6 +343,10 @@ def icg_sn_forward(w, u, sv, rows, Cin, R, eps, training, v_out, u_out, sigma_ou
             w_down_dgrad.copy_(wq.reshape(-1))
 
 
+def icg_sn_backward_scratch_bytes(rows, Cin, R):
+    return 256 * 8 + rows * Cin * R * R * 4
+
+
 def icg_sn_backward(dw_hwio, dw_ohwi, dw_up, dw_down, w_ohwi, u_saved, v_saved, sigma, rows, Cin, R, dw, accumulate,
                     scratch, scratch_bytes):
     g = torch.zeros(rows, Cin, R, R)

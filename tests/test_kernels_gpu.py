@@ -611,3 +611,27 @@ def test_sn_forward_multi_bit_identical():
             assert (a is None) == (b is None), name
             if a is not None:
                 assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("rows,Cin,taps", [(32, 32, 3), (3, 96, 3), (96, 3, 3), (1000, 64, 1), (130, 70, 3), (17, 5, 1)])
+def test_sn_backward_coalesced_path(rows, Cin, taps):
+    """icg_sn_backward with the large scratch (tile-transposed gather) == the minimum-scratch path == the CPU reference,
+    with every gradient source present at once."""
+    L = _L()
+    n = rows * Cin * taps * taps
+    wo = rnd(n, seed=1, scale=0.1)
+    uo, v, sg = rnd(rows, seed=2), rnd(Cin * taps * taps, seed=3), torch.tensor([1.7])
+    hw, oh = rnd(n, seed=4), rnd(n, seed=5)
+    up = rnd(16 * rows * Cin, seed=6) if taps == 3 else None
+    dn = rnd(16 * rows * Cin, seed=7) if taps == 3 else None
+    ref = torch.empty(rows, Cin, taps, taps)
+    R.icg_sn_backward(hw, oh, up, dn, wo, uo, v, sg, rows, Cin, taps, ref, 0, torch.empty(4096, dtype=torch.uint8), 4096)
+    c = lambda t: None if t is None else t.cuda()
+    outs = []
+    for nb in (256 * 8, L.query("icg_sn_backward_scratch_bytes", rows, Cin, taps)):
+        dw = torch.empty(rows, Cin, taps, taps, device="cuda")
+        sc = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        L.call("icg_sn_backward", c(hw), c(oh), c(up), c(dn), c(wo), c(uo), c(v), c(sg), rows, Cin, taps, dw, 0, sc, nb)
+        outs.append(dw)
+        close(dw, ref, rtol=5e-5, atol_rel=5e-5, what=f"sn bwd scratch={nb}")
+    close(outs[0], outs[1], rtol=1e-6, atol_rel=1e-6, what="two sn backward paths")
