@@ -254,6 +254,89 @@ def bench_stylegan2(args, device, rank, world, local_rank, use_ddp):
             "roofline": None, "cpu_baseline": None}), flush=True)
 
 
+def bench_biggan_deep(args, device, rank, world, local_rank, use_ddp):
+    """Secondary workload (BASELINE.json configs[4]): BigGAN-deep 256x256 ch=128, bs=128/GPU, class-conditional, attention
+    at 64.  The reference's IC-GAN step function cannot drive this model (its G_D has no feature arguments), so the step is
+    the plain BigGAN schedule it was written for: 1 D update (G forward without grad, D on fake||real, hinge) + 1 G update
+    (hinge) with Adam(beta1 = 0), toggle_grads on; no EMA."""
+    import ic_gan_amd.BigGANdeep as M
+    from ic_gan_amd import losses, utils
+    b = args.batch or 128
+    cfg = dict(G_ch=128, D_ch=128, G_depth=2, D_depth=2, dim_z=128, shared_dim=128, hier=True, G_shared=True,
+               resolution=256, G_attn="64", D_attn="64", n_classes=1000, SN_eps=1e-6, BN_eps=1e-5, adam_eps=1e-6,
+               G_lr=5e-5, D_lr=2e-4, G_B1=0.0, D_B1=0.0, G_B2=0.999, D_B2=0.999, G_init="N02", D_init="N02")
+    utils.seed_rng(rank)
+    G, D = M.Generator(**cfg).to(device), M.Discriminator(**cfg).to(device)
+    Gw, Dw = G, D
+    if use_ddp:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        Gw = DDP(G, device_ids=[local_rank], find_unused_parameters=True)
+        Dw = DDP(D, device_ids=[local_rank], find_unused_parameters=True)
+
+    class _GD(torch.nn.Module):            # G_D over the (possibly DDP-wrapped) modules, shared embedding from the bare G
+        def forward(self, z, gy, x=None, dy=None, train_G=False):
+            with torch.set_grad_enabled(train_G):
+                G_z = Gw(z, G.shared(gy))
+            if x is None:
+                return Dw(G_z, gy)
+            out = Dw(torch.cat([G_z, x], 0), torch.cat([gy, dy], 0))
+            return torch.split(out, [G_z.shape[0], x.shape[0]])
+
+    GD = _GD()
+    rs = np.random.RandomState(7 + rank)
+    x = torch.from_numpy(((rs.randint(0, 256, size=(b, 3, 256, 256)) / 255.0 - 0.5) * 2).astype(np.float32)).to(device)
+    x = x.contiguous(memory_format=torch.channels_last)
+    dy = torch.from_numpy(rs.randint(0, 1000, size=b).astype(np.int64)).to(device)
+
+    def one_step():
+        G.train(); D.train()
+        utils.toggle_grad(D, True); utils.toggle_grad(G, False)
+        D.optim.zero_grad()
+        z = torch.randn(b, 128, device=device)
+        gy = torch.randint(0, 1000, (b,), device=device)
+        D_fake, D_real = GD(z, gy, x, dy, train_G=False)
+        l_real, l_fake = losses.loss_hinge_dis(D_fake, D_real)
+        (l_real + l_fake).backward()
+        D.optim.step()
+        utils.toggle_grad(D, False); utils.toggle_grad(G, True)
+        G.optim.zero_grad()
+        z = torch.randn(b, 128, device=device)
+        gy = torch.randint(0, 1000, (b,), device=device)
+        loss = losses.loss_hinge_gen(GD(z, gy, train_G=True))
+        loss.backward()
+        G.optim.step()
+        return loss
+
+    for _ in range(args.warmup):
+        one_step()
+    if use_ddp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    if use_ddp:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if use_ddp:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec G+D train step, BigGAN-deep 256^2 ch=128 bs=128/GPU (cfg5, secondary workload)",
+            "value": round(b * world * args.steps / elapsed, 3), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg5: BigGAN-deep 256x256 ch=128 class-conditional, attention at 64, 1 D + 1 G update, fp32",
+                       "batch_per_gpu": b, "global_batch": b * world, "parallelism": f"dp{world}",
+                       "G_loss_last": float(loss)},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+
+
 def cpu_baseline(cfg, name):
     """CPU oracle (restatement of the reference step, pinned to reference goldens) on this box's host cores."""
     from oracle import biggan_oracle as O, synth
@@ -290,7 +373,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS) + ["cfg4"])
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS) + ["cfg4", "cfg5"])
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -321,6 +404,8 @@ def main():
 
     if args.workload == "cfg4":
         return bench_stylegan2(args, device, rank, world, local_rank, use_ddp)
+    if args.workload == "cfg5":
+        return bench_biggan_deep(args, device, rank, world, local_rank, use_ddp)
     over, batch = WORKLOADS[args.workload]
     batch = args.batch or batch
     cfg = dict(BASE_CFG)
