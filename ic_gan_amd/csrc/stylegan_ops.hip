@@ -383,6 +383,61 @@ extern "C" int icg_upfirdn2d_nhwc(const float* x, const float* f, float* y, int 
   return icg_check_launch();
 }
 
+// NCHW, 4x4 filter, no zero insertion, decimation 1 or 2: lanes run along x (coalesced 4-byte accesses), a thread produces
+// a vertical strip of TY outputs from (TY-1)*DOWN + 4 input rows x 4 columns, taps in registers, fully unrolled.
+template <int DOWN, int TY>
+__global__ __launch_bounds__(256) void upfirdn2d_nchw_f4_kernel(const float* __restrict__ x, const float* __restrict__ f,
+                                                                float* __restrict__ y, int NC, int H, int W, int padx0,
+                                                                int pady0, int flip, float gain, int outH, int outW) {
+  __shared__ float fs[16];
+  if (threadIdx.x < 16) {
+    const int ty = threadIdx.x >> 2, tx = threadIdx.x & 3;
+    fs[threadIdx.x] = f[(flip ? ty : 3 - ty) * 4 + (flip ? tx : 3 - tx)] * gain;
+  }
+  __syncthreads();
+  float w[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[a][c] = fs[a * 4 + c];
+  constexpr int NR = (TY - 1) * DOWN + 4;
+  const int strips = (outH + TY - 1) / TY;
+  const long total = (long)NC * strips * outW;
+  const long gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const int ox = (int)(i % outW);
+    long t = i / outW;
+    const int ys = (int)(t % strips);
+    const long nc = t / strips;
+    const int oy0 = ys * TY;
+    const int bx = ox * DOWN - padx0, by = oy0 * DOWN - pady0;
+    const float* xp = x + nc * (long)H * W;
+    float acc[TY];
+#pragma unroll
+    for (int j = 0; j < TY; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int iy = by + r;
+      const bool rok = (unsigned)iy < (unsigned)H;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ix = bx + c;
+        float v = 0.f;
+        if (rok && (unsigned)ix < (unsigned)W) v = xp[(long)iy * W + ix];
+#pragma unroll
+        for (int j = 0; j < TY; ++j) {
+          const int ty = r - j * DOWN;
+          if (ty >= 0 && ty < 4) acc[j] = fmaf(v, w[ty][c], acc[j]);
+        }
+      }
+    }
+    float* yp = y + (nc * outH + oy0) * (long)outW + ox;
+#pragma unroll
+    for (int j = 0; j < TY; ++j)
+      if (oy0 + j < outH) yp[(long)j * outW] = acc[j];
+  }
+}
+
 extern "C" int icg_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw,
                              int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1,
                              int flip, float gain, int outH, int outW, void* stream) {
@@ -391,6 +446,19 @@ extern "C" int icg_upfirdn2d(const float* x, const float* f, float* y, int N, in
   ICG_REQUIRE(outW == (W * upx + padx0 + padx1 - fw + downx) / downx);
   ICG_REQUIRE(outH == (H * upy + pady0 + pady1 - fh + downy) / downy);
   ICG_REQUIRE(outW >= 1 && outH >= 1);
+  if (fh == 4 && fw == 4 && upx == 1 && upy == 1 && downx == downy && (downx == 1 || downx == 2)) {
+    constexpr int TY = 4;
+    const long tot = (long)N * C * ((outH + TY - 1) / TY) * outW;
+    long nb = icg_cdiv(tot, 256);
+    if (nb > 256 * 32) nb = 256 * 32;
+    if (downx == 1)
+      hipLaunchKernelGGL((upfirdn2d_nchw_f4_kernel<1, TY>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, f, y,
+                         N * C, H, W, padx0, pady0, flip, gain, outH, outW);
+    else
+      hipLaunchKernelGGL((upfirdn2d_nchw_f4_kernel<2, TY>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, f, y,
+                         N * C, H, W, padx0, pady0, flip, gain, outH, outW);
+    return icg_check_launch();
+  }
   const long total = (long)N * C * outH * outW;
   long blocks = icg_cdiv(total, 256);
   if (blocks > 8192) blocks = 8192;
