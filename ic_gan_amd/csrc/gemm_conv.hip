@@ -162,6 +162,14 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
   bool f_rowok[2], f_ok[2];
   int f_tr = 0, f_ts = 0, f_c0 = 0;          // wave-uniform tap tracking (A_K)
   int f_btap = 0, f_bc0 = 0;                 // the same position, for the B operand (advanced by load_B_fast)
+  if (FAST && AMODE == A_K && kbeg > 0) {    // split-K: K-tile kbeg/BK of the tap-minor order = (slice, tap)
+    const int it0 = kbeg / 16, RRt = p.R * p.R;
+    const int sl = it0 / RRt, tap0 = it0 - sl * RRt;
+    f_c0 = f_bc0 = sl * 16;
+    f_btap = tap0;
+    f_tr = tap0 / p.R;
+    f_ts = tap0 - f_tr * p.R;
+  }
   unsigned f_mtap_c = 0;                      // A_M: channel of this thread's 4 columns
   int f_mr = 0, f_ms = 0;
   bool f_mok = false;
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
       // one tile past the end.
       unsigned kg;
       if (AMODE == A_K) {
-        kg = (unsigned)(min(f_btap * Cin + f_bc0, kend - BK) + 4 * kq);
+        kg = (unsigned)(min(f_btap * Cin + f_bc0, p.K - BK) + 4 * kq);
         if (++f_btap == p.R * p.R) { f_btap = 0; f_bc0 += BK; }
       } else {
         kg = (unsigned)(min(k0, kend - BK) + 4 * kq);
@@ -703,7 +711,7 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
   }
   int path = vec ? 1 : 0;
   if (vec && fast_ok && p.zmask == 0) {
-    if (AMODE == A_K && (p.Cin % 16 == 0) && p.kchunk == 0) path = 2;
+    if (AMODE == A_K && (p.Cin % 16 == 0) && (p.kchunk == 0 || (BMODE == B_K && p.kchunk % 16 == 0))) path = 2;
     if (AMODE == A_M && p.lw >= 0 && p.lh >= 0) path = 2;
   }
   const int tn = pick_tn(p.N);
@@ -741,10 +749,107 @@ size_t icg_narrow_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int icg_narrow_wgrad(const float* x, const float* dy, const float* scale, const float* shift, long ssb, float* dw,
                      void* workspace, int B, int H, int W, int Cin, int Cout, int affine, int relu, hipStream_t st);
 
+// ---- split-K for forward / data-gradient launches that cannot fill the chip ------------------------------------------
+// A [M x N] output with fewer than ~384 tiles leaves CUs idle while every tile walks the whole K (StyleGAN2 at batch 16 below
+// 32x32, small-batch sampling): the K range is cut into S slices (blockIdx.z), each writes a raw partial slab, and a second
+// kernel sums the slabs in fixed order and applies the epilogue (alpha, bias, residual).  Deterministic.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ slabs, int splits, long MN, int N,
+                                                              float alpha, const float* __restrict__ bias,
+                                                              const float* __restrict__ res, int res_up, int H, int W,
+                                                              float* __restrict__ out) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < MN; i += stride) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slabs[(long)z * MN + i];
+    const int n = (int)(i % N);
+    float v = alpha * s;
+    if (bias) v += bias[n];
+    if (res) {
+      long rr = i / N;
+      if (res_up) {
+        const int w = (int)(rr % W);
+        const long t = rr / W;
+        const int h = (int)(t % H);
+        const long b = t / H;
+        rr = (b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1);
+      }
+      v += res[rr * N + n];
+    }
+    out[i] = v;
+  }
+}
+
+static int fprop_splits(long M, int N, int K) {
+  const long tiles = icg_cdiv(M, 128) * icg_cdiv(N, 32 * pick_tn(N));
+  if (tiles >= 384) return 1;
+  const int nk = K / 16;
+  long s = 768 / tiles;
+  if (s > nk / 16) s = nk / 16;
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : (int)s;
+}
+
+static size_t fprop_splitk_bytes(long M, int N, int K, int Cin) {
+  if (Cin % 16 != 0) return 0;
+  const int s = fprop_splits(M, N, K);
+  return s <= 1 ? 0 : (size_t)s * (size_t)M * (size_t)N * sizeof(float);
+}
+
+// p: a complete plain (phase_mode 0, z = 1, fast-path eligible) A_K/B_K problem.  Returns -1 if split-K does not apply.
+static int launch_fprop_splitk(const GemmP& p0, bool vec, hipStream_t st, bool small, void* workspace,
+                               size_t workspace_bytes) {
+  if (!vec || !small || p0.Cin % 16 != 0 || p0.zmask != 0 || p0.phase_mode != 0 || workspace == nullptr) return -1;
+  const int S = fprop_splits(p0.M, p0.N, p0.K);
+  if (S <= 1 || workspace_bytes < (size_t)S * p0.M * p0.N * sizeof(float)) return -1;
+  GemmP p = p0;
+  const int nk = p.K / 16;
+  p.kchunk = (int)icg_cdiv(nk, S) * 16;
+  const int splits = (int)icg_cdiv(p.K, p.kchunk);
+  p.C = (float*)workspace;
+  p.ldc = p.N;
+  p.strideA = 0; p.strideB = 0; p.strideC = (long)p.M * p.N;
+  p.alpha = 1.f; p.bias = nullptr; p.res = nullptr; p.res_up = 0;
+  int rc = launch_gemm<A_K, B_K>(p, vec, splits, st, small);
+  if (rc != ICG_OK) return rc;
+  const long MN = (long)p.M * p.N;
+  long blocks = icg_cdiv(MN, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)workspace, splits, MN,
+                     p.N, p0.alpha, p0.bias, p0.res, p0.res_up, p0.H, p0.W, p0.C);
+  return icg_check_launch();
+}
+
+static int conv2d_fprop_impl(const float* x, const float* w, const float* bias, const float* residual, float* out,
+                             const float* scale, const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin,
+                             int Cout, int R, unsigned flags, float alpha, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+extern "C" size_t icg_conv2d_fprop_workspace_bytes(int B, int H, int W, int Cin, int Cout, int R, unsigned flags) {
+  if (flags & ICG_UPSAMPLE2X) return 0;
+  return fprop_splitk_bytes((long)B * H * W, Cout, R * R * Cin, Cin);
+}
+
+// icg_conv2d_fprop with an optional workspace (icg_conv2d_fprop_workspace_bytes; NULL / too small = single pass)
+extern "C" int icg_conv2d_fprop_ws(const float* x, const float* w, const float* bias, const float* residual, float* out,
+                                   const float* scale, const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin,
+                                   int Cout, int R, unsigned flags, float alpha, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  return conv2d_fprop_impl(x, w, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, R, flags, alpha,
+                           workspace, workspace_bytes, stream);
+}
+
 extern "C" int icg_conv2d_fprop(const float* x, const float* w, const float* bias, const float* residual,
                                 float* out, const float* scale, const float* shift, int64_t ss_bstride, int B,
                                 int H, int W, int Cin, int Cout, int R, unsigned flags, float alpha,
                                 void* stream) {
+  return conv2d_fprop_impl(x, w, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, R, flags, alpha,
+                           nullptr, 0, stream);
+}
+
+static int conv2d_fprop_impl(const float* x, const float* w, const float* bias, const float* residual,
+                             float* out, const float* scale, const float* shift, int64_t ss_bstride, int B,
+                             int H, int W, int Cin, int Cout, int R, unsigned flags, float alpha, void* workspace,
+                             size_t workspace_bytes, void* stream) {
   ICG_REQUIRE(x && w && out);
   ICG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (R == 1 || R == 3));
   const int up = (flags & ICG_UPSAMPLE2X) ? 1 : 0;
@@ -777,6 +882,10 @@ extern "C" int icg_conv2d_fprop(const float* x, const float* w, const float* bia
   if (p.pre_affine) vec = vec && (ss_bstride % 4 == 0) && aligned16(scale) && aligned16(shift);
   const bool small = ((long)B * p.Hs * p.Ws * Cin < 0x7fffffffL) && ((long)Cout * p.K < 0x7fffffffL) &&
                      ((long)B * (ss_bstride > 0 ? ss_bstride : 0) + Cin < 0x7fffffffL);
+  if (!up) {
+    const int rc = launch_fprop_splitk(p, vec, (hipStream_t)stream, small, workspace, workspace_bytes);
+    if (rc != -1) return rc;
+  }
   return launch_gemm<A_K, B_K>(p, vec, 1, (hipStream_t)stream, small);
 }
 
@@ -1103,9 +1212,33 @@ extern "C" int icg_conv2d_tr2_fprop(const float* x, const float* wp, const float
 //   src = x inside [0,Hin)x[0,Win), zero outside                                         (zero_insert = 0)
 //   src = x[(h/z, w/z)] where h, w are multiples of z = zero_insert's factor inside the zero-inserted extent
 //         [(Hin-1)*z+1] x [(Win-1)*z+1], zero elsewhere; stride must be 1                (zero_insert = z in {2, 4})
+static int conv2d_g_fprop_impl(const float* x, const float* w, const float* bias, float* out, int B, int Hin, int Win,
+                               int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, int zero_insert,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+extern "C" size_t icg_conv2d_g_fprop_workspace_bytes(int B, int Hout, int Wout, int Cin, int Cout, int R,
+                                                     int zero_insert) {
+  if (zero_insert) return 0;
+  return fprop_splitk_bytes((long)B * Hout * Wout, Cout, R * R * Cin, Cin);
+}
+
+extern "C" int icg_conv2d_g_fprop_ws(const float* x, const float* w, const float* bias, float* out, int B, int Hin,
+                                     int Win, int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad,
+                                     int zero_insert, void* workspace, size_t workspace_bytes, void* stream) {
+  return conv2d_g_fprop_impl(x, w, bias, out, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, zero_insert, workspace,
+                             workspace_bytes, stream);
+}
+
 extern "C" int icg_conv2d_g_fprop(const float* x, const float* w, const float* bias, float* out, int B, int Hin, int Win,
                                   int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, int zero_insert,
                                   void* stream) {
+  return conv2d_g_fprop_impl(x, w, bias, out, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, zero_insert, nullptr, 0,
+                             stream);
+}
+
+static int conv2d_g_fprop_impl(const float* x, const float* w, const float* bias, float* out, int B, int Hin, int Win,
+                               int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, int zero_insert,
+                               void* workspace, size_t workspace_bytes, void* stream) {
   ICG_REQUIRE(x && w && out && B > 0 && Hin > 0 && Win > 0 && Cin > 0 && Hout > 0 && Wout > 0 && Cout > 0);
   ICG_REQUIRE(R >= 1 && R <= 7 && stride >= 1 && stride <= 4 && pad >= 0 && pad <= 8);
   ICG_REQUIRE(zero_insert == 0 || ((zero_insert == 2 || zero_insert == 4) && stride == 1));
@@ -1129,6 +1262,10 @@ extern "C" int icg_conv2d_g_fprop(const float* x, const float* w, const float* b
   const bool vec = (Cin % 4 == 0) && aligned16(x) && aligned16(w);
   // the fast path decodes pixels with shifts: needs power-of-two OUTPUT grid only in A_M mode; A_K needs Cin % 16 == 0
   const bool small = ((long)B * Hin * Win * Cin < 0x7fffffffL) && ((long)Cout * p.K < 0x7fffffffL);
+  {
+    const int rc = launch_fprop_splitk(p, vec, (hipStream_t)stream, small, workspace, workspace_bytes);
+    if (rc != -1) return rc;
+  }
   return launch_gemm<A_K, B_K>(p, vec, 1, (hipStream_t)stream, small);
 }
 

@@ -136,6 +136,16 @@ def _sn_backward(dw_hwio, dw_ohwi, sn: SNState, like: torch.Tensor, dw_up=None, 
     return dw
 
 
+def _conv_fprop(x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, flags):
+    """icg_conv2d_fprop, with the split-K workspace when the launch would not fill the chip (small batch / low resolution)."""
+    nb = L.query("icg_conv2d_fprop_workspace_bytes", B, H, W, Cin, Cout, R, flags)
+    if nb:
+        L.call("icg_conv2d_fprop_ws", x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, flags, 1.0,
+               _bytes(nb, out.device), nb)
+    else:
+        L.call("icg_conv2d_fprop", x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, flags, 1.0)
+
+
 # ----------------------------------------------------------------------------------------------
 # fused [BN/ccbn apply + ReLU + nearest-upsample] -> conv / linear -> [+bias +residual]
 # (reference: layers.py:144-153, 164-165, 398-437, 485-503, 542-552, 587-613)
@@ -215,8 +225,7 @@ class FusedConvFn(Function):
             L.call("icg_conv2d_up_fprop", x, sn.w_up, bias, out, scale, shift, ssb, B, Hs, Ws, Cin, Cout,
                    flags & ~L.ICG_UPSAMPLE2X)
         else:
-            L.call("icg_conv2d_fprop", x, sn.w_ohwi, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, fflags,
-                   1.0)
+            _conv_fprop(x, sn.w_ohwi, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, fflags)
         ctx.phase, ctx.down = phase, down
         ctx.opt, ctx.flags, ctx.dims = opt, flags, (B, Cin, Hs, Ws, H, W, Cout, R, gb_rows, ssb, count)
         ctx.has = (bias is not None, residual is not None, gain is not None, beta is not None)
@@ -251,8 +260,7 @@ class FusedConvFn(Function):
                 if sn.w_dgrad is None:
                     raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
                 da = _empty_cl(B, Cin, H, W, dev)
-                L.call("icg_conv2d_fprop", dout, sn.w_dgrad, None, None, da, None, None, 0, B, H, W, Cout, Cin, R, 0,
-                       1.0)
+                _conv_fprop(dout, sn.w_dgrad, None, None, da, None, None, 0, B, H, W, Cout, Cin, R, 0)
             if bn is not None:
                 dx, dgain, dbeta = _bn_backward(x, da, bn, gain, scale, shift, ssb, mean, invstd, gb_rows, count,
                                                 flags, has_gain, has_beta, (B, Cin, Hs, Ws))

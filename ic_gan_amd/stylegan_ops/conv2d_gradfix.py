@@ -93,8 +93,13 @@ class _GatherConv(torch.autograd.Function):
             # stride-2 transposed 3x3 convolution: 4 phases of 2x2 taps instead of a gather over the zero-inserted source
             L.call("icg_conv2d_tr2_fprop", x, _phase_weights(w), None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout)
             return y
-        L.call("icg_conv2d_g_fprop", x, w, None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout, geo.R, geo.stride,
-               geo.pad, geo.zins)
+        nb = L.query("icg_conv2d_g_fprop_workspace_bytes", B, geo.out[0], geo.out[1], Cin, Cout, geo.R, geo.zins)
+        if nb:    # too few output tiles to fill the chip: split-K
+            L.call("icg_conv2d_g_fprop_ws", x, w, None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout, geo.R, geo.stride,
+                   geo.pad, geo.zins, _ops._bytes(nb, x.device), nb)
+        else:
+            L.call("icg_conv2d_g_fprop", x, w, None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout, geo.R, geo.stride,
+                   geo.pad, geo.zins)
         return y
 
     @staticmethod

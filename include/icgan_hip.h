@@ -64,6 +64,16 @@ int icg_conv2d_fprop(const float* x, const float* w, const float* bias, const fl
  * Split-K over pixels with a deterministic two-stage reduction through `workspace`.
  * Replaces the weight-gradient half of autograd's ConvolutionBackward for layers.py:144-153.
  */
+/*
+ * The same with an optional split-K workspace: launches whose [pixels x Cout] output has too few 128x128 tiles to fill
+ * 256 CUs (small batches, low resolutions) cut K into slices that run concurrently and are summed deterministically.
+ * icg_conv2d_fprop_workspace_bytes returns 0 when split-K does not apply; workspace NULL / too small = single pass.
+ */
+size_t icg_conv2d_fprop_workspace_bytes(int B, int H, int W, int Cin, int Cout, int R, unsigned flags);
+int icg_conv2d_fprop_ws(const float* x, const float* w, const float* bias, const float* residual, float* out,
+                        const float* scale, const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin,
+                        int Cout, int R, unsigned flags, float alpha, void* workspace, size_t workspace_bytes,
+                        void* stream);
 size_t icg_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int R);
 int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, const float* scale,
                      const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin, int Cout,
@@ -119,6 +129,10 @@ int icg_conv2d_down_wgrad(const float* x, const float* dy, float* dvdn, int B, i
 int icg_conv2d_g_fprop(const float* x, const float* w, const float* bias, float* out, int B, int Hin, int Win,
                        int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, int zero_insert,
                        void* stream);
+size_t icg_conv2d_g_fprop_workspace_bytes(int B, int Hout, int Wout, int Cin, int Cout, int R, int zero_insert);
+int icg_conv2d_g_fprop_ws(const float* x, const float* w, const float* bias, float* out, int B, int Hin, int Win,
+                          int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, int zero_insert,
+                          void* workspace, size_t workspace_bytes, void* stream);
 /*
  * The zero_insert = 2, R = 3, pad = 2 case of the above (conv_transpose2d(stride=2, padding=0) of the up-sampling
  * synthesis layers, conv2d_resample.py:163-186, and the data gradient of the discriminator's stride-2 convolutions) in

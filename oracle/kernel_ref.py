@@ -65,6 +65,15 @@ def icg_conv2d_fprop(x, w, bias, residual, out, scale, shift, ss_bstride, B, H, 
     mem(out)[: B * H * W * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))
 
 
+def icg_conv2d_fprop_workspace_bytes(B, H, W, Cin, Cout, R, flags):
+    return 0
+
+
+def icg_conv2d_fprop_ws(x, w, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, R, flags, alpha, workspace,
+                        workspace_bytes):
+    icg_conv2d_fprop(x, w, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, R, flags, alpha)
+
+
 def icg_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, R):
     return 16
 
@@ -595,6 +604,15 @@ def icg_conv2d_g_fprop(x, w, bias, out, B, Hin, Win, Cin, Hout, Wout, Cout, R, s
     if bias is not None:
         y = y + mem(bias)[:Cout].view(1, -1, 1, 1)
     mem(out)[: B * Hout * Wout * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_conv2d_g_fprop_workspace_bytes(B, Hout, Wout, Cin, Cout, R, zero_insert):
+    return 0
+
+
+def icg_conv2d_g_fprop_ws(x, w, bias, out, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, zero_insert, workspace,
+                          workspace_bytes):
+    icg_conv2d_g_fprop(x, w, bias, out, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, zero_insert)
 
 
 def icg_conv2d_tr2_fprop(x, wp, bias, out, B, Hin, Win, Cin, Hout, Wout, Cout):

@@ -635,3 +635,30 @@ def test_sn_backward_coalesced_path(rows, Cin, taps):
         outs.append(dw)
         close(dw, ref, rtol=5e-5, atol_rel=5e-5, what=f"sn bwd scratch={nb}")
     close(outs[0], outs[1], rtol=1e-6, atol_rel=1e-6, what="two sn backward paths")
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, R, flags, residual(0 none / 1 same / 2 half-res), bias
+    (2, 4, 4, 64, 64, 3, 0, 0, True),                      # 1 tile, K = 576 -> 2 slices
+    (4, 8, 8, 128, 96, 3, PRE_AFFINE | PRE_RELU, 1, True),  # affine prologue per slice, residual in the epilogue
+    (2, 16, 16, 256, 256, 3, PRE_RELU, 2, True),           # half-resolution residual in the split-K epilogue
+    (3, 4, 4, 512, 40, 1, 0, 0, False),                    # 1x1: slice = channel range
+    (2, 8, 8, 80, 64, 3, 0, 0, True),                      # 45 K-tiles in 2 slices: the boundary falls inside a tap sequence
+])
+def test_conv2d_fprop_split_k(case):
+    """icg_conv2d_fprop_ws (K cut into concurrent slices + deterministic slab reduction) against the CPU reference."""
+    B, H, W, Cin, Cout, R, flags, res, bias = case
+    L = _L()
+    x, w, bvec, r, sc, sh, ssb, rflags = _conv_inputs(case, 10)
+    nb = L.query("icg_conv2d_fprop_workspace_bytes", B, H, W, Cin, Cout, R, rflags)
+    assert nb > 0, "expected a split-K plan for this shape"
+    ws = torch.empty(nb, dtype=torch.uint8)
+    out = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
+    (pair,) = run_pair("icg_conv2d_fprop_ws", [x, w, bvec, r, out, sc, sh, ssb, B, H, W, Cin, Cout, R, rflags, 1.0, ws, nb], [4])
+    close(*pair, what=f"split-K fprop {case}")
+    # a too-small workspace falls back to the single-pass kernel with the same result
+    out2 = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last).cuda()
+    c = lambda t: None if t is None else t.cuda()
+    L.call("icg_conv2d_fprop_ws", c(x), c(w), c(bvec), c(r), out2, c(sc), c(sh), ssb, B, H, W, Cin, Cout, R, rflags, 1.0,
+           torch.empty(16, dtype=torch.uint8, device="cuda"), 16)
+    close(out2, pair[1], what="single-pass fallback")

@@ -45,6 +45,15 @@ LAYERS = [
     ("D.b0.conv2 96->96 @256 relu", 128, 256, 256, 96, 96, 3, P_RELU),
     ("D.b3.conv2 768->768 @32 relu", 128, 32, 32, 768, 768, 3, P_RELU),
     ("G.b5.sc 1x1 192->96 @128", 64, 128, 128, 192, 96, 1, 0),
+    # low-occupancy shapes: StyleGAN2 cfg4 (batch 16) and small-batch sampling
+    ("SG2 512->512 @4  B16", 16, 4, 4, 512, 512, 3, 0),
+    ("SG2 512->512 @8  B16", 16, 8, 8, 512, 512, 3, 0),
+    ("SG2 512->512 @16 B16", 16, 16, 16, 512, 512, 3, 0),
+    ("SG2 512->512 @32 B16", 16, 32, 32, 512, 512, 3, 0),
+    ("SG2 256->256 @64 B16", 16, 64, 64, 256, 256, 3, 0),
+    ("SG2 128->128 @128 B16", 16, 128, 128, 128, 128, 3, 0),
+    ("SG2 64->64 @256 B16", 16, 256, 256, 64, 64, 3, 0),
+    ("G.b0.conv2 1536->1536 @8 B8 (sampling)", 8, 8, 8, 1536, 1536, 3, P_RELU | P_AFF),
 ]
 
 def main():
@@ -64,8 +73,12 @@ def main():
         sh = torch.randn(B, Cin, device=dev) * 0.1 if flags & P_AFF else None
         ssb = Cin if flags & P_AFF else 0
         flops = 2.0 * B * H * W * Cin * Cout * R * R
-        t_f = ev_time(lambda: L.call("icg_conv2d_fprop", x, w, None, None, out, sc, sh, ssb, B, H, W, Cin, Cout, R, flags, 1.0))
-        t_d = ev_time(lambda: L.call("icg_conv2d_fprop", dy, wd, None, None, da, None, None, 0, B, H, W, Cout, Cin, R, 0, 1.0))
+        nf = L.query("icg_conv2d_fprop_workspace_bytes", B, H, W, Cin, Cout, R, flags)
+        wf = torch.empty(max(nf, 16), dtype=torch.uint8, device=dev)
+        t_f = ev_time(lambda: L.call("icg_conv2d_fprop_ws", x, w, None, None, out, sc, sh, ssb, B, H, W, Cin, Cout, R, flags, 1.0, wf, nf))
+        nd = L.query("icg_conv2d_fprop_workspace_bytes", B, H, W, Cout, Cin, R, 0)
+        wdd = torch.empty(max(nd, 16), dtype=torch.uint8, device=dev)
+        t_d = ev_time(lambda: L.call("icg_conv2d_fprop_ws", dy, wd, None, None, da, None, None, 0, B, H, W, Cout, Cin, R, 0, 1.0, wdd, nd))
         nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, Cin, Cout, R)
         ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
         dw = torch.empty(R * R * Cin * Cout, device=dev)
