@@ -254,6 +254,42 @@ def bench_stylegan2(args, device, rank, world, local_rank, use_ddp):
             "roofline": None, "cpu_baseline": None}), flush=True)
 
 
+def bench_sampling(args, device, rank, world):
+    """Secondary workload: the sampling engine (inference/utils.py:176-269) — G_ema in eval mode (stored BN statistics, no
+    SN update), class + instance conditioning drawn by the HBM-resident sampler, cfg3 generator (256x256, ch 96).  A step is
+    one `inference.sample` call of `--batch` images (default 64); data-parallel replicas, no collective."""
+    from ic_gan_amd import inference, utils
+    b = args.batch or 64
+    cfg = dict(BASE_CFG)
+    cfg.update(WORKLOADS["cfg3"][0])
+    utils.seed_rng(rank)
+    import ic_gan_amd.BigGAN as M
+    G = M.Generator(**{**cfg, "skip_init": True, "no_optim": True, "G_init": "N02"}).to(device)
+    G.init = "N02"
+    G.init_weights()
+    G.eval()
+    sampler = conditioning_sampler(cfg, G.dim_z, b, device, seed=1000 + rank)
+    if args.graph:
+        G = inference.GraphedGenerator(G, b, class_cond=True, instance_cond=True, device=device, static_weights=True)
+    for _ in range(args.warmup):
+        inference.sample(G, sampler, cfg, class_cond=True, instance_cond=True, device=device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img, _, _ = inference.sample(G, sampler, cfg, class_cond=True, instance_cond=True, device=device)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec sampling, IC-GAN BigGAN 256^2 generator (secondary workload)",
+            "value": round(b * world * args.steps / elapsed, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "sample: cfg3 generator in eval mode, class + instance conditioning from the resident table",
+                       "batch_per_gpu": b, "hip_graph": bool(args.graph), "finite": bool(torch.isfinite(img).all())},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+
+
 def bench_biggan_deep(args, device, rank, world, local_rank, use_ddp):
     """Secondary workload (BASELINE.json configs[4]): BigGAN-deep 256x256 ch=128, bs=128/GPU, class-conditional, attention
     at 64.  The reference's IC-GAN step function cannot drive this model (its G_D has no feature arguments), so the step is
@@ -373,12 +409,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS) + ["cfg4", "cfg5"])
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS) + ["cfg4", "cfg5", "sample"])
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--init", default="ortho", choices=["ortho", "N02"],
                     help="weight init; N02 skips the rocSOLVER QR (which crashes under rocprofv3 --pmc); timings are init-independent")
+    ap.add_argument("--graph", action="store_true", help="sample workload: replay the generator forward from a HIP graph")
     ap.add_argument("--sync-bn", action="store_true", help="cross-replica BN statistics over RCCL (cfg3 variant)")
     args = ap.parse_args()
 
@@ -402,6 +439,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
 
+    if args.workload == "sample":
+        return bench_sampling(args, device, rank, world)
     if args.workload == "cfg4":
         return bench_stylegan2(args, device, rank, world, local_rank, use_ddp)
     if args.workload == "cfg5":

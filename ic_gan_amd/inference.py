@@ -53,6 +53,65 @@ def sample(generator, sample_conditioning_func, config, class_cond=True, instanc
     return gen_samples, y_, feats_
 
 
+class GraphedGenerator:
+    """The eval-mode generator forward captured once in a HIP graph and replayed per call.
+
+    At small batch sizes the forward is launch-bound (≈400 kernel launches, a few ms of host time for 1-2 ms of GPU work);
+    the eval forward is static (stored BN statistics, no spectral-norm update, no autograd), so the whole launch sequence is
+    recorded on a capture stream with fixed input/output buffers and replayed with one host call.  `sample(...)` accepts a
+    GraphedGenerator in place of the module.  Changing batch size, conditioning kind or train/eval mode needs a new capture.
+    """
+
+    def __init__(self, generator, batch_size, class_cond=True, instance_cond=False, device="cuda", feature_dim=2048,
+                 static_weights=False):
+        """static_weights=False: the spectral-norm passes are part of the graph, replays always use the module's current
+        weights.  static_weights=True: W/sigma of every layer is computed once before capture and baked into the graph
+        (fewer, smaller replays — the right choice for serving a fixed checkpoint); call `refresh()` after loading weights."""
+        if generator.training:
+            raise RuntimeError("GraphedGenerator captures the eval-mode forward: call generator.eval() first")
+        self._args = (generator, batch_size, class_cond, instance_cond, device, feature_dim)
+        self.static_weights = static_weights
+        self.refresh()
+
+    def refresh(self):
+        from . import layers
+        was, layers.SN_EVAL_CACHE = layers.SN_EVAL_CACHE, bool(self.static_weights)
+        try:
+            self._capture(*self._args)
+        finally:
+            layers.SN_EVAL_CACHE = was
+
+    def _capture(self, generator, batch_size, class_cond, instance_cond, device, feature_dim):
+        self.generator, self.batch_size = generator, batch_size
+        dev = torch.device(device)
+        self._z = torch.zeros(batch_size, generator.dim_z, device=dev)
+        self._y = torch.zeros(batch_size, dtype=torch.int64, device=dev) if class_cond else None
+        self._f = torch.zeros(batch_size, feature_dim, device=dev) if instance_cond else None
+        if self._f is not None:
+            self._f[:, 0] = 1.0
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.no_grad(), torch.cuda.stream(side):
+            for _ in range(2):                      # warm-up outside capture (lazy initialisation, allocator pools)
+                generator(self._z, self._y, self._f)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self._graph):
+            self._out = generator(self._z, self._y, self._f)
+        # a graph holds raw pointers: the cached W/sigma buffers baked into it (static_weights) must outlive it even if
+        # the modules drop them from their caches later
+        self._pinned = [m._sn_eval for m in generator.modules() if getattr(m, "_sn_eval", None) is not None]
+
+    def __call__(self, z, y=None, feats=None):
+        self._z.copy_(z, non_blocking=True)
+        if self._y is not None:
+            self._y.copy_(y, non_blocking=True)
+        if self._f is not None:
+            self._f.copy_(feats, non_blocking=True)
+        self._graph.replay()
+        return self._out.clone()
+
+
 def _best_checkpoint(config):
     """inference/utils.py:284-308: the `best0`/`best1` checkpoint with the lower recorded FID ('' if neither exists)."""
     root = "/".join([config["weights_root"], config["experiment_name"]])

@@ -38,6 +38,7 @@ class SN(object):
         self.num_itrs, self.num_svs, self.transpose, self.eps = num_itrs, num_svs, transpose, eps
         self.register_buffer("u0", torch.randn(1, num_outputs))
         self.register_buffer("sv0", torch.ones(1))
+        self._sn_eval = None       # (key, SNState): eval-mode cache of W/sigma (see _sn_eval_key)
         self._sn_flags = {}        # grad mode -> (need_dgrad, upsample, downsample) of the last call (see sn_prefetch)
         self._sn_ready = None      # (flags, SNState) computed ahead by sn_prefetch, consumed by the next sn_state()
 
@@ -61,8 +62,20 @@ class SN(object):
             if ready[0] != flags:
                 raise RuntimeError("spectral-norm state was prefetched for layouts %r but is consumed with %r" % (ready[0], flags))
             return ready[1]
-        return ops.sn_prepare(self.weight, self.u0, self.sv0, self.eps, self.training, need_dgrad, upsample,
-                              downsample)
+        key = self._sn_eval_key(flags)
+        if key is not None and self._sn_eval is not None and self._sn_eval[0] == key:
+            return self._sn_eval[1]
+        st = ops.sn_prepare(self.weight, self.u0, self.sv0, self.eps, self.training, need_dgrad, upsample, downsample)
+        if key is not None:
+            self._sn_eval = (key, st)
+        return st
+
+    def _sn_eval_key(self, flags):
+        """In eval mode without autograd W/sigma is a pure function of (weight, u0): it is computed once and reused until
+        either tensor is written to (the reference recomputes it on every call; same values).  None = not cacheable."""
+        if self.training or torch.is_grad_enabled() or not SN_EVAL_CACHE:
+            return None
+        return (flags, self.weight._version, self.u0._version, self.weight.data_ptr(), self.u0.data_ptr())
 
     def W_(self):
         """Spectrally normalised weight in the parameter layout (debug / API parity; not on the hot path)."""
@@ -71,6 +84,9 @@ class SN(object):
         if w.dim() == 4:
             return st.w_ohwi.view(w.shape[0], w.shape[2], w.shape[3], w.shape[1]).permute(0, 3, 1, 2).contiguous()
         return st.w_ohwi.view_as(w)
+
+
+SN_EVAL_CACHE = True      # module switch for the eval-mode W/sigma cache (GraphedGenerator turns it off while capturing)
 
 
 def sn_prefetch(modules):
@@ -85,11 +101,17 @@ def sn_prefetch(modules):
             raise RuntimeError("%s: prefetched spectral-norm state was never consumed (the layer was not called in the "
                                "previous forward); its u/sv buffers have advanced — reload them" % type(m).__name__)
         if mode in m._sn_flags:
+            key = m._sn_eval_key(m._sn_flags[mode])
+            if key is not None and m._sn_eval is not None and m._sn_eval[0] == key:
+                continue                                   # eval-mode cache is current: nothing to compute
             groups.setdefault((float(m.eps), bool(m.training)), []).append(m)
     for (eps, training), ms in groups.items():
         items = [(m.weight, m.u0, m.sv0) + m._sn_flags[mode] for m in ms]
         for m, st in zip(ms, ops.sn_prepare_many(items, eps, training)):
             m._sn_ready = (m._sn_flags[mode], st)
+            key = m._sn_eval_key(m._sn_flags[mode])
+            if key is not None:
+                m._sn_eval = (key, st)
 
 
 class SNConv2d(nn.Conv2d, SN):

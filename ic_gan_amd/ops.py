@@ -98,6 +98,8 @@ def sn_prepare(weight: torch.Tensor, u: torch.Tensor, sv: Optional[torch.Tensor]
     w, st, scratch = _sn_alloc(weight, need_dgrad, upsample, downsample)
     L.call("icg_sn_forward", w, u, sv, st.rows, st.cin, st.R, float(eps), int(bool(training)), st.v, st.u, st.sigma,
            st.w_ohwi, st.w_dgrad, st.w_up, st.w_up_dgrad, st.w_down, st.w_down_dgrad, scratch, scratch.numel())
+    if training:
+        bump_version(u, sv)
     return st
 
 
@@ -124,6 +126,9 @@ def sn_prepare_many(items, eps: float, training: bool):
         d.rows, d.Cin, d.R = st.rows, st.cin, st.R
         states.append(st)
     L.call("icg_sn_forward_multi", ctypes.cast(arr, ctypes.c_void_p), len(items), float(eps), int(bool(training)))
+    if training:
+        for it in items:
+            bump_version(it[1], it[2])
     return states
 
 
@@ -598,6 +603,14 @@ def gemm(a, b, c, m, n, k, trans_a: bool, trans_b: bool, alpha=1.0):
 # ----------------------------------------------------------------------------------------------
 # optimiser / EMA kernels
 # ----------------------------------------------------------------------------------------------
+def bump_version(*tensors):
+    """The HIP kernels write through raw pointers, which autograd's version counters do not see; anything that caches values
+    derived from a tensor (the eval-mode W/sigma cache of layers.SN) relies on the counter, so writers bump it explicitly."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
 def adam_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step):
     import ctypes
     n = len(params)
@@ -610,6 +623,7 @@ def adam_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step
         arr[i].exp_avg, arr[i].exp_avg_sq, arr[i].numel = m.data_ptr(), v.data_ptr(), p.numel()
     L.call("icg_adam_multi", ctypes.cast(arr, ctypes.c_void_p), n, float(lr), float(beta1), float(beta2), float(eps),
            int(step))
+    bump_version(*params)
 
 
 def ema_multi(targets, sources, decay):

@@ -87,5 +87,6 @@ class TrainingStep:
         tg = [p for p in self.G_ema.parameters()]
         sr = [p.detach() for p in self.G.parameters()]
         ops.ema_multi([t.data for t in tg], sr, beta)          # p_ema <- lerp(p, p_ema, beta), one multi-tensor launch
+        ops.bump_version(*tg)
         for b_ema, b in zip(self.G_ema.buffers(), self.G.buffers()):
             b_ema.copy_(b)

@@ -47,6 +47,7 @@ class ema(object):
                 tg.append(t)
                 sr.append(s)
             ops.ema_multi(tg, sr, decay)
+            ops.bump_version(*self.target_dict.values())     # (the kernel wrote through `.data` aliases)
 
 
 def ortho(model, strength=1e-4, blacklist=[]):

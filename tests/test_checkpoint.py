@@ -186,3 +186,34 @@ def test_load_model_inference_picks_best_fid(tmp_path, emu):
     assert img.shape == (6, 3, 64, 64) and torch.isfinite(img).all()
     with pytest.raises(ValueError):
         inference.load_model_inference(dict(config, experiment_name="missing"), device="cpu")
+
+
+@pytest.mark.gpu
+def test_graphed_generator_matches_eager():
+    """HIP-graph replay of the eval forward == eager eval forward, for several inputs and after a weight change."""
+    from ic_gan_amd import inference
+    M, G, D, G_ema, og, od, state, ema = _build("cuda:0")
+    G_ema.eval()
+    gg = inference.GraphedGenerator(G_ema, 6, class_cond=True, instance_cond=True, device="cuda:0", feature_dim=2048)
+    z, y, f = (torch.from_numpy(GOLD["sample/" + k]).cuda() for k in ("z", "y", "feats"))
+    for scale in (1.0, 0.5):
+        with torch.no_grad():
+            ref = G_ema(z * scale, y, f)
+        got = gg(z * scale, y, f)
+        assert torch.equal(got, ref)
+    assert _rel_l2(gg(z, y, f).cpu().numpy(), GOLD["sample/G_ema"]) < 1e-3
+    with torch.no_grad():
+        G_ema.linear.weight.mul_(1.01)               # weights are read at replay time
+        ref = G_ema(z, y, f)
+    assert torch.equal(gg(z, y, f), ref)
+    img, _, _ = inference.sample(gg, lambda: (z.cpu(), y.cpu(), f.cpu()), CFG, class_cond=True, instance_cond=True, device="cuda:0")
+    assert torch.equal(img, ref)
+    # static_weights: W/sigma baked in at capture; refresh() picks up new weights
+    gs = inference.GraphedGenerator(G_ema, 6, class_cond=True, instance_cond=True, device="cuda:0", static_weights=True)
+    assert torch.equal(gs(z, y, f), ref)
+    with torch.no_grad():
+        G_ema.linear.weight.mul_(0.99)
+        ref2 = G_ema(z, y, f)
+    assert torch.equal(gs(z, y, f), ref) and not torch.equal(ref, ref2)
+    gs.refresh()
+    assert torch.equal(gs(z, y, f), ref2)

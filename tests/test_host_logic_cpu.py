@@ -136,3 +136,74 @@ def test_sn_prefetch_bookkeeping(emu):
         layers.sn_prefetch([G.linear])
         with pytest.raises(RuntimeError):
             G(z, lab, fg)
+
+
+def test_eval_mode_sn_cache_follows_weight_updates(emu):
+    _eval_cache_case("cpu")
+
+
+@pytest.mark.gpu
+def test_eval_mode_sn_cache_follows_weight_updates_hip():
+    _eval_cache_case("cuda:0")
+
+
+def _eval_cache_case(dev):
+    """eval-mode W/sigma is cached; the cache must be invalidated by everything that writes weights or u0 through raw
+    pointers (fused Adam, EMA, the training-mode power iteration) and by load_state_dict."""
+    from ic_gan_amd import layers, utils
+    from ic_gan_amd.optim import FusedAdam
+    g = load_golden("cc_ic_r64")
+    cfg = g["cfg"]
+    _, G, D = _build(g)
+    G = G.to(dev)
+    G.load_state_dict({k: v.to(dev) for k, v in synth.synth_state(g["gspec"], 11).items()})
+    z, lab, fg = (t.to(dev) for t in synth.CondSampler(cfg, G.dim_z, 2, seed=5)())
+    calls = {"n": 0}
+    real_one, real_many = layers.ops.sn_prepare, layers.ops.sn_prepare_many
+
+    def one(*a, **k):
+        calls["n"] += 1
+        return real_one(*a, **k)
+
+    layers.ops.sn_prepare = one
+    layers.ops.sn_prepare_many = lambda items, eps, training: [one(w, u, sv, eps, training, nd, up, dn) for (w, u, sv, nd, up, dn) in items]
+    try:
+        G.eval()
+        with torch.no_grad():
+            a = G(z, lab, fg)
+            n1 = calls["n"]
+            b = G(z, lab, fg)
+            assert calls["n"] == n1 and torch.equal(a, b)          # second eval forward: everything from the cache
+        opt = FusedAdam(G.parameters(), lr=1e-2, betas=(0.0, 0.999), eps=1e-6)
+        G.train()
+        G(z, lab, fg).sum().backward()
+        opt.step()
+        G.eval()
+        with torch.no_grad():
+            c = G(z, lab, fg)
+        assert calls["n"] > n1 and not torch.equal(a, c)            # Adam + power iteration invalidated the cache
+        G2 = copy_of(G)
+        with torch.no_grad():
+            assert torch.equal(G2(z, lab, fg), c)                   # a fresh module (no cache) agrees
+        # EMA writes through raw pointers as well
+        G_ema = copy_of(G)
+        with torch.no_grad():
+            before = G_ema(z, lab, fg)
+        e = utils.ema(G, G_ema, 0.5, 0)
+        with torch.no_grad():
+            G.linear.weight.add_(0.05)
+        e.update(1)
+        with torch.no_grad():
+            after = G_ema(z, lab, fg)
+        assert not torch.equal(before, after)
+    finally:
+        layers.ops.sn_prepare, layers.ops.sn_prepare_many = real_one, real_many
+
+
+def copy_of(m):
+    import copy
+    c = copy.deepcopy(m)
+    for mod in c.modules():
+        if hasattr(mod, "_sn_eval"):
+            mod._sn_eval = None
+    return c
