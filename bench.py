@@ -52,7 +52,8 @@ class KernelTimer:
     library (icg_gemm_last_variant), so they can be compared line by line with profiles/*_kernel_stats.csv."""
 
     # entry point -> (index of B in the argument list, kind)
-    SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wgrad": (6, "conv"), "icg_conv2d_up_fprop": (7, "up"),
+    SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"),
+            "icg_conv2d_wgrad": (6, "conv"), "icg_conv2d_up_fprop": (7, "up"),
             "icg_conv2d_up_dgrad": (3, "up"), "icg_conv2d_up_wgrad": (6, "up"), "icg_conv2d_down_fprop": (5, "up"),
             "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_wgrad": (3, "up")}
 
@@ -76,6 +77,11 @@ class KernelTimer:
                 B, H, W, Cin, Cout, R = args[sl:sl + 6]
                 alg = exe = 2.0 * B * H * W * Cout * Cin * R * R
                 byt = 4.0 * (B * H * W * (Cin + Cout) + Cout * Cin * R * R)
+            elif mode == "wino":   # Winograd F(2x2,3x3): 16 GEMMs over a quarter of the pixels = 16/36 of the direct MACs
+                B, H, W, Cin, Cout = args[sl:sl + 5]
+                alg = 2.0 * B * H * W * Cout * Cin * 9
+                exe = alg * 16.0 / 36.0
+                byt = 4.0 * (B * H * W * (Cin + Cout) + Cout * Cin * 9)
             else:       # upsample- / avgpool-fused conv (2x2-phase or 4x4-stride-2 form): executed MACs are 16/36 of the
                         # reference op graph's (3x3 at the HIGH resolution); tensors: low-res one side, high-res the other
                 B, Hs, Ws, Cin, Cout = args[sl:sl + 5]

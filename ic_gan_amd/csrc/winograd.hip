@@ -1,0 +1,191 @@
+// Winograd F(2x2, 3x3) for the wide 3x3 stride-1 convolutions (forward and data gradient):
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A          per 2x2 output tile / 4x4 input tile, summed over input channels
+// turns the convolution into 16 independent [tiles x Cin] x [Cin x Cout] GEMMs with 16/36 of the multiply-adds.  The GEMMs
+// run on the MFMA kernel (icg_gemm_batched, K = Cin); the input transform (with the fused BN-affine / ReLU prologue and the
+// zero padding) and the output transform (with bias / residual epilogue) are HBM-bound passes over 4x the activation volume,
+// so the form only pays for wide layers (Cin, Cout >= 256), where the GEMM time dominates; ops.py applies that rule.
+// Same mathematical result as the direct convolution; rounding differs at the 1e-6 level (fp32 transforms).
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+#include "icg_common.h"
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// V[xi][t][c] = (B^T d B)[xi],  d = act(x) on the 4x4 window of tile t (zero outside the image), xi = 4*i + j
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, long ssb, float* __restrict__ V,
+                                                         int B, int H, int W, int C4, int affine, int relu) {
+  const int th = H >> 1, tw = W >> 1;
+  const long T = (long)B * th * tw;
+  const long total = T * C4;
+  const long gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const int c4 = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long t2 = t / tw;
+    const int ty = (int)(t2 % th);
+    const int b = (int)(t2 / th);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (affine) {
+      sc = *reinterpret_cast<const float4*>(scale + (long)b * ssb + 4 * c4);
+      sh = *reinterpret_cast<const float4*>(shift + (long)b * ssb + 4 * c4);
+    }
+    const float4* xp = reinterpret_cast<const float4*>(x) + (long)b * H * W * C4 + c4;
+    float4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = 2 * ty - 1 + r;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int w = 2 * tx - 1 + s;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+          v = xp[((long)h * W + w) * C4];
+          if (affine) {
+            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+          }
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        d[r][s] = v;
+      }
+    }
+    float4 u[4][4];      // B^T d
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u[0][s] = f4sub(d[0][s], d[2][s]);
+      u[1][s] = f4add(d[1][s], d[2][s]);
+      u[2][s] = f4sub(d[2][s], d[1][s]);
+      u[3][s] = f4sub(d[1][s], d[3][s]);
+    }
+    float4* vp = reinterpret_cast<float4*>(V) + t * C4 + c4;
+    const long plane = T * C4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vp[(4 * r + 0) * plane] = f4sub(u[r][0], u[r][2]);
+      vp[(4 * r + 1) * plane] = f4add(u[r][1], u[r][2]);
+      vp[(4 * r + 2) * plane] = f4sub(u[r][2], u[r][1]);
+      vp[(4 * r + 3) * plane] = f4sub(u[r][1], u[r][3]);
+    }
+  }
+}
+
+// y[b, 2ty+a, 2tx+c, co] = (A^T m A)[a][c] + bias[co] + residual
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
+                                                          const float* __restrict__ res, int res_up, float alpha,
+                                                          float* __restrict__ y, int B, int H, int W, int C4) {
+  const int th = H >> 1, tw = W >> 1;
+  const long T = (long)B * th * tw;
+  const long total = T * C4;
+  const long plane = T * C4;
+  const long gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const int c4 = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long t2 = t / tw;
+    const int ty = (int)(t2 % th);
+    const long b = t2 / th;
+    const float4* mp = reinterpret_cast<const float4*>(Mb) + t * C4 + c4;
+    float4 s[2][4];      // A^T m
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 m0 = mp[(0 + c) * plane], m1 = mp[(4 + c) * plane], m2 = mp[(8 + c) * plane], m3 = mp[(12 + c) * plane];
+      s[0][c] = f4add(f4add(m0, m1), m2);
+      s[1][c] = f4sub(f4sub(m1, m2), m3);
+    }
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * c4);
+    float4 rlow = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res && res_up) rlow = reinterpret_cast<const float4*>(res)[((b * th + ty) * tw + tx) * C4 + c4];   // one source pixel per tile
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float4 o0 = f4add(f4add(s[a][0], s[a][1]), s[a][2]);
+      const float4 o1 = f4sub(f4sub(s[a][1], s[a][2]), s[a][3]);
+      const long p0 = ((b * H + (2 * ty + a)) * W + 2 * tx) * C4 + c4;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float4 o = c ? o1 : o0;
+        float4 v = make_float4(alpha * o.x + bv.x, alpha * o.y + bv.y, alpha * o.z + bv.z, alpha * o.w + bv.w);
+        if (res) {
+          const float4 r = res_up ? rlow : reinterpret_cast<const float4*>(res)[p0 + (long)c * C4];
+          v = f4add(v, r);
+        }
+        reinterpret_cast<float4*>(y)[p0 + (long)c * C4] = v;
+      }
+    }
+  }
+}
+
+// U[xi][n][k] = (G g G^T)[xi] for g = w[n][.][.][k]   (w: [N][3][3][K], the OHWI or the dgrad layout)
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int N, int K) {
+  const long total = (long)N * K;
+  const long gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const int k = (int)(i % K);
+    const long n = i / K;
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) g[r][s] = w[((n * 3 + r) * 3 + s) * K + k];
+    float t[4][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      t[0][s] = g[0][s];
+      t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+      t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+      t[3][s] = g[2][s];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      U[(4 * r + 0) * total + i] = t[r][0];
+      U[(4 * r + 1) * total + i] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
+      U[(4 * r + 2) * total + i] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
+      U[(4 * r + 3) * total + i] = t[r][2];
+    }
+  }
+}
+
+extern "C" int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int transA, int transB,
+                                int64_t strideA, int64_t strideB, int64_t strideC, int batch, float alpha, void* stream);
+
+extern "C" int icg_wino_weight_transform(const float* w, float* U, int N, int K, void* stream) {
+  ICG_REQUIRE(w && U && N > 0 && K > 0);
+  long blocks = icg_cdiv((long)N * K, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, U, N, K);
+  return icg_check_launch();
+}
+
+extern "C" size_t icg_conv2d_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  const size_t T = (size_t)B * (H / 2) * (W / 2);
+  return 16 * T * ((size_t)Cin + (size_t)Cout) * sizeof(float);
+}
+
+// out = conv3x3(act(x), w) + bias + residual with w given in the Winograd domain (U from icg_wino_weight_transform)
+extern "C" int icg_conv2d_wino_fprop(const float* x, const float* U, const float* bias, const float* residual, float* out,
+                                     const float* scale, const float* shift, int64_t ss_bstride, int B, int H, int W,
+                                     int Cin, int Cout, unsigned flags, float alpha, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  ICG_REQUIRE(x && U && out && workspace && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  ICG_REQUIRE((H % 2 == 0) && (W % 2 == 0) && (Cin % 4 == 0) && (Cout % 4 == 0) && !(flags & ICG_UPSAMPLE2X));
+  if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift && (ss_bstride % 4 == 0));
+  if (workspace_bytes < icg_conv2d_wino_workspace_bytes(B, H, W, Cin, Cout)) return ICG_ERR_WORKSPACE;
+  const long T = (long)B * (H / 2) * (W / 2);
+  ICG_REQUIRE(T * 16 < 0x7fffffffL);
+  hipStream_t st = (hipStream_t)stream;
+  float* V = (float*)workspace;
+  float* Mb = V + 16 * T * Cin;
+  long nb = icg_cdiv(T * (Cin / 4), 256);
+  if (nb > 256 * 64) nb = 256 * 64;
+  hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, (long)ss_bstride, V, B, H, W,
+                     Cin / 4, (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0);
+  int rc = icg_gemm_batched(V, U, Mb, (int)T, Cout, Cin, 0, 1, T * Cin, (long)Cout * Cin, T * Cout, 16, 1.0f, stream);
+  if (rc != ICG_OK) return rc;
+  nb = icg_cdiv(T * (Cout / 4), 256);
+  if (nb > 256 * 64) nb = 256 * 64;
+  hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)Mb, bias, residual,
+                     (flags & ICG_RES_UPSAMPLE2X) ? 1 : 0, alpha, out, B, H, W, Cout / 4);
+  return icg_check_launch();
+}

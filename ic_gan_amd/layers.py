@@ -50,11 +50,11 @@ class SN(object):
     def sv(self):
         return [self.sv0]
 
-    def sn_state(self, need_dgrad=None, upsample=False, downsample=False, _record=True) -> ops.SNState:
+    def sn_state(self, need_dgrad=None, upsample=False, downsample=False, _record=True, winograd=False) -> ops.SNState:
         """One power-iteration step (in place on u0/sv0 in training mode) + W/sigma in kernel layouts."""
         if need_dgrad is None:
             need_dgrad = torch.is_grad_enabled()
-        flags = (bool(need_dgrad), bool(upsample), bool(downsample))
+        flags = (bool(need_dgrad), bool(upsample), bool(downsample), bool(winograd))
         if _record:
             self._sn_flags[torch.is_grad_enabled()] = flags
         ready, self._sn_ready = self._sn_ready, None
@@ -65,7 +65,8 @@ class SN(object):
         key = self._sn_eval_key(flags)
         if key is not None and self._sn_eval is not None and self._sn_eval[0] == key:
             return self._sn_eval[1]
-        st = ops.sn_prepare(self.weight, self.u0, self.sv0, self.eps, self.training, need_dgrad, upsample, downsample)
+        st = ops.sn_prepare(self.weight, self.u0, self.sv0, self.eps, self.training, need_dgrad, upsample, downsample,
+                            winograd)
         if key is not None:
             self._sn_eval = (key, st)
         return st
@@ -129,7 +130,10 @@ class SNConv2d(nn.Conv2d, SN):
         phase = bool(fuse.get("upsample")) and self.kernel_size == (3, 3) and self.in_channels % 4 == 0 \
             and self.out_channels % 4 == 0 and fuse.get("residual") is None
         down = bool(fuse.get("downsample"))
-        return ops.fused_conv(x, self.weight, self.bias, self.sn_state(upsample=phase, downsample=down), **fuse)
+        wino = self.kernel_size == (3, 3) and not phase and not down and not fuse.get("upsample") and \
+            ops.winograd_applies(self.in_channels, self.out_channels, x.shape[2], x.shape[3], x.shape[0])
+        return ops.fused_conv(x, self.weight, self.bias, self.sn_state(upsample=phase, downsample=down, winograd=wino),
+                              **fuse)
 
 
 class SNLinear(nn.Linear, SN):

@@ -61,9 +61,11 @@ class SNState:
     w_up_dgrad: Optional[torch.Tensor] = None  # [Cin][4][4][Cout]
     w_down: Optional[torch.Tensor] = None    # 4x4/stride-2 kernel of conv3x3 -> avgpool2, [Cout][4][4][Cin]
     w_down_dgrad: Optional[torch.Tensor] = None  # [4][Cin][2][2][Cout]
+    w_wino: Optional[torch.Tensor] = None        # Winograd-domain weight [16][Cout][Cin] (wide 3x3 stride-1 layers)
+    w_wino_dgrad: Optional[torch.Tensor] = None  # the same for the data gradient, [16][Cin][Cout]
 
 
-def _sn_alloc(weight, need_dgrad, upsample, downsample):
+def _sn_alloc(weight, need_dgrad, upsample, downsample, winograd=False):
     """-> (contiguous weight, SNState with its output buffers, scratch buffer)"""
     w = weight.detach()
     if not w.is_contiguous():
@@ -86,34 +88,46 @@ def _sn_alloc(weight, need_dgrad, upsample, downsample):
     if down:
         st.w_down = _f32(16 * rows * cin, dev)
         st.w_down_dgrad = _f32(16 * rows * cin, dev) if need_dgrad else None
+    if winograd and R == 3 and not up and not down:
+        st.w_wino = _f32(16 * rows * cin, dev)
+        st.w_wino_dgrad = _f32(16 * rows * cin, dev) if need_dgrad else None
     nb = L.query("icg_sn_scratch_bytes", rows, cin, R)
     return w, st, _bytes(nb, dev)
 
 
+def _sn_winograd(st: SNState):
+    """Winograd-domain copies of W/sigma (after the spectral-norm pass filled w_ohwi / w_dgrad)."""
+    if st.w_wino is not None:
+        L.call("icg_wino_weight_transform", st.w_ohwi, st.w_wino, st.rows, st.cin)
+    if st.w_wino_dgrad is not None:
+        L.call("icg_wino_weight_transform", st.w_dgrad, st.w_wino_dgrad, st.cin, st.rows)
+
+
 def sn_prepare(weight: torch.Tensor, u: torch.Tensor, sv: Optional[torch.Tensor], eps: float, training: bool,
-               need_dgrad: bool, upsample: bool = False, downsample: bool = False) -> SNState:
+               need_dgrad: bool, upsample: bool = False, downsample: bool = False, winograd: bool = False) -> SNState:
     """One power iteration (updates `u`/`sv` in place when training) and W/sigma in kernel layouts.
     upsample=True (3x3 conv that follows a nearest x2 upsample) emits the 4-phase 2x2 layouts instead of OHWI-dgrad."""
     _require_gpu(weight)
-    w, st, scratch = _sn_alloc(weight, need_dgrad, upsample, downsample)
+    w, st, scratch = _sn_alloc(weight, need_dgrad, upsample, downsample, winograd)
     L.call("icg_sn_forward", w, u, sv, st.rows, st.cin, st.R, float(eps), int(bool(training)), st.v, st.u, st.sigma,
            st.w_ohwi, st.w_dgrad, st.w_up, st.w_up_dgrad, st.w_down, st.w_down_dgrad, scratch, scratch.numel())
     if training:
         bump_version(u, sv)
+    _sn_winograd(st)
     return st
 
 
 def sn_prepare_many(items, eps: float, training: bool):
     """`sn_prepare` for many layers in one batched pass (icg_sn_forward_multi): items = [(weight, u, sv, need_dgrad,
-    upsample, downsample), ...] -> [SNState, ...].  Bit-identical to calling sn_prepare per layer."""
+    upsample, downsample[, winograd]), ...] -> [SNState, ...].  Bit-identical to calling sn_prepare per layer."""
     import ctypes
     if not items:
         return []
     _require_gpu(items[0][0])
     arr = (L.SnLayer * len(items))()
     states, keep = [], []
-    for i, (weight, u, sv, need_dgrad, upsample, downsample) in enumerate(items):
-        w, st, scratch = _sn_alloc(weight, need_dgrad, upsample, downsample)
+    for i, (weight, u, sv, need_dgrad, upsample, downsample, *rest) in enumerate(items):
+        w, st, scratch = _sn_alloc(weight, need_dgrad, upsample, downsample, bool(rest and rest[0]))
         keep.append((w, scratch))
         d = arr[i]
         d.w, d.u, d.sv = w.data_ptr(), u.data_ptr(), (sv.data_ptr() if sv is not None else None)
@@ -129,6 +143,8 @@ def sn_prepare_many(items, eps: float, training: bool):
     if training:
         for it in items:
             bump_version(it[1], it[2])
+    for st in states:
+        _sn_winograd(st)
     return states
 
 
@@ -149,6 +165,21 @@ def _conv_fprop(x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, 
                _bytes(nb, out.device), nb)
     else:
         L.call("icg_conv2d_fprop", x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, flags, 1.0)
+
+
+def _wino_fprop(x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, flags):
+    nb = L.query("icg_conv2d_wino_workspace_bytes", B, H, W, Cin, Cout)
+    L.call("icg_conv2d_wino_fprop", x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, flags, 1.0,
+           _bytes(nb, out.device), nb)
+
+
+WINOGRAD_MIN_CHANNELS = 192      # measured cross-over on MI355X (tools/wino_bench.py): 96 ch 0.8x, 192 ch 1.17x, 384+ ch 1.6-2.7x
+
+
+def winograd_applies(cin, cout, h, w, batch):
+    """3x3 / stride-1 layers for which the Winograd form is faster than the direct implicit GEMM."""
+    return (min(cin, cout) >= WINOGRAD_MIN_CHANNELS and cin % 4 == 0 and cout % 4 == 0 and h % 2 == 0 and w % 2 == 0
+            and 4 * batch * h * w < 0x7FFFFFFF)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -229,6 +260,9 @@ class FusedConvFn(Function):
             assert res is None, "the phase path has no residual epilogue (GBlock conv1 has none)"
             L.call("icg_conv2d_up_fprop", x, sn.w_up, bias, out, scale, shift, ssb, B, Hs, Ws, Cin, Cout,
                    flags & ~L.ICG_UPSAMPLE2X)
+        elif sn.w_wino is not None and not up:
+            # wide 3x3 stride-1 layer: Winograd F(2x2,3x3), 16/36 of the multiply-adds (csrc/winograd.hip)
+            _wino_fprop(x, sn.w_wino, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, fflags)
         else:
             _conv_fprop(x, sn.w_ohwi, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, fflags)
         ctx.phase, ctx.down = phase, down
@@ -265,7 +299,10 @@ class FusedConvFn(Function):
                 if sn.w_dgrad is None:
                     raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
                 da = _empty_cl(B, Cin, H, W, dev)
-                _conv_fprop(dout, sn.w_dgrad, None, None, da, None, None, 0, B, H, W, Cout, Cin, R, 0)
+                if sn.w_wino_dgrad is not None:
+                    _wino_fprop(dout, sn.w_wino_dgrad, None, None, da, None, None, 0, B, H, W, Cout, Cin, 0)
+                else:
+                    _conv_fprop(dout, sn.w_dgrad, None, None, da, None, None, 0, B, H, W, Cout, Cin, R, 0)
             if bn is not None:
                 dx, dgain, dbeta = _bn_backward(x, da, bn, gain, scale, shift, ssb, mean, invstd, gb_rows, count,
                                                 flags, has_gain, has_beta, (B, Cin, Hs, Ws))

@@ -150,6 +150,20 @@ int icg_conv2d_g_wgrad(const float* x, const float* dy, float* dw, int B, int Hi
                        void* stream);
 
 /*
+ * Winograd F(2x2, 3x3) form of the stride-1 3x3 convolution (forward; data gradient with the dgrad-layout weight): 16/36 of the
+ * multiply-adds of icg_conv2d_fprop at the same result up to fp32 rounding (~1e-6); pays for wide layers (Cin, Cout >= 256).
+ *   icg_wino_weight_transform : w [N][3][3][K] (OHWI or dgrad layout)  ->  U [16][N][K] = G g G^T
+ *   icg_conv2d_wino_fprop     : out = alpha * conv3x3(act(x), w) + bias + residual;  flags: ICG_PRE_RELU, ICG_PRE_AFFINE,
+ *                               ICG_RES_UPSAMPLE2X;  H, W even, Cin % 4 == 0, Cout % 4 == 0;  workspace holds the transformed
+ *                               input and the 16 GEMM outputs (icg_conv2d_wino_workspace_bytes)
+ */
+int icg_wino_weight_transform(const float* w, float* U, int N, int K, void* stream);
+size_t icg_conv2d_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int icg_conv2d_wino_fprop(const float* x, const float* U, const float* bias, const float* residual, float* out,
+                          const float* scale, const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin,
+                          int Cout, unsigned flags, float alpha, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Batched fp32 GEMM  C[z] = alpha * op(A[z]) * op(B[z]) for the attention
  * contractions (layers.py:237-243: theta^T phi, g beta^T and their gradients).
  *   transA = 0: A is [M][K] row-major;  1: A is [K][M]

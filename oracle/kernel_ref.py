@@ -74,6 +74,27 @@ def icg_conv2d_fprop_ws(x, w, bias, residual, out, scale, shift, ss_bstride, B, 
     icg_conv2d_fprop(x, w, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, R, flags, alpha)
 
 
+_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+
+
+def icg_wino_weight_transform(w, U, N, K):
+    g = mem(w)[: N * 9 * K].view(N, 3, 3, K).double()
+    u = torch.einsum("ar,nrsk,bs->abnk", _WINO_G, g, _WINO_G)          # [4][4][N][K]
+    mem(U)[: 16 * N * K].copy_(u.reshape(-1).float())
+
+
+def icg_conv2d_wino_workspace_bytes(B, H, W, Cin, Cout):
+    return 16 * B * (H // 2) * (W // 2) * (Cin + Cout) * 4
+
+
+def icg_conv2d_wino_fprop(x, U, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, flags, alpha, workspace,
+                          workspace_bytes):
+    u = mem(U)[: 16 * Cout * Cin].view(4, 4, Cout, Cin).double()
+    inv = torch.tensor([[1.0, 0, 0, 0], [0, 1.0, -1.0, 0], [0, 0, 0, 1.0]], dtype=torch.float64)   # g = inv @ (G g)
+    g = torch.einsum("ra,abnk,sb->nrsk", inv, u, inv).float().contiguous()                          # [Cout][3][3][Cin]
+    icg_conv2d_fprop(x, g, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, 3, flags, alpha)
+
+
 def icg_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, R):
     return 16
 
@@ -666,4 +687,4 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "adam_multi", adam_multi_ref)
     monkeypatch.setattr(ops, "ema_multi", ema_multi_ref)
     monkeypatch.setattr(ops, "sn_prepare_many", lambda items, eps, training: [
-        ops.sn_prepare(w, u, sv, eps, training, nd, up, dn) for (w, u, sv, nd, up, dn) in items])
+        ops.sn_prepare(w, u, sv, eps, training, nd, up, dn, *rest) for (w, u, sv, nd, up, dn, *rest) in items])

@@ -57,8 +57,12 @@ def test_forward_host_logic(case, emu):
     check_group(g, "fwd/D_state/", D.state_dict(), rtol=1e-4, atol=1e-6, what="D buf ")
 
 
+@pytest.mark.parametrize("wino", [False, True])
 @pytest.mark.parametrize("case", ["cc_ic_r64", "ic_r64_acc2", "cc_r32_flat"])
-def test_train_step_host_logic(case, emu):
+def test_train_step_host_logic(case, emu, wino, monkeypatch):
+    if wino:      # force the Winograd F(2x2,3x3) form onto every eligible 3x3 layer of these narrow test networks
+        import ic_gan_amd.ops as _ops
+        monkeypatch.setattr(_ops, "WINOGRAD_MIN_CHANNELS", 4)
     from ic_gan_amd import train_fns, utils
     from ic_gan_amd.optim import FusedAdam
     g = load_golden(case)
@@ -166,7 +170,7 @@ def _eval_cache_case(dev):
         return real_one(*a, **k)
 
     layers.ops.sn_prepare = one
-    layers.ops.sn_prepare_many = lambda items, eps, training: [one(w, u, sv, eps, training, nd, up, dn) for (w, u, sv, nd, up, dn) in items]
+    layers.ops.sn_prepare_many = lambda items, eps, training: [one(w, u, sv, eps, training, nd, up, dn, *rest) for (w, u, sv, nd, up, dn, *rest) in items]
     try:
         G.eval()
         with torch.no_grad():

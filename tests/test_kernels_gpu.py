@@ -662,3 +662,24 @@ def test_conv2d_fprop_split_k(case):
     L.call("icg_conv2d_fprop_ws", c(x), c(w), c(bvec), c(r), out2, c(sc), c(sh), ssb, B, H, W, Cin, Cout, R, rflags, 1.0,
            torch.empty(16, dtype=torch.uint8, device="cuda"), 16)
     close(out2, pair[1], what="single-pass fallback")
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, flags, residual(0 none / 1 same / 2 half-res), bias
+    (2, 8, 8, 32, 32, 0, 0, True),
+    (2, 16, 16, 64, 48, PRE_AFFINE | PRE_RELU, 2, True),     # GBlock conv2: BN + ReLU prologue, upsampled skip
+    (1, 6, 10, 16, 40, PRE_RELU, 1, False),                 # DBlock conv1-like, ragged N, non-square
+    (3, 4, 4, 256, 256, 0, 0, True),
+])
+def test_conv2d_winograd(case):
+    """Winograd F(2x2,3x3) forward (weight transform + input transform + 16 GEMMs + output transform) vs the direct conv."""
+    B, H, W, Cin, Cout, flags, res, bias = case
+    L = _L()
+    x, w, bvec, r, sc, sh, ssb, rflags = _conv_inputs((B, H, W, Cin, Cout, 3, flags, res, bias), 10)
+    U = torch.empty(16, Cout, Cin)
+    (pu,) = run_pair("icg_wino_weight_transform", [w, U, Cout, Cin], [1]); close(*pu, what="wino U")
+    nb = L.query("icg_conv2d_wino_workspace_bytes", B, H, W, Cin, Cout)
+    ws = torch.empty(nb, dtype=torch.uint8)
+    out = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
+    (pair,) = run_pair("icg_conv2d_wino_fprop", [x, U, bvec, r, out, sc, sh, ssb, B, H, W, Cin, Cout, rflags, 1.0, ws, nb], [4])
+    close(*pair, rtol=1e-4, atol_rel=1e-4, what=f"winograd fprop {case}")

@@ -64,8 +64,12 @@ def test_forward_vs_golden(case):
     check_group(g, "fwd/D_state/", {k: v.cpu() for k, v in D.state_dict().items()}, 2e-4, 1e-6, "D buf ")
 
 
+@pytest.mark.parametrize("wino", [False, True])
 @pytest.mark.parametrize("case", CASES)
-def test_train_steps_vs_golden(case):
+def test_train_steps_vs_golden(case, wino, monkeypatch):
+    if wino:      # force the Winograd F(2x2,3x3) form onto every eligible 3x3 layer of these narrow test networks
+        import ic_gan_amd.ops as _ops
+        monkeypatch.setattr(_ops, "WINOGRAD_MIN_CHANNELS", 4)
     from ic_gan_amd import train_fns, utils
     from ic_gan_amd.optim import FusedAdam
     g = load_golden(case)

@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Winograd vs direct 3x3 convolution on the wide cfg3 layers (tools only)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import ic_gan_amd._lib as L
+from tools.conv_bench import ev_time
+
+LAYERS = [("G.b3.conv2 384->384 @64 B64", 64, 64, 64, 384, 384), ("G.b2.conv2 768->768 @32 B64", 64, 32, 32, 768, 768),
+          ("D.b3.conv1 384->768 @32 B128", 128, 32, 32, 384, 768), ("D.b4.conv1 768->768 @16 B128", 128, 16, 16, 768, 768),
+          ("G.b0.conv2 1536->1536 @8 B64", 64, 8, 8, 1536, 1536), ("G.b4.conv2 192->192 @128 B64", 64, 128, 128, 192, 192),
+          ("G.b5.conv2 96->96 @256 B64", 64, 256, 256, 96, 96)]
+for name, B, H, W, Cin, Cout in LAYERS:
+    dev = "cuda"
+    x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, 3, 3, Cin, device=dev) / (9 * Cin) ** 0.5
+    out = torch.empty(B, Cout, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    out2 = torch.empty_like(out)
+    sc, sh = torch.rand(B, Cin, device=dev) + 0.5, torch.randn(B, Cin, device=dev) * 0.1
+    fl = 3
+    nf = L.query("icg_conv2d_fprop_workspace_bytes", B, H, W, Cin, Cout, 3, fl)
+    wf = torch.empty(max(nf, 16), dtype=torch.uint8, device=dev)
+    t_d = ev_time(lambda: L.call("icg_conv2d_fprop_ws", x, w, None, None, out, sc, sh, Cin, B, H, W, Cin, Cout, 3, fl, 1.0, wf, nf))
+    U = torch.empty(16, Cout, Cin, device=dev)
+    L.call("icg_wino_weight_transform", w, U, Cout, Cin)
+    nb = L.query("icg_conv2d_wino_workspace_bytes", B, H, W, Cin, Cout)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    t_w = ev_time(lambda: L.call("icg_conv2d_wino_fprop", x, U, None, None, out2, sc, sh, Cin, B, H, W, Cin, Cout, fl, 1.0, ws, nb))
+    err = float((out2 - out).norm() / out.norm())
+    print(f"{name:34s} direct {t_d*1e3:7.3f} ms  winograd {t_w*1e3:7.3f} ms  speedup {t_d/t_w:5.2f}  rel L2 {err:.2e}  ws {nb>>20} MiB", flush=True)
