@@ -52,7 +52,7 @@ class KernelTimer:
     library (icg_gemm_last_variant), so they can be compared line by line with profiles/*_kernel_stats.csv."""
 
     # entry point -> (index of B in the argument list, kind)
-    SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"),
+    SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"), "icg_conv2d_wino_wgrad": (6, "wino"),
             "icg_conv2d_wgrad": (6, "conv"), "icg_conv2d_up_fprop": (7, "up"),
             "icg_conv2d_up_dgrad": (3, "up"), "icg_conv2d_up_wgrad": (6, "up"), "icg_conv2d_down_fprop": (5, "up"),
             "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_wgrad": (3, "up")}
@@ -95,7 +95,9 @@ class KernelTimer:
             e.record()
             query(last)
             if mode == "wino":     # three kernels behind one entry point: not comparable with a single rocprof row
-                kname = "composite: wino_input_kernel + icg_gemm_kernel<0, 0, %d, 2> (16 batched GEMMs) + wino_output_kernel" % last[2]
+                kname = ("composite: wino_input_kernel + wino_dy_kernel + icg_gemm_kernel<1, 1, %d, 2> (16 batched split-K GEMMs) + reduce + wino_dw_kernel" % last[2]
+                         if name.endswith("wgrad") else
+                         "composite: wino_input_kernel + icg_gemm_kernel<0, 0, %d, 2> (16 batched GEMMs) + wino_output_kernel" % last[2])
             elif last[0] == -2:      # direct narrow-output kernels (narrow_conv.hip): {-2, fprop/wgrad, Cout, Cin}
                 lp = 1
                 while lp < last[3] // 4:

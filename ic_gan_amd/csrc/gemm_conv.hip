@@ -49,6 +49,7 @@ struct GemmP {
   int phase_mode, nsplit;
   int oH, oW;                      // phase_mode 1: extent of the scattered output grid (0 = 2H x 2W); rows beyond are dropped
   int swz;                         // XCD-aware tile order (see kernel head)
+  int bsplit;                      // > 0: batched split-K, slices per batch (see kernel head)
   int zmask;                       // generic A_K paths only: source is zero-inserted by (zmask+1): hi, wi must be multiples
   int vec_b;                       // PATH 1 only: 16-byte loads allowed on the B operand (A is vectorised)
 };
@@ -91,11 +92,13 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
   const int mt = tile / p.ntiles_n;
   const int z = (int)zz;
   const int m0 = mt * BM, n0 = nt * BN;
-  const float* __restrict__ Ag = p.A + (long)z * p.strideA;
-  const float* __restrict__ Bg = p.B + (long)z * p.strideB;
+  // batched split-K (p.bsplit > 0): z = batch * bsplit + slice; operands advance per batch, the output per (batch, slice)
+  const int zb = (p.bsplit > 0) ? z / p.bsplit : z;
+  const float* __restrict__ Ag = p.A + (long)zb * p.strideA;
+  const float* __restrict__ Bg = p.B + (long)zb * p.strideB;
   float* __restrict__ Cg = p.C + (long)z * p.strideC;
   int kbeg = 0, kend = p.K;
-  int ksplit = z, ph_a = 0, ph_b = 0;
+  int ksplit = (p.bsplit > 0) ? z - zb * p.bsplit : z, ph_a = 0, ph_b = 0;
   int pad_h = p.pad_h, pad_w = p.pad_w;
   if (p.phase_mode) {
     const int phase = (p.phase_mode == 2) ? z / p.nsplit : z;
@@ -1310,6 +1313,72 @@ extern "C" int icg_conv2d_g_wgrad(const float* x, const float* dy, float* dw, in
     rc = icg_check_launch();
   }
   return rc;
+}
+
+// out[b][i] = sum_s slab[b * splits + s][i]   (deterministic order)
+__global__ void splitk_reduce_batched_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits) {
+  const long b = blockIdx.y;
+  const float* sl = slabs + b * splits * n;
+  float* o = out + b * n;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += sl[(long)z * n + i];
+    o[i] = s;
+  }
+}
+
+static int tn_batched_splits(long K, int M, int N, int batch) {
+  const long tiles = icg_cdiv(M, 128) * icg_cdiv(N, 32 * pick_tn(N)) * batch;
+  long s = 2048 / (tiles > 0 ? tiles : 1);
+  const long ksteps = icg_cdiv(K, 16);
+  if (s > ksteps / 8) s = ksteps / 8;
+  if (s > 256) s = 256;
+  return s < 1 ? 1 : (int)s;
+}
+
+extern "C" size_t icg_gemm_tn_batched_workspace_bytes(int M, int N, int K, int batch) {
+  const int s = tn_batched_splits(K, M, N, batch);
+  return s <= 1 ? 16 : (size_t)batch * s * (size_t)M * N * sizeof(float);
+}
+
+// C[b] = A[b]^T B[b] for A [K][M], B [K][N] with a long K (weight-gradient shaped: K = pixels or tiles): K is split into
+// slices so that batch x slices x tiles fills the chip; slabs are summed in fixed order.
+extern "C" int icg_gemm_tn_batched(const float* A, const float* B, float* C, int M, int N, int K, int64_t strideA,
+                                   int64_t strideB, int64_t strideC, int batch, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  ICG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0);
+  int S = tn_batched_splits(K, M, N, batch);
+  if (S > 1 && (workspace == nullptr || workspace_bytes < (size_t)batch * S * (size_t)M * N * sizeof(float))) S = 1;
+  GemmP p{};
+  p.A = A; p.B = B;
+  p.M = M; p.N = N; p.K = K;
+  p.H = 1; p.W = 1; p.R = 1; p.up = 0; p.Hs = 1; p.Ws = 1;
+  p.pad_h = 0; p.pad_w = 0; p.gs = 1; p.Hb = 1; p.Wb = 1;
+  p.Cin = M; p.ldb = N; p.ldc = N;
+  p.alpha = 1.f;
+  p.strideA = strideA; p.strideB = strideB;
+  const bool al = aligned16(A) && aligned16(B) && (strideA % 4 == 0) && (strideB % 4 == 0);
+  const bool vec = al && (M % 4 == 0) && (N % 4 == 0);
+  const bool small = ((long)M * K < 0x7fffffffL) && ((long)N * K < 0x7fffffffL);
+  hipStream_t st = (hipStream_t)stream;
+  if (S <= 1) {
+    p.C = C; p.strideC = strideC; p.kchunk = 0; p.bsplit = 0;
+    return launch_gemm<A_M, B_N>(p, vec, batch, st, small);
+  }
+  p.kchunk = (int)(icg_cdiv(icg_cdiv(K, S), 16) * 16);
+  const int splits = (int)icg_cdiv(K, p.kchunk);
+  p.bsplit = splits;
+  p.C = (float*)workspace; p.strideC = (long)M * N;
+  int rc = launch_gemm<A_M, B_N>(p, vec, batch * splits, st, small);
+  if (rc != ICG_OK) return rc;
+  ICG_REQUIRE(strideC == (int64_t)M * N);
+  const long n = (long)M * N;
+  long blocks = icg_cdiv(n, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(splitk_reduce_batched_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0, st,
+                     (const float*)workspace, C, n, splits);
+  return icg_check_launch();
 }
 
 extern "C" int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int transA,

@@ -147,6 +147,109 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   }
 }
 
+// DY[xi][t][c] = (A dy A^T)[xi] on the 2x2 output tile t,  A = [1 0; 1 1; 1 -1; 0 -1]     (weight-gradient side)
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ DY, int B, int H,
+                                                      int W, int C4) {
+  const int th = H >> 1, tw = W >> 1;
+  const long T = (long)B * th * tw;
+  const long total = T * C4, plane = T * C4;
+  const long gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const int c4 = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long t2 = t / tw;
+    const int ty = (int)(t2 % th);
+    const long b = t2 / th;
+    const float4* gp = reinterpret_cast<const float4*>(dy) + ((b * H + 2 * ty) * W + 2 * tx) * C4 + c4;
+    const float4 d00 = gp[0], d01 = gp[C4], d10 = gp[(long)W * C4], d11 = gp[(long)W * C4 + C4];
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    // rows of A dy: r0 = d0, r1 = d0 + d1, r2 = d0 - d1, r3 = -d1   (each a pair over the two columns)
+    const float4 r[4][2] = {{d00, d01}, {f4add(d00, d10), f4add(d01, d11)}, {f4sub(d00, d10), f4sub(d01, d11)},
+                            {f4sub(z, d10), f4sub(z, d11)}};
+    float4* op = reinterpret_cast<float4*>(DY) + t * C4 + c4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      op[(4 * a + 0) * plane] = r[a][0];
+      op[(4 * a + 1) * plane] = f4add(r[a][0], r[a][1]);
+      op[(4 * a + 2) * plane] = f4sub(r[a][0], r[a][1]);
+      op[(4 * a + 3) * plane] = f4sub(z, r[a][1]);
+    }
+  }
+}
+
+// dw[r][s][ci][co] = (G^T dU G)[r][s],  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]      (HWIO, like the direct weight gradient)
+__global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, long n) {
+  const long gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
+    float u[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) u[a][b] = dU[(long)(4 * a + b) * n + i];
+    float t[3][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
+      t[1][b] = 0.5f * (u[1][b] - u[2][b]);
+      t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      dw[(long)(3 * r + 0) * n + i] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+      dw[(long)(3 * r + 1) * n + i] = 0.5f * (t[r][1] - t[r][2]);
+      dw[(long)(3 * r + 2) * n + i] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+    }
+  }
+}
+
+extern "C" size_t icg_gemm_tn_batched_workspace_bytes(int M, int N, int K, int batch);
+extern "C" int icg_gemm_tn_batched(const float* A, const float* B, float* C, int M, int N, int K, int64_t strideA,
+                                   int64_t strideB, int64_t strideC, int batch, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+
+static size_t wino_al(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" size_t icg_conv2d_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  const size_t T = (size_t)B * (H / 2) * (W / 2);
+  return wino_al(16 * T * Cin * sizeof(float)) + wino_al(16 * T * Cout * sizeof(float)) +
+         wino_al((size_t)16 * Cin * Cout * sizeof(float)) + wino_al(icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, 16));
+}
+
+// dw[r][s][ci][co] of the 3x3 / stride-1 / pad-1 convolution of act(x) given dy, through the Winograd domain:
+//   dU[xi] = V[xi]^T DY[xi]   (V = B^T act(x) B per tile, DY = A dy A^T per tile),   dw = G^T dU G
+extern "C" int icg_conv2d_wino_wgrad(const float* x, const float* dy, float* dw, const float* scale, const float* shift,
+                                     int64_t ss_bstride, int B, int H, int W, int Cin, int Cout, unsigned flags,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(x && dy && dw && workspace && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  ICG_REQUIRE((H % 2 == 0) && (W % 2 == 0) && (Cin % 4 == 0) && (Cout % 4 == 0) && !(flags & ICG_UPSAMPLE2X));
+  if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift && (ss_bstride % 4 == 0));
+  if (workspace_bytes < icg_conv2d_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return ICG_ERR_WORKSPACE;
+  const long T = (long)B * (H / 2) * (W / 2);
+  ICG_REQUIRE(T * 16 < 0x7fffffffL);
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  float* V = (float*)base;                    base += wino_al(16 * T * Cin * sizeof(float));
+  float* DY = (float*)base;                   base += wino_al(16 * T * Cout * sizeof(float));
+  float* dU = (float*)base;                   base += wino_al((size_t)16 * Cin * Cout * sizeof(float));
+  void* gws = base;
+  const size_t gws_bytes = icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, 16);
+  long nb = icg_cdiv(T * (Cin / 4), 256);
+  if (nb > 256 * 64) nb = 256 * 64;
+  hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, (long)ss_bstride, V, B, H, W,
+                     Cin / 4, (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0);
+  nb = icg_cdiv(T * (Cout / 4), 256);
+  if (nb > 256 * 64) nb = 256 * 64;
+  hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, DY, B, H, W, Cout / 4);
+  int rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, 16, gws, gws_bytes, stream);
+  if (rc != ICG_OK) return rc;
+  const long n = (long)Cin * Cout;
+  nb = icg_cdiv(n, 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)dU, dw, n);
+  return icg_check_launch();
+}
+
 extern "C" int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int transA, int transB,
                                 int64_t strideA, int64_t strideB, int64_t strideC, int batch, float alpha, void* stream);
 

@@ -173,6 +173,7 @@ def _wino_fprop(x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, fla
            _bytes(nb, out.device), nb)
 
 
+WINOGRAD_WGRAD = True            # weight gradient of those layers through the Winograd domain as well
 WINOGRAD_MIN_CHANNELS = 192      # measured cross-over on MI355X (tools/wino_bench.py): 96 ch 0.8x, 192 ch 1.17x, 384+ ch 1.6-2.7x
 
 
@@ -327,10 +328,16 @@ class FusedConvFn(Function):
                    ctx.flags & ~L.ICG_UPSAMPLE2X, ws, nb)
             dweight = _sn_backward(None, None, sn, ctx.weight_like, dw_up=dw_up)
         elif need[1]:
-            nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, Cin, Cout, R)
-            ws = _bytes(nb, dev)
             dw_hwio = _f32(R * R * Cin * Cout, dev)
-            L.call("icg_conv2d_wgrad", x, dout, dw_hwio, scale, shift, ssb, B, H, W, Cin, Cout, R, ctx.flags, ws, nb)
+            if sn.w_wino is not None and WINOGRAD_WGRAD:
+                # wide 3x3 stride-1 layer: weight gradient through the Winograd domain (16/36 of the MACs)
+                nb = L.query("icg_conv2d_wino_wgrad_workspace_bytes", B, H, W, Cin, Cout)
+                L.call("icg_conv2d_wino_wgrad", x, dout, dw_hwio, scale, shift, ssb, B, H, W, Cin, Cout, ctx.flags,
+                       _bytes(nb, dev), nb)
+            else:
+                nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, Cin, Cout, R)
+                ws = _bytes(nb, dev)
+                L.call("icg_conv2d_wgrad", x, dout, dw_hwio, scale, shift, ssb, B, H, W, Cin, Cout, R, ctx.flags, ws, nb)
             dweight = _sn_backward(dw_hwio, None, sn, ctx.weight_like)
         if has_bias and need[2]:
             rows = B * H * W

@@ -163,6 +163,17 @@ int icg_conv2d_wino_fprop(const float* x, const float* U, const float* bias, con
                           const float* scale, const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin,
                           int Cout, unsigned flags, float alpha, void* workspace, size_t workspace_bytes, void* stream);
 
+/* weight gradient of the same layer through the Winograd domain (HWIO output like icg_conv2d_wgrad, 16/36 of its MACs):
+ * dU[xi] = V[xi]^T (A dy A^T)[xi] as 16 long-K GEMMs (icg_gemm_tn_batched), dw = G^T dU G */
+size_t icg_conv2d_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int icg_conv2d_wino_wgrad(const float* x, const float* dy, float* dw, const float* scale, const float* shift,
+                          int64_t ss_bstride, int B, int H, int W, int Cin, int Cout, unsigned flags, void* workspace,
+                          size_t workspace_bytes, void* stream);
+/* C[b] = A[b]^T B[b], A [K][M], B [K][N], long K: batched with deterministic split-K (strideC must be M*N) */
+size_t icg_gemm_tn_batched_workspace_bytes(int M, int N, int K, int batch);
+int icg_gemm_tn_batched(const float* A, const float* B, float* C, int M, int N, int K, int64_t strideA, int64_t strideB,
+                        int64_t strideC, int batch, void* workspace, size_t workspace_bytes, void* stream);
+
 /*
  * Batched fp32 GEMM  C[z] = alpha * op(A[z]) * op(B[z]) for the attention
  * contractions (layers.py:237-243: theta^T phi, g beta^T and their gradients).

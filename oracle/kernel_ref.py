@@ -95,6 +95,25 @@ def icg_conv2d_wino_fprop(x, U, bias, residual, out, scale, shift, ss_bstride, B
     icg_conv2d_fprop(x, g, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, 3, flags, alpha)
 
 
+def icg_conv2d_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout):
+    return 16
+
+
+def icg_conv2d_wino_wgrad(x, dy, dw, scale, shift, ss_bstride, B, H, W, Cin, Cout, flags, workspace, workspace_bytes):
+    icg_conv2d_wgrad(x, dy, dw, scale, shift, ss_bstride, B, H, W, Cin, Cout, 3, flags, None, 0)
+
+
+def icg_gemm_tn_batched_workspace_bytes(M, N, K, batch):
+    return 16
+
+
+def icg_gemm_tn_batched(A, B, C, M, N, K, strideA, strideB, strideC, batch, workspace, workspace_bytes):
+    for b in range(batch):
+        a = mem(A)[b * strideA: b * strideA + K * M].view(K, M).double()
+        bb = mem(B)[b * strideB: b * strideB + K * N].view(K, N).double()
+        mem(C)[b * strideC: b * strideC + M * N].copy_((a.t() @ bb).float().reshape(-1))
+
+
 def icg_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, R):
     return 16
 

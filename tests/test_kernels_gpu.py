@@ -683,3 +683,35 @@ def test_conv2d_winograd(case):
     out = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
     (pair,) = run_pair("icg_conv2d_wino_fprop", [x, U, bvec, r, out, sc, sh, ssb, B, H, W, Cin, Cout, rflags, 1.0, ws, nb], [4])
     close(*pair, rtol=1e-4, atol_rel=1e-4, what=f"winograd fprop {case}")
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, flags
+    (2, 8, 8, 32, 32, 0),
+    (2, 16, 16, 64, 48, PRE_AFFINE | PRE_RELU),
+    (1, 6, 10, 16, 40, PRE_RELU),
+    (4, 32, 32, 128, 128, 0),            # long K (tiles) -> batched split-K slabs
+])
+def test_conv2d_winograd_wgrad(case):
+    """Winograd-domain weight gradient (input + dy transforms, 16 long-K GEMMs with split-K, G^T dU G) vs the direct one."""
+    B, H, W, Cin, Cout, flags = case
+    L = _L()
+    x, w, bvec, r, sc, sh, ssb, rflags = _conv_inputs((B, H, W, Cin, Cout, 3, flags, 0, False), 20)
+    dy = cl(B, Cout, H, W, seed=31)
+    dw = torch.empty(9 * Cin * Cout)
+    nb = L.query("icg_conv2d_wino_wgrad_workspace_bytes", B, H, W, Cin, Cout)
+    ws = torch.empty(nb, dtype=torch.uint8)
+    (pair,) = run_pair("icg_conv2d_wino_wgrad", [x, dy, dw, sc, sh, ssb, B, H, W, Cin, Cout, flags, ws, nb], [2])
+    close(*pair, rtol=2e-4, atol_rel=2e-4, what=f"winograd wgrad {case}")
+
+
+def test_gemm_tn_batched_split_k():
+    L = _L()
+    M, N, K, batch = 96, 64, 5000, 5
+    A, Bm = rnd(batch, K, M, seed=1), rnd(batch, K, N, seed=2)
+    C = torch.empty(batch, M, N)
+    nb = L.query("icg_gemm_tn_batched_workspace_bytes", M, N, K, batch)
+    assert nb > 16
+    ws = torch.empty(nb, dtype=torch.uint8)
+    (pair,) = run_pair("icg_gemm_tn_batched", [A, Bm, C, M, N, K, K * M, K * N, M * N, batch, ws, nb], [2])
+    close(*pair, rtol=1e-4, atol_rel=1e-4, what="tn batched split-K")

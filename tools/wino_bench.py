@@ -29,3 +29,18 @@ for name, B, H, W, Cin, Cout in LAYERS:
     t_w = ev_time(lambda: L.call("icg_conv2d_wino_fprop", x, U, None, None, out2, sc, sh, Cin, B, H, W, Cin, Cout, fl, 1.0, ws, nb))
     err = float((out2 - out).norm() / out.norm())
     print(f"{name:34s} direct {t_d*1e3:7.3f} ms  winograd {t_w*1e3:7.3f} ms  speedup {t_d/t_w:5.2f}  rel L2 {err:.2e}  ws {nb>>20} MiB", flush=True)
+print("---- weight gradient")
+for name, B, H, W, Cin, Cout in LAYERS[:5]:
+    dev = "cuda"
+    x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(B, Cout, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    sc, sh = torch.rand(B, Cin, device=dev) + 0.5, torch.randn(B, Cin, device=dev) * 0.1
+    dw1, dw2 = torch.empty(9 * Cin * Cout, device=dev), torch.empty(9 * Cin * Cout, device=dev)
+    nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, Cin, Cout, 3)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+    t_d = ev_time(lambda: L.call("icg_conv2d_wgrad", x, dy, dw1, sc, sh, Cin, B, H, W, Cin, Cout, 3, 3, ws, nb))
+    nbw = L.query("icg_conv2d_wino_wgrad_workspace_bytes", B, H, W, Cin, Cout)
+    wsw = torch.empty(nbw, dtype=torch.uint8, device=dev)
+    t_w = ev_time(lambda: L.call("icg_conv2d_wino_wgrad", x, dy, dw2, sc, sh, Cin, B, H, W, Cin, Cout, 3, wsw, nbw))
+    err = float((dw2 - dw1).norm() / dw1.norm())
+    print(f"{name:34s} direct {t_d*1e3:7.3f} ms  winograd {t_w*1e3:7.3f} ms  speedup {t_d/t_w:5.2f}  rel L2 {err:.2e}  ws {nbw>>20} MiB", flush=True)
