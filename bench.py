@@ -52,7 +52,7 @@ class KernelTimer:
     library (icg_gemm_last_variant), so they can be compared line by line with profiles/*_kernel_stats.csv."""
 
     # entry point -> (index of B in the argument list, kind)
-    SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"), "icg_conv2d_wino_wgrad": (6, "wino"),
+    SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"), "icg_conv2d_wino4_fprop": (8, "wino4"), "icg_conv2d_wino_wgrad": (6, "wino"),
             "icg_conv2d_wgrad": (6, "conv"), "icg_conv2d_up_fprop": (7, "up"),
             "icg_conv2d_up_dgrad": (3, "up"), "icg_conv2d_up_wgrad": (6, "up"), "icg_conv2d_down_fprop": (5, "up"),
             "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_wgrad": (3, "up")}
@@ -77,10 +77,10 @@ class KernelTimer:
                 B, H, W, Cin, Cout, R = args[sl:sl + 6]
                 alg = exe = 2.0 * B * H * W * Cout * Cin * R * R
                 byt = 4.0 * (B * H * W * (Cin + Cout) + Cout * Cin * R * R)
-            elif mode == "wino":   # Winograd F(2x2,3x3): 16 GEMMs over a quarter of the pixels = 16/36 of the direct MACs
-                B, H, W, Cin, Cout = args[sl:sl + 5]
+            elif mode in ("wino", "wino4"):   # Winograd: 16 GEMMs over 1/4 of the pixels (16/36 of the direct MACs) or
+                B, H, W, Cin, Cout = args[sl:sl + 5]          # F(4x4,3x3): 36 GEMMs over 1/16 of the pixels (9/36)
                 alg = 2.0 * B * H * W * Cout * Cin * 9
-                exe = alg * 16.0 / 36.0
+                exe = alg * (9.0 if mode == "wino4" else 16.0) / 36.0
                 byt = 4.0 * (B * H * W * (Cin + Cout) + Cout * Cin * 9)
             else:       # upsample- / avgpool-fused conv (2x2-phase or 4x4-stride-2 form): executed MACs are 16/36 of the
                         # reference op graph's (3x3 at the HIGH resolution); tensors: low-res one side, high-res the other
@@ -94,10 +94,12 @@ class KernelTimer:
             raw(name, *args)
             e.record()
             query(last)
-            if mode == "wino":     # three kernels behind one entry point: not comparable with a single rocprof row
+            if mode in ("wino", "wino4"):     # three kernels behind one entry point: not comparable with a single rocprof row
                 kname = ("composite: wino_input_kernel + wino_dy_kernel + icg_gemm_kernel<1, 1, %d, 2> (16 batched split-K GEMMs) + reduce + wino_dw_kernel" % last[2]
                          if name.endswith("wgrad") else
-                         "composite: wino_input_kernel + icg_gemm_kernel<0, 0, %d, 2> (16 batched GEMMs) + wino_output_kernel" % last[2])
+                         ("composite: wino4_input_kernel + icg_gemm_kernel<0, 0, %d, 2> (36 batched GEMMs) + wino4_output_kernel" % last[2]
+                          if mode == "wino4" else
+                          "composite: wino_input_kernel + icg_gemm_kernel<0, 0, %d, 2> (16 batched GEMMs) + wino_output_kernel" % last[2]))
             elif last[0] == -2:      # direct narrow-output kernels (narrow_conv.hip): {-2, fprop/wgrad, Cout, Cin}
                 lp = 1
                 while lp < last[3] // 4:

@@ -54,7 +54,7 @@ class SN(object):
         """One power-iteration step (in place on u0/sv0 in training mode) + W/sigma in kernel layouts."""
         if need_dgrad is None:
             need_dgrad = torch.is_grad_enabled()
-        flags = (bool(need_dgrad), bool(upsample), bool(downsample), bool(winograd))
+        flags = (bool(need_dgrad), bool(upsample), bool(downsample), int(winograd))
         if _record:
             self._sn_flags[torch.is_grad_enabled()] = flags
         ready, self._sn_ready = self._sn_ready, None
@@ -130,8 +130,9 @@ class SNConv2d(nn.Conv2d, SN):
         phase = bool(fuse.get("upsample")) and self.kernel_size == (3, 3) and self.in_channels % 4 == 0 \
             and self.out_channels % 4 == 0 and fuse.get("residual") is None
         down = bool(fuse.get("downsample"))
-        wino = self.kernel_size == (3, 3) and not phase and not down and not fuse.get("upsample") and \
-            ops.winograd_applies(self.in_channels, self.out_channels, x.shape[2], x.shape[3], x.shape[0])
+        wino = 0
+        if self.kernel_size == (3, 3) and not phase and not down and not fuse.get("upsample"):
+            wino = ops.winograd_applies(self.in_channels, self.out_channels, x.shape[2], x.shape[3], x.shape[0])
         return ops.fused_conv(x, self.weight, self.bias, self.sn_state(upsample=phase, downsample=down, winograd=wino),
                               **fuse)
 

@@ -63,6 +63,7 @@ class SNState:
     w_down_dgrad: Optional[torch.Tensor] = None  # [4][Cin][2][2][Cout]
     w_wino: Optional[torch.Tensor] = None        # Winograd-domain weight [16][Cout][Cin] (wide 3x3 stride-1 layers)
     w_wino_dgrad: Optional[torch.Tensor] = None  # the same for the data gradient, [16][Cin][Cout]
+    wino_m: int = 0                              # 2: F(2x2,3x3), 16 planes;  4: F(4x4,3x3), 36 planes
 
 
 def _sn_alloc(weight, need_dgrad, upsample, downsample, winograd=False):
@@ -89,18 +90,21 @@ def _sn_alloc(weight, need_dgrad, upsample, downsample, winograd=False):
         st.w_down = _f32(16 * rows * cin, dev)
         st.w_down_dgrad = _f32(16 * rows * cin, dev) if need_dgrad else None
     if winograd and R == 3 and not up and not down:
-        st.w_wino = _f32(16 * rows * cin, dev)
-        st.w_wino_dgrad = _f32(16 * rows * cin, dev) if need_dgrad else None
+        st.wino_m = 4 if int(winograd) == 4 else 2
+        planes = 36 if st.wino_m == 4 else 16
+        st.w_wino = _f32(planes * rows * cin, dev)
+        st.w_wino_dgrad = _f32(planes * rows * cin, dev) if need_dgrad else None
     nb = L.query("icg_sn_scratch_bytes", rows, cin, R)
     return w, st, _bytes(nb, dev)
 
 
 def _sn_winograd(st: SNState):
     """Winograd-domain copies of W/sigma (after the spectral-norm pass filled w_ohwi / w_dgrad)."""
+    fn = "icg_wino4_weight_transform" if st.wino_m == 4 else "icg_wino_weight_transform"
     if st.w_wino is not None:
-        L.call("icg_wino_weight_transform", st.w_ohwi, st.w_wino, st.rows, st.cin)
+        L.call(fn, st.w_ohwi, st.w_wino, st.rows, st.cin)
     if st.w_wino_dgrad is not None:
-        L.call("icg_wino_weight_transform", st.w_dgrad, st.w_wino_dgrad, st.cin, st.rows)
+        L.call(fn, st.w_dgrad, st.w_wino_dgrad, st.cin, st.rows)
 
 
 def sn_prepare(weight: torch.Tensor, u: torch.Tensor, sv: Optional[torch.Tensor], eps: float, training: bool,
@@ -127,7 +131,7 @@ def sn_prepare_many(items, eps: float, training: bool):
     arr = (L.SnLayer * len(items))()
     states, keep = [], []
     for i, (weight, u, sv, need_dgrad, upsample, downsample, *rest) in enumerate(items):
-        w, st, scratch = _sn_alloc(weight, need_dgrad, upsample, downsample, bool(rest and rest[0]))
+        w, st, scratch = _sn_alloc(weight, need_dgrad, upsample, downsample, int(rest[0]) if rest else 0)
         keep.append((w, scratch))
         d = arr[i]
         d.w, d.u, d.sv = w.data_ptr(), u.data_ptr(), (sv.data_ptr() if sv is not None else None)
@@ -167,20 +171,28 @@ def _conv_fprop(x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, 
         L.call("icg_conv2d_fprop", x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, flags, 1.0)
 
 
-def _wino_fprop(x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, flags):
-    nb = L.query("icg_conv2d_wino_workspace_bytes", B, H, W, Cin, Cout)
-    L.call("icg_conv2d_wino_fprop", x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, flags, 1.0,
+def _wino_fprop(x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, flags, m=2):
+    v = "wino4" if m == 4 else "wino"
+    nb = L.query("icg_conv2d_%s_workspace_bytes" % v, B, H, W, Cin, Cout)
+    L.call("icg_conv2d_%s_fprop" % v, x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, flags, 1.0,
            _bytes(nb, out.device), nb)
 
 
 WINOGRAD_WGRAD = True            # weight gradient of those layers through the Winograd domain as well
-WINOGRAD_MIN_CHANNELS = 192      # measured cross-over on MI355X (tools/wino_bench.py): 96 ch 0.8x, 192 ch 1.17x, 384+ ch 1.6-2.7x
+# measured cross-overs on MI355X (tools/wino_bench.py, speed-up over the direct implicit GEMM):
+#   F(2x2,3x3): 96 ch 0.8x, 192 ch 1.2x, 384 ch 1.7x, 768 ch 1.9x, 1536 ch 2.7x;  F(4x4,3x3): 192 ch 1.2x, 384 ch 1.8x, 768 ch 2.5x, 1536 ch 3.6x
+WINOGRAD_MIN_CHANNELS = 192      # from here F(2x2,3x3)
+WINOGRAD4_MIN_CHANNELS = 256     # from here (and H, W multiples of 4) F(4x4,3x3)
 
 
 def winograd_applies(cin, cout, h, w, batch):
-    """3x3 / stride-1 layers for which the Winograd form is faster than the direct implicit GEMM."""
-    return (min(cin, cout) >= WINOGRAD_MIN_CHANNELS and cin % 4 == 0 and cout % 4 == 0 and h % 2 == 0 and w % 2 == 0
-            and 4 * batch * h * w < 0x7FFFFFFF)
+    """0, or the Winograd output-tile size (2 / 4) to use for a 3x3 / stride-1 layer of this shape."""
+    c = min(cin, cout)
+    if c < WINOGRAD_MIN_CHANNELS or cin % 4 or cout % 4 or h % 2 or w % 2 or 4 * batch * h * w >= 0x7FFFFFFF:
+        return 0
+    if h % 4 == 0 and w % 4 == 0 and c >= max(WINOGRAD4_MIN_CHANNELS, WINOGRAD_MIN_CHANNELS):
+        return 4
+    return 2
 
 
 # ----------------------------------------------------------------------------------------------
@@ -263,7 +275,7 @@ class FusedConvFn(Function):
                    flags & ~L.ICG_UPSAMPLE2X)
         elif sn.w_wino is not None and not up:
             # wide 3x3 stride-1 layer: Winograd F(2x2,3x3), 16/36 of the multiply-adds (csrc/winograd.hip)
-            _wino_fprop(x, sn.w_wino, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, fflags)
+            _wino_fprop(x, sn.w_wino, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, fflags, sn.wino_m)
         else:
             _conv_fprop(x, sn.w_ohwi, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, fflags)
         ctx.phase, ctx.down = phase, down
@@ -301,7 +313,7 @@ class FusedConvFn(Function):
                     raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
                 da = _empty_cl(B, Cin, H, W, dev)
                 if sn.w_wino_dgrad is not None:
-                    _wino_fprop(dout, sn.w_wino_dgrad, None, None, da, None, None, 0, B, H, W, Cout, Cin, 0)
+                    _wino_fprop(dout, sn.w_wino_dgrad, None, None, da, None, None, 0, B, H, W, Cout, Cin, 0, sn.wino_m)
                 else:
                     _conv_fprop(dout, sn.w_dgrad, None, None, da, None, None, 0, B, H, W, Cout, Cin, R, 0)
             if bn is not None:

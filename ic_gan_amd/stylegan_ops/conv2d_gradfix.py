@@ -97,10 +97,12 @@ class _GatherConv(torch.autograd.Function):
                 _ops.winograd_applies(Cin, Cout, H, W, B):
             # wide 3x3 'same' convolution (synthesis conv1 / discriminator conv0 and the data gradients of both):
             # Winograd F(2x2,3x3), 16/36 of the multiply-adds and 16x the parallelism at low resolutions
-            U = torch.empty(16 * Cout * Cin, device=x.device, dtype=torch.float32)
-            L.call("icg_wino_weight_transform", w, U, Cout, Cin)
-            nbw = L.query("icg_conv2d_wino_workspace_bytes", B, H, W, Cin, Cout)
-            L.call("icg_conv2d_wino_fprop", x, U, None, None, y, None, None, 0, B, H, W, Cin, Cout, 0, 1.0,
+            m = _ops.winograd_applies(Cin, Cout, H, W, B)
+            v = "wino4" if m == 4 else "wino"
+            U = torch.empty((36 if m == 4 else 16) * Cout * Cin, device=x.device, dtype=torch.float32)
+            L.call("icg_%s_weight_transform" % v, w, U, Cout, Cin)
+            nbw = L.query("icg_conv2d_%s_workspace_bytes" % v, B, H, W, Cin, Cout)
+            L.call("icg_conv2d_%s_fprop" % v, x, U, None, None, y, None, None, 0, B, H, W, Cin, Cout, 0, 1.0,
                    _ops._bytes(nbw, x.device), nbw)
             return y
         nb = L.query("icg_conv2d_g_fprop_workspace_bytes", B, geo.out[0], geo.out[1], Cin, Cout, geo.R, geo.zins)

@@ -163,6 +163,13 @@ int icg_conv2d_wino_fprop(const float* x, const float* U, const float* bias, con
                           const float* scale, const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin,
                           int Cout, unsigned flags, float alpha, void* workspace, size_t workspace_bytes, void* stream);
 
+/* F(4x4, 3x3) variant: 36 GEMMs over 1/16 of the pixels = 1/4 of the direct multiply-adds, transforms over 2.25x the activation
+ * volume; H, W multiples of 4; agreement with the direct kernel ~1e-5 relative (interpolation points 0, +-1, +-2, inf) */
+int icg_wino4_weight_transform(const float* w, float* U, int N, int K, void* stream);     /* U [36][N][K] */
+size_t icg_conv2d_wino4_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int icg_conv2d_wino4_fprop(const float* x, const float* U, const float* bias, const float* residual, float* out,
+                           const float* scale, const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin,
+                           int Cout, unsigned flags, float alpha, void* workspace, size_t workspace_bytes, void* stream);
 /* weight gradient of the same layer through the Winograd domain (HWIO output like icg_conv2d_wgrad, 16/36 of its MACs):
  * dU[xi] = V[xi]^T (A dy A^T)[xi] as 16 long-K GEMMs (icg_gemm_tn_batched), dw = G^T dU G */
 size_t icg_conv2d_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);

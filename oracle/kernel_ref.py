@@ -95,6 +95,28 @@ def icg_conv2d_wino_fprop(x, U, bias, residual, out, scale, shift, ss_bstride, B
     icg_conv2d_fprop(x, g, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, 3, flags, alpha)
 
 
+_WINO4_G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                         [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
+
+
+def icg_wino4_weight_transform(w, U, N, K):
+    g = mem(w)[: N * 9 * K].view(N, 3, 3, K).double()
+    u = torch.einsum("ar,nrsk,bs->abnk", _WINO4_G, g, _WINO4_G)
+    mem(U)[: 36 * N * K].copy_(u.reshape(-1).float())
+
+
+def icg_conv2d_wino4_workspace_bytes(B, H, W, Cin, Cout):
+    return 36 * B * (H // 4) * (W // 4) * (Cin + Cout) * 4
+
+
+def icg_conv2d_wino4_fprop(x, U, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, flags, alpha, workspace,
+                           workspace_bytes):
+    u = mem(U)[: 36 * Cout * Cin].view(6, 6, Cout, Cin).double()
+    inv = torch.tensor([[4.0, 0, 0, 0, 0, 0], [0, -3.0, 3.0, 0, 0, 0], [0, 0, 0, 0, 0, 1.0]], dtype=torch.float64)
+    g = torch.einsum("ra,abnk,sb->nrsk", inv, u, inv).float().contiguous()
+    icg_conv2d_fprop(x, g, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, 3, flags, alpha)
+
+
 def icg_conv2d_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout):
     return 16
 

@@ -715,3 +715,24 @@ def test_gemm_tn_batched_split_k():
     ws = torch.empty(nb, dtype=torch.uint8)
     (pair,) = run_pair("icg_gemm_tn_batched", [A, Bm, C, M, N, K, K * M, K * N, M * N, batch, ws, nb], [2])
     close(*pair, rtol=1e-4, atol_rel=1e-4, what="tn batched split-K")
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, flags, residual(0 none / 1 same / 2 half-res), bias
+    (2, 8, 8, 32, 32, 0, 0, True),
+    (2, 16, 16, 64, 48, PRE_AFFINE | PRE_RELU, 2, True),
+    (1, 8, 12, 16, 40, PRE_RELU, 1, False),
+    (3, 4, 4, 256, 256, 0, 0, True),
+])
+def test_conv2d_winograd4(case):
+    """Winograd F(4x4,3x3) forward vs the direct convolution (tolerance 2e-4 of max|ref|: fp32 transforms with entries up to 8)."""
+    B, H, W, Cin, Cout, flags, res, bias = case
+    L = _L()
+    x, w, bvec, r, sc, sh, ssb, rflags = _conv_inputs((B, H, W, Cin, Cout, 3, flags, res, bias), 10)
+    U = torch.empty(36, Cout, Cin)
+    (pu,) = run_pair("icg_wino4_weight_transform", [w, U, Cout, Cin], [1]); close(*pu, what="wino4 U")
+    nb = L.query("icg_conv2d_wino4_workspace_bytes", B, H, W, Cin, Cout)
+    ws = torch.empty(nb, dtype=torch.uint8)
+    out = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
+    (pair,) = run_pair("icg_conv2d_wino4_fprop", [x, U, bvec, r, out, sc, sh, ssb, B, H, W, Cin, Cout, rflags, 1.0, ws, nb], [4])
+    close(*pair, rtol=2e-4, atol_rel=2e-4, what=f"winograd4 fprop {case}")

@@ -64,12 +64,17 @@ def test_forward_vs_golden(case):
     check_group(g, "fwd/D_state/", {k: v.cpu() for k, v in D.state_dict().items()}, 2e-4, 1e-6, "D buf ")
 
 
-@pytest.mark.parametrize("wino", [False, True])
+@pytest.mark.parametrize("wino", [0, 2, 4])
 @pytest.mark.parametrize("case", CASES)
 def test_train_steps_vs_golden(case, wino, monkeypatch):
     if wino:      # force the Winograd F(2x2,3x3) form onto every eligible 3x3 layer of these narrow test networks
         import ic_gan_amd.ops as _ops
         monkeypatch.setattr(_ops, "WINOGRAD_MIN_CHANNELS", 4)
+        monkeypatch.setattr(_ops, "WINOGRAD4_MIN_CHANNELS", 4 if wino == 4 else 10 ** 9)      # F(4x4,3x3) / F(2x2,3x3)
+    # F(4x4,3x3) forced onto 8..128-channel layers (production uses it from 256 channels, where the error averages over a
+    # long K): its fp32 transforms (coefficients up to 8) cost about half a digit on these tiny ill-conditioned networks
+    grad_rtol = GRAD_RTOL * (3.0 if wino == 4 else 1.0)
+    state_rtol = STATE_RTOL * (2.0 if wino == 4 else 1.0)
     from ic_gan_amd import train_fns, utils
     from ic_gan_amd.optim import FusedAdam
     g = load_golden(case)
@@ -96,14 +101,14 @@ def test_train_steps_vs_golden(case, wino, monkeypatch):
                                    rtol=1e-3, atol=1e-3)
         if s == 0:
             check_group(g, "step1/G_grad/", {n: p.grad.cpu() for n, p in G.named_parameters() if p.grad is not None},
-                        GRAD_RTOL, 1e-6, "G grad ")
+                        grad_rtol, 1e-6, "G grad ")
             check_group(g, "step1/D_grad/", {n: p.grad.cpu() for n, p in D.named_parameters() if p.grad is not None},
-                        GRAD_RTOL, 1e-6, "D grad ")
+                        grad_rtol, 1e-6, "D grad ")
         gx = adam_slack(g, "step1/G_grad/", cfg["G_lr"], s + 1, G.state_dict().keys())
         dx = adam_slack(g, "step1/D_grad/", cfg["D_lr"], s + 1, D.state_dict().keys())
-        check_group(g, f"step{s + 1}/G_state/", cpu(G.state_dict()), STATE_RTOL, 2e-6, "G ", extra_atol=gx)
-        check_group(g, f"step{s + 1}/D_state/", cpu(D.state_dict()), STATE_RTOL, 2e-6, "D ", extra_atol=dx)
-        check_group(g, f"step{s + 1}/EMA_state/", cpu(G_ema.state_dict()), STATE_RTOL, 2e-6, "EMA ", extra_atol=gx)
+        check_group(g, f"step{s + 1}/G_state/", cpu(G.state_dict()), state_rtol, 2e-6, "G ", extra_atol=gx)
+        check_group(g, f"step{s + 1}/D_state/", cpu(D.state_dict()), state_rtol, 2e-6, "D ", extra_atol=dx)
+        check_group(g, f"step{s + 1}/EMA_state/", cpu(G_ema.state_dict()), state_rtol, 2e-6, "EMA ", extra_atol=gx)
 
 
 WIDE = dict(dim_z=120, shared_dim=128, shared_dim_feat=512, G_shared=True, G_shared_feat=True, hier=True,
@@ -112,7 +117,10 @@ WIDE = dict(dim_z=120, shared_dim=128, shared_dim_feat=512, G_shared=True, G_sha
 
 
 def test_forward_backward_vs_live_oracle_wide():
-    """ch=32 (channel counts 64..512, every vectorised kernel path) against the CPU oracle run here."""
+    """ch=32 (channel counts 64..512, every vectorised kernel path, F(2x2,3x3) and F(4x4,3x3) Winograd at their production
+    thresholds) against the CPU oracle run here in fp64: the fp32 oracle's own gradients sit 1.0e-3 (rel. L2) from that
+    truth on this network, the direct HIP path 1.4e-3, F(4x4,3x3) 1.6e-3 (2.4e-3 on the scalar attention gamma) --
+    tests/diag_winograd_accuracy.py prints the table."""
     cfg = dict(WIDE)
     _, G, D, gspec, dspec = _build(cfg)
     gsd, dsd = synth.synth_state(gspec, 11), synth.synth_state(dspec, 22)
@@ -126,7 +134,10 @@ def test_forward_backward_vs_live_oracle_wide():
     out = D(d_in, torch.cat([_d(lab), _d(y)]), torch.cat([_d(fg), _d(f)]))
     loss = out[:B].mean() - 0.5 * out[B:].mean()
     loss.backward()
-    # --- oracle
+    # --- oracle (fp64)
+    c64 = lambda t: t.double() if t.is_floating_point() else t
+    gsd, dsd = {k: c64(v) for k, v in gsd.items()}, {k: c64(v) for k, v in dsd.items()}
+    z, fg, x, f = z.double(), fg.double(), x.double(), f.double()
     for k in O.param_names(gsd):
         gsd[k].requires_grad_(True)
     for k in O.param_names(dsd):

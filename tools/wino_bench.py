@@ -28,7 +28,14 @@ for name, B, H, W, Cin, Cout in LAYERS:
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     t_w = ev_time(lambda: L.call("icg_conv2d_wino_fprop", x, U, None, None, out2, sc, sh, Cin, B, H, W, Cin, Cout, fl, 1.0, ws, nb))
     err = float((out2 - out).norm() / out.norm())
-    print(f"{name:34s} direct {t_d*1e3:7.3f} ms  winograd {t_w*1e3:7.3f} ms  speedup {t_d/t_w:5.2f}  rel L2 {err:.2e}  ws {nb>>20} MiB", flush=True)
+    U4 = torch.empty(36, Cout, Cin, device=dev)
+    L.call("icg_wino4_weight_transform", w, U4, Cout, Cin)
+    nb4 = L.query("icg_conv2d_wino4_workspace_bytes", B, H, W, Cin, Cout)
+    ws4 = torch.empty(nb4, dtype=torch.uint8, device=dev)
+    out3 = torch.empty_like(out)
+    t_4 = ev_time(lambda: L.call("icg_conv2d_wino4_fprop", x, U4, None, None, out3, sc, sh, Cin, B, H, W, Cin, Cout, fl, 1.0, ws4, nb4))
+    err4 = float((out3 - out).norm() / out.norm())
+    print(f"{name:34s} direct {t_d*1e3:7.3f} ms  F(2,3) {t_w*1e3:7.3f} ms ({t_d/t_w:4.2f}x, {err:.1e})  F(4,3) {t_4*1e3:7.3f} ms ({t_d/t_4:4.2f}x, {err4:.1e})", flush=True)
 print("---- weight gradient")
 for name, B, H, W, Cin, Cout in LAYERS[:5]:
     dev = "cuda"
