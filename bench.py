@@ -52,7 +52,7 @@ class KernelTimer:
     library (icg_gemm_last_variant), so they can be compared line by line with profiles/*_kernel_stats.csv."""
 
     # entry point -> (index of B in the argument list, kind)
-    SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"), "icg_conv2d_wino4_fprop": (8, "wino4"), "icg_conv2d_wino_wgrad": (6, "wino"),
+    SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"), "icg_conv2d_wino4_fprop": (8, "wino4"), "icg_conv2d_wino_wgrad": (6, "wino"), "icg_conv2d_wino4_wgrad": (6, "wino4"),
             "icg_conv2d_wgrad": (6, "conv"), "icg_conv2d_up_fprop": (7, "up"),
             "icg_conv2d_up_dgrad": (3, "up"), "icg_conv2d_up_wgrad": (6, "up"), "icg_conv2d_down_fprop": (5, "up"),
             "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_wgrad": (3, "up")}
@@ -95,7 +95,9 @@ class KernelTimer:
             e.record()
             query(last)
             if mode in ("wino", "wino4"):     # three kernels behind one entry point: not comparable with a single rocprof row
-                kname = ("composite: wino_input_kernel + wino_dy_kernel + icg_gemm_kernel<1, 1, %d, 2> (16 batched split-K GEMMs) + reduce + wino_dw_kernel" % last[2]
+                kname = (("composite: wino4_input_kernel + wino4_dy_kernel + icg_gemm_kernel<1, 1, %d, 2> (36 batched split-K GEMMs) + reduce + wino4_dw_kernel" % last[2]
+                          if mode == "wino4" else
+                          "composite: wino_input_kernel + wino_dy_kernel + icg_gemm_kernel<1, 1, %d, 2> (16 batched split-K GEMMs) + reduce + wino_dw_kernel" % last[2])
                          if name.endswith("wgrad") else
                          ("composite: wino4_input_kernel + icg_gemm_kernel<0, 0, %d, 2> (36 batched GEMMs) + wino4_output_kernel" % last[2]
                           if mode == "wino4" else

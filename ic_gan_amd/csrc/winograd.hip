@@ -317,19 +317,17 @@ __device__ __forceinline__ void w4_in6(const float4 d[6], float4 t[6]) {
   t[5] = f4add(f4fma(d[3], -5.f, f4s(d[1], 4.f)), d[5]);
 }
 
-// one thread per (tile, channel quad, output column j): E[r] = (row r of the window) . B[:, j], then V[i][j] = (B^T E)[i]
+// one thread per (tile, channel quad): 36 loads, 36 stores; V[i][j] = (B^T d B)[i][j]
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, long ssb, float* __restrict__ V,
-                                                          int B, int H, int W, int C4, int affine, int relu) {
+                                                               const float* __restrict__ shift, long ssb, float* __restrict__ V,
+                                                               int B, int H, int W, int C4, int affine, int relu) {
   const int th = H >> 2, tw = W >> 2;
   const long T = (long)B * th * tw;
-  const long total = T * C4 * 6, plane = T * C4;
+  const long total = T * C4, plane = T * C4;
   const long gstride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
     const int c4 = (int)(i % C4);
-    long q = i / C4;
-    const int j = (int)(q % 6);
-    const long t = q / 6;
+    const long t = i / C4;
     const int tx = (int)(t % tw);
     const long t2 = t / tw;
     const int ty = (int)(t2 % th);
@@ -340,7 +338,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
       sh = *reinterpret_cast<const float4*>(shift + (long)b * ssb + 4 * c4);
     }
     const float4* xp = reinterpret_cast<const float4*>(x) + (long)b * H * W * C4 + c4;
-    float4 E[6];
+    float4 E[6][6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       const int h = 4 * ty - 1 + r;
@@ -358,18 +356,17 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
         }
         d[s] = v;
       }
-      float4 tr[6];
-      w4_in6(d, tr);
-      E[r] = tr[0];
-#pragma unroll
-      for (int k = 1; k < 6; ++k)
-        if (j == k) E[r] = tr[k];
+      w4_in6(d, E[r]);
     }
-    float4 o[6];
-    w4_in6(E, o);
     float4* vp = reinterpret_cast<float4*>(V) + t * C4 + c4;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) vp[(long)(6 * r + j) * plane] = o[r];
+    for (int j = 0; j < 6; ++j) {
+      const float4 col[6] = {E[0][j], E[1][j], E[2][j], E[3][j], E[4][j], E[5][j]};
+      float4 o[6];
+      w4_in6(col, o);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) vp[(long)(6 * r + j) * plane] = o[r];
+    }
   }
 }
 
@@ -381,50 +378,49 @@ __device__ __forceinline__ void w4_out4(const float4 m[6], float4 y[4]) {
   y[3] = f4add(f4fma(s, 8.f, q), m[5]);
 }
 
-// one thread per (tile, channel quad, output row a): s[j] = (A^T M)[a][j], then y[a][c] = (s A)[c]
+// one thread per (tile, channel quad): 36 loads, 16 stores
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
-                                                           const float* __restrict__ res, int res_up, float alpha,
-                                                           float* __restrict__ y, int B, int H, int W, int C4) {
+                                                                const float* __restrict__ res, int res_up, float alpha,
+                                                                float* __restrict__ y, int B, int H, int W, int C4) {
   const int th = H >> 2, tw = W >> 2;
   const long T = (long)B * th * tw;
-  const long total = T * C4 * 4, plane = T * C4;
+  const long total = T * C4, plane = T * C4;
   const long gstride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
     const int c4 = (int)(i % C4);
-    long q = i / C4;
-    const int a = (int)(q & 3);
-    const long t = q >> 2;
+    const long t = i / C4;
     const int tx = (int)(t % tw);
     const long t2 = t / tw;
     const int ty = (int)(t2 % th);
     const long b = t2 / th;
     const float4* mp = reinterpret_cast<const float4*>(Mb) + t * C4 + c4;
-    float4 s[6];
+    float4 s[4][6];                     // s[a][j] = (A^T M)[a][j]
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       float4 col[6], yy[4];
 #pragma unroll
       for (int r = 0; r < 6; ++r) col[r] = mp[(long)(6 * r + j) * plane];
       w4_out4(col, yy);
-      s[j] = yy[0];
 #pragma unroll
-      for (int k = 1; k < 4; ++k)
-        if (a == k) s[j] = yy[k];
+      for (int a = 0; a < 4; ++a) s[a][j] = yy[a];
     }
-    float4 o[4];
-    w4_out4(s, o);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * c4);
-    const int oy = 4 * ty + a;
-    const long p0 = ((b * H + oy) * W + 4 * tx) * C4 + c4;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float4 v = make_float4(alpha * o[c].x + bv.x, alpha * o[c].y + bv.y, alpha * o[c].z + bv.z, alpha * o[c].w + bv.w);
-      if (res) {
-        const long rp = res_up ? ((b * (H >> 1) + (oy >> 1)) * (W >> 1) + ((4 * tx + c) >> 1)) * C4 + c4 : p0 + (long)c * C4;
-        v = f4add(v, reinterpret_cast<const float4*>(res)[rp]);
+    for (int a = 0; a < 4; ++a) {
+      float4 o[4];
+      w4_out4(s[a], o);
+      const int oy = 4 * ty + a;
+      const long p0 = ((b * H + oy) * W + 4 * tx) * C4 + c4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float4 v = make_float4(alpha * o[c].x + bv.x, alpha * o[c].y + bv.y, alpha * o[c].z + bv.z, alpha * o[c].w + bv.w);
+        if (res) {
+          const long rp = res_up ? ((b * (H >> 1) + (oy >> 1)) * (W >> 1) + ((4 * tx + c) >> 1)) * C4 + c4 : p0 + (long)c * C4;
+          v = f4add(v, reinterpret_cast<const float4*>(res)[rp]);
+        }
+        reinterpret_cast<float4*>(y)[p0 + (long)c * C4] = v;
       }
-      reinterpret_cast<float4*>(y)[p0 + (long)c * C4] = v;
     }
   }
 }
@@ -465,6 +461,15 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
   }
 }
 
+static void launch_wino4_input(hipStream_t st, const float* x, const float* scale, const float* shift, long ssb, float* V, int B,
+                               int H, int W, int Cin, unsigned flags) {
+  const long T = (long)B * (H / 4) * (W / 4);
+  long nb = icg_cdiv(T * (Cin / 4), 256);
+  if (nb > 256 * 64) nb = 256 * 64;
+  hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, ssb, V, B, H, W, Cin / 4,
+                     (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0);
+}
+
 extern "C" int icg_wino4_weight_transform(const float* w, float* U, int N, int K, void* stream) {
   ICG_REQUIRE(w && U && N > 0 && K > 0);
   long blocks = icg_cdiv((long)N * K, 256);
@@ -491,15 +496,129 @@ extern "C" int icg_conv2d_wino4_fprop(const float* x, const float* U, const floa
   hipStream_t st = (hipStream_t)stream;
   float* V = (float*)workspace;
   float* Mb = V + 36 * T * Cin;
-  long nb = icg_cdiv(T * (Cin / 4) * 6, 256);
-  if (nb > 256 * 64) nb = 256 * 64;
-  hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, (long)ss_bstride, V, B, H, W,
-                     Cin / 4, (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0);
+  launch_wino4_input(st, x, scale, shift, (long)ss_bstride, V, B, H, W, Cin, flags);
   int rc = icg_gemm_batched(V, U, Mb, (int)T, Cout, Cin, 0, 1, T * Cin, (long)Cout * Cin, T * Cout, 36, 1.0f, stream);
   if (rc != ICG_OK) return rc;
-  nb = icg_cdiv(T * (Cout / 4) * 4, 256);
+  long nb = icg_cdiv(T * (Cout / 4), 256);
   if (nb > 256 * 64) nb = 256 * 64;
   hipLaunchKernelGGL(wino4_output_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)Mb, bias, residual,
                      (flags & ICG_RES_UPSAMPLE2X) ? 1 : 0, alpha, out, B, H, W, Cout / 4);
+  return icg_check_launch();
+}
+
+// ---- weight gradient through the F(4x4,3x3) domain: dw = G^T [ sum_tiles (A dy A^T) .* (B^T act(x) B) ] G --------------------
+// (the adjoint of the forward form in g: 36 [Cin x tiles] x [tiles x Cout] GEMMs, 1/4 of the direct multiply-adds, both
+// transform passes over 2.25x the activation volume)
+//   1-D  s = A d : s0 = d0, s1 = d0+d1+d2+d3, s2 = d0-d1+d2-d3, s3 = d0+2d1+4d2+8d3, s4 = d0-2d1+4d2-8d3, s5 = d3
+//   1-D  g = G^T u : g0 = u0/4-(u1+u2)/6+(u3+u4)/24, g1 = (u2-u1)/6+(u3-u4)/12, g2 = (u3+u4-u1-u2)/6+u5
+__device__ __forceinline__ void w4_dy6(const float4 d[4], float4 s[6]) {
+  const float4 e = f4add(d[0], d[2]), o = f4add(d[1], d[3]);
+  s[0] = d[0];
+  s[1] = f4add(e, o);
+  s[2] = f4sub(e, o);
+  const float4 e4 = f4fma(d[2], 4.f, d[0]), o4 = f4fma(d[3], 8.f, f4s(d[1], 2.f));
+  s[3] = f4add(e4, o4);
+  s[4] = f4sub(e4, o4);
+  s[5] = d[3];
+}
+
+// one thread per (tile, channel quad): 16 loads, 36 stores
+__global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ DY, int B, int H,
+                                                            int W, int C4) {
+  const int th = H >> 2, tw = W >> 2;
+  const long T = (long)B * th * tw;
+  const long total = T * C4, plane = T * C4;
+  const long gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const int c4 = (int)(i % C4);
+    const long t = i / C4;
+    const int tx = (int)(t % tw);
+    const long t2 = t / tw;
+    const int ty = (int)(t2 % th);
+    const long b = t2 / th;
+    const float4* gp = reinterpret_cast<const float4*>(dy) + ((b * H + 4 * ty) * W + 4 * tx) * C4 + c4;
+    float4 E[4][6];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float4 d[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d[c] = gp[((long)r * W + c) * C4];
+      w4_dy6(d, E[r]);
+    }
+    float4* op = reinterpret_cast<float4*>(DY) + t * C4 + c4;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const float4 col[4] = {E[0][j], E[1][j], E[2][j], E[3][j]};
+      float4 o[6];
+      w4_dy6(col, o);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) op[(long)(6 * r + j) * plane] = o[r];
+    }
+  }
+}
+
+__device__ __forceinline__ void w4_gt3(const float u[6], float g[3]) {
+  const float p = u[1] + u[2], q = u[3] + u[4];
+  g[0] = 0.25f * u[0] - p * (1.f / 6.f) + q * (1.f / 24.f);
+  g[1] = (u[2] - u[1]) * (1.f / 6.f) + (u[3] - u[4]) * (1.f / 12.f);
+  g[2] = (q - p) * (1.f / 6.f) + u[5];
+}
+
+// dw[r][s][ci][co] = (G^T dU G)[r][s]   (HWIO, like the direct weight gradient)
+__global__ __launch_bounds__(256) void wino4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, long n) {
+  const long gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
+    float t[3][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      float u[6], g[3];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) u[a] = dU[(long)(6 * a + b) * n + i];
+      w4_gt3(u, g);
+      t[0][b] = g[0]; t[1][b] = g[1]; t[2][b] = g[2];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float g[3];
+      w4_gt3(t[r], g);
+      dw[(long)(3 * r + 0) * n + i] = g[0];
+      dw[(long)(3 * r + 1) * n + i] = g[1];
+      dw[(long)(3 * r + 2) * n + i] = g[2];
+    }
+  }
+}
+
+extern "C" size_t icg_conv2d_wino4_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  const size_t T = (size_t)B * (H / 4) * (W / 4);
+  return wino_al(36 * T * Cin * sizeof(float)) + wino_al(36 * T * Cout * sizeof(float)) +
+         wino_al((size_t)36 * Cin * Cout * sizeof(float)) + wino_al(icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, 36));
+}
+
+extern "C" int icg_conv2d_wino4_wgrad(const float* x, const float* dy, float* dw, const float* scale, const float* shift,
+                                      int64_t ss_bstride, int B, int H, int W, int Cin, int Cout, unsigned flags,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(x && dy && dw && workspace && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  ICG_REQUIRE((H % 4 == 0) && (W % 4 == 0) && (Cin % 4 == 0) && (Cout % 4 == 0) && !(flags & ICG_UPSAMPLE2X));
+  if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift && (ss_bstride % 4 == 0));
+  if (workspace_bytes < icg_conv2d_wino4_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return ICG_ERR_WORKSPACE;
+  const long T = (long)B * (H / 4) * (W / 4);
+  ICG_REQUIRE(T * 36 < 0x7fffffffL);
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  float* V = (float*)base;                    base += wino_al(36 * T * Cin * sizeof(float));
+  float* DY = (float*)base;                   base += wino_al(36 * T * Cout * sizeof(float));
+  float* dU = (float*)base;                   base += wino_al((size_t)36 * Cin * Cout * sizeof(float));
+  void* gws = base;
+  const size_t gws_bytes = icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, 36);
+  launch_wino4_input(st, x, scale, shift, (long)ss_bstride, V, B, H, W, Cin, flags);
+  long nb = icg_cdiv(T * (Cout / 4), 256);
+  if (nb > 256 * 64) nb = 256 * 64;
+  hipLaunchKernelGGL(wino4_dy_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, DY, B, H, W, Cout / 4);
+  int rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, 36, gws, gws_bytes, stream);
+  if (rc != ICG_OK) return rc;
+  const long n = (long)Cin * Cout;
+  nb = icg_cdiv(n, 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)dU, dw, n);
   return icg_check_launch();
 }

@@ -179,10 +179,12 @@ def _wino_fprop(x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, fla
 
 
 WINOGRAD_WGRAD = True            # weight gradient of those layers through the Winograd domain as well
-# measured cross-overs on MI355X (tools/wino_bench.py, speed-up over the direct implicit GEMM):
-#   F(2x2,3x3): 96 ch 0.8x, 192 ch 1.2x, 384 ch 1.7x, 768 ch 1.9x, 1536 ch 2.7x;  F(4x4,3x3): 192 ch 1.2x, 384 ch 1.8x, 768 ch 2.5x, 1536 ch 3.6x
-WINOGRAD_MIN_CHANNELS = 192      # from here F(2x2,3x3)
-WINOGRAD4_MIN_CHANNELS = 256     # from here (and H, W multiples of 4) F(4x4,3x3)
+# measured on MI355X (tools/wino_bench.py -> profiles/r01_wino_microbench.txt, speed-up over the direct implicit GEMM, B = 64):
+#   F(2x2,3x3): 96 ch 0.8x, 192 ch 1.2x, 384 ch 1.6x, 768 ch 1.9x, 1536 ch 2.8x
+#   F(4x4,3x3): 96 ch 1.3x, 192 ch 1.9x, 384 ch 2.4x, 768 ch 3.2x, 1536 ch 4.2x   (weight gradient: 1.3 / 1.8 / 2.6 / 3.0 / 3.2x)
+WINOGRAD_MIN_CHANNELS = 96       # from here a Winograd form: F(4x4,3x3) when H, W are multiples of 4 ...
+WINOGRAD4_MIN_CHANNELS = 96
+WINOGRAD2_MIN_CHANNELS = 192     # ... else F(2x2,3x3), which needs 192 channels to pay for its 4x-volume transforms
 
 
 def winograd_applies(cin, cout, h, w, batch):
@@ -192,7 +194,17 @@ def winograd_applies(cin, cout, h, w, batch):
         return 0
     if h % 4 == 0 and w % 4 == 0 and c >= max(WINOGRAD4_MIN_CHANNELS, WINOGRAD_MIN_CHANNELS):
         return 4
-    return 2
+    return 2 if c >= WINOGRAD2_MIN_CHANNELS else 0
+
+
+WINOGRAD4_WGRAD_MIN_CHANNELS = 96       # weight gradient: F(4x4,3x3) domain from here (2.25x transform volume instead of 4x)
+
+
+def winograd_wgrad_tile(cin, cout, h, w, batch):
+    """0 (direct weight gradient), or the Winograd tile size (2 / 4) for the weight gradient of a 3x3 / stride-1 layer."""
+    if not WINOGRAD_WGRAD or not winograd_applies(cin, cout, h, w, batch):
+        return 0
+    return 4 if (h % 4 == 0 and w % 4 == 0 and min(cin, cout) >= WINOGRAD4_WGRAD_MIN_CHANNELS) else 2
 
 
 # ----------------------------------------------------------------------------------------------
@@ -341,10 +353,12 @@ class FusedConvFn(Function):
             dweight = _sn_backward(None, None, sn, ctx.weight_like, dw_up=dw_up)
         elif need[1]:
             dw_hwio = _f32(R * R * Cin * Cout, dev)
-            if sn.w_wino is not None and WINOGRAD_WGRAD:
-                # wide 3x3 stride-1 layer: weight gradient through the Winograd domain (16/36 of the MACs)
-                nb = L.query("icg_conv2d_wino_wgrad_workspace_bytes", B, H, W, Cin, Cout)
-                L.call("icg_conv2d_wino_wgrad", x, dout, dw_hwio, scale, shift, ssb, B, H, W, Cin, Cout, ctx.flags,
+            wt = winograd_wgrad_tile(Cin, Cout, H, W, B) if sn.w_wino is not None else 0
+            if wt:
+                # wide 3x3 stride-1 layer: weight gradient through the Winograd domain (16/36 or 9/36 of the MACs)
+                v = "wino4" if wt == 4 else "wino"
+                nb = L.query("icg_conv2d_%s_wgrad_workspace_bytes" % v, B, H, W, Cin, Cout)
+                L.call("icg_conv2d_%s_wgrad" % v, x, dout, dw_hwio, scale, shift, ssb, B, H, W, Cin, Cout, ctx.flags,
                        _bytes(nb, dev), nb)
             else:
                 nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, Cin, Cout, R)

@@ -146,11 +146,11 @@ class _GatherWgrad(torch.autograd.Function):
             L.call("icg_conv2d_g_wgrad", dy, x, t, B, geo.out[0], geo.out[1], Cout, H, W, Cin, R, adj.stride, adj.pad,
                    _ops._bytes(ws_bytes, x.device), ws_bytes)
             dw = t.flip(0, 1).permute(2, 0, 1, 3).contiguous()
-        elif R == 3 and geo.stride == 1 and geo.pad == 1 and geo.out == (H, W) and _ops.WINOGRAD_WGRAD and \
-                _ops.winograd_applies(Cin, Cout, H, W, B):
-            nbw = L.query("icg_conv2d_wino_wgrad_workspace_bytes", B, H, W, Cin, Cout)      # Winograd-domain wgrad
+        elif R == 3 and geo.stride == 1 and geo.pad == 1 and geo.out == (H, W) and _ops.winograd_wgrad_tile(Cin, Cout, H, W, B):
+            v = "wino4" if _ops.winograd_wgrad_tile(Cin, Cout, H, W, B) == 4 else "wino"      # Winograd-domain wgrad
+            nbw = L.query("icg_conv2d_%s_wgrad_workspace_bytes" % v, B, H, W, Cin, Cout)
             t = torch.empty(R, R, Cin, Cout, device=x.device, dtype=torch.float32)
-            L.call("icg_conv2d_wino_wgrad", x, dy, t, None, None, 0, B, H, W, Cin, Cout, 0, _ops._bytes(nbw, x.device), nbw)
+            L.call("icg_conv2d_%s_wgrad" % v, x, dy, t, None, None, 0, B, H, W, Cin, Cout, 0, _ops._bytes(nbw, x.device), nbw)
             dw = t.permute(3, 0, 1, 2).contiguous()
         else:
             ws_bytes = L.query("icg_conv2d_g_wgrad_workspace_bytes", B, geo.out[0], geo.out[1], Cin, Cout, R)

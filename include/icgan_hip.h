@@ -176,6 +176,12 @@ size_t icg_conv2d_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int C
 int icg_conv2d_wino_wgrad(const float* x, const float* dy, float* dw, const float* scale, const float* shift,
                           int64_t ss_bstride, int B, int H, int W, int Cin, int Cout, unsigned flags, void* workspace,
                           size_t workspace_bytes, void* stream);
+/* the same through the F(4x4,3x3) domain (H, W multiples of 4): 36 GEMMs, 9/36 of the direct MACs, both transform passes over
+ * 2.25x the activation volume; dw = G^T [ sum_tiles (A dy A^T) .* (B^T act(x) B) ] G with the F(4x4,3x3) matrices */
+size_t icg_conv2d_wino4_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int icg_conv2d_wino4_wgrad(const float* x, const float* dy, float* dw, const float* scale, const float* shift,
+                           int64_t ss_bstride, int B, int H, int W, int Cin, int Cout, unsigned flags, void* workspace,
+                           size_t workspace_bytes, void* stream);
 /* C[b] = A[b]^T B[b], A [K][M], B [K][N], long K: batched with deterministic split-K (strideC must be M*N) */
 size_t icg_gemm_tn_batched_workspace_bytes(int M, int N, int K, int batch);
 int icg_gemm_tn_batched(const float* A, const float* B, float* C, int M, int N, int K, int64_t strideA, int64_t strideB,

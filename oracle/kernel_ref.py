@@ -125,6 +125,14 @@ def icg_conv2d_wino_wgrad(x, dy, dw, scale, shift, ss_bstride, B, H, W, Cin, Cou
     icg_conv2d_wgrad(x, dy, dw, scale, shift, ss_bstride, B, H, W, Cin, Cout, 3, flags, None, 0)
 
 
+def icg_conv2d_wino4_wgrad_workspace_bytes(B, H, W, Cin, Cout):
+    return 16
+
+
+def icg_conv2d_wino4_wgrad(x, dy, dw, scale, shift, ss_bstride, B, H, W, Cin, Cout, flags, workspace, workspace_bytes):
+    icg_conv2d_wgrad(x, dy, dw, scale, shift, ss_bstride, B, H, W, Cin, Cout, 3, flags, None, 0)
+
+
 def icg_gemm_tn_batched_workspace_bytes(M, N, K, batch):
     return 16
 

@@ -38,13 +38,15 @@ def main():
         worst = sorted(((rel_l2(v.double().cpu(), gg64[n]), "G." + n) for n, v in gg.items() if float(gg64[n].norm()) >= 1e-4 * top), reverse=True)
         worst += sorted(((rel_l2(v.double().cpu(), dg64[n]), "D." + n) for n, v in dg.items()), reverse=True)[:3]
         worst.sort(reverse=True)
-        print(f"{tag:10s} img {rel_l2(img.double().cpu(), i64):.2e} out {rel_l2(out.double().cpu(), o64):.2e}  worst grads: "
+        print(f"{tag:12s} img {rel_l2(img.double().cpu(), i64):.2e} out {rel_l2(out.double().cpu(), o64):.2e}  worst grads: "
               + ", ".join(f"{n} {e:.2e}" for e, n in worst[:4]))
 
     report("oracle32", i32, o32, gg32, dg32)
-    for tag, m2, m4 in (("direct", 10 ** 9, 10 ** 9), ("F(2,3)", ops.WINOGRAD_MIN_CHANNELS, 10 ** 9), ("F(4,3)", ops.WINOGRAD_MIN_CHANNELS, ops.WINOGRAD4_MIN_CHANNELS),
-                        ("F(2,3)all", 4, 10 ** 9), ("F(4,3)all", 4, 4)):
-        ops.WINOGRAD_MIN_CHANNELS, ops.WINOGRAD4_MIN_CHANNELS = m2, m4
+    BIG = 10 ** 9
+    prod = (ops.WINOGRAD_MIN_CHANNELS, ops.WINOGRAD2_MIN_CHANNELS, ops.WINOGRAD4_MIN_CHANNELS, ops.WINOGRAD4_WGRAD_MIN_CHANNELS)
+    for tag, knobs in (("direct", (BIG, BIG, BIG, BIG)), ("F(2,3)>=192", (192, 192, BIG, BIG)), ("product", prod),
+                       ("F(2,3)all", (4, 4, BIG, BIG)), ("F(4,3)all", (4, 4, 4, 4))):
+        ops.WINOGRAD_MIN_CHANNELS, ops.WINOGRAD2_MIN_CHANNELS, ops.WINOGRAD4_MIN_CHANNELS, ops.WINOGRAD4_WGRAD_MIN_CHANNELS = knobs
         _, G, D, _, _ = _build(cfg)
         G.train(); D.train()
         img = G(_d(z), _d(lab), _d(fg))

@@ -63,7 +63,9 @@ def test_train_step_host_logic(case, emu, wino, monkeypatch):
     if wino:      # force the Winograd F(2x2,3x3) form onto every eligible 3x3 layer of these narrow test networks
         import ic_gan_amd.ops as _ops
         monkeypatch.setattr(_ops, "WINOGRAD_MIN_CHANNELS", 4)
+        monkeypatch.setattr(_ops, "WINOGRAD2_MIN_CHANNELS", 4)
         monkeypatch.setattr(_ops, "WINOGRAD4_MIN_CHANNELS", 4 if wino == 4 else 10 ** 9)      # F(4x4,3x3) / F(2x2,3x3)
+        monkeypatch.setattr(_ops, "WINOGRAD4_WGRAD_MIN_CHANNELS", 4 if wino == 4 else 10 ** 9)
     from ic_gan_amd import train_fns, utils
     from ic_gan_amd.optim import FusedAdam
     g = load_golden(case)

@@ -705,6 +705,26 @@ def test_conv2d_winograd_wgrad(case):
     close(*pair, rtol=2e-4, atol_rel=2e-4, what=f"winograd wgrad {case}")
 
 
+@pytest.mark.parametrize("case", [
+    (2, 8, 8, 32, 32, 0),
+    (2, 16, 16, 64, 48, PRE_AFFINE | PRE_RELU),
+    (1, 4, 12, 16, 40, PRE_RELU),
+    (4, 32, 32, 128, 128, 0),            # long K (tiles) -> batched split-K slabs
+    (3, 4, 4, 64, 64, 0),                # one tile per image
+])
+def test_conv2d_winograd4_wgrad(case):
+    """F(4x4,3x3)-domain weight gradient (36 long-K GEMMs) vs the direct one."""
+    B, H, W, Cin, Cout, flags = case
+    L = _L()
+    x, w, bvec, r, sc, sh, ssb, rflags = _conv_inputs((B, H, W, Cin, Cout, 3, flags, 0, False), 20)
+    dy = cl(B, Cout, H, W, seed=31)
+    dw = torch.empty(9 * Cin * Cout)
+    nb = L.query("icg_conv2d_wino4_wgrad_workspace_bytes", B, H, W, Cin, Cout)
+    ws = torch.empty(nb, dtype=torch.uint8)
+    (pair,) = run_pair("icg_conv2d_wino4_wgrad", [x, dy, dw, sc, sh, ssb, B, H, W, Cin, Cout, flags, ws, nb], [2])
+    close(*pair, rtol=5e-4, atol_rel=5e-4, what=f"winograd4 wgrad {case}")
+
+
 def test_gemm_tn_batched_split_k():
     L = _L()
     M, N, K, batch = 96, 64, 5000, 5

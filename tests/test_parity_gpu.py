@@ -70,7 +70,9 @@ def test_train_steps_vs_golden(case, wino, monkeypatch):
     if wino:      # force the Winograd F(2x2,3x3) form onto every eligible 3x3 layer of these narrow test networks
         import ic_gan_amd.ops as _ops
         monkeypatch.setattr(_ops, "WINOGRAD_MIN_CHANNELS", 4)
+        monkeypatch.setattr(_ops, "WINOGRAD2_MIN_CHANNELS", 4)
         monkeypatch.setattr(_ops, "WINOGRAD4_MIN_CHANNELS", 4 if wino == 4 else 10 ** 9)      # F(4x4,3x3) / F(2x2,3x3)
+        monkeypatch.setattr(_ops, "WINOGRAD4_WGRAD_MIN_CHANNELS", 4 if wino == 4 else 10 ** 9)
     # F(4x4,3x3) forced onto 8..128-channel layers (production uses it from 256 channels, where the error averages over a
     # long K): its fp32 transforms (coefficients up to 8) cost about half a digit on these tiny ill-conditioned networks
     grad_rtol = GRAD_RTOL * (3.0 if wino == 4 else 1.0)

@@ -130,14 +130,18 @@ def test_no_weight_gradients_context(emu):
         cg.conv2d(x, w, padding=1, dilation=2)
 
 
+@pytest.mark.parametrize("m", [2, 4])
 @pytest.mark.parametrize("dev", ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)])
-def test_conv2d_gradfix_winograd_path(dev, monkeypatch):
+def test_conv2d_gradfix_winograd_path(dev, m, monkeypatch):
     """the wide-layer Winograd route of conv2d_gradfix (forced onto narrow layers here) reproduces the same reference
     goldens, including second-order gradients (the data gradient of a 'same' 3x3 conv is again a 'same' 3x3 conv)."""
     import ic_gan_amd.ops as _ops
     if dev == "cpu":
         kernel_ref.install(monkeypatch)
     monkeypatch.setattr(_ops, "WINOGRAD_MIN_CHANNELS", 4)
+    monkeypatch.setattr(_ops, "WINOGRAD2_MIN_CHANNELS", 4)
+    monkeypatch.setattr(_ops, "WINOGRAD4_MIN_CHANNELS", 4 if m == 4 else 10 ** 9)
+    monkeypatch.setattr(_ops, "WINOGRAD4_WGRAD_MIN_CHANNELS", 4 if m == 4 else 10 ** 9)
     _conv_case(0, dev)        # 8 -> 12 channels, 9x9: odd size -> stays on the direct path
     _conv_case(9, dev)        # 32 -> 32 channels, 16x16, stride 1, pad 1 -> Winograd
     _resample_case(4, dev)    # plain 3x3 through conv2d_resample
