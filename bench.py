@@ -53,6 +53,8 @@ class KernelTimer:
 
     # entry point -> (index of B in the argument list, kind)
     SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"), "icg_conv2d_wino4_fprop": (8, "wino4"), "icg_conv2d_wino_wgrad": (6, "wino"), "icg_conv2d_wino4_wgrad": (6, "wino4"),
+            "icg_conv2d_up_wino_fprop": (7, "rs_up"), "icg_conv2d_up_wino_dgrad": (3, "rs_up"), "icg_conv2d_up_wino_wgrad": (6, "rs_up"),
+            "icg_conv2d_down_wino_fprop": (5, "rs_down"), "icg_conv2d_down_wino_dgrad": (3, "rs_down"), "icg_conv2d_down_wino_wgrad": (3, "rs_down"),
             "icg_conv2d_wgrad": (6, "conv"), "icg_conv2d_up_fprop": (7, "up"),
             "icg_conv2d_up_dgrad": (3, "up"), "icg_conv2d_up_wgrad": (6, "up"), "icg_conv2d_down_fprop": (5, "up"),
             "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_wgrad": (3, "up")}
@@ -82,6 +84,12 @@ class KernelTimer:
                 alg = 2.0 * B * H * W * Cout * Cin * 9
                 exe = alg * (9.0 if mode == "wino4" else 16.0) / 36.0
                 byt = 4.0 * (B * H * W * (Cin + Cout) + Cout * Cin * 9)
+            elif mode in ("rs_up", "rs_down"):      # resample-fused layer in the 25-plane F(4x4,3x3) domain: 25 GEMMs over 1/16 of
+                B, Hs, Ws, Cin, Cout = args[sl:sl + 5]      # the full-resolution pixels = 25/144 of the reference graph's MACs
+                alg = 2.0 * B * (4 * Hs * Ws) * Cout * Cin * 9
+                exe = 2.0 * B * (Hs * Ws // 4) * Cout * Cin * 25
+                lo, hi = (Cin, Cout) if mode == "rs_up" else (Cout, Cin)
+                byt = 4.0 * (B * Hs * Ws * (lo + 4 * hi) + 9 * Cout * Cin)
             else:       # upsample- / avgpool-fused conv (2x2-phase or 4x4-stride-2 form): executed MACs are 16/36 of the
                         # reference op graph's (3x3 at the HIGH resolution); tensors: low-res one side, high-res the other
                 B, Hs, Ws, Cin, Cout = args[sl:sl + 5]
@@ -94,7 +102,11 @@ class KernelTimer:
             raw(name, *args)
             e.record()
             query(last)
-            if mode in ("wino", "wino4"):     # three kernels behind one entry point: not comparable with a single rocprof row
+            if mode in ("rs_up", "rs_down"):
+                kind = name.rsplit("_", 1)[1]
+                kname = "composite: %s-fused conv %s in the 25-plane F(4x4,3x3) domain (transforms + 25 batched icg_gemm_kernel<%s, %d, 2> GEMMs)" % (
+                    "upsample" if mode == "rs_up" else "avgpool", kind, "1, 1" if kind == "wgrad" else "0, 0", last[2])
+            elif mode in ("wino", "wino4"):     # three kernels behind one entry point: not comparable with a single rocprof row
                 kname = (("composite: wino4_input_kernel + wino4_dy_kernel + icg_gemm_kernel<1, 1, %d, 2> (36 batched split-K GEMMs) + reduce + wino4_dw_kernel" % last[2]
                           if mode == "wino4" else
                           "composite: wino_input_kernel + wino_dy_kernel + icg_gemm_kernel<1, 1, %d, 2> (16 batched split-K GEMMs) + reduce + wino_dw_kernel" % last[2])
@@ -430,6 +442,8 @@ def main():
     ap.add_argument("--init", default="ortho", choices=["ortho", "N02"],
                     help="weight init; N02 skips the rocSOLVER QR (which crashes under rocprofv3 --pmc); timings are init-independent")
     ap.add_argument("--graph", action="store_true", help="sample workload: replay the generator forward from a HIP graph")
+    ap.add_argument("--no-winograd", action="store_true",
+                    help="implicit-GEMM / phase / 4x4-stride-2 kernels only (ops.disable_winograd): the strict-parity route")
     ap.add_argument("--sync-bn", action="store_true", help="cross-replica BN statistics over RCCL (cfg3 variant)")
     args = ap.parse_args()
 
@@ -452,6 +466,9 @@ def main():
     assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
+    if args.no_winograd:
+        import ic_gan_amd.ops as _ops
+        _ops.disable_winograd()
 
     if args.workload == "sample":
         return bench_sampling(args, device, rank, world)
@@ -543,7 +560,8 @@ def main():
                                    f" class_cond={cfg['class_cond']} instance_cond={cfg['instance_cond']} hier attn@64,"
                                    f" 1 D step + 1 G step + Adam x2 + EMA, fp32 exact MFMA",
                        "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
-                       "init": init, "sync_bn": bool(args.sync_bn), "losses_last_step": metrics},
+                       "init": init, "sync_bn": bool(args.sync_bn), "winograd": not args.no_winograd,
+                       "losses_last_step": metrics},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -302,10 +302,22 @@ extern "C" int icg_conv2d_wino_fprop(const float* x, const float* U, const float
 //   1-D output y = A^T m : y0 = m0+m1+m2+m3+m4, y1 = m1-m2+2m3-2m4, y2 = m1+m2+4m3+4m4, y3 = m1-m2+8m3-8m4+m5
 //   1-D weight u = G g   : u0 = g0/4, u1 = -(g0+g1+g2)/6, u2 = -(g0-g1+g2)/6, u3 = g0/24+g1/12+g2/6,
 //                          u4 = g0/24-g1/12+g2/6, u5 = g2
+//
+// Resample-fused layers (GBlock conv1 = nearest x2 upsample -> conv3x3, DBlock conv2 = conv3x3 -> 2x2 average pool) in the
+// same domain: the 6-pixel window of an upsampled signal is d = [l0 l1 l1 l2 l2 l3] (tiles start on even pixels), for which
+// t2 = 4d1-4d2-d3+d4 = 0 identically, and the pooled output p0 = y0+y1 = m0+2m1+3m3-m4, p1 = y2+y3 = 2m1+12m3-4m4+m5 does not
+// read m2.  Component 2 therefore drops out in both dimensions: 25 GEMMs instead of 36 per tile, i.e. 25/64 of the
+// multiply-adds of the 2x2-phase / 4x4-stride-2 forms (and 25/144 of the reference op graph's).  NP = 5 below selects that
+// 25-plane layout (components 0,1,3,4,5 -> slots 0..4); the adjoint operations (data and weight gradients) have the same
+// structure: the gradient of a pooled output is an upsampled signal and vice versa.
 __device__ __forceinline__ float4 f4s(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 f4fma(float4 a, float s, float4 c) {
   return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
 }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <int NP> __device__ __forceinline__ constexpr int w4_slot(int k) { return NP == 6 ? k : (k < 2 ? k : k - 1); }
+template <int NP> __device__ __forceinline__ constexpr bool w4_has(int k) { return NP == 6 || k != 2; }
+
 __device__ __forceinline__ void w4_in6(const float4 d[6], float4 t[6]) {
   t[0] = f4add(f4fma(d[2], -5.f, f4s(d[0], 4.f)), d[4]);
   const float4 a = f4fma(d[2], -4.f, d[4]), b = f4fma(d[1], -4.f, d[3]);     // a = d4-4d2, b = d3-4d1
@@ -316,15 +328,31 @@ __device__ __forceinline__ void w4_in6(const float4 d[6], float4 t[6]) {
   t[4] = f4sub(c, e);
   t[5] = f4add(f4fma(d[3], -5.f, f4s(d[1], 4.f)), d[5]);
 }
+// the same for the upsampled window d = [l0 l1 l1 l2 l2 l3]:  t0 = 4l0-5l1+l2, t1 = -8l1+2l2, t2 = 0, t3 = 3(l2-l1),
+// t4 = l1-l2, t5 = 4l1-5l2+l3
+__device__ __forceinline__ void w4_in_up(const float4 l[4], float4 t[6]) {
+  t[0] = f4add(f4fma(l[1], -5.f, f4s(l[0], 4.f)), l[2]);
+  t[1] = f4fma(l[1], -8.f, f4s(l[2], 2.f));
+  t[2] = f4zero();
+  const float4 c = f4sub(l[2], l[1]);
+  t[3] = f4s(c, 3.f);
+  t[4] = f4s(c, -1.f);
+  t[5] = f4add(f4fma(l[2], -5.f, f4s(l[1], 4.f)), l[3]);
+}
 
-// one thread per (tile, channel quad): 36 loads, 36 stores; V[i][j] = (B^T d B)[i][j]
+// V[slot(i)*NP + slot(j)][t][c] = (B^T d B)[i][j], one thread per (tile, channel quad).  UP = 0: d = act(x) on the 6x6 window
+// of tile t of x [B][H][W][C];  UP = 1: d = the window of the nearest-x2 upsampled act(x), x [B][H/2][W/2][C] (4x4 loads).
+template <int UP, int NP>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                               const float* __restrict__ shift, long ssb, float* __restrict__ V,
-                                                               int B, int H, int W, int C4, int affine, int relu) {
+                                                          const float* __restrict__ shift, long ssb, float* __restrict__ V,
+                                                          int B, int H, int W, int C4, int affine, int relu) {
+  static_assert(!UP || NP == 5, "the upsampled window has no component 2");
   const int th = H >> 2, tw = W >> 2;
   const long T = (long)B * th * tw;
   const long total = T * C4, plane = T * C4;
   const long gstride = (long)gridDim.x * blockDim.x;
+  const int Hx = UP ? (H >> 1) : H, Wx = UP ? (W >> 1) : W;       // dims of the stored tensor
+  constexpr int NL = UP ? 4 : 6;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
     const int c4 = (int)(i % C4);
     const long t = i / C4;
@@ -332,23 +360,24 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     const long t2 = t / tw;
     const int ty = (int)(t2 % th);
     const int b = (int)(t2 / th);
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
     if (affine) {
       sc = *reinterpret_cast<const float4*>(scale + (long)b * ssb + 4 * c4);
       sh = *reinterpret_cast<const float4*>(shift + (long)b * ssb + 4 * c4);
     }
-    const float4* xp = reinterpret_cast<const float4*>(x) + (long)b * H * W * C4 + c4;
-    float4 E[6][6];
+    const float4* xp = reinterpret_cast<const float4*>(x) + (long)b * Hx * Wx * C4 + c4;
+    const int h0 = UP ? 2 * ty - 1 : 4 * ty - 1, w0 = UP ? 2 * tx - 1 : 4 * tx - 1;
+    float4 E[NL][6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const int h = 4 * ty - 1 + r;
-      float4 d[6];
+    for (int r = 0; r < NL; ++r) {
+      const int h = h0 + r;
+      float4 d[NL];
 #pragma unroll
-      for (int s = 0; s < 6; ++s) {
-        const int w = 4 * tx - 1 + s;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
-          v = xp[((long)h * W + w) * C4];
+      for (int s = 0; s < NL; ++s) {
+        const int w = w0 + s;
+        float4 v = f4zero();
+        if ((unsigned)h < (unsigned)Hx && (unsigned)w < (unsigned)Wx) {
+          v = xp[((long)h * Wx + w) * C4];
           if (affine) {
             v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
           }
@@ -356,16 +385,19 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
         }
         d[s] = v;
       }
-      w4_in6(d, E[r]);
+      if constexpr (UP) w4_in_up(d, E[r]); else w4_in6(d, E[r]);
     }
     float4* vp = reinterpret_cast<float4*>(V) + t * C4 + c4;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      const float4 col[6] = {E[0][j], E[1][j], E[2][j], E[3][j], E[4][j], E[5][j]};
-      float4 o[6];
-      w4_in6(col, o);
+      if (!w4_has<NP>(j)) continue;
+      float4 col[NL], o[6];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) vp[(long)(6 * r + j) * plane] = o[r];
+      for (int r = 0; r < NL; ++r) col[r] = E[r][j];
+      if constexpr (UP) w4_in_up(col, o); else w4_in6(col, o);
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+        if (w4_has<NP>(r)) vp[(long)(w4_slot<NP>(r) * NP + w4_slot<NP>(j)) * plane] = o[r];
     }
   }
 }
@@ -377,15 +409,25 @@ __device__ __forceinline__ void w4_out4(const float4 m[6], float4 y[4]) {
   y[2] = f4fma(r, 4.f, p);
   y[3] = f4add(f4fma(s, 8.f, q), m[5]);
 }
+// 2-pixel sums of the above (m[2] is not read):  p0 = m0+2m1+3m3-m4,  p1 = 2m1+12m3-4m4+m5
+__device__ __forceinline__ void w4_out_pool(const float4 m[6], float4 y[2]) {
+  const float4 a = f4s(m[1], 2.f);
+  y[0] = f4sub(f4fma(m[3], 3.f, f4add(m[0], a)), m[4]);
+  y[1] = f4add(f4fma(m[4], -4.f, f4fma(m[3], 12.f, a)), m[5]);
+}
 
-// one thread per (tile, channel quad): 36 loads, 16 stores
+// one thread per (tile, channel quad).  POOL = 0: y[b, 4ty+a, 4tx+c] = alpha (A^T m A)[a][c] + bias + residual on [B][H][W][C];
+// POOL = 1: the 2x2 sums of each tile, y [B][H/2][W/2][C] (alpha = 1/4 makes it the average pool), bias / residual at that size
+template <int POOL, int NP>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
-                                                                const float* __restrict__ res, int res_up, float alpha,
-                                                                float* __restrict__ y, int B, int H, int W, int C4) {
+                                                           const float* __restrict__ res, int res_up, float alpha,
+                                                           float* __restrict__ y, int B, int H, int W, int C4) {
+  static_assert(!POOL || NP == 5, "the pooled output does not read component 2");
   const int th = H >> 2, tw = W >> 2;
   const long T = (long)B * th * tw;
   const long total = T * C4, plane = T * C4;
   const long gstride = (long)gridDim.x * blockDim.x;
+  constexpr int NO = POOL ? 2 : 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
     const int c4 = (int)(i % C4);
     const long t = i / C4;
@@ -394,29 +436,35 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     const int ty = (int)(t2 % th);
     const long b = t2 / th;
     const float4* mp = reinterpret_cast<const float4*>(Mb) + t * C4 + c4;
-    float4 s[4][6];                     // s[a][j] = (A^T M)[a][j]
+    float4 s[NO][6];                     // s[a][j] = (A^T M)[a][j]
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
+      if (!w4_has<NP>(j)) {
+#pragma unroll
+        for (int a = 0; a < NO; ++a) s[a][j] = f4zero();
+        continue;
+      }
       float4 col[6], yy[4];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) col[r] = mp[(long)(6 * r + j) * plane];
-      w4_out4(col, yy);
+      for (int r = 0; r < 6; ++r) col[r] = w4_has<NP>(r) ? mp[(long)(w4_slot<NP>(r) * NP + w4_slot<NP>(j)) * plane] : f4zero();
+      if constexpr (POOL) w4_out_pool(col, yy); else w4_out4(col, yy);
 #pragma unroll
-      for (int a = 0; a < 4; ++a) s[a][j] = yy[a];
+      for (int a = 0; a < NO; ++a) s[a][j] = yy[a];
     }
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bv = f4zero();
     if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * c4);
+    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < NO; ++a) {
       float4 o[4];
-      w4_out4(s[a], o);
-      const int oy = 4 * ty + a;
-      const long p0 = ((b * H + oy) * W + 4 * tx) * C4 + c4;
+      if constexpr (POOL) w4_out_pool(s[a], o); else w4_out4(s[a], o);
+      const int oy = NO * ty + a;
+      const long p0 = ((b * Ho + oy) * Wo + NO * tx) * C4 + c4;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < NO; ++c) {
         float4 v = make_float4(alpha * o[c].x + bv.x, alpha * o[c].y + bv.y, alpha * o[c].z + bv.z, alpha * o[c].w + bv.w);
         if (res) {
-          const long rp = res_up ? ((b * (H >> 1) + (oy >> 1)) * (W >> 1) + ((4 * tx + c) >> 1)) * C4 + c4 : p0 + (long)c * C4;
+          const long rp = (!POOL && res_up) ? ((b * (H >> 1) + (oy >> 1)) * (W >> 1) + ((4 * tx + c) >> 1)) * C4 + c4 : p0 + (long)c * C4;
           v = f4add(v, reinterpret_cast<const float4*>(res)[rp]);
         }
         reinterpret_cast<float4*>(y)[p0 + (long)c * C4] = v;
@@ -434,7 +482,8 @@ __device__ __forceinline__ void w4_g6(const float g[3], float u[6]) {
   u[5] = g[2];
 }
 
-// U[xi][n][k] = (G g G^T)[xi], xi = 6*i + j
+// U[slot(i)*NP + slot(j)][n][k] = (G g G^T)[i][j]
+template <int NP>
 __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int N, int K) {
   const long total = (long)N * K;
   const long gstride = (long)gridDim.x * blockDim.x;
@@ -453,34 +502,74 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
+      if (!w4_has<NP>(r)) continue;
       float u[6];
       w4_g6(t[r], u);
 #pragma unroll
-      for (int j = 0; j < 6; ++j) U[(long)(6 * r + j) * total + i] = u[j];
+      for (int j = 0; j < 6; ++j)
+        if (w4_has<NP>(j)) U[(long)(w4_slot<NP>(r) * NP + w4_slot<NP>(j)) * total + i] = u[j];
     }
   }
 }
 
-static void launch_wino4_input(hipStream_t st, const float* x, const float* scale, const float* shift, long ssb, float* V, int B,
-                               int H, int W, int Cin, unsigned flags) {
+static void launch_wino4_input(hipStream_t st, int up, int np, const float* x, const float* scale, const float* shift, long ssb,
+                               float* V, int B, int H, int W, int Cin, unsigned flags) {
   const long T = (long)B * (H / 4) * (W / 4);
   long nb = icg_cdiv(T * (Cin / 4), 256);
   if (nb > 256 * 64) nb = 256 * 64;
-  hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, ssb, V, B, H, W, Cin / 4,
-                     (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0);
+  const int aff = (flags & ICG_PRE_AFFINE) ? 1 : 0, relu = (flags & ICG_PRE_RELU) ? 1 : 0;
+  const dim3 g((unsigned)nb), blk(256);
+  if (up) hipLaunchKernelGGL((wino4_input_kernel<1, 5>), g, blk, 0, st, x, scale, shift, ssb, V, B, H, W, Cin / 4, aff, relu);
+  else if (np == 5) hipLaunchKernelGGL((wino4_input_kernel<0, 5>), g, blk, 0, st, x, scale, shift, ssb, V, B, H, W, Cin / 4, aff, relu);
+  else hipLaunchKernelGGL((wino4_input_kernel<0, 6>), g, blk, 0, st, x, scale, shift, ssb, V, B, H, W, Cin / 4, aff, relu);
+}
+
+static void launch_wino4_output(hipStream_t st, int pool, int np, const float* Mb, const float* bias, const float* res, int res_up,
+                                float alpha, float* y, int B, int H, int W, int Cout) {
+  const long T = (long)B * (H / 4) * (W / 4);
+  long nb = icg_cdiv(T * (Cout / 4), 256);
+  if (nb > 256 * 64) nb = 256 * 64;
+  const dim3 g((unsigned)nb), blk(256);
+  if (pool) hipLaunchKernelGGL((wino4_output_kernel<1, 5>), g, blk, 0, st, Mb, bias, res, res_up, alpha, y, B, H, W, Cout / 4);
+  else if (np == 5) hipLaunchKernelGGL((wino4_output_kernel<0, 5>), g, blk, 0, st, Mb, bias, res, res_up, alpha, y, B, H, W, Cout / 4);
+  else hipLaunchKernelGGL((wino4_output_kernel<0, 6>), g, blk, 0, st, Mb, bias, res, res_up, alpha, y, B, H, W, Cout / 4);
 }
 
 extern "C" int icg_wino4_weight_transform(const float* w, float* U, int N, int K, void* stream) {
   ICG_REQUIRE(w && U && N > 0 && K > 0);
   long blocks = icg_cdiv((long)N * K, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wino4_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, U, N, K);
+  hipLaunchKernelGGL((wino4_weight_kernel<6>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, U, N, K);
+  return icg_check_launch();
+}
+
+extern "C" int icg_wino4r_weight_transform(const float* w, float* U, int N, int K, void* stream) {
+  ICG_REQUIRE(w && U && N > 0 && K > 0);
+  long blocks = icg_cdiv((long)N * K, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((wino4_weight_kernel<5>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, U, N, K);
   return icg_check_launch();
 }
 
 extern "C" size_t icg_conv2d_wino4_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   const size_t T = (size_t)B * (H / 4) * (W / 4);
   return 36 * T * ((size_t)Cin + (size_t)Cout) * sizeof(float);
+}
+
+// shared driver: V = input transform, M[xi] = V[xi] U[xi]^T (np*np batched GEMMs), output transform
+static int wino4_run(const float* x, int in_up, const float* U, const float* bias, const float* residual, int res_up, float* out,
+                     int out_pool, const float* scale, const float* shift, int64_t ssb, int B, int H, int W, int Cin, int Cout,
+                     unsigned flags, float alpha, int np, void* workspace, void* stream) {
+  const long T = (long)B * (H / 4) * (W / 4);
+  ICG_REQUIRE(T * 36 < 0x7fffffffL);
+  hipStream_t st = (hipStream_t)stream;
+  float* V = (float*)workspace;
+  float* Mb = V + (long)np * np * T * Cin;
+  launch_wino4_input(st, in_up, np, x, scale, shift, (long)ssb, V, B, H, W, Cin, flags);
+  int rc = icg_gemm_batched(V, U, Mb, (int)T, Cout, Cin, 0, 1, T * Cin, (long)Cout * Cin, T * Cout, np * np, 1.0f, stream);
+  if (rc != ICG_OK) return rc;
+  launch_wino4_output(st, out_pool, np, Mb, bias, residual, res_up, alpha, out, B, H, W, Cout);
+  return icg_check_launch();
 }
 
 extern "C" int icg_conv2d_wino4_fprop(const float* x, const float* U, const float* bias, const float* residual, float* out,
@@ -491,19 +580,61 @@ extern "C" int icg_conv2d_wino4_fprop(const float* x, const float* U, const floa
   ICG_REQUIRE((H % 4 == 0) && (W % 4 == 0) && (Cin % 4 == 0) && (Cout % 4 == 0) && !(flags & ICG_UPSAMPLE2X));
   if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift && (ss_bstride % 4 == 0));
   if (workspace_bytes < icg_conv2d_wino4_workspace_bytes(B, H, W, Cin, Cout)) return ICG_ERR_WORKSPACE;
-  const long T = (long)B * (H / 4) * (W / 4);
-  ICG_REQUIRE(T * 36 < 0x7fffffffL);
-  hipStream_t st = (hipStream_t)stream;
-  float* V = (float*)workspace;
-  float* Mb = V + 36 * T * Cin;
-  launch_wino4_input(st, x, scale, shift, (long)ss_bstride, V, B, H, W, Cin, flags);
-  int rc = icg_gemm_batched(V, U, Mb, (int)T, Cout, Cin, 0, 1, T * Cin, (long)Cout * Cin, T * Cout, 36, 1.0f, stream);
-  if (rc != ICG_OK) return rc;
-  long nb = icg_cdiv(T * (Cout / 4), 256);
-  if (nb > 256 * 64) nb = 256 * 64;
-  hipLaunchKernelGGL(wino4_output_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)Mb, bias, residual,
-                     (flags & ICG_RES_UPSAMPLE2X) ? 1 : 0, alpha, out, B, H, W, Cout / 4);
-  return icg_check_launch();
+  return wino4_run(x, 0, U, bias, residual, (flags & ICG_RES_UPSAMPLE2X) ? 1 : 0, out, 0, scale, shift, ss_bstride, B, H, W, Cin,
+                   Cout, flags, alpha, 6, workspace, stream);
+}
+
+// ---- resample-fused layers in the 25-plane domain (H, W below are always the FULL resolution of the layer) -----------------
+extern "C" size_t icg_conv2d_rs_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  const size_t T = (size_t)B * (H / 4) * (W / 4);
+  return 25 * T * ((size_t)Cin + (size_t)Cout) * sizeof(float);
+}
+
+#define ICG_RS_REQUIRE(B, Hl, Wl, Cin, Cout)                                                                           \
+  ICG_REQUIRE(B > 0 && Hl > 0 && Wl > 0 && Cin > 0 && Cout > 0 && (Hl % 2 == 0) && (Wl % 2 == 0) && (Cin % 4 == 0) && \
+              (Cout % 4 == 0))
+
+// out [B][2Hs][2Ws][Cout] = conv3x3(upsample2(act(x))) + bias,  x [B][Hs][Ws][Cin],  U = icg_wino4r_weight_transform(w_ohwi)
+extern "C" int icg_conv2d_up_wino_fprop(const float* x, const float* U, const float* bias, float* out, const float* scale,
+                                        const float* shift, int64_t ss_bstride, int B, int Hs, int Ws, int Cin, int Cout,
+                                        unsigned flags, void* workspace, size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(x && U && out && workspace);
+  ICG_RS_REQUIRE(B, Hs, Ws, Cin, Cout);
+  if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift && (ss_bstride % 4 == 0));
+  if (workspace_bytes < icg_conv2d_rs_wino_workspace_bytes(B, 2 * Hs, 2 * Ws, Cin, Cout)) return ICG_ERR_WORKSPACE;
+  return wino4_run(x, 1, U, bias, nullptr, 0, out, 0, scale, shift, ss_bstride, B, 2 * Hs, 2 * Ws, Cin, Cout, flags, 1.0f, 5,
+                   workspace, stream);
+}
+
+// da [B][Hs][Ws][Cin] = sum-pool2(conv3x3^T(dy)),  dy [B][2Hs][2Ws][Cout],  U = icg_wino4r_weight_transform(w_dgrad)
+extern "C" int icg_conv2d_up_wino_dgrad(const float* dy, const float* U, float* da, int B, int Hs, int Ws, int Cin, int Cout,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(dy && U && da && workspace);
+  ICG_RS_REQUIRE(B, Hs, Ws, Cin, Cout);
+  if (workspace_bytes < icg_conv2d_rs_wino_workspace_bytes(B, 2 * Hs, 2 * Ws, Cout, Cin)) return ICG_ERR_WORKSPACE;
+  return wino4_run(dy, 0, U, nullptr, nullptr, 0, da, 1, nullptr, nullptr, 0, B, 2 * Hs, 2 * Ws, Cout, Cin, 0, 1.0f, 5, workspace,
+                   stream);
+}
+
+// out [B][Hp][Wp][Cout] = avgpool2(conv3x3(act(x))) + bias + residual,  x [B][2Hp][2Wp][Cin]
+extern "C" int icg_conv2d_down_wino_fprop(const float* x, const float* U, const float* bias, const float* residual, float* out,
+                                          int B, int Hp, int Wp, int Cin, int Cout, unsigned flags, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(x && U && out && workspace && !(flags & ~ICG_PRE_RELU));
+  ICG_RS_REQUIRE(B, Hp, Wp, Cin, Cout);
+  if (workspace_bytes < icg_conv2d_rs_wino_workspace_bytes(B, 2 * Hp, 2 * Wp, Cin, Cout)) return ICG_ERR_WORKSPACE;
+  return wino4_run(x, 0, U, bias, residual, 0, out, 1, nullptr, nullptr, 0, B, 2 * Hp, 2 * Wp, Cin, Cout, flags, 0.25f, 5,
+                   workspace, stream);
+}
+
+// da [B][2Hp][2Wp][Cin] = conv3x3^T(upsample2(dy) / 4),  dy [B][Hp][Wp][Cout]
+extern "C" int icg_conv2d_down_wino_dgrad(const float* dy, const float* U, float* da, int B, int Hp, int Wp, int Cin, int Cout,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(dy && U && da && workspace);
+  ICG_RS_REQUIRE(B, Hp, Wp, Cin, Cout);
+  if (workspace_bytes < icg_conv2d_rs_wino_workspace_bytes(B, 2 * Hp, 2 * Wp, Cout, Cin)) return ICG_ERR_WORKSPACE;
+  return wino4_run(dy, 1, U, nullptr, nullptr, 0, da, 0, nullptr, nullptr, 0, B, 2 * Hp, 2 * Wp, Cout, Cin, 0, 0.25f, 5, workspace,
+                   stream);
 }
 
 // ---- weight gradient through the F(4x4,3x3) domain: dw = G^T [ sum_tiles (A dy A^T) .* (B^T act(x) B) ] G --------------------
@@ -521,14 +652,29 @@ __device__ __forceinline__ void w4_dy6(const float4 d[4], float4 s[6]) {
   s[4] = f4sub(e4, o4);
   s[5] = d[3];
 }
+// the same for the upsampled tile d = [l0 l0 l1 l1]:  s0 = l0, s1 = 2l0+2l1, s2 = 0, s3 = 3l0+12l1, s4 = -l0-4l1, s5 = l1
+__device__ __forceinline__ void w4_dy_up(const float4 l[2], float4 s[6]) {
+  s[0] = l[0];
+  s[1] = f4s(f4add(l[0], l[1]), 2.f);
+  s[2] = f4zero();
+  const float4 q = f4fma(l[1], 4.f, l[0]);
+  s[3] = f4s(q, 3.f);
+  s[4] = f4s(q, -1.f);
+  s[5] = l[1];
+}
 
-// one thread per (tile, channel quad): 16 loads, 36 stores
+// DY[slot(i)*NP + slot(j)][t][c] = alpha (A d A^T)[i][j], one thread per (tile, channel quad);  UP = 0: d = the 4x4 tile of
+// dy [B][H][W][C];  UP = 1: d = the tile of the nearest-x2 upsampled dy [B][H/2][W/2][C] (2x2 loads)
+template <int UP, int NP>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ DY, int B, int H,
-                                                            int W, int C4) {
+                                                       int W, int C4, float alpha) {
+  static_assert(!UP || NP == 5, "the upsampled tile has no component 2");
   const int th = H >> 2, tw = W >> 2;
   const long T = (long)B * th * tw;
   const long total = T * C4, plane = T * C4;
   const long gstride = (long)gridDim.x * blockDim.x;
+  constexpr int NL = UP ? 2 : 4;
+  const int Hx = UP ? (H >> 1) : H, Wx = UP ? (W >> 1) : W;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
     const int c4 = (int)(i % C4);
     const long t = i / C4;
@@ -536,23 +682,26 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
     const long t2 = t / tw;
     const int ty = (int)(t2 % th);
     const long b = t2 / th;
-    const float4* gp = reinterpret_cast<const float4*>(dy) + ((b * H + 4 * ty) * W + 4 * tx) * C4 + c4;
-    float4 E[4][6];
+    const float4* gp = reinterpret_cast<const float4*>(dy) + ((b * Hx + NL * ty) * Wx + NL * tx) * C4 + c4;
+    float4 E[NL][6];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float4 d[4];
+    for (int r = 0; r < NL; ++r) {
+      float4 d[NL];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) d[c] = gp[((long)r * W + c) * C4];
-      w4_dy6(d, E[r]);
+      for (int c = 0; c < NL; ++c) d[c] = f4s(gp[((long)r * Wx + c) * C4], alpha);
+      if constexpr (UP) w4_dy_up(d, E[r]); else w4_dy6(d, E[r]);
     }
     float4* op = reinterpret_cast<float4*>(DY) + t * C4 + c4;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      const float4 col[4] = {E[0][j], E[1][j], E[2][j], E[3][j]};
-      float4 o[6];
-      w4_dy6(col, o);
+      if (!w4_has<NP>(j)) continue;
+      float4 col[NL], o[6];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) op[(long)(6 * r + j) * plane] = o[r];
+      for (int r = 0; r < NL; ++r) col[r] = E[r][j];
+      if constexpr (UP) w4_dy_up(col, o); else w4_dy6(col, o);
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+        if (w4_has<NP>(r)) op[(long)(w4_slot<NP>(r) * NP + w4_slot<NP>(j)) * plane] = o[r];
     }
   }
 }
@@ -564,7 +713,8 @@ __device__ __forceinline__ void w4_gt3(const float u[6], float g[3]) {
   g[2] = (q - p) * (1.f / 6.f) + u[5];
 }
 
-// dw[r][s][ci][co] = (G^T dU G)[r][s]   (HWIO, like the direct weight gradient)
+// dw[r][s][ci][co] = (G^T dU G)[r][s]   (HWIO, like the direct weight gradient); NP = 5: component 2 of dU is zero
+template <int NP>
 __global__ __launch_bounds__(256) void wino4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, long n) {
   const long gstride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gstride) {
@@ -573,7 +723,8 @@ __global__ __launch_bounds__(256) void wino4_dw_kernel(const float* __restrict__
     for (int b = 0; b < 6; ++b) {
       float u[6], g[3];
 #pragma unroll
-      for (int a = 0; a < 6; ++a) u[a] = dU[(long)(6 * a + b) * n + i];
+      for (int a = 0; a < 6; ++a)
+        u[a] = (w4_has<NP>(a) && w4_has<NP>(b)) ? dU[(long)(w4_slot<NP>(a) * NP + w4_slot<NP>(b)) * n + i] : 0.f;
       w4_gt3(u, g);
       t[0][b] = g[0]; t[1][b] = g[1]; t[2][b] = g[2];
     }
@@ -588,10 +739,45 @@ __global__ __launch_bounds__(256) void wino4_dw_kernel(const float* __restrict__
   }
 }
 
+static size_t wino4_wgrad_bytes(int np, int B, int H, int W, int Cin, int Cout) {
+  const size_t T = (size_t)B * (H / 4) * (W / 4), P = (size_t)np * np;
+  return wino_al(P * T * Cin * sizeof(float)) + wino_al(P * T * Cout * sizeof(float)) + wino_al(P * Cin * Cout * sizeof(float)) +
+         wino_al(icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, (int)P));
+}
+
+// shared driver: V = input transform of x (x_up: of the upsampled x), DY = transform of dy (dy_up: of the upsampled dy, scaled),
+// dU[xi] = V[xi]^T DY[xi], dw = G^T dU G.  H, W: full resolution.
+static int wino4_wgrad_run(const float* x, int x_up, const float* dy, int dy_up, float dy_alpha, float* dw, const float* scale,
+                           const float* shift, int64_t ssb, int B, int H, int W, int Cin, int Cout, unsigned flags, int np,
+                           void* workspace, void* stream) {
+  const long T = (long)B * (H / 4) * (W / 4), P = (long)np * np;
+  ICG_REQUIRE(T * 36 < 0x7fffffffL);
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  float* V = (float*)base;                    base += wino_al(P * T * Cin * sizeof(float));
+  float* DY = (float*)base;                   base += wino_al(P * T * Cout * sizeof(float));
+  float* dU = (float*)base;                   base += wino_al((size_t)P * Cin * Cout * sizeof(float));
+  void* gws = base;
+  const size_t gws_bytes = icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, (int)P);
+  launch_wino4_input(st, x_up, np, x, scale, shift, (long)ssb, V, B, H, W, Cin, flags);
+  long nb = icg_cdiv(T * (Cout / 4), 256);
+  if (nb > 256 * 64) nb = 256 * 64;
+  const dim3 g((unsigned)nb), blk(256);
+  if (dy_up) hipLaunchKernelGGL((wino4_dy_kernel<1, 5>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha);
+  else if (np == 5) hipLaunchKernelGGL((wino4_dy_kernel<0, 5>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha);
+  else hipLaunchKernelGGL((wino4_dy_kernel<0, 6>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha);
+  int rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, (int)P, gws, gws_bytes, stream);
+  if (rc != ICG_OK) return rc;
+  const long n = (long)Cin * Cout;
+  nb = icg_cdiv(n, 256);
+  if (nb > 4096) nb = 4096;
+  if (np == 5) hipLaunchKernelGGL((wino4_dw_kernel<5>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)dU, dw, n);
+  else hipLaunchKernelGGL((wino4_dw_kernel<6>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)dU, dw, n);
+  return icg_check_launch();
+}
+
 extern "C" size_t icg_conv2d_wino4_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
-  const size_t T = (size_t)B * (H / 4) * (W / 4);
-  return wino_al(36 * T * Cin * sizeof(float)) + wino_al(36 * T * Cout * sizeof(float)) +
-         wino_al((size_t)36 * Cin * Cout * sizeof(float)) + wino_al(icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, 36));
+  return wino4_wgrad_bytes(6, B, H, W, Cin, Cout);
 }
 
 extern "C" int icg_conv2d_wino4_wgrad(const float* x, const float* dy, float* dw, const float* scale, const float* shift,
@@ -601,24 +787,29 @@ extern "C" int icg_conv2d_wino4_wgrad(const float* x, const float* dy, float* dw
   ICG_REQUIRE((H % 4 == 0) && (W % 4 == 0) && (Cin % 4 == 0) && (Cout % 4 == 0) && !(flags & ICG_UPSAMPLE2X));
   if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift && (ss_bstride % 4 == 0));
   if (workspace_bytes < icg_conv2d_wino4_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return ICG_ERR_WORKSPACE;
-  const long T = (long)B * (H / 4) * (W / 4);
-  ICG_REQUIRE(T * 36 < 0x7fffffffL);
-  hipStream_t st = (hipStream_t)stream;
-  char* base = (char*)workspace;
-  float* V = (float*)base;                    base += wino_al(36 * T * Cin * sizeof(float));
-  float* DY = (float*)base;                   base += wino_al(36 * T * Cout * sizeof(float));
-  float* dU = (float*)base;                   base += wino_al((size_t)36 * Cin * Cout * sizeof(float));
-  void* gws = base;
-  const size_t gws_bytes = icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, 36);
-  launch_wino4_input(st, x, scale, shift, (long)ss_bstride, V, B, H, W, Cin, flags);
-  long nb = icg_cdiv(T * (Cout / 4), 256);
-  if (nb > 256 * 64) nb = 256 * 64;
-  hipLaunchKernelGGL(wino4_dy_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, DY, B, H, W, Cout / 4);
-  int rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, 36, gws, gws_bytes, stream);
-  if (rc != ICG_OK) return rc;
-  const long n = (long)Cin * Cout;
-  nb = icg_cdiv(n, 256);
-  if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)dU, dw, n);
-  return icg_check_launch();
+  return wino4_wgrad_run(x, 0, dy, 0, 1.0f, dw, scale, shift, ss_bstride, B, H, W, Cin, Cout, flags, 6, workspace, stream);
+}
+
+extern "C" size_t icg_conv2d_rs_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  return wino4_wgrad_bytes(5, B, H, W, Cin, Cout);
+}
+
+// dw [3][3][Cin][Cout] of out = conv3x3(upsample2(act(x))):  x [B][Hs][Ws][Cin], dy [B][2Hs][2Ws][Cout]
+extern "C" int icg_conv2d_up_wino_wgrad(const float* x, const float* dy, float* dw, const float* scale, const float* shift,
+                                        int64_t ss_bstride, int B, int Hs, int Ws, int Cin, int Cout, unsigned flags,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(x && dy && dw && workspace);
+  ICG_RS_REQUIRE(B, Hs, Ws, Cin, Cout);
+  if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift && (ss_bstride % 4 == 0));
+  if (workspace_bytes < icg_conv2d_rs_wino_wgrad_workspace_bytes(B, 2 * Hs, 2 * Ws, Cin, Cout)) return ICG_ERR_WORKSPACE;
+  return wino4_wgrad_run(x, 1, dy, 0, 1.0f, dw, scale, shift, ss_bstride, B, 2 * Hs, 2 * Ws, Cin, Cout, flags, 5, workspace, stream);
+}
+
+// dw [3][3][Cin][Cout] of out = avgpool2(conv3x3(act(x))):  x [B][2Hp][2Wp][Cin], dy [B][Hp][Wp][Cout]
+extern "C" int icg_conv2d_down_wino_wgrad(const float* x, const float* dy, float* dw, int B, int Hp, int Wp, int Cin, int Cout,
+                                          unsigned flags, void* workspace, size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(x && dy && dw && workspace && !(flags & ~ICG_PRE_RELU));
+  ICG_RS_REQUIRE(B, Hp, Wp, Cin, Cout);
+  if (workspace_bytes < icg_conv2d_rs_wino_wgrad_workspace_bytes(B, 2 * Hp, 2 * Wp, Cin, Cout)) return ICG_ERR_WORKSPACE;
+  return wino4_wgrad_run(x, 0, dy, 1, 0.25f, dw, nullptr, nullptr, 0, B, 2 * Hp, 2 * Wp, Cin, Cout, flags, 5, workspace, stream);
 }

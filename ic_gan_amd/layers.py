@@ -133,6 +133,11 @@ class SNConv2d(nn.Conv2d, SN):
         wino = 0
         if self.kernel_size == (3, 3) and not phase and not down and not fuse.get("upsample"):
             wino = ops.winograd_applies(self.in_channels, self.out_channels, x.shape[2], x.shape[3], x.shape[0])
+        elif self.kernel_size == (3, 3) and (phase or down):
+            # resample-fused layer: 25-plane F(4x4,3x3) domain where it pays (per direction, ops.RS_WINOGRAD_MIN_CHANNELS)
+            up = 1 if phase else 0
+            wino = ops.resample_winograd_applies(self.in_channels, self.out_channels, x.shape[2] << up, x.shape[3] << up,
+                                                 x.shape[0])
         return ops.fused_conv(x, self.weight, self.bias, self.sn_state(upsample=phase, downsample=down, winograd=wino),
                               **fuse)
 

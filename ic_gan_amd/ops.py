@@ -63,7 +63,9 @@ class SNState:
     w_down_dgrad: Optional[torch.Tensor] = None  # [4][Cin][2][2][Cout]
     w_wino: Optional[torch.Tensor] = None        # Winograd-domain weight [16][Cout][Cin] (wide 3x3 stride-1 layers)
     w_wino_dgrad: Optional[torch.Tensor] = None  # the same for the data gradient, [16][Cin][Cout]
-    wino_m: int = 0                              # 2: F(2x2,3x3), 16 planes;  4: F(4x4,3x3), 36 planes
+    wino_m: int = 0                              # 2: F(2x2,3x3), 16 planes;  4: F(4x4,3x3), 36 planes;
+    #                                              5: resample-fused layer in the 25-plane F(4x4,3x3) domain, per direction:
+    rs: tuple = (False, False, False)            # (fprop, dgrad, wgrad) run in that domain (else phase / 4x4-stride-2 form)
 
 
 def _sn_alloc(weight, need_dgrad, upsample, downsample, winograd=False):
@@ -81,14 +83,21 @@ def _sn_alloc(weight, need_dgrad, upsample, downsample, winograd=False):
     n = rows * cin * R * R
     up = bool(upsample) and R == 3
     down = bool(downsample) and R == 3
-    st = SNState(_f32(n, dev), _f32(n, dev) if (need_dgrad and not up and not down) else None, _f32(rows, dev),
+    rs = (False, False, False)
+    if (up or down) and int(winograd) == 5:
+        rs = resample_winograd_directions(cin, rows, up)
+    st = SNState(_f32(n, dev), _f32(n, dev) if (need_dgrad and ((not up and not down) or rs[1])) else None, _f32(rows, dev),
                  _f32(cin * R * R, dev), _f32(1, dev), rows, cin, R)
+    if any(rs):
+        st.wino_m, st.rs = 5, rs
+        st.w_wino = _f32(25 * rows * cin, dev) if rs[0] else None
+        st.w_wino_dgrad = _f32(25 * rows * cin, dev) if (need_dgrad and rs[1]) else None
     if up:
-        st.w_up = _f32(16 * rows * cin, dev)
-        st.w_up_dgrad = _f32(16 * rows * cin, dev) if need_dgrad else None
+        st.w_up = _f32(16 * rows * cin, dev) if not rs[0] else None
+        st.w_up_dgrad = _f32(16 * rows * cin, dev) if (need_dgrad and not rs[1]) else None
     if down:
-        st.w_down = _f32(16 * rows * cin, dev)
-        st.w_down_dgrad = _f32(16 * rows * cin, dev) if need_dgrad else None
+        st.w_down = _f32(16 * rows * cin, dev) if not rs[0] else None
+        st.w_down_dgrad = _f32(16 * rows * cin, dev) if (need_dgrad and not rs[1]) else None
     if winograd and R == 3 and not up and not down:
         st.wino_m = 4 if int(winograd) == 4 else 2
         planes = 36 if st.wino_m == 4 else 16
@@ -100,7 +109,7 @@ def _sn_alloc(weight, need_dgrad, upsample, downsample, winograd=False):
 
 def _sn_winograd(st: SNState):
     """Winograd-domain copies of W/sigma (after the spectral-norm pass filled w_ohwi / w_dgrad)."""
-    fn = "icg_wino4_weight_transform" if st.wino_m == 4 else "icg_wino_weight_transform"
+    fn = {5: "icg_wino4r_weight_transform", 4: "icg_wino4_weight_transform"}.get(st.wino_m, "icg_wino_weight_transform")
     if st.w_wino is not None:
         L.call(fn, st.w_ohwi, st.w_wino, st.rows, st.cin)
     if st.w_wino_dgrad is not None:
@@ -197,7 +206,37 @@ def winograd_applies(cin, cout, h, w, batch):
     return 2 if c >= WINOGRAD2_MIN_CHANNELS else 0
 
 
+# resample-fused layers in the 25-plane domain (tools/rs_wino_bench.py, speed-up over the phase / 4x4-stride-2 forms at
+# min(Cin, Cout) = 96 / 192 / 384 / 768 / 1536):  upsample-fused fprop 1.1 / 1.6 / 2.0 / 2.1 / 2.6x, dgrad 0.9 / 1.3 / 1.8 / 2.0 / 4.8x,
+# wgrad 1.2 / 1.9 / 2.1 / 2.2 / 2.0x;  pool-fused fprop 0.7 / 1.1 / 1.6 / 1.9 / 2.2x, dgrad 0.9 / 1.3 / 1.7 / 2.1 / 2.3x, wgrad 0.7 / 1.05 / 1.6 / 1.8 / 2.1x
+RS_WINOGRAD_MIN_CHANNELS = {True: (96, 192, 96), False: (192, 192, 192)}       # upsample?: (fprop, dgrad, wgrad)
+
+
+def resample_winograd_applies(cin, cout, h, w, batch):
+    """5 when a resample-fused 3x3 layer (h, w: its FULL resolution) can run in the 25-plane Winograd domain, else 0.
+    Deliberately independent of the batch size (up to the index-range check): the layouts a layer's spectral-norm pass
+    emits are prefetched from its previous call (layers.sn_prefetch), and D alternates between batch 2B and B."""
+    if cin % 4 or cout % 4 or h % 4 or w % 4 or 36 * batch * (h // 4) * (w // 4) >= 0x7FFFFFFF:
+        return 0
+    return 5 if any(resample_winograd_directions(cin, cout, True)) or any(resample_winograd_directions(cin, cout, False)) else 0
+
+
+def resample_winograd_directions(cin, cout, upsample):
+    c = min(cin, cout)
+    return tuple(c >= m for m in RS_WINOGRAD_MIN_CHANNELS[bool(upsample)])
+
+
 WINOGRAD4_WGRAD_MIN_CHANNELS = 96       # weight gradient: F(4x4,3x3) domain from here (2.25x transform volume instead of 4x)
+
+
+def disable_winograd():
+    """Route every 3x3 layer through the implicit-GEMM / 2x2-phase / 4x4-stride-2 kernels only (no Winograd transforms):
+    the arithmetic then differs from a direct convolution by summation order alone.  `bench.py --no-winograd`."""
+    global WINOGRAD_MIN_CHANNELS, WINOGRAD2_MIN_CHANNELS, WINOGRAD4_MIN_CHANNELS, WINOGRAD4_WGRAD_MIN_CHANNELS
+    global RS_WINOGRAD_MIN_CHANNELS
+    big = 10 ** 9
+    WINOGRAD_MIN_CHANNELS = WINOGRAD2_MIN_CHANNELS = WINOGRAD4_MIN_CHANNELS = WINOGRAD4_WGRAD_MIN_CHANNELS = big
+    RS_WINOGRAD_MIN_CHANNELS = {True: (big, big, big), False: (big, big, big)}
 
 
 def winograd_wgrad_tile(cin, cout, h, w, batch):
@@ -254,7 +293,7 @@ class FusedConvFn(Function):
         Cout, R = sn.rows, sn.R
         down = bool(opt.downsample)
         if down:
-            assert sn.w_down is not None and opt.bn is None and not up and Hs % 2 == 0 and Ws % 2 == 0
+            assert (sn.w_down is not None or sn.rs[0]) and opt.bn is None and not up and Hs % 2 == 0 and Ws % 2 == 0
             H, W = Hs // 2, Ws // 2
         dev = x.device
         flags = (L.ICG_PRE_RELU if opt.relu else 0) | (L.ICG_UPSAMPLE2X if up else 0)
@@ -276,10 +315,19 @@ class FusedConvFn(Function):
             else:
                 assert res.shape == (B, Cout, H, W)
         out = _empty_cl(B, Cout, H, W, dev)
-        phase = bool(up and sn.w_up is not None)
-        if down:
+        phase = bool(up and (sn.w_up is not None or sn.rs[0]))
+        if down and sn.rs[0]:
+            # conv3x3 + avgpool2 in the 25-plane F(4x4,3x3) domain (25/64 of the 4x4-stride-2 form's MACs)
+            nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, Hs, Ws, Cin, Cout)
+            L.call("icg_conv2d_down_wino_fprop", x, sn.w_wino, bias, res, out, B, H, W, Cin, Cout, flags, _bytes(nb, dev), nb)
+        elif down:
             # conv3x3 + avgpool2 as one 4x4 / stride-2 conv at the pooled resolution (2.25x fewer MACs)
             L.call("icg_conv2d_down_fprop", x, sn.w_down, bias, res, out, B, H, W, Cin, Cout, flags)
+        elif phase and sn.rs[0]:
+            assert res is None, "the upsample-fused path has no residual epilogue (GBlock conv1 has none)"
+            nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cin, Cout)
+            L.call("icg_conv2d_up_wino_fprop", x, sn.w_wino, bias, out, scale, shift, ssb, B, Hs, Ws, Cin, Cout,
+                   flags & ~L.ICG_UPSAMPLE2X, _bytes(nb, dev), nb)
         elif phase:
             # nearest-x2 + 3x3 as 4 phases of 2x2 taps on the source tensor (2.25x fewer MACs)
             assert res is None, "the phase path has no residual epilogue (GBlock conv1 has none)"
@@ -310,15 +358,23 @@ class FusedConvFn(Function):
         dx = dweight = dbias = dres = dgain = dbeta = None
         if need[0] or (bn is not None and (need[4] or need[5])):
             if ctx.down:
-                if sn.w_down_dgrad is None:
+                if (sn.w_wino_dgrad if sn.rs[1] else sn.w_down_dgrad) is None:
                     raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
                 da = _empty_cl(B, Cin, Hs, Ws, dev)          # full (input) resolution
-                L.call("icg_conv2d_down_dgrad", dout, sn.w_down_dgrad, da, B, H, W, Cin, Cout)
+                if sn.rs[1]:
+                    nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, Hs, Ws, Cout, Cin)
+                    L.call("icg_conv2d_down_wino_dgrad", dout, sn.w_wino_dgrad, da, B, H, W, Cin, Cout, _bytes(nb, dev), nb)
+                else:
+                    L.call("icg_conv2d_down_dgrad", dout, sn.w_down_dgrad, da, B, H, W, Cin, Cout)
             elif ctx.phase:
-                if sn.w_up_dgrad is None:
+                if (sn.w_wino_dgrad if sn.rs[1] else sn.w_up_dgrad) is None:
                     raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
                 da = _empty_cl(B, Cin, Hs, Ws, dev)          # already at source resolution (upsample adjoint folded)
-                L.call("icg_conv2d_up_dgrad", dout, sn.w_up_dgrad, da, B, Hs, Ws, Cin, Cout)
+                if sn.rs[1]:
+                    nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cout, Cin)
+                    L.call("icg_conv2d_up_wino_dgrad", dout, sn.w_wino_dgrad, da, B, Hs, Ws, Cin, Cout, _bytes(nb, dev), nb)
+                else:
+                    L.call("icg_conv2d_up_dgrad", dout, sn.w_up_dgrad, da, B, Hs, Ws, Cin, Cout)
                 flags = flags & ~L.ICG_UPSAMPLE2X
             else:
                 if sn.w_dgrad is None:
@@ -338,7 +394,18 @@ class FusedConvFn(Function):
                 dx = da
             if not need[0]:
                 dx = None
-        if need[1] and ctx.down:
+        if need[1] and (ctx.down or ctx.phase) and sn.rs[2]:
+            # weight gradient of the resample-fused layer in the 25-plane domain: plain HWIO 3x3 result
+            dw_hwio = _f32(9 * Cin * Cout, dev)
+            if ctx.down:
+                nb = L.query("icg_conv2d_rs_wino_wgrad_workspace_bytes", B, Hs, Ws, Cin, Cout)
+                L.call("icg_conv2d_down_wino_wgrad", x, dout, dw_hwio, B, H, W, Cin, Cout, ctx.flags, _bytes(nb, dev), nb)
+            else:
+                nb = L.query("icg_conv2d_rs_wino_wgrad_workspace_bytes", B, H, W, Cin, Cout)
+                L.call("icg_conv2d_up_wino_wgrad", x, dout, dw_hwio, scale, shift, ssb, B, Hs, Ws, Cin, Cout,
+                       ctx.flags & ~L.ICG_UPSAMPLE2X, _bytes(nb, dev), nb)
+            dweight = _sn_backward(dw_hwio, None, sn, ctx.weight_like)
+        elif need[1] and ctx.down:
             nb = L.query("icg_conv2d_down_wgrad_workspace_bytes", B, H, W, Cin, Cout)
             ws = _bytes(nb, dev)
             dw_down = _f32(16 * Cin * Cout, dev)

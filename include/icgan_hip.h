@@ -182,6 +182,35 @@ size_t icg_conv2d_wino4_wgrad_workspace_bytes(int B, int H, int W, int Cin, int 
 int icg_conv2d_wino4_wgrad(const float* x, const float* dy, float* dw, const float* scale, const float* shift,
                            int64_t ss_bstride, int B, int H, int W, int Cin, int Cout, unsigned flags, void* workspace,
                            size_t workspace_bytes, void* stream);
+/*
+ * The resample-fused layers in the F(4x4,3x3) Winograd domain — same contracts as icg_conv2d_up_* (GBlock conv1: nearest x2
+ * upsample -> SNConv2d 3x3, layers.py:545-548) and icg_conv2d_down_* (DBlock conv2 -> nn.AvgPool2d(2), layers.py:603-606,
+ * BigGAN.py:528), for wide layers.  The 6-pixel window of an upsampled signal [l0 l1 l1 l2 l2 l3] has a vanishing third
+ * transform component and the 2-pixel sums of the output transform do not read it, so only 25 of the 36 per-tile GEMMs
+ * remain: 25/64 of the multiply-adds of the 2x2-phase / 4x4-stride-2 forms.  U [25][N][K] comes from
+ * icg_wino4r_weight_transform applied to the PLAIN 3x3 layouts of icg_sn_forward (w_ohwi for fprop, w_dgrad for the data
+ * gradients); the weight gradients are plain HWIO [3][3][Cin][Cout] (icg_sn_backward's dw_hwio).  Hs/Ws: source resolution
+ * of the upsampling layer, Hp/Wp: pooled resolution of the downsampling layer; both must be even, Cin and Cout multiples
+ * of 4.  Workspace queries take the FULL resolution (2Hs x 2Ws, 2Hp x 2Wp) and the (Cin, Cout) of the GEMM as called.
+ */
+int icg_wino4r_weight_transform(const float* w, float* U, int N, int K, void* stream);    /* U [25][N][K] */
+size_t icg_conv2d_rs_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+size_t icg_conv2d_rs_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int icg_conv2d_up_wino_fprop(const float* x, const float* U, const float* bias, float* out, const float* scale,
+                             const float* shift, int64_t ss_bstride, int B, int Hs, int Ws, int Cin, int Cout,
+                             unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
+int icg_conv2d_up_wino_dgrad(const float* dy, const float* U, float* da, int B, int Hs, int Ws, int Cin, int Cout,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int icg_conv2d_up_wino_wgrad(const float* x, const float* dy, float* dw, const float* scale, const float* shift,
+                             int64_t ss_bstride, int B, int Hs, int Ws, int Cin, int Cout, unsigned flags,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int icg_conv2d_down_wino_fprop(const float* x, const float* U, const float* bias, const float* residual, float* out,
+                               int B, int Hp, int Wp, int Cin, int Cout, unsigned flags, void* workspace,
+                               size_t workspace_bytes, void* stream);
+int icg_conv2d_down_wino_dgrad(const float* dy, const float* U, float* da, int B, int Hp, int Wp, int Cin, int Cout,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int icg_conv2d_down_wino_wgrad(const float* x, const float* dy, float* dw, int B, int Hp, int Wp, int Cin, int Cout,
+                               unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
 /* C[b] = A[b]^T B[b], A [K][M], B [K][N], long K: batched with deterministic split-K (strideC must be M*N) */
 size_t icg_gemm_tn_batched_workspace_bytes(int M, int N, int K, int batch);
 int icg_gemm_tn_batched(const float* A, const float* B, float* C, int M, int N, int K, int64_t strideA, int64_t strideB,

@@ -230,6 +230,73 @@ def icg_conv2d_down_wgrad(x, dy, dvdn, B, Hp, Wp, Cin, Cout, flags, workspace, w
     mem(dvdn)[: 16 * Cin * Cout].copy_(gw.permute(2, 3, 1, 0).reshape(-1))       # [P][Q][ci][co]
 
 
+# ---- resample-fused layers in the 25-plane F(4x4,3x3) domain: recover the 3x3 kernel from U and evaluate the op graph itself
+_W4R = [0, 1, 3, 4, 5]                              # transform components kept in the 25-plane layout
+
+
+def icg_wino4r_weight_transform(w, U, N, K):
+    g = mem(w)[: N * 9 * K].view(N, 3, 3, K).double()
+    u = torch.einsum("ar,nrsk,bs->abnk", _WINO4_G[_W4R], g, _WINO4_G[_W4R])
+    mem(U)[: 25 * N * K].copy_(u.reshape(-1).float())
+
+
+def _w4r_kernel(U, N, K):
+    """[N][3][3][K] from U [5][5][N][K]:  g0 = 4 u0,  g2 = u5,  g1 = -6 u1 - g0 - g2"""
+    u = mem(U)[: 25 * N * K].view(5, 5, N, K).double()
+    inv = torch.tensor([[4.0, 0, 0, 0, 0], [-4.0, -6.0, 0, 0, -1.0], [0, 0, 0, 0, 1.0]], dtype=torch.float64)
+    return torch.einsum("ra,abnk,sb->nrsk", inv, u, inv).float().contiguous()
+
+
+def icg_conv2d_rs_wino_workspace_bytes(B, H, W, Cin, Cout):
+    return 25 * B * (H // 4) * (W // 4) * (Cin + Cout) * 4
+
+
+def icg_conv2d_rs_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout):
+    return 16
+
+
+def icg_conv2d_up_wino_fprop(x, U, bias, out, scale, shift, ss_bstride, B, Hs, Ws, Cin, Cout, flags, workspace, workspace_bytes):
+    g = _w4r_kernel(U, Cout, Cin)
+    icg_conv2d_fprop(x, g, bias, None, out, scale, shift, ss_bstride, B, 2 * Hs, 2 * Ws, Cin, Cout, 3, flags | UPSAMPLE2X, 1.0)
+
+
+def icg_conv2d_up_wino_dgrad(dy, U, da, B, Hs, Ws, Cin, Cout, workspace, workspace_bytes):
+    wd = _w4r_kernel(U, Cin, Cout)                                       # dgrad layout [Cin][3][3][Cout], taps flipped
+    g = _nhwc(dy, B, 2 * Hs, 2 * Ws, Cout).permute(0, 3, 1, 2)
+    r = F.conv2d(g, wd.permute(0, 3, 1, 2), None, 1, 1)                  # gradient at the upsampled resolution
+    r = F.avg_pool2d(r, 2) * 4.0                                         # adjoint of the nearest upsample
+    mem(da)[: B * Hs * Ws * Cin].copy_(r.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_conv2d_up_wino_wgrad(x, dy, dw, scale, shift, ss_bstride, B, Hs, Ws, Cin, Cout, flags, workspace, workspace_bytes):
+    icg_conv2d_wgrad(x, dy, dw, scale, shift, ss_bstride, B, 2 * Hs, 2 * Ws, Cin, Cout, 3, flags | UPSAMPLE2X, None, 0)
+
+
+def icg_conv2d_down_wino_fprop(x, U, bias, residual, out, B, Hp, Wp, Cin, Cout, flags, workspace, workspace_bytes):
+    a = _act(x, None, None, 0, flags, B, 2 * Hp, 2 * Wp, Cin)
+    g = _w4r_kernel(U, Cout, Cin)
+    y = F.avg_pool2d(F.conv2d(a, g.permute(0, 3, 1, 2), None, 1, 1), 2)
+    if bias is not None:
+        y = y + mem(bias)[:Cout].view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + _nhwc(residual, B, Hp, Wp, Cout).permute(0, 3, 1, 2)
+    mem(out)[: B * Hp * Wp * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_conv2d_down_wino_dgrad(dy, U, da, B, Hp, Wp, Cin, Cout, workspace, workspace_bytes):
+    wd = _w4r_kernel(U, Cin, Cout)
+    g = F.interpolate(_nhwc(dy, B, Hp, Wp, Cout).permute(0, 3, 1, 2), scale_factor=2) * 0.25
+    r = F.conv2d(g, wd.permute(0, 3, 1, 2), None, 1, 1)
+    mem(da)[: B * 4 * Hp * Wp * Cin].copy_(r.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_conv2d_down_wino_wgrad(x, dy, dw, B, Hp, Wp, Cin, Cout, flags, workspace, workspace_bytes):
+    a = _act(x, None, None, 0, flags, B, 2 * Hp, 2 * Wp, Cin)
+    g = F.interpolate(_nhwc(dy, B, Hp, Wp, Cout).permute(0, 3, 1, 2), scale_factor=2) * 0.25
+    gw = torch.nn.grad.conv2d_weight(a.contiguous(), (Cout, Cin, 3, 3), g.contiguous(), padding=1)
+    mem(dw)[: 9 * Cin * Cout].copy_(gw.permute(2, 3, 1, 0).reshape(-1))       # HWIO
+
+
 def icg_gemm_batched(A, Bm, C, M, N, K, transA, transB, strideA, strideB, strideC, batch, alpha):
     a, b, c = mem(A), mem(Bm), mem(C)
     for z in range(batch):

@@ -43,10 +43,14 @@ def main():
 
     report("oracle32", i32, o32, gg32, dg32)
     BIG = 10 ** 9
-    prod = (ops.WINOGRAD_MIN_CHANNELS, ops.WINOGRAD2_MIN_CHANNELS, ops.WINOGRAD4_MIN_CHANNELS, ops.WINOGRAD4_WGRAD_MIN_CHANNELS)
-    for tag, knobs in (("direct", (BIG, BIG, BIG, BIG)), ("F(2,3)>=192", (192, 192, BIG, BIG)), ("product", prod),
-                       ("F(2,3)all", (4, 4, BIG, BIG)), ("F(4,3)all", (4, 4, 4, 4))):
-        ops.WINOGRAD_MIN_CHANNELS, ops.WINOGRAD2_MIN_CHANNELS, ops.WINOGRAD4_MIN_CHANNELS, ops.WINOGRAD4_WGRAD_MIN_CHANNELS = knobs
+    off, allrs = {True: (BIG,) * 3, False: (BIG,) * 3}, {True: (4, 4, 4), False: (4, 4, 4)}
+    prod = (ops.WINOGRAD_MIN_CHANNELS, ops.WINOGRAD2_MIN_CHANNELS, ops.WINOGRAD4_MIN_CHANNELS, ops.WINOGRAD4_WGRAD_MIN_CHANNELS,
+            ops.RS_WINOGRAD_MIN_CHANNELS)
+    for tag, knobs in (("no winograd", (BIG, BIG, BIG, BIG, off)), ("F(2,3)>=192", (192, 192, BIG, BIG, off)),
+                       ("F(4,3) prod", prod[:4] + (off,)), ("product", prod),
+                       ("F(2,3)all", (4, 4, BIG, BIG, off)), ("F(4,3)all", (4, 4, 4, 4, off)), ("all+rs all", (4, 4, 4, 4, allrs))):
+        (ops.WINOGRAD_MIN_CHANNELS, ops.WINOGRAD2_MIN_CHANNELS, ops.WINOGRAD4_MIN_CHANNELS, ops.WINOGRAD4_WGRAD_MIN_CHANNELS,
+         ops.RS_WINOGRAD_MIN_CHANNELS) = knobs
         _, G, D, _, _ = _build(cfg)
         G.train(); D.train()
         img = G(_d(z), _d(lab), _d(fg))

@@ -57,15 +57,17 @@ def test_forward_host_logic(case, emu):
     check_group(g, "fwd/D_state/", D.state_dict(), rtol=1e-4, atol=1e-6, what="D buf ")
 
 
-@pytest.mark.parametrize("wino", [0, 2, 4])
+@pytest.mark.parametrize("wino", [0, 2, 4, 5])
 @pytest.mark.parametrize("case", ["cc_ic_r64", "ic_r64_acc2", "cc_r32_flat"])
 def test_train_step_host_logic(case, emu, wino, monkeypatch):
     if wino:      # force the Winograd F(2x2,3x3) form onto every eligible 3x3 layer of these narrow test networks
         import ic_gan_amd.ops as _ops
         monkeypatch.setattr(_ops, "WINOGRAD_MIN_CHANNELS", 4)
         monkeypatch.setattr(_ops, "WINOGRAD2_MIN_CHANNELS", 4)
-        monkeypatch.setattr(_ops, "WINOGRAD4_MIN_CHANNELS", 4 if wino == 4 else 10 ** 9)      # F(4x4,3x3) / F(2x2,3x3)
-        monkeypatch.setattr(_ops, "WINOGRAD4_WGRAD_MIN_CHANNELS", 4 if wino == 4 else 10 ** 9)
+        monkeypatch.setattr(_ops, "WINOGRAD4_MIN_CHANNELS", 4 if wino >= 4 else 10 ** 9)      # F(4x4,3x3) / F(2x2,3x3)
+        monkeypatch.setattr(_ops, "WINOGRAD4_WGRAD_MIN_CHANNELS", 4 if wino >= 4 else 10 ** 9)
+        if wino == 5:     # ... and the resample-fused layers (GBlock conv1, DBlock conv2) in the 25-plane domain, all directions
+            monkeypatch.setattr(_ops, "RS_WINOGRAD_MIN_CHANNELS", {True: (4, 4, 4), False: (4, 4, 4)})
     from ic_gan_amd import train_fns, utils
     from ic_gan_amd.optim import FusedAdam
     g = load_golden(case)

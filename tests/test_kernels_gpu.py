@@ -284,6 +284,82 @@ def test_conv2d_down_fused_triplet(case):
     close(*p, rtol=5e-5, atol_rel=5e-5, what=f"down_wgrad {case}")
 
 
+RS_WINO_CASES = [
+    # B, Hl, Wl (low resolution: source of the upsample / pooled output), Cin, Cout, flags
+    (2, 4, 4, 32, 32, 0),
+    (2, 8, 8, 64, 48, PRE_AFFINE | PRE_RELU),
+    (1, 2, 6, 16, 40, PRE_RELU),              # one tile row, non-square
+    (3, 16, 16, 128, 96, PRE_RELU),           # long K (tiles) -> batched split-K slabs in the weight gradient
+]
+
+
+def _rs_weights(Cin, Cout):
+    """-> (w_ohwi [Cout][3][3][Cin], w_dgrad [Cin][3][3][Cout] with flipped taps, U25 of each)"""
+    w = rnd(Cout, 3, 3, Cin, seed=5, scale=1 / np.sqrt(9 * Cin))
+    wd = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+    U, Ud = torch.empty(25 * Cout * Cin), torch.empty(25 * Cout * Cin)
+    (pu,) = run_pair("icg_wino4r_weight_transform", [w, U, Cout, Cin], [1])
+    close(*pu, what="wino4r weight transform")
+    R.icg_wino4r_weight_transform(wd, Ud, Cin, Cout)
+    return w, wd, U, Ud
+
+
+@pytest.mark.parametrize("case", RS_WINO_CASES)
+def test_conv2d_up_winograd_triplet(case):
+    """upsample-fused 3x3 conv in the 25-plane F(4x4,3x3) domain: fprop / dgrad / wgrad vs the op graph evaluated directly."""
+    B, Hs, Ws, Cin, Cout, flags = case
+    L = _L()
+    w, wd, U, Ud = _rs_weights(Cin, Cout)
+    x = cl(B, Cin, Hs, Ws, seed=6)
+    bias = rnd(Cout, seed=7)
+    sc = sh = None
+    ssb = 0
+    if flags & PRE_AFFINE:
+        sc, sh, ssb = (1 + 0.3 * rnd(B, Cin, seed=8)).contiguous(), (0.3 * rnd(B, Cin, seed=9)).contiguous(), Cin
+    nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, 2 * Hs, 2 * Ws, Cin, Cout)
+    ws = torch.empty(nb, dtype=torch.uint8)
+    out = torch.empty(B, Cout, 2 * Hs, 2 * Ws).contiguous(memory_format=torch.channels_last)
+    (p,) = run_pair("icg_conv2d_up_wino_fprop", [x, U, bias, out, sc, sh, ssb, B, Hs, Ws, Cin, Cout, flags, ws, nb], [3])
+    close(*p, rtol=2e-4, atol_rel=2e-4, what=f"up_wino_fprop {case}")
+    dy = cl(B, Cout, 2 * Hs, 2 * Ws, seed=11)
+    da = torch.empty(B, Cin, Hs, Ws).contiguous(memory_format=torch.channels_last)
+    nbd = L.query("icg_conv2d_rs_wino_workspace_bytes", B, 2 * Hs, 2 * Ws, Cout, Cin)
+    (p,) = run_pair("icg_conv2d_up_wino_dgrad", [dy, Ud, da, B, Hs, Ws, Cin, Cout, torch.empty(nbd, dtype=torch.uint8), nbd], [2])
+    close(*p, rtol=2e-4, atol_rel=2e-4, what=f"up_wino_dgrad {case}")
+    nbw = L.query("icg_conv2d_rs_wino_wgrad_workspace_bytes", B, 2 * Hs, 2 * Ws, Cin, Cout)
+    (p,) = run_pair("icg_conv2d_up_wino_wgrad", [x, dy, torch.empty(9 * Cin * Cout), sc, sh, ssb, B, Hs, Ws, Cin, Cout, flags,
+                                                 torch.empty(nbw, dtype=torch.uint8), nbw], [2])
+    close(*p, rtol=5e-4, atol_rel=5e-4, what=f"up_wino_wgrad {case}")
+
+
+@pytest.mark.parametrize("case", RS_WINO_CASES)
+@pytest.mark.parametrize("has_res", [False, True])
+def test_conv2d_down_winograd_triplet(case, has_res):
+    """conv3x3 -> avgpool2 in the 25-plane F(4x4,3x3) domain: fprop / dgrad / wgrad vs conv-then-pool."""
+    B, Hp, Wp, Cin, Cout, flags = case
+    flags &= PRE_RELU
+    L = _L()
+    w, wd, U, Ud = _rs_weights(Cin, Cout)
+    H, W = 2 * Hp, 2 * Wp
+    x = cl(B, Cin, H, W, seed=6)
+    bias = rnd(Cout, seed=7)
+    res = cl(B, Cout, Hp, Wp, seed=8) if has_res else None
+    nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cin, Cout)
+    out = torch.empty(B, Cout, Hp, Wp).contiguous(memory_format=torch.channels_last)
+    (p,) = run_pair("icg_conv2d_down_wino_fprop", [x, U, bias, res, out, B, Hp, Wp, Cin, Cout, flags,
+                                                   torch.empty(nb, dtype=torch.uint8), nb], [4])
+    close(*p, rtol=2e-4, atol_rel=2e-4, what=f"down_wino_fprop {case}")
+    dy = cl(B, Cout, Hp, Wp, seed=11)
+    da = torch.empty(B, Cin, H, W).contiguous(memory_format=torch.channels_last)
+    nbd = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cout, Cin)
+    (p,) = run_pair("icg_conv2d_down_wino_dgrad", [dy, Ud, da, B, Hp, Wp, Cin, Cout, torch.empty(nbd, dtype=torch.uint8), nbd], [2])
+    close(*p, rtol=2e-4, atol_rel=2e-4, what=f"down_wino_dgrad {case}")
+    nbw = L.query("icg_conv2d_rs_wino_wgrad_workspace_bytes", B, H, W, Cin, Cout)
+    (p,) = run_pair("icg_conv2d_down_wino_wgrad", [x, dy, torch.empty(9 * Cin * Cout), B, Hp, Wp, Cin, Cout, flags,
+                                                   torch.empty(nbw, dtype=torch.uint8), nbw], [2])
+    close(*p, rtol=5e-4, atol_rel=5e-4, what=f"down_wino_wgrad {case}")
+
+
 GEMM_CASES = [
     # M, N, K, transA, transB, batch
     (256, 64, 4, 0, 1, 3), (256, 16, 64, 0, 0, 3), (64, 16, 256, 1, 0, 3), (64, 4, 256, 1, 0, 2),

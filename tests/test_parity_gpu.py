@@ -64,19 +64,44 @@ def test_forward_vs_golden(case):
     check_group(g, "fwd/D_state/", {k: v.cpu() for k, v in D.state_dict().items()}, 2e-4, 1e-6, "D buf ")
 
 
-@pytest.mark.parametrize("wino", [0, 2, 4])
-@pytest.mark.parametrize("case", CASES)
-def test_train_steps_vs_golden(case, wino, monkeypatch):
-    if wino:      # force the Winograd F(2x2,3x3) form onto every eligible 3x3 layer of these narrow test networks
-        import ic_gan_amd.ops as _ops
+# Winograd variants of the golden train-step test.  The goldens come from the reference run on the CPU (direct convolution);
+#  -1: every Winograd route off (implicit GEMM, 2x2-phase and 4x4-stride-2 forms only) -> the strict tolerances of helpers.py
+#   0: production thresholds (ops.WINOGRAD*_MIN_CHANNELS, ops.RS_WINOGRAD_MIN_CHANNELS: the 96..128-channel layers of these
+#      test networks run in the F(4x4,3x3) / 25-plane domains)
+#   2 / 4: F(2x2,3x3) / F(4x4,3x3) forced onto every eligible 3x3 stride-1 layer;  5: 4 + every resample-fused layer in the
+#      25-plane domain in all three directions
+# fp32 Winograd transforms (coefficients up to 12, cancellation in the output transform) put ~5e-6 relative error on a
+# layer's output where the direct MFMA kernel has ~5e-7 (tests/test_kernels_gpu.py); these tiny ill-conditioned networks
+# amplify per-layer errors ~2000x into the gradients (the fp32 reference itself sits 1e-3 from an fp64 run of the same graph,
+# tests/diag_winograd_accuracy.py), hence the documented multipliers.  Samples stay 100x inside the 1e-3 north_star bound.
+WINO_VARIANTS = [-1, 0, 2, 4, 5]
+WINO_GRAD_MULT = {-1: 1.0, 0: 3.0, 2: 3.0, 4: 5.0, 5: 5.0}
+WINO_STATE_MULT = {-1: 1.0, 0: 2.0, 2: 2.0, 4: 3.0, 5: 3.0}
+WINO_SLACK_MULT = {-1: 1.0, 0: 1.0, 2: 1.0, 4: 2.0, 5: 2.0}     # Adam (beta1 = 0) moves an element by +-lr: noisier small gradients flip more signs
+
+
+def _set_winograd(monkeypatch, wino):
+    import ic_gan_amd.ops as _ops
+    BIG = 10 ** 9
+    if wino == -1:
+        for k in ("WINOGRAD_MIN_CHANNELS", "WINOGRAD2_MIN_CHANNELS", "WINOGRAD4_MIN_CHANNELS", "WINOGRAD4_WGRAD_MIN_CHANNELS"):
+            monkeypatch.setattr(_ops, k, BIG)
+        monkeypatch.setattr(_ops, "RS_WINOGRAD_MIN_CHANNELS", {True: (BIG, BIG, BIG), False: (BIG, BIG, BIG)})
+    elif wino:
         monkeypatch.setattr(_ops, "WINOGRAD_MIN_CHANNELS", 4)
         monkeypatch.setattr(_ops, "WINOGRAD2_MIN_CHANNELS", 4)
-        monkeypatch.setattr(_ops, "WINOGRAD4_MIN_CHANNELS", 4 if wino == 4 else 10 ** 9)      # F(4x4,3x3) / F(2x2,3x3)
-        monkeypatch.setattr(_ops, "WINOGRAD4_WGRAD_MIN_CHANNELS", 4 if wino == 4 else 10 ** 9)
-    # F(4x4,3x3) forced onto 8..128-channel layers (production uses it from 256 channels, where the error averages over a
-    # long K): its fp32 transforms (coefficients up to 8) cost about half a digit on these tiny ill-conditioned networks
-    grad_rtol = GRAD_RTOL * (3.0 if wino == 4 else 1.0)
-    state_rtol = STATE_RTOL * (2.0 if wino == 4 else 1.0)
+        monkeypatch.setattr(_ops, "WINOGRAD4_MIN_CHANNELS", 4 if wino >= 4 else BIG)      # F(4x4,3x3) / F(2x2,3x3)
+        monkeypatch.setattr(_ops, "WINOGRAD4_WGRAD_MIN_CHANNELS", 4 if wino >= 4 else BIG)
+        if wino == 5:
+            monkeypatch.setattr(_ops, "RS_WINOGRAD_MIN_CHANNELS", {True: (4, 4, 4), False: (4, 4, 4)})
+
+
+@pytest.mark.parametrize("wino", WINO_VARIANTS)
+@pytest.mark.parametrize("case", CASES)
+def test_train_steps_vs_golden(case, wino, monkeypatch):
+    _set_winograd(monkeypatch, wino)
+    grad_rtol = GRAD_RTOL * WINO_GRAD_MULT[wino]
+    state_rtol = STATE_RTOL * WINO_STATE_MULT[wino]
     from ic_gan_amd import train_fns, utils
     from ic_gan_amd.optim import FusedAdam
     g = load_golden(case)
@@ -106,8 +131,8 @@ def test_train_steps_vs_golden(case, wino, monkeypatch):
                         grad_rtol, 1e-6, "G grad ")
             check_group(g, "step1/D_grad/", {n: p.grad.cpu() for n, p in D.named_parameters() if p.grad is not None},
                         grad_rtol, 1e-6, "D grad ")
-        gx = adam_slack(g, "step1/G_grad/", cfg["G_lr"], s + 1, G.state_dict().keys())
-        dx = adam_slack(g, "step1/D_grad/", cfg["D_lr"], s + 1, D.state_dict().keys())
+        gx = {k: v * WINO_SLACK_MULT[wino] for k, v in adam_slack(g, "step1/G_grad/", cfg["G_lr"], s + 1, G.state_dict().keys()).items()}
+        dx = {k: v * WINO_SLACK_MULT[wino] for k, v in adam_slack(g, "step1/D_grad/", cfg["D_lr"], s + 1, D.state_dict().keys()).items()}
         check_group(g, f"step{s + 1}/G_state/", cpu(G.state_dict()), state_rtol, 2e-6, "G ", extra_atol=gx)
         check_group(g, f"step{s + 1}/D_state/", cpu(D.state_dict()), state_rtol, 2e-6, "D ", extra_atol=dx)
         check_group(g, f"step{s + 1}/EMA_state/", cpu(G_ema.state_dict()), state_rtol, 2e-6, "EMA ", extra_atol=gx)
@@ -120,9 +145,9 @@ WIDE = dict(dim_z=120, shared_dim=128, shared_dim_feat=512, G_shared=True, G_sha
 
 def test_forward_backward_vs_live_oracle_wide():
     """ch=32 (channel counts 64..512, every vectorised kernel path, F(2x2,3x3) and F(4x4,3x3) Winograd at their production
-    thresholds) against the CPU oracle run here in fp64: the fp32 oracle's own gradients sit 1.0e-3 (rel. L2) from that
-    truth on this network, the direct HIP path 1.4e-3, F(4x4,3x3) 1.6e-3 (2.4e-3 on the scalar attention gamma) --
-    tests/diag_winograd_accuracy.py prints the table."""
+    thresholds, the resample-fused layers in the 25-plane domain) against the CPU oracle run here in fp64: the fp32 oracle's
+    own gradients sit 1.0e-3 (rel. L2) from that truth on this network, the HIP path without Winograd 1.4e-3, with the
+    production routes 2.9e-3 -- tests/diag_winograd_accuracy.py prints the table; bound 5e-3."""
     cfg = dict(WIDE)
     _, G, D, gspec, dspec = _build(cfg)
     gsd, dsd = synth.synth_state(gspec, 11), synth.synth_state(dspec, 22)
@@ -155,9 +180,9 @@ def test_forward_backward_vs_live_oracle_wide():
         ref = gsd[n].grad
         if float(ref.norm()) < 1e-4 * top:
             continue                                   # mathematically-zero gradients (bias feeding BN)
-        assert rel_l2(p.grad, ref) < 3e-3, (n, rel_l2(p.grad, ref))
+        assert rel_l2(p.grad, ref) < 5e-3, (n, rel_l2(p.grad, ref))
     for n, p in D.named_parameters():
-        assert rel_l2(p.grad, dsd[n].grad) < 3e-3, (n, rel_l2(p.grad, dsd[n].grad))
+        assert rel_l2(p.grad, dsd[n].grad) < 5e-3, (n, rel_l2(p.grad, dsd[n].grad))
     for k, v in G.state_dict().items():
         if k.endswith(("u0", "sv0", "stored_mean", "stored_var")):
             assert rel_l2(v, gsd[k]) < 1e-4, k
