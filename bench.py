@@ -114,6 +114,8 @@ class KernelTimer:
                          ("composite: wino4_input_kernel + icg_gemm_kernel<0, 0, %d, 2> (36 batched GEMMs) + wino4_output_kernel" % last[2]
                           if mode == "wino4" else
                           "composite: wino_input_kernel + icg_gemm_kernel<0, 0, %d, 2> (16 batched GEMMs) + wino_output_kernel" % last[2]))
+            elif last[0] == -3:      # skinny linear kernels (narrow_conv.hip): {-3, fprop/wgrad, Cout, Cin}
+                kname = "skinny_wgrad_kernel" if last[1] else "void skinny_fprop_kernel<8>"
             elif last[0] == -2:      # direct narrow-output kernels (narrow_conv.hip): {-2, fprop/wgrad, Cout, Cin}
                 lp = 1
                 while lp < last[3] // 4:

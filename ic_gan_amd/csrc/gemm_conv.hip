@@ -752,6 +752,11 @@ size_t icg_narrow_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int icg_narrow_wgrad(const float* x, const float* dy, const float* scale, const float* shift, long ssb, float* dw,
                      void* workspace, int B, int H, int W, int Cin, int Cout, int affine, int relu, hipStream_t st);
 
+// skinny linear layers (batch rows x odd K; narrow_conv.hip)
+bool icg_skinny_ok(long M, int Cin, int R);
+int icg_skinny_fprop(const float* x, const float* w, const float* bias, float* out, int M, int N, int K, float alpha, hipStream_t st);
+int icg_skinny_wgrad(const float* x, const float* dy, float* dw, int M, int N, int K, hipStream_t st);
+
 // ---- split-K for forward / data-gradient launches that cannot fill the chip ------------------------------------------
 // A [M x N] output with fewer than ~384 tiles leaves CUs idle while every tile walks the whole K (StyleGAN2 at batch 16 below
 // 32x32, small-batch sampling): the K range is cut into S slices (blockIdx.z), each writes a raw partial slab, and a second
@@ -869,6 +874,10 @@ static int conv2d_fprop_impl(const float* x, const float* w, const float* bias, 
     return icg_narrow_fprop(x, w, bias, scale, shift, ss_bstride, out, B, H, W, Cin, Cout,
                             (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0, alpha, (hipStream_t)stream);
   }
+  if (!up && !residual && !(flags & (ICG_PRE_AFFINE | ICG_PRE_RELU)) && icg_skinny_ok(M, Cin, R)) {
+    g_last_variant[0] = -3; g_last_variant[1] = 0; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
+    return icg_skinny_fprop(x, w, bias, out, (int)M, Cout, Cin, alpha, (hipStream_t)stream);
+  }
   GemmP p{};
   p.A = x; p.B = w; p.C = out;
   p.M = (int)M; p.N = Cout; p.K = R * R * Cin;
@@ -944,6 +953,11 @@ extern "C" int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
     g_last_variant[0] = -2; g_last_variant[1] = 1; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
     return icg_narrow_wgrad(x, dy, scale, shift, ss_bstride, dw, workspace, B, H, W, Cin, Cout,
                             (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0, (hipStream_t)stream);
+  }
+  if (!up && !(flags & (ICG_PRE_AFFINE | ICG_PRE_RELU)) && (Cout % 4 == 0) && aligned16(dy) && aligned16(dw) &&
+      icg_skinny_ok(K, Cin, R)) {
+    g_last_variant[0] = -3; g_last_variant[1] = 1; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
+    return icg_skinny_wgrad(x, dy, dw, (int)K, Cout, Cin, (hipStream_t)stream);
   }
   WgradPlan pl = wgrad_plan(K, M, Cout);
   const size_t need = (pl.splits <= 1) ? 0 : (size_t)pl.splits * M * Cout * sizeof(float);

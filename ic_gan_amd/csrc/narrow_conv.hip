@@ -261,3 +261,81 @@ int icg_narrow_wgrad(const float* x, const float* dy, const float* scale, const 
                      blocks);
   return icg_check_launch();
 }
+
+// ---- skinny linear layers: out[M][N] = x[M][K] w[N][K]^T with M = batch rows (<= 256) and K not a multiple of 4 -----------------
+// (the conditional-BN gain / bias projections of the generator, layers.py:367-374: K = 657 = 17 z + 128 class + 512 feature
+// inputs, N = the block's channel count, M = 64.  On the implicit-GEMM kernel these are one row of tiles walking K with the
+// scalar gather loader: 0.1-0.3 ms each, 60 per step.)  One wavefront per 8 output columns, lane = row: x is read once per
+// wave with per-lane row streams, w through wave-uniform loads; the weight gradient dw[K][N] = x^T dy is one thread per
+// (k, 4 columns) looping over the M rows.
+template <int NB>
+__global__ __launch_bounds__(64) void skinny_fprop_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int M, int N,
+                                                          int K, float alpha) {
+  const int row = blockIdx.y * 64 + threadIdx.x;
+  const int n0 = blockIdx.x * NB;
+  const float* xr = x + (long)min(row, M - 1) * K;
+  const float* wr[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) wr[j] = w + (long)min(n0 + j, N - 1) * K;
+  float acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) acc[j] = 0.f;
+  int k = 0;
+  for (; k + 4 <= K; k += 4) {
+    const float x0 = xr[k], x1 = xr[k + 1], x2 = xr[k + 2], x3 = xr[k + 3];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      acc[j] = fmaf(x0, wr[j][k], acc[j]);
+      acc[j] = fmaf(x1, wr[j][k + 1], acc[j]);
+      acc[j] = fmaf(x2, wr[j][k + 2], acc[j]);
+      acc[j] = fmaf(x3, wr[j][k + 3], acc[j]);
+    }
+  }
+  for (; k < K; ++k) {
+    const float x0 = xr[k];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = fmaf(x0, wr[j][k], acc[j]);
+  }
+  if (row < M) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (n0 + j < N) out[(long)row * N + n0 + j] = alpha * acc[j] + (bias ? bias[n0 + j] : 0.f);
+  }
+}
+
+// dw[k][n..n+3] = sum_b x[b][k] dy[b][n..n+3]   (HWIO with R = 1: [K][N])
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dw, int M, int N4, int K) {
+  const long total = (long)K * N4;
+  const long gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const int n4 = (int)(i % N4);
+    const int k = (int)(i / N4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* g = reinterpret_cast<const float4*>(dy) + n4;
+    for (int b = 0; b < M; ++b) {
+      const float xv = x[(long)b * K + k];
+      const float4 d = g[(long)b * N4];
+      acc.x = fmaf(xv, d.x, acc.x); acc.y = fmaf(xv, d.y, acc.y); acc.z = fmaf(xv, d.z, acc.z); acc.w = fmaf(xv, d.w, acc.w);
+    }
+    reinterpret_cast<float4*>(dw)[i] = acc;
+  }
+}
+
+bool icg_skinny_ok(long M, int Cin, int R) { return R == 1 && M <= 256 && (Cin % 4) != 0 && Cin >= 16; }
+
+int icg_skinny_fprop(const float* x, const float* w, const float* bias, float* out, int M, int N, int K, float alpha,
+                     hipStream_t st) {
+  hipLaunchKernelGGL((skinny_fprop_kernel<8>), dim3((unsigned)icg_cdiv(N, 8), (unsigned)icg_cdiv(M, 64)), dim3(64), 0, st, x, w,
+                     bias, out, M, N, K, alpha);
+  return icg_check_launch();
+}
+
+int icg_skinny_wgrad(const float* x, const float* dy, float* dw, int M, int N, int K, hipStream_t st) {
+  const long total = (long)K * (N / 4);
+  long nb = icg_cdiv(total, 256);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(skinny_wgrad_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, dy, dw, M, N / 4, K);
+  return icg_check_launch();
+}

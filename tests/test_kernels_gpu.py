@@ -70,7 +70,10 @@ CONV_CASES = [
     (2, 8, 8, 64, 48, 1, 0, 0, False),                   # attention theta
     (2, 8, 8, 192, 24, 1, 0, 0, False),
     (2, 16, 16, 96, 3, 3, PRE_AFFINE | PRE_RELU, 0, True),        # generator RGB tail (N = 3)
-    (64, 1, 1, 657, 96, 1, 0, 0, False),                 # ccbn gain linear (K = 657: scalar path)
+    (64, 1, 1, 657, 96, 1, 0, 0, False),                 # ccbn gain linear (K = 657): skinny linear kernels
+    (100, 1, 1, 657, 1536, 1, 0, 0, True),               # two row groups, bias
+    (7, 1, 1, 21, 20, 1, 0, 0, False),                   # N not a multiple of 8, K tail
+    (300, 1, 1, 657, 96, 1, 0, 0, False),                # more than 256 rows: stays on the implicit-GEMM scalar path
     (64, 1, 1, 17, 256, 1, 0, 0, True),                  # z-chunk linear
     (4, 1, 1, 2048, 512, 1, 0, 0, True),                 # shared_feat
     (8, 1, 1, 128, 1, 1, 0, 0, True),                    # D output linear (N = 1)
