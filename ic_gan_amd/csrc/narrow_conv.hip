@@ -1,13 +1,21 @@
 // 3x3 convolutions with 1..4 output channels (the generator's to-RGB layer, BigGAN.py:251-262, and the data gradient of
 // the discriminator's from-RGB layer) and their weight gradient.  A GEMM tile would waste >= 29/32 of every MFMA on
 // them; they are HBM-bound (one pass over the wide tensor), so they get direct kernels:
-//   * a group of LP lanes (LP = power of two >= Cin/4, <= 64) owns one pixel, lane q the channel quad q: the 16-byte loads
-//     of a group are contiguous, the 9 x NOUT weight quads of a lane stay in registers for the whole kernel;
+//   * a group of LP lanes (LP = power of two >= Cin/4, <= 64) owns one image column of a 32-row segment and walks down it, lane q
+//     the channel quad q: the 16-byte loads of a group are contiguous, the 9 x NOUT weight quads of a lane stay in registers
+//     for the whole kernel, and the 3x3 window slides: 3 new pixels per step instead of 9 (the neighbouring columns belong to
+//     the other groups of the same block, so their re-reads hit the L1);
 //   * fprop: per-lane partial dot products over the 9 taps, then a log2(LP)-step shuffle reduction per output channel;
 //   * wgrad: per-lane accumulators dw[tap][quad][co] over the block's pixels, combined across pixel groups through LDS
 //     into one slab per block; the slabs are summed by the deterministic split-K reduction kernel.
 // Prologue (per-sample affine + ReLU, zero padding applied AFTER the activation) as in the GEMM loader.
 #include "icg_common.h"
+
+#define NC_ROWS 32      // rows of a column segment (2 halo rows per segment are re-read)
+
+typedef float nc_v2 __attribute__((ext_vector_type(2)));      // v_pk_fma_f32: two fp32 FMAs per lane and issue slot
+__device__ __forceinline__ nc_v2 nc_lo(const float4& v) { return nc_v2{v.x, v.y}; }
+__device__ __forceinline__ nc_v2 nc_hi(const float4& v) { return nc_v2{v.z, v.w}; }
 
 __device__ __forceinline__ float4 nc_act(float4 v, const float4& sc, const float4& sh, bool affine, bool relu) {
   if (affine) {
@@ -37,46 +45,73 @@ __global__ __launch_bounds__(256) void narrow_fprop_kernel(const float* __restri
       wr[o][t] = lane_on ? *reinterpret_cast<const float4*>(wgt + ((long)o * 9 + t) * Cin + 4 * q)
                          : make_float4(0.f, 0.f, 0.f, 0.f);
   // 32-bit index arithmetic throughout (the host checks that every offset fits)
-  const unsigned npix = (unsigned)B * H * W, HW = (unsigned)H * W;
-  const unsigned gstride = gridDim.x * GPW;
-  for (unsigned p = blockIdx.x * GPW + grp; p < npix; p += gstride) {
-    const unsigned b = p / HW, rem = p - b * HW;
-    const int h0 = (int)(rem / (unsigned)W);
-    const int w0 = (int)(rem - (unsigned)h0 * W);
+  const unsigned cbs = (unsigned)(W + GPW - 1) / GPW, rss = (unsigned)(H + NC_ROWS - 1) / NC_ROWS;
+  const unsigned units = (unsigned)B * cbs * rss;
+  for (unsigned u = blockIdx.x; u < units; u += gridDim.x) {
+    const unsigned b = u / (cbs * rss), r2 = u - b * cbs * rss;
+    const int hb = (int)(r2 / cbs) * NC_ROWS, w0 = (int)(r2 % cbs) * GPW + grp;
+    const int he = min(H, hb + NC_ROWS);
+    const bool col_on = w0 < W;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (affine) {
       sc = *reinterpret_cast<const float4*>(scale + b * (unsigned)ssb + 4 * qa);
       sh = *reinterpret_cast<const float4*>(shift + b * (unsigned)ssb + 4 * qa);
     }
-    float acc[NOUT];
+    const float* xb = x + (b * (unsigned)H * W) * (unsigned)Cin + 4 * qa;
+    // raw (unactivated) loads of the three pixels (w0-1, w0, w0+1) of row hi, clamped addresses
+    auto load_row = [&](int hi, float4 (&v)[3]) {
+      const unsigned hc = (unsigned)min(max(hi, 0), H - 1);
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) acc[o] = 0.f;
-    // all nine loads are issued before the first use (clamped addresses, no branches): one memory latency per pixel
-    float4 v[9];
-    bool ok[9];
+      for (int s = 0; s < 3; ++s) {
+        const unsigned wc = (unsigned)min(max(w0 + s - 1, 0), W - 1);
+        v[s] = *reinterpret_cast<const float4*>(xb + (hc * (unsigned)W + wc) * (unsigned)Cin);
+      }
+    };
+    auto act_row = [&](int hi, float4 (&v)[3]) {      // activation, then the zero padding of the ACTIVATED tensor
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int hi = h0 + t / 3 - 1, wi = w0 + t % 3 - 1;
-      ok[t] = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-      const unsigned hc = (unsigned)min(max(hi, 0), H - 1), wc = (unsigned)min(max(wi, 0), W - 1);
-      v[t] = *reinterpret_cast<const float4*>(x + ((b * H + hc) * W + wc) * (unsigned)Cin + 4 * qa);
-    }
+      for (int s = 0; s < 3; ++s) {
+        const bool ok = (unsigned)hi < (unsigned)H && (unsigned)(w0 + s - 1) < (unsigned)W;
+        v[s] = ok ? nc_act(v[s], sc, sh, affine, relu) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    float4 win[3][3], nxt[3];
+    load_row(hb - 1, win[0]);
+    load_row(hb, win[1]);
+    load_row(hb + 1, win[2]);
+    act_row(hb - 1, win[0]);
+    act_row(hb, win[1]);
+    act_row(hb + 1, win[2]);
+    for (int h = hb; h < he; ++h) {
+      load_row(h + 2, nxt);                            // in flight while this row is computed
+      nc_v2 acc2[NOUT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float4 a = nc_act(v[t], sc, sh, affine, relu);
-      if (!ok[t]) a = make_float4(0.f, 0.f, 0.f, 0.f);            // zero padding applies to the activated tensor
+      for (int o = 0; o < NOUT; ++o) acc2[o] = nc_v2{0.f, 0.f};
 #pragma unroll
-      for (int o = 0; o < NOUT; ++o)
-        acc[o] += (a.x * wr[o][t].x + a.y * wr[o][t].y) + (a.z * wr[o][t].z + a.w * wr[o][t].w);   // wr = 0 on idle lanes
-    }
+      for (int t = 0; t < 9; ++t) {
+        const float4 a = win[t / 3][t % 3];
+        const nc_v2 alo = nc_lo(a), ahi = nc_hi(a);
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
+        for (int o = 0; o < NOUT; ++o) {                                   // wr = 0 on idle lanes
+          acc2[o] = __builtin_elementwise_fma(alo, nc_lo(wr[o][t]), acc2[o]);
+          acc2[o] = __builtin_elementwise_fma(ahi, nc_hi(wr[o][t]), acc2[o]);
+        }
+      }
+      float acc[NOUT];
 #pragma unroll
-      for (int d = LP / 2; d >= 1; d >>= 1) acc[o] += __shfl_xor(acc[o], d, 64);
-    }
-    if (q == 0) {
+      for (int o = 0; o < NOUT; ++o) acc[o] = acc2[o].x + acc2[o].y;
 #pragma unroll
-      for (int o = 0; o < NOUT; ++o) out[(long)p * NOUT + o] = alpha * acc[o] + (bias ? bias[o] : 0.f);
+      for (int o = 0; o < NOUT; ++o) {
+#pragma unroll
+        for (int d = LP / 2; d >= 1; d >>= 1) acc[o] += __shfl_xor(acc[o], d, 64);
+      }
+      if (q == 0 && col_on) {
+        const long p = ((long)b * H + h) * W + w0;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) out[p * NOUT + o] = alpha * acc[o] + (bias ? bias[o] : 0.f);
+      }
+      act_row(h + 2, nxt);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) { win[0][s] = win[1][s]; win[1][s] = win[2][s]; win[2][s] = nxt[s]; }
     }
   }
 }
@@ -98,38 +133,61 @@ __global__ __launch_bounds__(256) void narrow_wgrad_kernel(const float* __restri
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) acc[t][o] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const unsigned npix = (unsigned)B * H * W, HW = (unsigned)H * W;
-  const unsigned gstride = gridDim.x * GPW;
-  for (unsigned p = blockIdx.x * GPW + grp; p < npix; p += gstride) {
-    const unsigned b = p / HW, rem = p - b * HW;
-    const int h0 = (int)(rem / (unsigned)W);
-    const int w0 = (int)(rem - (unsigned)h0 * W);
+  const unsigned cbs = (unsigned)(W + GPW - 1) / GPW, rss = (unsigned)(H + NC_ROWS - 1) / NC_ROWS;
+  const unsigned units = (unsigned)B * cbs * rss;
+  for (unsigned u = blockIdx.x; u < units; u += gridDim.x) {
+    const unsigned b = u / (cbs * rss), r2 = u - b * cbs * rss;
+    const int hb = (int)(r2 / cbs) * NC_ROWS, w0 = (int)(r2 % cbs) * GPW + grp;
+    const int he = min(H, hb + NC_ROWS);
+    const bool col_on = w0 < W;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (affine) {
       sc = *reinterpret_cast<const float4*>(scale + b * (unsigned)ssb + 4 * qa);
       sh = *reinterpret_cast<const float4*>(shift + b * (unsigned)ssb + 4 * qa);
     }
-    float g[NOUT];
+    const float* xb = x + (b * (unsigned)H * W) * (unsigned)Cin + 4 * qa;
+    auto load_row = [&](int hi, float4 (&v)[3]) {
+      const unsigned hc = (unsigned)min(max(hi, 0), H - 1);
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) g[o] = dy[(long)p * NOUT + o];
-    float4 v[9];
-    bool ok[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int hi = h0 + t / 3 - 1, wi = w0 + t % 3 - 1;
-      ok[t] = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-      const unsigned hc = (unsigned)min(max(hi, 0), H - 1), wc = (unsigned)min(max(wi, 0), W - 1);
-      v[t] = *reinterpret_cast<const float4*>(x + ((b * H + hc) * W + wc) * (unsigned)Cin + 4 * qa);
-    }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float4 a = nc_act(v[t], sc, sh, affine, relu);
-      if (!ok[t]) a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int o = 0; o < NOUT; ++o) {          // idle lanes accumulate garbage that is never written out
-        acc[t][o].x = fmaf(a.x, g[o], acc[t][o].x); acc[t][o].y = fmaf(a.y, g[o], acc[t][o].y);
-        acc[t][o].z = fmaf(a.z, g[o], acc[t][o].z); acc[t][o].w = fmaf(a.w, g[o], acc[t][o].w);
+      for (int s = 0; s < 3; ++s) {
+        const unsigned wc = (unsigned)min(max(w0 + s - 1, 0), W - 1);
+        v[s] = *reinterpret_cast<const float4*>(xb + (hc * (unsigned)W + wc) * (unsigned)Cin);
       }
+    };
+    auto act_row = [&](int hi, float4 (&v)[3]) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const bool ok = (unsigned)hi < (unsigned)H && (unsigned)(w0 + s - 1) < (unsigned)W;
+        v[s] = ok ? nc_act(v[s], sc, sh, affine, relu) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    float4 win[3][3], nxt[3];
+    load_row(hb - 1, win[0]);
+    load_row(hb, win[1]);
+    load_row(hb + 1, win[2]);
+    act_row(hb - 1, win[0]);
+    act_row(hb, win[1]);
+    act_row(hb + 1, win[2]);
+    for (int h = hb; h < he; ++h) {
+      load_row(h + 2, nxt);
+      const long p = ((long)b * H + h) * W + min(w0, W - 1);
+      float g[NOUT];
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) g[o] = col_on ? dy[p * NOUT + o] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float4 a = win[t / 3][t % 3];
+        const nc_v2 alo = nc_lo(a), ahi = nc_hi(a);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {          // idle lanes accumulate garbage that is never written out
+          const nc_v2 gg = nc_v2{g[o], g[o]};
+          const nc_v2 lo = __builtin_elementwise_fma(alo, gg, nc_lo(acc[t][o])), hi = __builtin_elementwise_fma(ahi, gg, nc_hi(acc[t][o]));
+          acc[t][o] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+      }
+      act_row(h + 2, nxt);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) { win[0][s] = win[1][s]; win[1][s] = win[2][s]; win[2][s] = nxt[s]; }
     }
   }
   // combine the GPW pixel groups of the block (fixed order), lane q of group 0 writes its channel quad
@@ -178,9 +236,9 @@ static int narrow_lp(int Cin) {
   return lp;
 }
 
-static int narrow_blocks(long npix, int lp, int cap = 4096) {
+static int narrow_blocks(int B, int H, int W, int lp, int cap = 4096) {
   const long groups = 256 / lp;
-  long b = icg_cdiv(npix, groups * 8);
+  long b = (long)B * icg_cdiv(W, groups) * icg_cdiv(H, NC_ROWS);          // (image, 8-column block, 32-row segment) units
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
@@ -212,7 +270,7 @@ int icg_narrow_fprop(const float* x, const float* w, const float* bias, const fl
                      float* out, int B, int H, int W, int Cin, int Cout, int affine, int relu, float alpha,
                      hipStream_t st) {
   const int lp = narrow_lp(Cin);
-  const dim3 grid((unsigned)narrow_blocks((long)B * H * W, lp));
+  const dim3 grid((unsigned)narrow_blocks(B, H, W, lp, 1 << 20));
   switch (Cout) {
     case 1: narrow_fprop_lp<1>(lp, grid, st, x, w, bias, scale, shift, ssb, out, B, H, W, Cin, affine, relu, alpha); break;
     case 2: narrow_fprop_lp<2>(lp, grid, st, x, w, bias, scale, shift, ssb, out, B, H, W, Cin, affine, relu, alpha); break;
@@ -224,7 +282,7 @@ int icg_narrow_fprop(const float* x, const float* w, const float* bias, const fl
 
 size_t icg_narrow_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   const int lp = narrow_lp(Cin);
-  return (size_t)narrow_blocks((long)B * H * W, lp, 768) * 9 * Cin * Cout * sizeof(float);
+  return (size_t)narrow_blocks(B, H, W, lp, 768) * 9 * Cin * Cout * sizeof(float);
 }
 
 template <int NOUT>
@@ -247,7 +305,7 @@ static void narrow_wgrad_lp(int lp, dim3 grid, hipStream_t st, const float* x, c
 int icg_narrow_wgrad(const float* x, const float* dy, const float* scale, const float* shift, long ssb, float* dw,
                      void* workspace, int B, int H, int W, int Cin, int Cout, int affine, int relu, hipStream_t st) {
   const int lp = narrow_lp(Cin);
-  const int blocks = narrow_blocks((long)B * H * W, lp, 768);
+  const int blocks = narrow_blocks(B, H, W, lp, 768);
   float* slabs = (float*)workspace;
   const dim3 grid((unsigned)blocks);
   switch (Cout) {
@@ -265,15 +323,19 @@ int icg_narrow_wgrad(const float* x, const float* dy, const float* scale, const 
 // ---- skinny linear layers: out[M][N] = x[M][K] w[N][K]^T with M = batch rows (<= 256) and K not a multiple of 4 -----------------
 // (the conditional-BN gain / bias projections of the generator, layers.py:367-374: K = 657 = 17 z + 128 class + 512 feature
 // inputs, N = the block's channel count, M = 64.  On the implicit-GEMM kernel these are one row of tiles walking K with the
-// scalar gather loader: 0.1-0.3 ms each, 60 per step.)  One wavefront per 8 output columns, lane = row: x is read once per
-// wave with per-lane row streams, w through wave-uniform loads; the weight gradient dw[K][N] = x^T dy is one thread per
+// scalar gather loader: 0.1-0.3 ms each, 60 per step.)  One block per 8 output columns, lane = row, the K range split over the
+// block's 4 wavefronts (fixed-order LDS combine): x is read with per-lane row streams, w through wave-uniform loads; the weight gradient dw[K][N] = x^T dy is one thread per
 // (k, 4 columns) looping over the M rows.
 template <int NB>
-__global__ __launch_bounds__(64) void skinny_fprop_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, float* __restrict__ out, int M, int N,
-                                                          int K, float alpha) {
-  const int row = blockIdx.y * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void skinny_fprop_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int M, int N,
+                                                           int K, float alpha) {
+  __shared__ float red[3][64][NB];                 // partial sums of waves 1..3 (the K range is split over the 4 waves)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = blockIdx.y * 64 + lane;
   const int n0 = blockIdx.x * NB;
+  const int kq = ((K + 3) / 4 + 3) & ~3;           // K range of a wave, a multiple of 4
+  const int kb = min(wv * kq, K), ke = min(kb + kq, K);
   const float* xr = x + (long)min(row, M - 1) * K;
   const float* wr[NB];
 #pragma unroll
@@ -281,8 +343,8 @@ __global__ __launch_bounds__(64) void skinny_fprop_kernel(const float* __restric
   float acc[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) acc[j] = 0.f;
-  int k = 0;
-  for (; k + 4 <= K; k += 4) {
+  int k = kb;
+  for (; k + 4 <= ke; k += 4) {
     const float x0 = xr[k], x1 = xr[k + 1], x2 = xr[k + 2], x3 = xr[k + 3];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -292,15 +354,22 @@ __global__ __launch_bounds__(64) void skinny_fprop_kernel(const float* __restric
       acc[j] = fmaf(x3, wr[j][k + 3], acc[j]);
     }
   }
-  for (; k < K; ++k) {
+  for (; k < ke; ++k) {
     const float x0 = xr[k];
 #pragma unroll
     for (int j = 0; j < NB; ++j) acc[j] = fmaf(x0, wr[j][k], acc[j]);
   }
-  if (row < M) {
+  if (wv > 0) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
-      if (n0 + j < N) out[(long)row * N + n0 + j] = alpha * acc[j] + (bias ? bias[n0 + j] : 0.f);
+    for (int j = 0; j < NB; ++j) red[wv - 1][lane][j] = acc[j];
+  }
+  __syncthreads();
+  if (wv == 0 && row < M) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const float s = ((acc[j] + red[0][lane][j]) + red[1][lane][j]) + red[2][lane][j];      // fixed order
+      if (n0 + j < N) out[(long)row * N + n0 + j] = alpha * s + (bias ? bias[n0 + j] : 0.f);
+    }
   }
 }
 
@@ -327,7 +396,7 @@ bool icg_skinny_ok(long M, int Cin, int R) { return R == 1 && M <= 256 && (Cin %
 
 int icg_skinny_fprop(const float* x, const float* w, const float* bias, float* out, int M, int N, int K, float alpha,
                      hipStream_t st) {
-  hipLaunchKernelGGL((skinny_fprop_kernel<8>), dim3((unsigned)icg_cdiv(N, 8), (unsigned)icg_cdiv(M, 64)), dim3(64), 0, st, x, w,
+  hipLaunchKernelGGL((skinny_fprop_kernel<8>), dim3((unsigned)icg_cdiv(N, 8), (unsigned)icg_cdiv(M, 64)), dim3(256), 0, st, x, w,
                      bias, out, M, N, K, alpha);
   return icg_check_launch();
 }
