@@ -104,16 +104,16 @@ class KernelTimer:
             query(last)
             if mode in ("rs_up", "rs_down"):
                 kind = name.rsplit("_", 1)[1]
-                kname = "composite: %s-fused conv %s in the 25-plane F(4x4,3x3) domain (transforms + 25 batched icg_gemm_kernel<%s, %d, 2> GEMMs)" % (
+                kname = "composite: %s-fused conv %s in the 25-plane F(4x4,3x3) domain (transforms + 25 batched icg_gemm_planes_kernel<%s, %d> GEMMs)" % (
                     "upsample" if mode == "rs_up" else "avgpool", kind, "1, 1" if kind == "wgrad" else "0, 0", last[2])
             elif mode in ("wino", "wino4"):     # three kernels behind one entry point: not comparable with a single rocprof row
-                kname = (("composite: wino4_input_kernel + wino4_dy_kernel + icg_gemm_kernel<1, 1, %d, 2> (36 batched split-K GEMMs) + reduce + wino4_dw_kernel" % last[2]
+                kname = (("composite: wino4_input_kernel + wino4_dy_kernel + icg_gemm_planes_kernel<1, 1, %d> (36 batched split-K GEMMs) + reduce + wino4_dw_kernel" % last[2]
                           if mode == "wino4" else
-                          "composite: wino_input_kernel + wino_dy_kernel + icg_gemm_kernel<1, 1, %d, 2> (16 batched split-K GEMMs) + reduce + wino_dw_kernel" % last[2])
+                          "composite: wino_input_kernel + wino_dy_kernel + icg_gemm_planes_kernel<1, 1, %d> (16 batched split-K GEMMs) + reduce + wino_dw_kernel" % last[2])
                          if name.endswith("wgrad") else
-                         ("composite: wino4_input_kernel + icg_gemm_kernel<0, 0, %d, 2> (36 batched GEMMs) + wino4_output_kernel" % last[2]
+                         ("composite: wino4_input_kernel + icg_gemm_planes_kernel<0, 0, %d> (36 batched GEMMs) + wino4_output_kernel" % last[2]
                           if mode == "wino4" else
-                          "composite: wino_input_kernel + icg_gemm_kernel<0, 0, %d, 2> (16 batched GEMMs) + wino_output_kernel" % last[2]))
+                          "composite: wino_input_kernel + icg_gemm_planes_kernel<0, 0, %d> (16 batched GEMMs) + wino_output_kernel" % last[2]))
             elif last[0] == -3:      # skinny linear kernels (narrow_conv.hip): {-3, fprop/wgrad, Cout, Cin}
                 kname = "skinny_wgrad_kernel" if last[1] else "void skinny_fprop_kernel<8>"
             elif last[0] == -2:      # direct narrow-output kernels (narrow_conv.hip): {-2, fprop/wgrad, Cout, Cin}
@@ -126,6 +126,30 @@ class KernelTimer:
             timer.records.append((kname, alg, exe, byt, s, e))
 
         L.call = timed_call
+
+    @staticmethod
+    def planes(enable):
+        """the Winograd-plane GEMMs run inside the composite entry points: the library brackets them with HIP events on the
+        launch stream itself (icg_planes_timing)"""
+        import ic_gan_amd._lib as L
+        L.lib().icg_planes_timing(1 if enable else 0)
+
+    @staticmethod
+    def planes_summary():
+        """{rocprofv3 kernel name: [algorithmic flops, seconds, launches, executed flops, operand bytes]} of those GEMMs."""
+        import ctypes
+        import ic_gan_amd._lib as L
+        buf = (ctypes.c_double * (7 * 64))()
+        rows = L.lib().icg_planes_timing_drain(ctypes.cast(buf, ctypes.c_void_p), 64)
+        out = {}
+        for r in range(max(rows, 0)):
+            amode, tn, planes, n, ms, flops, byt = buf[7 * r: 7 * r + 7]
+            mode = "1, 1" if int(amode) == 1 else "0, 0"
+            # executed MACs -> MACs of the reference op graph: 36 of 144 (F(4x4,3x3)), 25 of 144 (resample-fused), 16 of 36 (F(2x2,3x3))
+            alg = flops * {36: 144 / 36, 25: 144 / 25, 16: 36 / 16}.get(int(planes), 1.0)
+            a = out.setdefault("void icg_gemm_planes_kernel<%s, %d>(GemmP)" % (mode, int(tn)), [0.0, 0.0, 0, 0.0, 0.0])
+            a[0] += alg; a[1] += ms * 1e-3; a[2] += int(n); a[3] += flops; a[4] += byt
+        return out
 
     def summary(self):
         agg = {}
@@ -515,6 +539,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    timer.planes(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         metrics = one_step()
@@ -531,6 +556,7 @@ def main():
 
     if rank == 0:
         agg = timer.summary()
+        agg.update(timer.planes_summary())       # inner GEMMs of the composites (their time is part of the composite rows too)
         roof = None
         if agg:
             variant, (flops, secs, n, exe, byt) = max(((k, v) for k, v in agg.items() if not k.startswith("composite:")),

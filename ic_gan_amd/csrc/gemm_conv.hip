@@ -61,7 +61,7 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // branch-free loads (clamped address + select), scalar tap tracking (A_K: Cin % 16 == 0) / shift-mask pixel decode
 // (A_M: H, W powers of two).  PATH 2 cuts the per-K-tile address section from ~330 to ~90 instructions.
 template <int AMODE, int BMODE, int TN, int PATH>
-__global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
+__device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
   // PATH 3 = PATH 2 with the BN/ccbn affine prologue compiled in (PATH 2 itself has none): keeps the hot loop
   // free of uniform branches so that the scheduler can interleave the staging work with the MFMAs
   constexpr bool VEC = PATH >= 1;
@@ -656,6 +656,21 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
   }
 }
 
+template <int AMODE, int BMODE, int TN, int PATH>
+__global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
+  icg_gemm_body<AMODE, BMODE, TN, PATH>(p);
+}
+
+// the same code under a second name for the batched GEMMs over Winograd planes (winograd.hip), so that a profile separates
+// them from the convolutions that run on the kernel directly (only the fast loader is instantiated)
+template <int AMODE, int BMODE, int TN>
+__global__ __launch_bounds__(256) void icg_gemm_planes_kernel(GemmP p) {
+  icg_gemm_body<AMODE, BMODE, TN, 2>(p);
+}
+
+static thread_local int g_gemm_planes = 0;
+void icg_gemm_mark_planes(int on) { g_gemm_planes = on; }
+
 // deterministic second stage of split-K: out[i] = sum_z slab[z][i]
 __global__ void icg_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n,
                                          int splits) {
@@ -735,7 +750,14 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
   }
   if (path == 2 && p.pre_affine) path = 3;
   g_last_variant[0] = AMODE; g_last_variant[1] = BMODE; g_last_variant[2] = tn; g_last_variant[3] = path;
-  if (path == 3) { ICG_LAUNCH_TN(3) } else if (path == 2) { ICG_LAUNCH_TN(2) } else if (path == 1) { ICG_LAUNCH_TN(1) }
+  if (path == 2 && g_gemm_planes) {
+    switch (tn) {
+      case 1: hipLaunchKernelGGL((icg_gemm_planes_kernel<AMODE, BMODE, 1>), grid, block, 0, st, p); break;
+      case 2: hipLaunchKernelGGL((icg_gemm_planes_kernel<AMODE, BMODE, 2>), grid, block, 0, st, p); break;
+      case 3: hipLaunchKernelGGL((icg_gemm_planes_kernel<AMODE, BMODE, 3>), grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL((icg_gemm_planes_kernel<AMODE, BMODE, 4>), grid, block, 0, st, p); break;
+    }
+  } else if (path == 3) { ICG_LAUNCH_TN(3) } else if (path == 2) { ICG_LAUNCH_TN(2) } else if (path == 1) { ICG_LAUNCH_TN(1) }
   else { ICG_LAUNCH_TN(0) }
 #undef ICG_LAUNCH_TN
 #undef ICG_LAUNCH

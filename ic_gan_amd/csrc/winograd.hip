@@ -7,6 +7,7 @@
 // Same mathematical result as the direct convolution; rounding differs at the 1e-6 level (fp32 transforms).
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
 #include "icg_common.h"
+#include <vector>
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -203,6 +204,69 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
   }
 }
 
+void icg_gemm_mark_planes(int on);       // gemm_conv.hip: launch the following GEMMs as icg_gemm_planes_kernel (profile name)
+extern "C" int icg_gemm_last_variant(int* out4);
+
+// measurement hook for bench.py: HIP events on the launch stream around every plane-GEMM launch (off by default)
+struct PlanesRecord { hipEvent_t e0, e1; int amode, tn, planes; double flops, bytes; };
+static std::vector<PlanesRecord> g_planes_records;
+static bool g_planes_timing = false;
+
+struct PlanesScope {
+  hipStream_t st;
+  int planes;
+  double flops, bytes;
+  hipEvent_t e0 = nullptr;
+  // M x N x K per plane
+  PlanesScope(void* stream, int planes_, double M, double N, double K)
+      : st((hipStream_t)stream), planes(planes_), flops(2.0 * planes_ * M * N * K), bytes(4.0 * planes_ * (M * K + K * N + M * N)) {
+    icg_gemm_mark_planes(1);
+    if (g_planes_timing && hipEventCreate(&e0) == hipSuccess) hipEventRecord(e0, st);
+  }
+  ~PlanesScope() {
+    icg_gemm_mark_planes(0);
+    if (e0) {
+      PlanesRecord r{e0, nullptr, 0, 0, planes, flops, bytes};
+      int v[4] = {0, 0, 0, 0};
+      icg_gemm_last_variant(v);
+      r.amode = v[0]; r.tn = v[2];
+      if (hipEventCreate(&r.e1) == hipSuccess) {
+        hipEventRecord(r.e1, st);
+        g_planes_records.push_back(r);
+      }
+    }
+  }
+};
+
+extern "C" int icg_planes_timing(int enable) {
+  for (auto& r : g_planes_records) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  g_planes_records.clear();
+  g_planes_timing = enable != 0;
+  return ICG_OK;
+}
+
+// out[i] = {amode, tn, planes, launches, total ms, total executed flops, total operand bytes} per distinct (amode, tn, planes);
+// returns the number of rows written (synchronises on the recorded events)
+extern "C" int icg_planes_timing_drain(double* out, int max_rows) {
+  ICG_REQUIRE(out && max_rows > 0);
+  int rows = 0;
+  for (auto& r : g_planes_records) {
+    if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    int k = 0;
+    for (; k < rows; ++k)
+      if ((int)out[7 * k] == r.amode && (int)out[7 * k + 1] == r.tn && (int)out[7 * k + 2] == r.planes) break;
+    if (k == rows) {
+      if (rows == max_rows) continue;
+      out[7 * k] = r.amode; out[7 * k + 1] = r.tn; out[7 * k + 2] = r.planes;
+      out[7 * k + 3] = out[7 * k + 4] = out[7 * k + 5] = out[7 * k + 6] = 0.0;
+      ++rows;
+    }
+    out[7 * k + 3] += 1.0; out[7 * k + 4] += ms; out[7 * k + 5] += r.flops; out[7 * k + 6] += r.bytes;
+  }
+  return rows;
+}
 extern "C" size_t icg_gemm_tn_batched_workspace_bytes(int M, int N, int K, int batch);
 extern "C" int icg_gemm_tn_batched(const float* A, const float* B, float* C, int M, int N, int K, int64_t strideA,
                                    int64_t strideB, int64_t strideC, int batch, void* workspace, size_t workspace_bytes,
@@ -241,7 +305,8 @@ extern "C" int icg_conv2d_wino_wgrad(const float* x, const float* dy, float* dw,
   nb = icg_cdiv(T * (Cout / 4), 256);
   if (nb > 256 * 64) nb = 256 * 64;
   hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, DY, B, H, W, Cout / 4);
-  int rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, 16, gws, gws_bytes, stream);
+  int rc;
+  { PlanesScope ps(stream, 16, Cin, Cout, (double)T); rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, 16, gws, gws_bytes, stream); }
   if (rc != ICG_OK) return rc;
   const long n = (long)Cin * Cout;
   nb = icg_cdiv(n, 256);
@@ -284,7 +349,8 @@ extern "C" int icg_conv2d_wino_fprop(const float* x, const float* U, const float
   if (nb > 256 * 64) nb = 256 * 64;
   hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, (long)ss_bstride, V, B, H, W,
                      Cin / 4, (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0);
-  int rc = icg_gemm_batched(V, U, Mb, (int)T, Cout, Cin, 0, 1, T * Cin, (long)Cout * Cin, T * Cout, 16, 1.0f, stream);
+  int rc;
+  { PlanesScope ps(stream, 16, (double)T, Cout, Cin); rc = icg_gemm_batched(V, U, Mb, (int)T, Cout, Cin, 0, 1, T * Cin, (long)Cout * Cin, T * Cout, 16, 1.0f, stream); }
   if (rc != ICG_OK) return rc;
   nb = icg_cdiv(T * (Cout / 4), 256);
   if (nb > 256 * 64) nb = 256 * 64;
@@ -577,7 +643,8 @@ static int wino4_run(const float* x, int in_up, const float* U, const float* bia
   float* V = (float*)workspace;
   float* Mb = V + (long)np * np * T * Cin;
   launch_wino4_input(st, in_up, np, x, scale, shift, (long)ssb, V, B, H, W, Cin, flags);
-  int rc = icg_gemm_batched(V, U, Mb, (int)T, Cout, Cin, 0, 1, T * Cin, (long)Cout * Cin, T * Cout, np * np, 1.0f, stream);
+  int rc;
+  { PlanesScope ps(stream, np * np, (double)T, Cout, Cin); rc = icg_gemm_batched(V, U, Mb, (int)T, Cout, Cin, 0, 1, T * Cin, (long)Cout * Cin, T * Cout, np * np, 1.0f, stream); }
   if (rc != ICG_OK) return rc;
   launch_wino4_output(st, out_pool, np, Mb, bias, residual, res_up, alpha, out, B, H, W, Cout);
   return icg_check_launch();
@@ -777,7 +844,8 @@ static int wino4_wgrad_run(const float* x, int x_up, const float* dy, int dy_up,
   if (dy_up) hipLaunchKernelGGL((wino4_dy_kernel<1, 5>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha);
   else if (np == 5) hipLaunchKernelGGL((wino4_dy_kernel<0, 5>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha);
   else hipLaunchKernelGGL((wino4_dy_kernel<0, 6>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha);
-  int rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, (int)P, gws, gws_bytes, stream);
+  int rc;
+  { PlanesScope ps(stream, (int)P, Cin, Cout, (double)T); rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, (int)P, gws, gws_bytes, stream); }
   if (rc != ICG_OK) return rc;
   const long n = (long)Cin * Cout;
   nb = icg_cdiv(n, 256);

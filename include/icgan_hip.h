@@ -211,6 +211,11 @@ int icg_conv2d_down_wino_dgrad(const float* dy, const float* U, float* da, int B
                                void* workspace, size_t workspace_bytes, void* stream);
 int icg_conv2d_down_wino_wgrad(const float* x, const float* dy, float* dw, int B, int Hp, int Wp, int Cin, int Cout,
                                unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
+/* measurement hook (bench.py): with timing enabled every batched GEMM over Winograd planes (rocprofv3 name
+ * icg_gemm_planes_kernel<AMODE, BMODE, TN>) is bracketed by HIP events on its launch stream.  drain() writes rows of
+ * {amode, tn, planes, launches, total ms, total executed flops, total operand bytes} and returns the row count. */
+int icg_planes_timing(int enable);
+int icg_planes_timing_drain(double* out, int max_rows);
 /* C[b] = A[b]^T B[b], A [K][M], B [K][N], long K: batched with deterministic split-K (strideC must be M*N) */
 size_t icg_gemm_tn_batched_workspace_bytes(int M, int N, int K, int batch);
 int icg_gemm_tn_batched(const float* A, const float* B, float* C, int M, int N, int K, int64_t strideA, int64_t strideB,
