@@ -115,22 +115,42 @@ __global__ __launch_bounds__(1024) void sn_u_kernel(const float* __restrict__ s,
 }
 
 // w_ohwi[co][r][s][ci] = w[co][ci][r][s]/sigma ; w_dgrad[ci][R-1-r][R-1-s][co] = same
+// Both outputs are transposes of the parameter layout: a 32(co) x 32(ci) x R*R tile goes through LDS so that the read
+// (R*R*32 contiguous floats per co) and both writes (32 contiguous floats per (co, tap) / (ci, tap)) are coalesced; the
+// direct form wrote w_dgrad with a stride of R*R*rows floats between neighbouring lanes.
 __device__ __forceinline__ void sn_scale_body(int bx, int by, int gx, const float* __restrict__ w, const float* __restrict__ sigma,
                                                        int rows, int Cin, int R, float* __restrict__ w_ohwi,
                                                        float* __restrict__ w_dgrad) {
-  const int RR = R * R;
-  const long total = (long)rows * Cin * RR;
+  __shared__ float tile[32 * 9 * 33];
+  const int RR = R * R;                      // 1 or 9
   const float sg = sigma[0];
-  const long stride = (long)gx * blockDim.x;
-  for (long idx = (long)bx * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-    // idx enumerates the OHWI destination so that the stores are coalesced
-    const int ci = (int)(idx % Cin);
-    long t = idx / Cin;
-    const int tap = (int)(t % RR);
-    const int co = (int)(t / RR);
-    const float val = w[((long)co * Cin + ci) * RR + tap] / sg;
-    w_ohwi[idx] = val;
-    if (w_dgrad) w_dgrad[((long)ci * RR + (RR - 1 - tap)) * rows + co] = val;
+  const int tco = (rows + 31) >> 5, tci = (Cin + 31) >> 5;
+  const int per = 32 * 32 * RR;
+  for (int t = bx; t < tco * tci; t += gx) {
+    const int co0 = (t / tci) << 5, ci0 = (t % tci) << 5;
+    __syncthreads();
+    for (int e = threadIdx.x; e < per; e += blockDim.x) {          // read: (co_l, ci_l, tap), tap fastest
+      const int co_l = e / (32 * RR), rem = e - co_l * 32 * RR;
+      const int ci_l = rem / RR, tap = rem - ci_l * RR;
+      float v = 0.f;
+      if (co0 + co_l < rows && ci0 + ci_l < Cin) v = w[((long)(co0 + co_l) * Cin + ci0) * RR + rem] / sg;
+      tile[(co_l * RR + tap) * 33 + ci_l] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < per; e += blockDim.x) {          // OHWI: (co_l, tap, ci_l), ci fastest
+      const int ci_l = e & 31, q = e >> 5;
+      const int tap = q % RR, co_l = q / RR;
+      if (co0 + co_l < rows && ci0 + ci_l < Cin)
+        w_ohwi[((long)(co0 + co_l) * RR + tap) * Cin + ci0 + ci_l] = tile[(co_l * RR + tap) * 33 + ci_l];
+    }
+    if (w_dgrad) {
+      for (int e = threadIdx.x; e < per; e += blockDim.x) {        // dgrad: (ci_l, tap, co_l), co fastest, taps flipped
+        const int co_l = e & 31, q = e >> 5;
+        const int tap = q % RR, ci_l = q / RR;
+        if (co0 + co_l < rows && ci0 + ci_l < Cin)
+          w_dgrad[((long)(ci0 + ci_l) * RR + (RR - 1 - tap)) * rows + co0 + co_l] = tile[(co_l * RR + tap) * 33 + ci_l];
+      }
+    }
   }
 }
 __global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__ w, const float* __restrict__ sigma,
