@@ -774,6 +774,14 @@ size_t icg_narrow_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int icg_narrow_wgrad(const float* x, const float* dy, const float* scale, const float* shift, long ssb, float* dw,
                      void* workspace, int B, int H, int W, int Cin, int Cout, int affine, int relu, hipStream_t st);
 
+// 3x3 convolutions with <= 4 input channels (narrow_conv.hip)
+bool icg_thin_conv_ok(int Cin, int Cout, int R);
+size_t icg_thin_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int icg_thin_fprop(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
+                   float alpha, hipStream_t st);
+int icg_thin_wgrad(const float* x, const float* dy, float* dw, void* workspace, int B, int H, int W, int Cin, int Cout,
+                   hipStream_t st);
+
 // skinny linear layers (batch rows x odd K; narrow_conv.hip)
 bool icg_skinny_ok(long M, int Cin, int R);
 int icg_skinny_fprop(const float* x, const float* w, const float* bias, float* out, int M, int N, int K, float alpha, hipStream_t st);
@@ -896,6 +904,11 @@ static int conv2d_fprop_impl(const float* x, const float* w, const float* bias, 
     return icg_narrow_fprop(x, w, bias, scale, shift, ss_bstride, out, B, H, W, Cin, Cout,
                             (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0, alpha, (hipStream_t)stream);
   }
+  if (!up && !residual && !(flags & (ICG_PRE_AFFINE | ICG_PRE_RELU)) && icg_thin_conv_ok(Cin, Cout, R) && aligned16(out) &&
+      (!bias || aligned16(bias)) && M * Cout < 0x7fffffffL) {
+    g_last_variant[0] = -4; g_last_variant[1] = 0; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
+    return icg_thin_fprop(x, w, bias, out, B, H, W, Cin, Cout, alpha, (hipStream_t)stream);
+  }
   if (!up && !residual && !(flags & (ICG_PRE_AFFINE | ICG_PRE_RELU)) && icg_skinny_ok(M, Cin, R)) {
     g_last_variant[0] = -3; g_last_variant[1] = 0; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
     return icg_skinny_fprop(x, w, bias, out, (int)M, Cout, Cin, alpha, (hipStream_t)stream);
@@ -953,6 +966,10 @@ extern "C" size_t icg_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin,
     const size_t nn = icg_narrow_wgrad_workspace_bytes(B, H, W, Cin, Cout);
     if (nn > need) need = nn;
   }
+  if (icg_thin_conv_ok(Cin, Cout, R)) {
+    const size_t nn = icg_thin_wgrad_workspace_bytes(B, H, W, Cin, Cout);
+    if (nn > need) need = nn;
+  }
   return need;
 }
 
@@ -975,6 +992,11 @@ extern "C" int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
     g_last_variant[0] = -2; g_last_variant[1] = 1; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
     return icg_narrow_wgrad(x, dy, scale, shift, ss_bstride, dw, workspace, B, H, W, Cin, Cout,
                             (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0, (hipStream_t)stream);
+  }
+  if (!up && !(flags & (ICG_PRE_AFFINE | ICG_PRE_RELU)) && icg_thin_conv_ok(Cin, Cout, R) && aligned16(dy) && aligned16(dw)) {
+    if (workspace == nullptr || workspace_bytes < icg_thin_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return ICG_ERR_WORKSPACE;
+    g_last_variant[0] = -4; g_last_variant[1] = 1; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
+    return icg_thin_wgrad(x, dy, dw, workspace, B, H, W, Cin, Cout, (hipStream_t)stream);
   }
   if (!up && !(flags & (ICG_PRE_AFFINE | ICG_PRE_RELU)) && (Cout % 4 == 0) && aligned16(dy) && aligned16(dw) &&
       icg_skinny_ok(K, Cin, R)) {

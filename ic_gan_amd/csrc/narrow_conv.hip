@@ -408,3 +408,218 @@ int icg_skinny_wgrad(const float* x, const float* dy, float* dw, int M, int N, i
   hipLaunchKernelGGL(skinny_wgrad_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, dy, dw, M, N / 4, K);
   return icg_check_launch();
 }
+
+// ---- 3x3 convolutions with <= 4 INPUT channels (the discriminator's from-RGB layer, BigGAN.py:480-492 / layers.py:587-600 with
+// preactivation = False) and their weight gradient.  K = 27 is too short for the implicit GEMM (scalar gather loader, 16-wide
+// K tiles): lanes own output-channel quads, a group of LP lanes walks down an image column with the 3 x 3 x Cin window in
+// registers (9*Cin dwords per lane, 3*Cin new ones per step, the same addresses for all lanes of a group: one L1 request);
+// HBM-bound on the Cout-wide tensor.  No prologue (the layer reads the raw image).
+template <int CIN, int LP>
+__global__ __launch_bounds__(256) void thin_fprop_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int B, int H,
+                                                         int W, int Cout, float alpha) {
+  constexpr int GPW = 256 / LP;
+  const int q = threadIdx.x % LP, grp = threadIdx.x / LP;
+  const int Q = Cout >> 2;
+  const bool lane_on = q < Q;
+  const int qa = lane_on ? q : Q - 1;
+  nc_v2 wlo[9][CIN], whi[9][CIN];                    // w[co..co+3][tap][ci]  (OHWI: [Cout][3][3][CIN])
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      const float* wp = wgt + ((long)(4 * qa) * 9 + t) * CIN + c;
+      wlo[t][c] = nc_v2{wp[0], wp[9 * CIN]};
+      whi[t][c] = nc_v2{wp[18 * CIN], wp[27 * CIN]};
+    }
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * qa);
+  const unsigned cbs = (unsigned)(W + GPW - 1) / GPW, rss = (unsigned)(H + NC_ROWS - 1) / NC_ROWS;
+  const unsigned units = (unsigned)B * cbs * rss;
+  for (unsigned u = blockIdx.x; u < units; u += gridDim.x) {
+    const unsigned b = u / (cbs * rss), r2 = u - b * cbs * rss;
+    const int hb = (int)(r2 / cbs) * NC_ROWS, w0 = (int)(r2 % cbs) * GPW + grp;
+    const int he = min(H, hb + NC_ROWS);
+    const bool col_on = w0 < W;
+    const float* xb = x + (long)b * H * W * CIN;
+    auto load_row = [&](int hi, float (&v)[3][CIN]) {
+      const int hc = min(max(hi, 0), H - 1);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int wi = w0 + s - 1;
+        const int wc = min(max(wi, 0), W - 1);
+        const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          const float t = xb[((long)hc * W + wc) * CIN + c];
+          v[s][c] = ok ? t : 0.f;
+        }
+      }
+    };
+    float win[3][3][CIN], nxt[3][CIN];
+    load_row(hb - 1, win[0]);
+    load_row(hb, win[1]);
+    load_row(hb + 1, win[2]);
+    for (int h = hb; h < he; ++h) {
+      load_row(h + 2, nxt);
+      nc_v2 lo = nc_v2{0.f, 0.f}, hi = nc_v2{0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          const float a = win[t / 3][t % 3][c];
+          const nc_v2 aa = nc_v2{a, a};
+          lo = __builtin_elementwise_fma(aa, wlo[t][c], lo);
+          hi = __builtin_elementwise_fma(aa, whi[t][c], hi);
+        }
+      if (lane_on && col_on) {
+        const long p = ((long)b * H + h) * W + w0;
+        *reinterpret_cast<float4*>(out + p * Cout + 4 * q) =
+            make_float4(alpha * lo.x + bv.x, alpha * lo.y + bv.y, alpha * hi.x + bv.z, alpha * hi.y + bv.w);
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) { win[0][s][c] = win[1][s][c]; win[1][s][c] = win[2][s][c]; win[2][s][c] = nxt[s][c]; }
+    }
+  }
+}
+
+// slab[block][tap][ci][co] = sum over the block's pixels of x[pix + tap][ci] * dy[pix][co]      (HWIO)
+template <int CIN, int LP>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ slabs, int B, int H, int W, int Cout) {
+  constexpr int GPW = 256 / LP;
+  __shared__ float red[256 * 4];
+  const int q = threadIdx.x % LP, grp = threadIdx.x / LP;
+  const int Q = Cout >> 2;
+  const bool lane_on = q < Q;
+  const int qa = lane_on ? q : Q - 1;
+  nc_v2 alo[9][CIN], ahi[9][CIN];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) { alo[t][c] = nc_v2{0.f, 0.f}; ahi[t][c] = nc_v2{0.f, 0.f}; }
+  const unsigned cbs = (unsigned)(W + GPW - 1) / GPW, rss = (unsigned)(H + NC_ROWS - 1) / NC_ROWS;
+  const unsigned units = (unsigned)B * cbs * rss;
+  for (unsigned u = blockIdx.x; u < units; u += gridDim.x) {
+    const unsigned b = u / (cbs * rss), r2 = u - b * cbs * rss;
+    const int hb = (int)(r2 / cbs) * NC_ROWS, w0 = (int)(r2 % cbs) * GPW + grp;
+    const int he = min(H, hb + NC_ROWS);
+    const bool col_on = w0 < W;
+    const float* xb = x + (long)b * H * W * CIN;
+    auto load_row = [&](int hi, float (&v)[3][CIN]) {
+      const int hc = min(max(hi, 0), H - 1);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int wi = w0 + s - 1;
+        const int wc = min(max(wi, 0), W - 1);
+        const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          const float t = xb[((long)hc * W + wc) * CIN + c];
+          v[s][c] = ok ? t : 0.f;
+        }
+      }
+    };
+    float win[3][3][CIN], nxt[3][CIN];
+    load_row(hb - 1, win[0]);
+    load_row(hb, win[1]);
+    load_row(hb + 1, win[2]);
+    for (int h = hb; h < he; ++h) {
+      load_row(h + 2, nxt);
+      const long p = ((long)b * H + h) * W + min(w0, W - 1);
+      float4 g = *reinterpret_cast<const float4*>(dy + p * Cout + 4 * qa);
+      if (!col_on) g = make_float4(0.f, 0.f, 0.f, 0.f);
+      const nc_v2 glo = nc_v2{g.x, g.y}, ghi = nc_v2{g.z, g.w};
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          const float a = win[t / 3][t % 3][c];
+          const nc_v2 aa = nc_v2{a, a};
+          alo[t][c] = __builtin_elementwise_fma(aa, glo, alo[t][c]);
+          ahi[t][c] = __builtin_elementwise_fma(aa, ghi, ahi[t][c]);
+        }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) { win[0][s][c] = win[1][s][c]; win[1][s][c] = win[2][s][c]; win[2][s][c] = nxt[s][c]; }
+    }
+  }
+  // combine the GPW pixel groups of the block (fixed order); lane q of group 0 writes its output-channel quad
+  float* slab = slabs + (long)blockIdx.x * 9 * CIN * Cout;
+  float4* red4 = reinterpret_cast<float4*>(red);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      __syncthreads();
+      red4[threadIdx.x] = make_float4(alo[t][c].x, alo[t][c].y, ahi[t][c].x, ahi[t][c].y);
+      __syncthreads();
+      if (grp == 0 && lane_on) {
+        float4 s = red4[q];
+        for (int gI = 1; gI < GPW; ++gI) {
+          const float4 v = red4[gI * LP + q];
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(slab + ((long)t * CIN + c) * Cout + 4 * q) = s;
+      }
+    }
+}
+
+bool icg_thin_conv_ok(int Cin, int Cout, int R) { return R == 3 && Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && Cout >= 16 && Cout <= 256; }
+
+static int thin_lp(int Cout) {
+  int lp = 4;
+  while (lp < Cout / 4) lp <<= 1;
+  return lp;
+}
+
+size_t icg_thin_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  return (size_t)narrow_blocks(B, H, W, thin_lp(Cout), 768) * 9 * Cin * Cout * sizeof(float);
+}
+
+template <int CIN>
+static void thin_launch(bool wgrad, int lp, dim3 grid, hipStream_t st, const float* x, const float* w_or_dy, const float* bias,
+                        float* out, int B, int H, int W, int Cout, float alpha) {
+#define ICG_TH(LP_)                                                                                                              \
+  if (wgrad) hipLaunchKernelGGL((thin_wgrad_kernel<CIN, LP_>), grid, dim3(256), 0, st, x, w_or_dy, out, B, H, W, Cout);            \
+  else hipLaunchKernelGGL((thin_fprop_kernel<CIN, LP_>), grid, dim3(256), 0, st, x, w_or_dy, bias, out, B, H, W, Cout, alpha)
+  switch (lp) {
+    case 4: ICG_TH(4); break;
+    case 8: ICG_TH(8); break;
+    case 16: ICG_TH(16); break;
+    case 32: ICG_TH(32); break;
+    default: ICG_TH(64); break;
+  }
+#undef ICG_TH
+}
+
+static void thin_dispatch(bool wgrad, int Cin, int lp, dim3 grid, hipStream_t st, const float* x, const float* w_or_dy,
+                          const float* bias, float* out, int B, int H, int W, int Cout, float alpha) {
+  switch (Cin) {
+    case 1: thin_launch<1>(wgrad, lp, grid, st, x, w_or_dy, bias, out, B, H, W, Cout, alpha); break;
+    case 2: thin_launch<2>(wgrad, lp, grid, st, x, w_or_dy, bias, out, B, H, W, Cout, alpha); break;
+    case 3: thin_launch<3>(wgrad, lp, grid, st, x, w_or_dy, bias, out, B, H, W, Cout, alpha); break;
+    default: thin_launch<4>(wgrad, lp, grid, st, x, w_or_dy, bias, out, B, H, W, Cout, alpha); break;
+  }
+}
+
+int icg_thin_fprop(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
+                   float alpha, hipStream_t st) {
+  const int lp = thin_lp(Cout);
+  thin_dispatch(false, Cin, lp, dim3((unsigned)narrow_blocks(B, H, W, lp, 1 << 20)), st, x, w, bias, out, B, H, W, Cout, alpha);
+  return icg_check_launch();
+}
+
+int icg_thin_wgrad(const float* x, const float* dy, float* dw, void* workspace, int B, int H, int W, int Cin, int Cout,
+                   hipStream_t st) {
+  const int lp = thin_lp(Cout);
+  const int blocks = narrow_blocks(B, H, W, lp, 768);
+  float* slabs = (float*)workspace;
+  thin_dispatch(true, Cin, lp, dim3((unsigned)blocks), st, x, dy, nullptr, slabs, B, H, W, Cout, 1.f);
+  const long n = 9L * Cin * Cout;
+  hipLaunchKernelGGL(narrow_reduce_kernel, dim3((unsigned)icg_cdiv(n, 32)), dim3(256), 0, st, (const float*)slabs, dw, n, blocks);
+  return icg_check_launch();
+}

@@ -62,7 +62,11 @@ CONV_CASES = [
     # B, H, W, Cin, Cout, R, flags, residual(0 none / 1 same / 2 half-res), bias
     (2, 8, 8, 32, 32, 3, 0, 0, True),
     (2, 8, 8, 8, 16, 3, PRE_RELU, 1, True),              # K-tile straddles taps (Cin = 8)
-    (1, 16, 16, 3, 96, 3, 0, 0, True),                   # RGB stem: scalar gather path
+    (1, 16, 16, 3, 96, 3, 0, 0, True),                   # RGB stem: thin-input direct kernels (narrow_conv.hip)
+    (2, 9, 7, 3, 40, 3, 0, 0, False),                    # ... LP = 16 with 10 active lanes, odd sizes
+    (1, 40, 5, 4, 256, 3, 0, 0, True),                   # ... LP = 64, two row segments, Cin = 4
+    (2, 8, 8, 1, 16, 3, 0, 0, True),                     # ... single input channel
+    (1, 8, 8, 3, 96, 3, PRE_RELU, 0, True),              # prologue requested -> stays on the implicit-GEMM path
     (2, 16, 16, 96, 96, 3, PRE_AFFINE | PRE_RELU | UP, 2, True),   # GBlock conv1-like + half-res residual
     (2, 16, 16, 96, 96, 3, PRE_AFFINE | PRE_RELU, 2, True),
     (3, 6, 10, 16, 40, 3, PRE_AFFINE | PRE_RELU | UP, 0, False),  # non-square, ragged N
