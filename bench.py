@@ -594,7 +594,7 @@ def main():
                                    f" 1 D step + 1 G step + Adam x2 + EMA, fp32 exact MFMA",
                        "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
                        "init": init, "sync_bn": bool(args.sync_bn), "winograd": not args.no_winograd,
-                       "losses_last_step": metrics},
+                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "losses_last_step": metrics},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

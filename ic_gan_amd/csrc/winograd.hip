@@ -827,17 +827,19 @@ static size_t wino4_wgrad_bytes(int np, int B, int H, int W, int Cin, int Cout) 
 // dU[xi] = V[xi]^T DY[xi], dw = G^T dU G.  H, W: full resolution.
 static int wino4_wgrad_run(const float* x, int x_up, const float* dy, int dy_up, float dy_alpha, float* dw, const float* scale,
                            const float* shift, int64_t ssb, int B, int H, int W, int Cin, int Cout, unsigned flags, int np,
-                           void* workspace, void* stream) {
+                           void* workspace, void* stream, const float* v_saved = nullptr) {
   const long T = (long)B * (H / 4) * (W / 4), P = (long)np * np;
   ICG_REQUIRE(T * 36 < 0x7fffffffL);
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)workspace;
-  float* V = (float*)base;                    base += wino_al(P * T * Cin * sizeof(float));
+  float* V = (float*)base;
+  if (x) base += wino_al(P * T * Cin * sizeof(float));          // (no V region when the caller supplies it)
   float* DY = (float*)base;                   base += wino_al(P * T * Cout * sizeof(float));
   float* dU = (float*)base;                   base += wino_al((size_t)P * Cin * Cout * sizeof(float));
   void* gws = base;
   const size_t gws_bytes = icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, (int)P);
-  launch_wino4_input(st, x_up, np, x, scale, shift, (long)ssb, V, B, H, W, Cin, flags);
+  if (x) launch_wino4_input(st, x_up, np, x, scale, shift, (long)ssb, V, B, H, W, Cin, flags);
+  else V = const_cast<float*>(v_saved);        // the forward pass's V, kept by the caller (icg_conv2d_wino4_wgrad_from_v)
   long nb = icg_cdiv(T * (Cout / 4), 256);
   if (nb > 256 * 64) nb = 256 * 64;
   const dim3 g((unsigned)nb), blk(256);
@@ -891,4 +893,26 @@ extern "C" int icg_conv2d_down_wino_wgrad(const float* x, const float* dy, float
   ICG_RS_REQUIRE(B, Hp, Wp, Cin, Cout);
   if (workspace_bytes < icg_conv2d_rs_wino_wgrad_workspace_bytes(B, 2 * Hp, 2 * Wp, Cin, Cout)) return ICG_ERR_WORKSPACE;
   return wino4_wgrad_run(x, 0, dy, 1, 0.25f, dw, nullptr, nullptr, 0, B, 2 * Hp, 2 * Wp, Cin, Cout, flags, 5, workspace, stream);
+}
+
+// Weight gradient from the V planes the FORWARD pass of the same layer computed (icg_conv2d_wino4_fprop and the *_wino_fprop
+// entries leave V = transform(act(x)) in the first planes * T * Cin floats of their workspace, T = B * H/4 * W/4 at the full
+// resolution H x W): a caller that keeps that region alive until the backward pass (2.25x / 1.56x the activation; sized for
+// 288 GB) skips the input transform here.  planes = 36 (plain 3x3) or 25 (resample-fused); dy_up = 1 with dy_alpha = 0.25
+// for the avgpool-fused layer (dy at the pooled resolution), else 0 / 1.
+extern "C" size_t icg_conv2d_wino4_wgrad_from_v_workspace_bytes(int B, int H, int W, int Cin, int Cout, int planes) {
+  const size_t T = (size_t)B * (H / 4) * (W / 4), P = (size_t)planes;
+  return wino_al(P * T * Cout * sizeof(float)) + wino_al(P * Cin * Cout * sizeof(float)) +
+         wino_al(icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, planes));
+}
+
+extern "C" int icg_conv2d_wino4_wgrad_from_v(const float* V, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                                             int planes, int dy_up, float dy_alpha, void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+  ICG_REQUIRE(V && dy && dw && workspace && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  ICG_REQUIRE((H % 4 == 0) && (W % 4 == 0) && (Cin % 4 == 0) && (Cout % 4 == 0) && (planes == 36 || planes == 25));
+  ICG_REQUIRE(!dy_up || planes == 25);
+  if (workspace_bytes < icg_conv2d_wino4_wgrad_from_v_workspace_bytes(B, H, W, Cin, Cout, planes)) return ICG_ERR_WORKSPACE;
+  return wino4_wgrad_run(nullptr, 0, dy, dy_up ? 1 : 0, dy_alpha, dw, nullptr, nullptr, 0, B, H, W, Cin, Cout, 0,
+                         planes == 25 ? 5 : 6, workspace, stream, V);
 }

@@ -180,11 +180,21 @@ def _conv_fprop(x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, 
         L.call("icg_conv2d_fprop", x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, flags, 1.0)
 
 
-def _wino_fprop(x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, flags, m=2):
+KEEP_WINOGRAD_V = True          # keep the forward pass's transformed input for the weight gradient (memory for one HBM pass)
+
+
+def _saved_v(ws, planes, B, H, W, Cin):
+    """the V = transform(act(x)) region the F(4x4,3x3) forward entries leave at the start of their workspace (H, W: full
+    resolution); the view keeps the workspace alive until the backward pass has used it"""
+    return ws[: planes * B * (H // 4) * (W // 4) * Cin * 4].view(torch.float32)
+
+
+def _wino_fprop(x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, flags, m=2, keep_v=False):
     v = "wino4" if m == 4 else "wino"
     nb = L.query("icg_conv2d_%s_workspace_bytes" % v, B, H, W, Cin, Cout)
-    L.call("icg_conv2d_%s_fprop" % v, x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, flags, 1.0,
-           _bytes(nb, out.device), nb)
+    ws = _bytes(nb, out.device)
+    L.call("icg_conv2d_%s_fprop" % v, x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, flags, 1.0, ws, nb)
+    return _saved_v(ws, 36, B, H, W, Cin) if (keep_v and m == 4 and KEEP_WINOGRAD_V) else None
 
 
 WINOGRAD_WGRAD = True            # weight gradient of those layers through the Winograd domain as well
@@ -316,18 +326,26 @@ class FusedConvFn(Function):
                 assert res.shape == (B, Cout, H, W)
         out = _empty_cl(B, Cout, H, W, dev)
         phase = bool(up and (sn.w_up is not None or sn.rs[0]))
+        keep_v = bool(ctx.needs_input_grad[1]) and KEEP_WINOGRAD_V
+        saved_v = None                 # (V planes of the forward transform, plane count) for the weight gradient
         if down and sn.rs[0]:
             # conv3x3 + avgpool2 in the 25-plane F(4x4,3x3) domain (25/64 of the 4x4-stride-2 form's MACs)
             nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, Hs, Ws, Cin, Cout)
-            L.call("icg_conv2d_down_wino_fprop", x, sn.w_wino, bias, res, out, B, H, W, Cin, Cout, flags, _bytes(nb, dev), nb)
+            ws = _bytes(nb, dev)
+            L.call("icg_conv2d_down_wino_fprop", x, sn.w_wino, bias, res, out, B, H, W, Cin, Cout, flags, ws, nb)
+            if keep_v and sn.rs[2]:
+                saved_v = (_saved_v(ws, 25, B, Hs, Ws, Cin), 25)
         elif down:
             # conv3x3 + avgpool2 as one 4x4 / stride-2 conv at the pooled resolution (2.25x fewer MACs)
             L.call("icg_conv2d_down_fprop", x, sn.w_down, bias, res, out, B, H, W, Cin, Cout, flags)
         elif phase and sn.rs[0]:
             assert res is None, "the upsample-fused path has no residual epilogue (GBlock conv1 has none)"
             nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cin, Cout)
+            ws = _bytes(nb, dev)
             L.call("icg_conv2d_up_wino_fprop", x, sn.w_wino, bias, out, scale, shift, ssb, B, Hs, Ws, Cin, Cout,
-                   flags & ~L.ICG_UPSAMPLE2X, _bytes(nb, dev), nb)
+                   flags & ~L.ICG_UPSAMPLE2X, ws, nb)
+            if keep_v and sn.rs[2]:
+                saved_v = (_saved_v(ws, 25, B, H, W, Cin), 25)
         elif phase:
             # nearest-x2 + 3x3 as 4 phases of 2x2 taps on the source tensor (2.25x fewer MACs)
             assert res is None, "the phase path has no residual epilogue (GBlock conv1 has none)"
@@ -335,9 +353,12 @@ class FusedConvFn(Function):
                    flags & ~L.ICG_UPSAMPLE2X)
         elif sn.w_wino is not None and not up:
             # wide 3x3 stride-1 layer: Winograd F(2x2,3x3), 16/36 of the multiply-adds (csrc/winograd.hip)
-            _wino_fprop(x, sn.w_wino, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, fflags, sn.wino_m)
+            v = _wino_fprop(x, sn.w_wino, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, fflags, sn.wino_m,
+                            keep_v and winograd_wgrad_tile(Cin, Cout, H, W, B) == 4)
+            saved_v = (v, 36) if v is not None else None
         else:
             _conv_fprop(x, sn.w_ohwi, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, fflags)
+        ctx.saved_v = saved_v
         ctx.phase, ctx.down = phase, down
         ctx.opt, ctx.flags, ctx.dims = opt, flags, (B, Cin, Hs, Ws, H, W, Cout, R, gb_rows, ssb, count)
         ctx.has = (bias is not None, residual is not None, gain is not None, beta is not None)
@@ -397,7 +418,13 @@ class FusedConvFn(Function):
         if need[1] and (ctx.down or ctx.phase) and sn.rs[2]:
             # weight gradient of the resample-fused layer in the 25-plane domain: plain HWIO 3x3 result
             dw_hwio = _f32(9 * Cin * Cout, dev)
-            if ctx.down:
+            Hf, Wf = (Hs, Ws) if ctx.down else (H, W)                # full resolution of the layer
+            if ctx.saved_v is not None and ctx.saved_v[1] == 25:
+                nb = L.query("icg_conv2d_wino4_wgrad_from_v_workspace_bytes", B, Hf, Wf, Cin, Cout, 25)
+                L.call("icg_conv2d_wino4_wgrad_from_v", ctx.saved_v[0], dout, dw_hwio, B, Hf, Wf, Cin, Cout, 25,
+                       1 if ctx.down else 0, 0.25 if ctx.down else 1.0, _bytes(nb, dev), nb)
+                ctx.saved_v = None
+            elif ctx.down:
                 nb = L.query("icg_conv2d_rs_wino_wgrad_workspace_bytes", B, Hs, Ws, Cin, Cout)
                 L.call("icg_conv2d_down_wino_wgrad", x, dout, dw_hwio, B, H, W, Cin, Cout, ctx.flags, _bytes(nb, dev), nb)
             else:
@@ -421,7 +448,12 @@ class FusedConvFn(Function):
         elif need[1]:
             dw_hwio = _f32(R * R * Cin * Cout, dev)
             wt = winograd_wgrad_tile(Cin, Cout, H, W, B) if sn.w_wino is not None else 0
-            if wt:
+            if wt == 4 and ctx.saved_v is not None and ctx.saved_v[1] == 36:
+                nb = L.query("icg_conv2d_wino4_wgrad_from_v_workspace_bytes", B, H, W, Cin, Cout, 36)
+                L.call("icg_conv2d_wino4_wgrad_from_v", ctx.saved_v[0], dout, dw_hwio, B, H, W, Cin, Cout, 36, 0, 1.0,
+                       _bytes(nb, dev), nb)
+                ctx.saved_v = None
+            elif wt:
                 # wide 3x3 stride-1 layer: weight gradient through the Winograd domain (16/36 or 9/36 of the MACs)
                 v = "wino4" if wt == 4 else "wino"
                 nb = L.query("icg_conv2d_%s_wgrad_workspace_bytes" % v, B, H, W, Cin, Cout)

@@ -211,6 +211,14 @@ int icg_conv2d_down_wino_dgrad(const float* dy, const float* U, float* da, int B
                                void* workspace, size_t workspace_bytes, void* stream);
 int icg_conv2d_down_wino_wgrad(const float* x, const float* dy, float* dw, int B, int Hp, int Wp, int Cin, int Cout,
                                unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
+/* Weight gradient from the V planes the FORWARD pass of the same layer left in its workspace: icg_conv2d_wino4_fprop,
+ * icg_conv2d_up_wino_fprop and icg_conv2d_down_wino_fprop write V = transform(act(x)) to the first
+ * planes * T * Cin floats of the workspace (T = B * H/4 * W/4 at the FULL resolution H x W; planes = 36 / 25).  A caller that
+ * keeps that region until the backward pass (memory for HBM passes: sized for 288 GB) skips the input transform.  dy_up = 1,
+ * dy_alpha = 0.25 for the avgpool-fused layer (dy at the pooled resolution), else 0 / 1.  Same result as the *_wgrad entries. */
+size_t icg_conv2d_wino4_wgrad_from_v_workspace_bytes(int B, int H, int W, int Cin, int Cout, int planes);
+int icg_conv2d_wino4_wgrad_from_v(const float* V, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                                  int planes, int dy_up, float dy_alpha, void* workspace, size_t workspace_bytes, void* stream);
 /* measurement hook (bench.py): with timing enabled every batched GEMM over Winograd planes (rocprofv3 name
  * icg_gemm_planes_kernel<AMODE, BMODE, TN>) is bracketed by HIP events on its launch stream.  drain() writes rows of
  * {amode, tn, planes, launches, total ms, total executed flops, total operand bytes} and returns the row count. */

@@ -115,6 +115,7 @@ def icg_conv2d_wino4_fprop(x, U, bias, residual, out, scale, shift, ss_bstride, 
     inv = torch.tensor([[4.0, 0, 0, 0, 0, 0], [0, -3.0, 3.0, 0, 0, 0], [0, 0, 0, 0, 0, 1.0]], dtype=torch.float64)
     g = torch.einsum("ra,abnk,sb->nrsk", inv, u, inv).float().contiguous()
     icg_conv2d_fprop(x, g, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, 3, flags, alpha)
+    _w4_store_v(workspace, _act(x, scale, shift, ss_bstride, flags, B, H, W, Cin), 36)
 
 
 def icg_conv2d_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout):
@@ -131,6 +132,52 @@ def icg_conv2d_wino4_wgrad_workspace_bytes(B, H, W, Cin, Cout):
 
 def icg_conv2d_wino4_wgrad(x, dy, dw, scale, shift, ss_bstride, B, H, W, Cin, Cout, flags, workspace, workspace_bytes):
     icg_conv2d_wgrad(x, dy, dw, scale, shift, ss_bstride, B, H, W, Cin, Cout, 3, flags, None, 0)
+
+
+def icg_conv2d_wino4_wgrad_from_v_workspace_bytes(B, H, W, Cin, Cout, planes):
+    return 16
+
+
+_W4_BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0],
+                       [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=torch.float64)
+
+
+def _w4_store_v(workspace, a, planes):
+    """what the HIP forward entries leave at the start of their workspace: V[i][j][tile][c] = (B^T d B)[i][j] of the activated
+    (and, for the upsample-fused layer, upsampled) input a [B, C, H, W]"""
+    Bn, C, H, W = a.shape
+    th, tw = H // 4, W // 4
+    ap = F.pad(a.double(), (1, 1, 1, 1)).permute(0, 2, 3, 1)                   # [B, H+2, W+2, C]
+    d = torch.stack([torch.stack([ap[:, r: r + 4 * th: 4, s_: s_ + 4 * tw: 4, :] for s_ in range(6)], 0) for r in range(6)], 0)
+    v = torch.einsum("ir,rsbyxc,js->ijbyxc", _W4_BT, d, _W4_BT)
+    if planes == 25:
+        idx = torch.tensor(_W4R)
+        v = v[idx[:, None], idx[None, :]]
+    flat = v.reshape(-1).float()
+    workspace.view(-1)[: flat.numel() * 4].view(torch.float32).copy_(flat)
+
+
+_W4_AT = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)
+
+
+def icg_conv2d_wino4_wgrad_from_v(V, dy, dw, B, H, W, Cin, Cout, planes, dy_up, dy_alpha, workspace, workspace_bytes):
+    """reference in the Winograd domain (fp64): dw = G^T [ sum_tiles (A dy A^T) .* V ] G over the stored planes"""
+    th, tw = H // 4, W // 4
+    T = B * th * tw
+    comps = list(range(6)) if planes == 36 else _W4R
+    n = len(comps)
+    v = mem(V)[: planes * T * Cin].view(n, n, T, Cin).double()
+    if dy_up:
+        g = F.interpolate(_nhwc(dy, B, H // 2, W // 2, Cout).permute(0, 3, 1, 2), scale_factor=2)
+    else:
+        g = _nhwc(dy, B, H, W, Cout).permute(0, 3, 1, 2)
+    g = (g.double() * dy_alpha).permute(0, 2, 3, 1).reshape(B, th, 4, tw, 4, Cout)          # [b, y, a, x, c, co]
+    A = _W4_AT.t()[comps]                                                                   # [n][4]
+    DY = torch.einsum("ia,byaxco,jc->ijbyxo", A, g, A).reshape(n, n, T, Cout)
+    dU = torch.einsum("ijtc,ijto->ijco", v, DY)
+    G = _WINO4_G[comps]                                                                     # [n][3]
+    gw = torch.einsum("ir,ijco,js->rsco", G, dU, G)                                         # HWIO
+    mem(dw)[: 9 * Cin * Cout].copy_(gw.reshape(-1).float())
 
 
 def icg_gemm_tn_batched_workspace_bytes(M, N, K, batch):
@@ -258,6 +305,7 @@ def icg_conv2d_rs_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout):
 def icg_conv2d_up_wino_fprop(x, U, bias, out, scale, shift, ss_bstride, B, Hs, Ws, Cin, Cout, flags, workspace, workspace_bytes):
     g = _w4r_kernel(U, Cout, Cin)
     icg_conv2d_fprop(x, g, bias, None, out, scale, shift, ss_bstride, B, 2 * Hs, 2 * Ws, Cin, Cout, 3, flags | UPSAMPLE2X, 1.0)
+    _w4_store_v(workspace, _act(x, scale, shift, ss_bstride, flags | UPSAMPLE2X, B, Hs, Ws, Cin), 25)
 
 
 def icg_conv2d_up_wino_dgrad(dy, U, da, B, Hs, Ws, Cin, Cout, workspace, workspace_bytes):
@@ -281,6 +329,7 @@ def icg_conv2d_down_wino_fprop(x, U, bias, residual, out, B, Hp, Wp, Cin, Cout, 
     if residual is not None:
         y = y + _nhwc(residual, B, Hp, Wp, Cout).permute(0, 3, 1, 2)
     mem(out)[: B * Hp * Wp * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))
+    _w4_store_v(workspace, a, 25)
 
 
 def icg_conv2d_down_wino_dgrad(dy, U, da, B, Hp, Wp, Cin, Cout, workspace, workspace_bytes):

@@ -367,6 +367,62 @@ def test_conv2d_down_winograd_triplet(case, has_res):
     close(*p, rtol=5e-4, atol_rel=5e-4, what=f"down_wino_wgrad {case}")
 
 
+@pytest.mark.parametrize("kind", ["plain", "up", "down"])
+@pytest.mark.parametrize("case", [(2, 4, 4, 32, 32, 0), (2, 8, 8, 64, 48, PRE_RELU), (3, 16, 16, 128, 96, PRE_RELU)])
+def test_conv2d_winograd4_wgrad_from_saved_v(case, kind):
+    """the forward entries leave V = transform(act(x)) at the start of their workspace; the weight gradient computed from
+    those planes equals the one that re-transforms x"""
+    B, Hl, Wl, Cin, Cout, flags = case
+    L = _L()
+    w, wd, U25, _ = _rs_weights(Cin, Cout)
+    H, W = 2 * Hl, 2 * Wl                                    # full resolution of the layer
+    bias = rnd(Cout, seed=7)
+    planes = 36 if kind == "plain" else 25
+    if kind == "plain":
+        U = torch.empty(36 * Cout * Cin)
+        R.icg_wino4_weight_transform(w, U, Cout, Cin)
+        x = cl(B, Cin, H, W, seed=6)
+        nb = L.query("icg_conv2d_wino4_workspace_bytes", B, H, W, Cin, Cout)
+        ws = torch.zeros(nb, dtype=torch.uint8)
+        out = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
+        pairs = run_pair("icg_conv2d_wino4_fprop", [x, U, bias, None, out, None, None, 0, B, H, W, Cin, Cout, flags, 1.0, ws, nb], [15])
+        dy = cl(B, Cout, H, W, seed=11)
+        ref_args = ("icg_conv2d_wino4_wgrad", [x, dy, None, None, None, 0, B, H, W, Cin, Cout, flags, None, 0])
+        dy_up, alpha = 0, 1.0
+    elif kind == "up":
+        x = cl(B, Cin, Hl, Wl, seed=6)
+        nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cin, Cout)
+        ws = torch.zeros(nb, dtype=torch.uint8)
+        out = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
+        pairs = run_pair("icg_conv2d_up_wino_fprop", [x, U25, bias, out, None, None, 0, B, Hl, Wl, Cin, Cout, flags, ws, nb], [13])
+        dy = cl(B, Cout, H, W, seed=11)
+        ref_args = ("icg_conv2d_up_wino_wgrad", [x, dy, None, None, None, 0, B, Hl, Wl, Cin, Cout, flags, None, 0])
+        dy_up, alpha = 0, 1.0
+    else:
+        x = cl(B, Cin, H, W, seed=6)
+        nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cin, Cout)
+        ws = torch.zeros(nb, dtype=torch.uint8)
+        out = torch.empty(B, Cout, Hl, Wl).contiguous(memory_format=torch.channels_last)
+        pairs = run_pair("icg_conv2d_down_wino_fprop", [x, U25, bias, None, out, B, Hl, Wl, Cin, Cout, flags, ws, nb], [11])
+        dy = cl(B, Cout, Hl, Wl, seed=11)
+        ref_args = ("icg_conv2d_down_wino_wgrad", [x, dy, None, B, Hl, Wl, Cin, Cout, flags, None, 0])
+        dy_up, alpha = 1, 0.25
+    nv = planes * B * (H // 4) * (W // 4) * Cin
+    (gws, cws), = pairs
+    v_gpu, v_cpu = gws.view(torch.float32)[:nv], cws.view(torch.float32)[:nv]
+    close(v_gpu, v_cpu, rtol=2e-5, atol_rel=2e-5, what=f"V planes left by the {kind} forward {case}")
+    nbw = L.query("icg_conv2d_wino4_wgrad_from_v_workspace_bytes", B, H, W, Cin, Cout, planes)
+    dw = torch.empty(9 * Cin * Cout)
+    (p,) = run_pair("icg_conv2d_wino4_wgrad_from_v", [v_cpu.clone(), dy, dw, B, H, W, Cin, Cout, planes, dy_up, alpha,
+                                                      torch.empty(nbw, dtype=torch.uint8), nbw], [2])
+    close(*p, rtol=5e-4, atol_rel=5e-4, what=f"wgrad from saved V {kind} {case}")
+    name, a = ref_args                      # ... and equals the reference of the entry that re-transforms x
+    dw_ref = torch.empty(9 * Cin * Cout)
+    a[2] = dw_ref
+    getattr(R, name)(*a)
+    close(p[0], dw_ref, rtol=5e-4, atol_rel=5e-4, what=f"wgrad from saved V vs re-transform {kind} {case}")
+
+
 GEMM_CASES = [
     # M, N, K, transA, transB, batch
     (256, 64, 4, 0, 1, 3), (256, 16, 64, 0, 0, 3), (64, 16, 256, 1, 0, 3), (64, 4, 256, 1, 0, 2),
