@@ -52,7 +52,7 @@ class KernelTimer:
     library (icg_gemm_last_variant), so they can be compared line by line with profiles/*_kernel_stats.csv."""
 
     # entry point -> (index of B in the argument list, kind)
-    SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"), "icg_conv2d_wino4_fprop": (8, "wino4"), "icg_conv2d_wino_wgrad": (6, "wino"), "icg_conv2d_wino4_wgrad": (6, "wino4"),
+    SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"), "icg_conv2d_wino4_fprop": (8, "wino4"), "icg_conv2d_wino_wgrad": (6, "wino"), "icg_conv2d_wino4_wgrad": (6, "wino4"), "icg_conv2d_wino4_wgrad_from_v": (3, "from_v"),
             "icg_conv2d_up_wino_fprop": (7, "rs_up"), "icg_conv2d_up_wino_dgrad": (3, "rs_up"), "icg_conv2d_up_wino_wgrad": (6, "rs_up"),
             "icg_conv2d_down_wino_fprop": (5, "rs_down"), "icg_conv2d_down_wino_dgrad": (3, "rs_down"), "icg_conv2d_down_wino_wgrad": (3, "rs_down"),
             "icg_conv2d_wgrad": (6, "conv"), "icg_conv2d_up_fprop": (7, "up"),
@@ -84,6 +84,11 @@ class KernelTimer:
                 alg = 2.0 * B * H * W * Cout * Cin * 9
                 exe = alg * (9.0 if mode == "wino4" else 16.0) / 36.0
                 byt = 4.0 * (B * H * W * (Cin + Cout) + Cout * Cin * 9)
+            elif mode == "from_v":                  # weight gradient from the forward pass's V planes (H, W: full resolution)
+                B, H, W, Cin, Cout, planes = args[sl:sl + 6]
+                alg = 2.0 * B * H * W * Cout * Cin * 9
+                exe = alg * planes / 144.0
+                byt = 4.0 * (B * H * W * (Cin + Cout) + Cout * Cin * 9)
             elif mode in ("rs_up", "rs_down"):      # resample-fused layer in the 25-plane F(4x4,3x3) domain: 25 GEMMs over 1/16 of
                 B, Hs, Ws, Cin, Cout = args[sl:sl + 5]      # the full-resolution pixels = 25/144 of the reference graph's MACs
                 alg = 2.0 * B * (4 * Hs * Ws) * Cout * Cin * 9
@@ -102,7 +107,9 @@ class KernelTimer:
             raw(name, *args)
             e.record()
             query(last)
-            if mode in ("rs_up", "rs_down"):
+            if mode == "from_v":
+                kname = "composite: weight gradient from the saved V planes (wino4_dy_kernel + %d batched split-K icg_gemm_planes_kernel<1, 1, %d> GEMMs + reduce + wino4_dw_kernel)" % (args[sl + 5], last[2])
+            elif mode in ("rs_up", "rs_down"):
                 kind = name.rsplit("_", 1)[1]
                 kname = "composite: %s-fused conv %s in the 25-plane F(4x4,3x3) domain (transforms + 25 batched icg_gemm_planes_kernel<%s, %d> GEMMs)" % (
                     "upsample" if mode == "rs_up" else "avgpool", kind, "1, 1" if kind == "wgrad" else "0, 0", last[2])
