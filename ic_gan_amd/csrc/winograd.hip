@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
 void icg_gemm_mark_planes(int on);       // gemm_conv.hip: launch the following GEMMs as icg_gemm_planes_kernel (profile name)
 extern "C" int icg_gemm_last_variant(int* out4);
 
-// measurement hook for bench.py: HIP events on the launch stream around every plane-GEMM launch (off by default)
+// measurement hook for bench.py: HIP events on the launch stream around every plane-GEMM launch (off by default; the
+// record list is process-global and unsynchronised: enable it from the one thread that launches the work, as bench.py does)
 struct PlanesRecord { hipEvent_t e0, e1; int amode, tn, planes; double flops, bytes; };
 static std::vector<PlanesRecord> g_planes_records;
 static bool g_planes_timing = false;

@@ -216,3 +216,30 @@ def copy_of(m):
         if hasattr(mod, "_sn_eval"):
             mod._sn_eval = None
     return c
+
+
+def test_winograd_routing_rules(monkeypatch):
+    """which form a 3x3 layer takes is a pure function of its channel counts and (full) resolution -- never of the batch
+    size, because the spectral-norm layouts are prefetched from the previous call (D sees batch 2B and B alternately)."""
+    import ic_gan_amd.ops as ops
+    # plain 3x3 stride-1 layers
+    assert ops.winograd_applies(96, 96, 256, 256, 64) == 4 and ops.winograd_applies(96, 96, 256, 256, 1) == 4
+    assert ops.winograd_applies(64, 96, 256, 256, 64) == 0                   # below the channel threshold
+    assert ops.winograd_applies(192, 192, 6, 6, 64) == 2                     # not a multiple of 4: F(2x2,3x3) from 192 channels
+    assert ops.winograd_applies(96, 96, 6, 6, 64) == 0
+    assert ops.winograd_applies(96, 98, 8, 8, 64) == 0                       # channel quads only
+    assert ops.winograd_wgrad_tile(96, 192, 128, 128, 128) == 4
+    # resample-fused layers (h, w: full resolution)
+    for batch in (1, 64, 128):
+        assert ops.resample_winograd_applies(192, 96, 256, 256, batch) == 5
+    assert ops.resample_winograd_applies(192, 96, 6, 6, 64) == 0
+    assert ops.resample_winograd_directions(192, 96, True) == (True, False, True)      # upsample-fused: fprop / dgrad / wgrad
+    assert ops.resample_winograd_directions(96, 96, False) == (False, False, False)    # pool-fused pays from 192 channels
+    assert ops.resample_winograd_directions(384, 192, False) == (True, True, True)
+    # the strict route
+    for k in ("WINOGRAD_MIN_CHANNELS", "WINOGRAD2_MIN_CHANNELS", "WINOGRAD4_MIN_CHANNELS", "WINOGRAD4_WGRAD_MIN_CHANNELS",
+              "RS_WINOGRAD_MIN_CHANNELS"):
+        monkeypatch.setattr(ops, k, getattr(ops, k))                          # restored after the test
+    ops.disable_winograd()
+    assert ops.winograd_applies(1536, 1536, 8, 8, 64) == 0 and ops.winograd_wgrad_tile(1536, 1536, 8, 8, 64) == 0
+    assert ops.resample_winograd_applies(1536, 1536, 8, 8, 64) == 0
