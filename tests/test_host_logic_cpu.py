@@ -243,3 +243,21 @@ def test_winograd_routing_rules(monkeypatch):
     ops.disable_winograd()
     assert ops.winograd_applies(1536, 1536, 8, 8, 64) == 0 and ops.winograd_wgrad_tile(1536, 1536, 8, 8, 64) == 0
     assert ops.resample_winograd_applies(1536, 1536, 8, 8, 64) == 0
+
+
+def test_bench_accounts_every_convolution_entry_point():
+    """bench.py's KernelTimer must know every convolution entry point the host code can dispatch (a missing one would silently
+    drop its FLOPs and time from the roofline table)."""
+    import importlib.util
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    src = open(os.path.join(root, "ic_gan_amd", "ops.py")).read()
+    called = set(re.findall(r'L\.call\("(icg_conv2d_[a-z0-9_]+)"', src))
+    called |= {"icg_conv2d_%s_%s" % (v, k) for v in ("wino", "wino4") for k in ("fprop", "wgrad")}      # "%s" call sites
+    called = {n for n in called if "%" not in n}
+    missing = sorted(called - set(bench.KernelTimer.SPEC))
+    assert not missing, missing
