@@ -2,7 +2,7 @@
 
 Drop-in for the model module the reference selects with ``__import__(config["model"])``
 (BigGAN_PyTorch/trainer.py:122): same constructor keywords, ``forward`` signatures, attributes read by
-callers (``dim_z``, ``shared``, ``fp16``, ``optim``) and — checked by tests/test_state_dict_contract.py —
+callers (``dim_z``, ``shared``, ``fp16``, ``optim``) and — checked by tests/test_host_logic_cpu.py::test_state_dict_contract —
 the same ``state_dict()`` names and shapes as BigGAN_PyTorch/BigGAN.py, so checkpoints written by either
 implementation load into the other with ``strict=True``.
 
@@ -195,7 +195,14 @@ class Generator(nn.Module):
     def forward(self, z, label=None, feats=None):
         """z [B,dim_z], label [B] int64 or None, feats [B,2048] or None -> images [B,3,R,R] in [-1,1]
         (BigGAN.py:364-386)."""
-        layers.sn_prefetch(self._sn_layers(feats is not None))
+        sn_layers = self._sn_layers(feats is not None)
+        layers.sn_prefetch(sn_layers)
+        try:
+            return self._forward(z, label, feats)
+        finally:
+            layers.sn_drop_prefetched(sn_layers)      # no-op after a complete forward; un-bricks the module after an abort
+
+    def _forward(self, z, label, feats):
         y = self.get_condition_embeddings(label, feats)
         if self.hier:
             zs = torch.split(z, self.z_chunk_size, 1)
@@ -272,7 +279,14 @@ class Discriminator(nn.Module):
             skip |= {id(m) for m in self.embed.modules()}
         if feat is None and hasattr(self, "linear_feat"):
             skip |= {id(m) for m in self.linear_feat.modules()}
-        layers.sn_prefetch([m for m in self.modules() if isinstance(m, layers.SN) and id(m) not in skip])
+        sn_layers = [m for m in self.modules() if isinstance(m, layers.SN) and id(m) not in skip]
+        layers.sn_prefetch(sn_layers)
+        try:
+            return self._forward(x, y, feat)
+        finally:
+            layers.sn_drop_prefetched(sn_layers)
+
+    def _forward(self, x, y, feat):
         h = x
         for stage in self.blocks:
             for block in stage:

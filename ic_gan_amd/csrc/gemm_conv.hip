@@ -16,6 +16,11 @@
 //     exists in HBM
 //   * NHWC activations: the K-slice of an im2col row is contiguous (coalesced 16-byte loads)
 #include "icg_common.h"
+#include <type_traits>
+
+#ifndef ICG_PLANES_BLOCKED
+#define ICG_PLANES_BLOCKED 1     // two-level accumulation in the Winograd-plane GEMMs (0: ablation build of tools/)
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -60,7 +65,13 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // PATH 0: element-wise gather (any Cin); 1: 16-byte loads, generic index decode; 2: 16-byte loads, 32-bit offsets,
 // branch-free loads (clamped address + select), scalar tap tracking (A_K: Cin % 16 == 0) / shift-mask pixel decode
 // (A_M: H, W powers of two).  PATH 2 cuts the per-K-tile address section from ~330 to ~90 instructions.
-template <int AMODE, int BMODE, int TN, int PATH>
+// BLK = 1: two-level ("blocked") accumulation.  The MFMA is a k-ordered fp32 fmaf chain; in the Winograd domain the partial
+// sums are ~40x larger than the result they cancel to in the output transform, so the rounding of a chain of length K = Cin
+// (forward / data gradient) or K = tiles-per-slice (weight gradient) IS the Winograd error (tools/winograd_error_model.py:
+// 3.5e-6 -> 1.2e-6 per layer at C = 384).  Every 2 K-tiles (32 k-values) the first MFMA of the pair starts a fresh chain
+// from C = 0 and the finished chain is added into a second accumulator set by VALU adds that sit in the shadow of the
+// preceding MFMA (their operands were produced TN MFMAs earlier: no dependency stall).  Cost: 16*TN more registers.
+template <int AMODE, int BMODE, int TN, int PATH, int BLK = 0>
 __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
   // PATH 3 = PATH 2 with the BN/ccbn affine prologue compiled in (PATH 2 itself has none): keeps the hot loop
   // free of uniform branches so that the scheduler can interleave the staging work with the MFMAs
@@ -525,10 +536,17 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
 
   // ------------------------------------------------------------------ main loop
   f32x16 acc[TN];
+  f32x16 acc2[BLK ? TN : 1];       // BLK: the finished 32-deep chains (second accumulation level)
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  if (BLK) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+  }
 
   const int lane = tid & 63, wv = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -567,7 +585,9 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
     for (int j = 0; j < TN; ++j) fb[0][j] = Bs[0][li + lh * LDB + 32 * j];
   }
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
+  // one K-tile; FLUSH (compile time): its first k-step starts fresh chains (see BLK above)
+  auto tile_body = [&](int kt, auto flush_c) {
+    constexpr bool FLUSH = decltype(flush_c)::value;
     const int nxt = (cur == NBUF - 1) ? 0 : cur + 1;
     const float* as = As[cur] + 32 * wv + li + lh * LDA;
     const float* bs = Bs[cur] + li + lh * LDB;
@@ -588,7 +608,20 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
       const float* fbs = wrap ? bsn : bs + (2 * t + 2) * LDB;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1], fb[t & 1][j], acc[j], 0, 0, 0);
+        if (FLUSH && t == 0) {
+          // fold the finished chain into the second level, restart from C = 0 (inline constant: no register zeroing)
+          asm volatile("" : "+a"(acc[j]));    // ... and the accumulator -> VGPR copies must not be hoisted to the loop head
+          acc2[j] += acc[j];
+          // pin the adds HERE: they are pure, their result is not read before the next flush, and instruction selection would
+          // otherwise sink them to the end of the loop body, keeping all 16*TN accumulator copies live in VGPRs meanwhile
+          asm volatile("" : "+v"(acc2[j]));
+          f32x16 zero;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1], fb[t & 1][j], zero, 0, 0, 0);
+        } else {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1], fb[t & 1][j], acc[j], 0, 0, 0);
+        }
         if (j == 0) fa[wrap ? 0 : pn] = fas[0];
         fb[wrap ? 0 : pn][j] = fbs[32 * j];
         // 12 staging pieces over the 8*TN MFMA gaps (PPG pieces per gap; 1 for TN >= 2)
@@ -624,6 +657,16 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
       }
     }
     cur = nxt;
+  };
+  if (BLK) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      tile_body(kt, std::true_type{});
+      if (kt + 1 < nk) tile_body(kt + 1, std::false_type{});
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[j] += acc2[j];
+  } else {
+    for (int kt = 0; kt < nk; ++kt) tile_body(kt, std::false_type{});
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -665,7 +708,7 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
 // them from the convolutions that run on the kernel directly (only the fast loader is instantiated)
 template <int AMODE, int BMODE, int TN>
 __global__ __launch_bounds__(256) void icg_gemm_planes_kernel(GemmP p) {
-  icg_gemm_body<AMODE, BMODE, TN, 2>(p);
+  icg_gemm_body<AMODE, BMODE, TN, 2, ICG_PLANES_BLOCKED>(p);
 }
 
 static thread_local int g_gemm_planes = 0;

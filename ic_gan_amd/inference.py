@@ -76,6 +76,8 @@ class GraphedGenerator:
     def refresh(self):
         from . import layers
         was, layers.SN_EVAL_CACHE = layers.SN_EVAL_CACHE, bool(self.static_weights)
+        if self.static_weights:
+            layers.enable_sn_eval_cache(self._args[0], True)      # fixed checkpoint: W/sigma computed once, baked in
         try:
             self._capture(*self._args)
         finally:
@@ -155,4 +157,8 @@ def load_model_inference(config, device="cuda"):
                            strict=False, load_optim=False)
     if config.get("G_eval_mode", False):
         generator.eval()
+    # a sampling generator's weights are frozen from here on: W/sigma of every layer is computed once and reused
+    # (layers.invalidate_sn_cache(generator) after any manual weight edit through `.data`)
+    from . import layers
+    layers.enable_sn_eval_cache(generator, True)
     return generator, config

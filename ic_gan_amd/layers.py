@@ -18,6 +18,8 @@ variant (use `sync_bn=True`: cross-replica statistics over RCCL with the same bu
 """
 from __future__ import annotations
 
+import warnings
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -73,10 +75,19 @@ class SN(object):
 
     def _sn_eval_key(self, flags):
         """In eval mode without autograd W/sigma is a pure function of (weight, u0): it is computed once and reused until
-        either tensor is written to (the reference recomputes it on every call; same values).  None = not cacheable."""
-        if self.training or torch.is_grad_enabled() or not SN_EVAL_CACHE:
+        either tensor is written to (the reference recomputes it on every call; same values).  None = not cacheable.
+
+        OPT-IN per network (enable_sn_eval_cache): the key relies on autograd version counters, which writes through
+        `.data` aliases (the reference's utils.ema.update, any p.data.copy_()) do not bump.  A network whose weights
+        may be written that way (G_ema under the reference's trainer) must not cache; the owners of frozen weights
+        (inference.load_model_inference, inference.GraphedGenerator, bench.py's sampling workload) opt in."""
+        if self.training or torch.is_grad_enabled() or not SN_EVAL_CACHE or not getattr(self, "_sn_cache_ok", False):
             return None
         return (flags, self.weight._version, self.u0._version, self.weight.data_ptr(), self.u0.data_ptr())
+
+    def _sn_invalidate(self):
+        self._sn_eval = None
+        self._sn_ready = None
 
     def W_(self):
         """Spectrally normalised weight in the parameter layout (debug / API parity; not on the hot path)."""
@@ -87,7 +98,32 @@ class SN(object):
         return st.w_ohwi.view_as(w)
 
 
-SN_EVAL_CACHE = True      # module switch for the eval-mode W/sigma cache (GraphedGenerator turns it off while capturing)
+SN_EVAL_CACHE = True      # global kill switch for the eval-mode W/sigma cache (GraphedGenerator turns it off while capturing)
+
+
+def enable_sn_eval_cache(module, on=True):
+    """Opt a network's spectral-norm layers in to (or out of) the eval-mode W/sigma cache.  Only for networks whose
+    weights are frozen or written exclusively by this package's kernels (FusedAdam, utils.ema, the power iteration: they
+    bump the version counters the cache key reads)."""
+    for m in module.modules():
+        if isinstance(m, SN):
+            m._sn_cache_ok = bool(on)
+            m._sn_invalidate()
+    return module
+
+
+def invalidate_sn_cache(module):
+    """Drop every cached / prefetched W/sigma under `module` (call after writing weights or u0 through `.data`)."""
+    for m in module.modules():
+        if isinstance(m, SN):
+            m._sn_invalidate()
+    return module
+
+
+def sn_drop_prefetched(modules):
+    """Forget spectral-norm states that sn_prefetch computed and the forward did not consume (aborted forward)."""
+    for m in modules:
+        m._sn_ready = None
 
 
 def sn_prefetch(modules):
@@ -99,8 +135,12 @@ def sn_prefetch(modules):
     groups = {}
     for m in modules:
         if m._sn_ready is not None:
-            raise RuntimeError("%s: prefetched spectral-norm state was never consumed (the layer was not called in the "
-                               "previous forward); its u/sv buffers have advanced — reload them" % type(m).__name__)
+            # an earlier forward aborted (OOM, shape error, KeyboardInterrupt) or skipped this layer: the state is stale.
+            # Its power-iteration step has already been applied to u0/sv0 (one extra iteration, harmless for the
+            # estimate); drop it and carry on instead of bricking the module.
+            warnings.warn("%s: dropping a prefetched spectral-norm state that the previous forward never consumed"
+                          % type(m).__name__, RuntimeWarning, stacklevel=2)
+            m._sn_ready = None
         if mode in m._sn_flags:
             key = m._sn_eval_key(m._sn_flags[mode])
             if key is not None and m._sn_eval is not None and m._sn_eval[0] == key:
@@ -116,6 +156,14 @@ def sn_prefetch(modules):
 
 
 class SNConv2d(nn.Conv2d, SN):
+    def train(self, mode=True):
+        self._sn_invalidate()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._sn_invalidate()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
                  num_svs=1, num_itrs=1, eps=1e-12):
         nn.Conv2d.__init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
@@ -143,6 +191,14 @@ class SNConv2d(nn.Conv2d, SN):
 
 
 class SNLinear(nn.Linear, SN):
+    def train(self, mode=True):
+        self._sn_invalidate()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._sn_invalidate()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def __init__(self, in_features, out_features, bias=True, num_svs=1, num_itrs=1, eps=1e-12):
         nn.Linear.__init__(self, in_features, out_features, bias)
         self._sn_init(num_svs, num_itrs, out_features, eps=eps)
@@ -154,6 +210,14 @@ class SNLinear(nn.Linear, SN):
 
 
 class SNEmbedding(nn.Embedding, SN):
+    def train(self, mode=True):
+        self._sn_invalidate()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._sn_invalidate()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def __init__(self, num_embeddings, embedding_dim, padding_idx=None, max_norm=None, norm_type=2,
                  scale_grad_by_freq=False, sparse=False, _weight=None, num_svs=1, num_itrs=1, eps=1e-12):
         nn.Embedding.__init__(self, num_embeddings, embedding_dim, padding_idx, max_norm, norm_type,

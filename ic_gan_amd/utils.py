@@ -35,6 +35,7 @@ class ema(object):
         with torch.no_grad():
             for key in self.source_dict:
                 self.target_dict[key].data.copy_(self.source_dict[key].data)
+        ops.bump_version(*self.target_dict.values())         # `.data` writes do not bump autograd's version counters
 
     def update(self, itr=None):
         decay = 0.0 if (itr and itr < self.start_itr) else self.decay
@@ -42,8 +43,10 @@ class ema(object):
             tg, sr = [], []
             for key in self.source_dict:
                 t, s = self.target_dict[key].data, self.source_dict[key].data
-                if t.dtype != torch.float32 or not t.is_contiguous() or not s.is_contiguous():
-                    raise RuntimeError(f"ema: unsupported tensor for key {key}")
+                if t.dtype != torch.float32 or s.dtype != torch.float32 or not t.is_contiguous() or not s.is_contiguous():
+                    # entries the multi-tensor kernel does not take (non-fp32 / strided): the reference's expression
+                    t.copy_(t * decay + s * (1 - decay))
+                    continue
                 tg.append(t)
                 sr.append(s)
             ops.ema_multi(tg, sr, decay)
@@ -102,8 +105,10 @@ def load_weights(G, D, state_dict, weights_root, experiment_name, name_suffix=No
         return
 
     def load(stem):
+        # G / D / G_ema / optimizer files hold tensors and plain containers only; state_dict.pth pickles the whole config
+        # (incl. nn.ReLU objects) and needs the full unpickler
         return torch.load("%s/%s.pth" % (root, join_strings("_", [stem, name_suffix])), map_location=map_location,
-                          weights_only=False)
+                          weights_only=(stem != "state_dict"))
 
     print("Loading %sweights from %s..." % ((name_suffix + " ") if name_suffix else "", root))
     if G is not None:

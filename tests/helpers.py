@@ -8,6 +8,9 @@ import torch
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NS = 64
 CASES = ["cc_ic_r64", "ic_r64_acc2", "cc_r32_flat", "cc_ic_r128", "cc_ic_r256"]
+# BASELINE.json's configurations at their REAL widths (tests/golden/make_golden_real_widths.py): configs[0] exactly
+# (64x64, ch 64, B 8, 2 steps), configs[1] / configs[2] at ch 96 with the batch cut to 2
+REAL_CASES = ["cfg1_icgan_res64", "cfg2_w96_r128", "cfg3_w96_r256"]
 
 
 def load_golden(case):
@@ -40,6 +43,18 @@ def noise_grad_names(gold, prefix, rel=1e-3):
     return {n for n, r in zip(names, rms) if r < rel * top}
 
 
+SOFT_REPORT = None      # tools/parity_report.py sets this to a list: failures are recorded as (label, err/tol) instead of raised
+
+
+def _fail(cond, msg, ratio):
+    if cond:
+        return
+    if SOFT_REPORT is not None:
+        SOFT_REPORT.append((msg, ratio))
+    else:
+        raise AssertionError(msg)
+
+
 def check_group(gold, prefix, tensors, rtol, atol, what="", noise_floor=2e-3, extra_atol=None):
     """Compare a dict name->tensor with the packed fingerprints stored under `prefix`.
 
@@ -62,9 +77,13 @@ def check_group(gold, prefix, tensors, rtol, atol, what="", noise_floor=2e-3, ex
         err = float(np.max(np.abs(samp - gsamp)))
         if err / tol > worst[0]:
             worst = (err / tol, n)
-        assert err <= tol, f"{what}{n}: samples differ, max abs {err:.3e} > tol {tol:.3e} (rms {scales[i]:.3e})"
-        assert abs(np.sqrt(q / n_el) - np.sqrt(gq / n_el)) <= 4 * tol, f"{what}{n}: rms {q} vs {gq}"
-        assert abs(s - gs) <= 32 * tol * n_el ** 0.5 + atol * n_el, f"{what}{n}: sum {s} vs {gs}"
+        _fail(err <= tol, f"{what}{n}: samples differ, max abs {err:.3e} > tol {tol:.3e} (rms {scales[i]:.3e})", err / tol)
+        _fail(abs(np.sqrt(q / n_el) - np.sqrt(gq / n_el)) <= 4 * tol, f"{what}{n}: rms {q} vs {gq}",
+              abs(np.sqrt(q / n_el) - np.sqrt(gq / n_el)) / (4 * tol))
+        _fail(abs(s - gs) <= 32 * tol * n_el ** 0.5 + atol * n_el, f"{what}{n}: sum {s} vs {gs}",
+              abs(s - gs) / (32 * tol * n_el ** 0.5 + atol * n_el))
+    if SOFT_REPORT is not None and worst[1] is not None:
+        SOFT_REPORT.append((f"{what}worst={worst[1]}", worst[0]))
     return worst
 
 

@@ -107,7 +107,7 @@ def test_train_step_host_logic(case, emu, wino, monkeypatch):
 
 def test_sn_prefetch_bookkeeping(emu):
     """the batched spectral-norm pass is used from the second forward on, gives the same buffers as the per-layer path,
-    and an unconsumed prefetch is reported instead of silently advancing u twice."""
+    and a forward that aborts midway leaves the module usable (prefetch is transactional)."""
     import copy
     from ic_gan_amd import layers
     g = load_golden("cc_ic_r64")
@@ -140,11 +140,21 @@ def test_sn_prefetch_bookkeeping(emu):
     assert torch.equal(a1, b1) and torch.equal(a2, b2)
     for (k, v), (_, v2) in zip(G.state_dict().items(), G2.state_dict().items()):
         assert torch.equal(v, v2), k
-    # a prefetched layer that is then not called is detected at the next forward
+    # an aborted forward must not brick the module: unconsumed prefetched states are dropped by the network's
+    # try/finally; a state left behind by a bare sn_prefetch call is dropped with a warning at the next prefetch
+    boom = G.blocks[1][0].conv2.forward
+    G.blocks[1][0].conv2.forward = lambda *a, **k: (_ for _ in ()).throw(ValueError("abort mid-forward"))
     with torch.no_grad():
-        layers.sn_prefetch([G.linear])
-        with pytest.raises(RuntimeError):
+        with pytest.raises(ValueError):
             G(z, lab, fg)
+    G.blocks[1][0].conv2.forward = boom
+    assert all(m._sn_ready is None for m in G.modules() if isinstance(m, layers.SN))
+    with torch.no_grad():
+        out = G(z, lab, fg)                       # usable again
+        assert torch.isfinite(out).all()
+        layers.sn_prefetch([G.linear])            # prefetched, never consumed ...
+        with pytest.warns(RuntimeWarning, match="never consumed"):
+            G(z, lab, fg)                         # ... dropped with a warning, forward completes
 
 
 def test_eval_mode_sn_cache_follows_weight_updates(emu):
@@ -179,10 +189,28 @@ def _eval_cache_case(dev):
     try:
         G.eval()
         with torch.no_grad():
+            a0 = G(z, lab, fg)
+            n0 = calls["n"]
+            G(z, lab, fg)
+            assert calls["n"] > n0                                  # the cache is OPT-IN: off by default
+            # a `.data` write (the reference's utils.ema.update) bumps no version counter: without the opt-in it must still
+            # be seen by the next eval forward
+            G.linear.weight.data.mul_(1.5)
+            assert not torch.equal(G(z, lab, fg), a0)
+            G.linear.weight.data.div_(1.5)
+        layers.enable_sn_eval_cache(G)
+        with torch.no_grad():
             a = G(z, lab, fg)
             n1 = calls["n"]
             b = G(z, lab, fg)
             assert calls["n"] == n1 and torch.equal(a, b)          # second eval forward: everything from the cache
+            G.linear.weight.data.mul_(1.5)                         # opted in + `.data` write: explicit invalidation hook
+            layers.invalidate_sn_cache(G)
+            assert not torch.equal(G(z, lab, fg), a)
+            G.linear.weight.data.div_(1.5)
+            layers.invalidate_sn_cache(G)
+            a = G(z, lab, fg)
+            n1 = calls["n"]
         opt = FusedAdam(G.parameters(), lr=1e-2, betas=(0.0, 0.999), eps=1e-6)
         G.train()
         G(z, lab, fg).sum().backward()
@@ -195,7 +223,7 @@ def _eval_cache_case(dev):
         with torch.no_grad():
             assert torch.equal(G2(z, lab, fg), c)                   # a fresh module (no cache) agrees
         # EMA writes through raw pointers as well
-        G_ema = copy_of(G)
+        G_ema = layers.enable_sn_eval_cache(copy_of(G))
         with torch.no_grad():
             before = G_ema(z, lab, fg)
         e = utils.ema(G, G_ema, 0.5, 0)

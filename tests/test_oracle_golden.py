@@ -6,14 +6,14 @@ import torch
 
 from oracle import biggan_oracle as O
 from oracle import synth
-from tests.helpers import CASES, check_group, load_golden
+from tests.helpers import CASES, REAL_CASES, check_group, load_golden
 
 
 def _fresh(g):
     return synth.synth_state(g["gspec"], seed=11), synth.synth_state(g["dspec"], seed=22)
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + REAL_CASES)
 def test_oracle_forward_matches_reference(case):
     g = load_golden(case)
     cfg = g["cfg"]
@@ -38,7 +38,7 @@ def test_oracle_forward_matches_reference(case):
     check_group(g, "fwd/D_state/", dsd, rtol=1e-5, atol=1e-7, what="D buf ")
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + REAL_CASES)
 def test_oracle_train_step_matches_reference(case):
     g = load_golden(case)
     cfg = g["cfg"]

@@ -5,13 +5,15 @@
       triplet, normalisation statistics, value range / finiteness of a full cfg3-shaped step).
 Tolerances: forward activations / losses ~1e-4 relative (north_star: samples within 1e-3 rel L2);
 gradients and post-step parameters are compared through fingerprints at 5e-3 of the tensor rms."""
+import json
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import biggan_oracle as O
 from oracle import synth
-from tests.helpers import CASES, GRAD_RTOL, STATE_RTOL, adam_slack, check_group, load_golden
+from tests.helpers import CASES, GRAD_RTOL, REAL_CASES, STATE_RTOL, adam_slack, check_group, fingerprint, load_golden
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -45,7 +47,7 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + REAL_CASES)
 def test_forward_vs_golden(case):
     g = load_golden(case)
     cfg = g["cfg"]
@@ -59,7 +61,17 @@ def test_forward_vs_golden(case):
     if "fwd/img" in g:
         assert rel_l2(img, torch.from_numpy(g["fwd/img"])) < 1e-4          # north_star bound is 1e-3
         np.testing.assert_allclose(img.cpu().numpy(), g["fwd/img"], rtol=5e-4, atol=1e-4)
-    np.testing.assert_allclose(logit.cpu().numpy(), g["fwd/logit"], rtol=5e-4, atol=5e-4)
+    # every case (also the fingerprint-only ones at real widths): the image's 64 strided samples and its rms against the
+    # reference's -- rel. L2 over the samples < 1e-3 is north_star's sample-parity bound, we hold 2e-4
+    names = json.loads(str(g["fwd/taps/names"]))
+    gi = names.index("img")
+    _, sq, samp = fingerprint(img)
+    gsamp = g["fwd/taps/samp"][gi]
+    rel = float(np.linalg.norm(samp - gsamp) / np.linalg.norm(gsamp))
+    assert rel < 2e-4, ("image samples rel-L2", rel)
+    assert abs(np.sqrt(sq) - np.sqrt(g["fwd/taps/sq"][gi])) <= 2e-4 * np.sqrt(g["fwd/taps/sq"][gi])
+    scale = max(1.0, float(np.abs(g["fwd/logit"]).max()))
+    np.testing.assert_allclose(logit.cpu().numpy(), g["fwd/logit"], rtol=5e-4, atol=5e-4 * scale)
     check_group(g, "fwd/G_state/", {k: v.cpu() for k, v in G.state_dict().items()}, 2e-4, 1e-6, "G buf ")
     check_group(g, "fwd/D_state/", {k: v.cpu() for k, v in D.state_dict().items()}, 2e-4, 1e-6, "D buf ")
 
@@ -99,9 +111,23 @@ def _set_winograd(monkeypatch, wino):
 @pytest.mark.parametrize("wino", WINO_VARIANTS)
 @pytest.mark.parametrize("case", CASES)
 def test_train_steps_vs_golden(case, wino, monkeypatch):
+    _train_steps_case(case, wino, monkeypatch)
+
+
+@pytest.mark.parametrize("wino", [-1, 0])
+@pytest.mark.parametrize("case", REAL_CASES)
+def test_train_steps_vs_golden_real_widths(case, wino, monkeypatch):
+    """BASELINE.json's configurations at their real widths (cfg1 exactly; cfg2 / cfg3 at ch 96, batch 2) against the
+    reference-generated goldens: the production kernel routes (wino = 0: F(4x4,3x3) from 96 channels, 25-plane
+    resample-fused layers) and the Winograd-free route (-1), both at the STRICT tolerances of tests/helpers.py."""
+    _train_steps_case(case, wino, monkeypatch, strict=True)
+
+
+def _train_steps_case(case, wino, monkeypatch, strict=False):
     _set_winograd(monkeypatch, wino)
-    grad_rtol = GRAD_RTOL * WINO_GRAD_MULT[wino]
-    state_rtol = STATE_RTOL * WINO_STATE_MULT[wino]
+    grad_rtol = GRAD_RTOL * (1.0 if strict else WINO_GRAD_MULT[wino])
+    state_rtol = STATE_RTOL * (1.0 if strict else WINO_STATE_MULT[wino])
+    slack_mult = 1.0 if strict else WINO_SLACK_MULT[wino]
     from ic_gan_amd import train_fns, utils
     from ic_gan_amd.optim import FusedAdam
     g = load_golden(case)
@@ -131,8 +157,8 @@ def test_train_steps_vs_golden(case, wino, monkeypatch):
                         grad_rtol, 1e-6, "G grad ")
             check_group(g, "step1/D_grad/", {n: p.grad.cpu() for n, p in D.named_parameters() if p.grad is not None},
                         grad_rtol, 1e-6, "D grad ")
-        gx = {k: v * WINO_SLACK_MULT[wino] for k, v in adam_slack(g, "step1/G_grad/", cfg["G_lr"], s + 1, G.state_dict().keys()).items()}
-        dx = {k: v * WINO_SLACK_MULT[wino] for k, v in adam_slack(g, "step1/D_grad/", cfg["D_lr"], s + 1, D.state_dict().keys()).items()}
+        gx = {k: v * slack_mult for k, v in adam_slack(g, "step1/G_grad/", cfg["G_lr"], s + 1, G.state_dict().keys()).items()}
+        dx = {k: v * slack_mult for k, v in adam_slack(g, "step1/D_grad/", cfg["D_lr"], s + 1, D.state_dict().keys()).items()}
         check_group(g, f"step{s + 1}/G_state/", cpu(G.state_dict()), state_rtol, 2e-6, "G ", extra_atol=gx)
         check_group(g, f"step{s + 1}/D_state/", cpu(D.state_dict()), state_rtol, 2e-6, "D ", extra_atol=dx)
         check_group(g, f"step{s + 1}/EMA_state/", cpu(G_ema.state_dict()), state_rtol, 2e-6, "EMA ", extra_atol=gx)

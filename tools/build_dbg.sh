@@ -1,0 +1,23 @@
+#!/bin/bash
+# Ablation builds of libicgan_hip.so (tools only, never the product): tools/libdbg_<NAME>.so, selected by tools/*.py through ICG_LIB.
+#   NOBLK : plane GEMMs with single-level accumulation (-DICG_PLANES_BLOCKED=0)
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+SRC="$HERE/../ic_gan_amd/csrc"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-sometimes-uninitialized -Wno-uninitialized"
+mkdir -p "$HERE/obj"
+build_variant() {   # name, define, source file
+  /opt/rocm/bin/hipcc $FLAGS "$2" -c "$SRC/$3.hip" -o "$HERE/obj/$3_$1.o"
+  objs=""
+  for o in "$SRC"/obj/*.o; do
+    [ "$(basename "$o")" = "$3.o" ] || objs="$objs $o"
+  done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs "$HERE/obj/$3_$1.o" -o "$HERE/libdbg_$1.so"
+  echo "built $HERE/libdbg_$1.so"
+}
+for v in "$@"; do
+  case "$v" in
+    NOBLK) build_variant NOBLK -DICG_PLANES_BLOCKED=0 gemm_conv ;;
+    *) echo "unknown variant $v"; exit 1 ;;
+  esac
+done
