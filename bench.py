@@ -12,9 +12,14 @@ instance conditional BigGAN 256x256, ch 96, B = 64 per GPU (the configuration th
 288 GB MI355X).  Weights: the reference's orthogonal init; data: synthetic.
 
 Output: ONE JSON line on rank 0 (see the driver contract) with two extra objects:
-  roofline     — for the dominant kernel (the fp32-MFMA implicit-GEMM convolution): algorithmic FLOPs (2*M*N*K per
-                 launch, the reference op graph's count) / HIP-event time of those launches inside the timed region
-  cpu_baseline — the CPU oracle ("port") timed on this box's host cores on a bounded sample of the same workload
+  roofline     — for the dominant kernel by time (an fp32-MFMA GEMM): FLOPs the kernel EXECUTED per launch / its average
+                 launch duration (HIP events on the launch stream, inside the timed region) / the 157.3 TFLOP/s fp32-MFMA
+                 peak = `frac`.  The same time priced on the reference op graph's FLOPs is `algorithmic_tflops` (above the
+                 peak where Winograd / resample-fused identities remove multiply-adds: `algorithmic_speedup`).
+                 `roofline.step` prices the whole step: executed TFLOP at the MFMA peak vs measured HBM GB at 8 TB/s.
+  cpu_baseline — the CPU oracle ("port": oracle/biggan_oracle.py, pinned to reference-generated goldens incl. the real
+                 widths) timed on this box's host cores on a bounded sample of the same workload; the unmodified reference
+                 cannot be timed here (/root/reference does not exist on the GPU box)
 """
 import argparse
 import json
@@ -31,6 +36,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable by a float4 copy)
 
 WORKLOADS = {
     # name: (config overrides, per-GPU batch)
@@ -178,15 +184,20 @@ class KernelTimer:
 def measured_traffic(kname):
     """HBM bytes per launch of `kname` from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE
     / --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction; tools/pmc_hbm.py writes the
-    summary).  PMC collection cannot run inside the timed process, hence the file; None when it is absent."""
+    summary).  PMC collection cannot run inside the timed process, hence the file; None when it is absent.
+    -> (bytes per launch of kname, source string, HBM GB per training step over ALL kernels, commit the file was taken at)"""
     import glob
     paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_hbm_traffic.json")))
     try:
         with open(paths[-1]) as f:
             table = json.load(f)
-        return table["kernels"][kname]["hbm_bytes_per_launch"], table.get("source")
-    except (OSError, KeyError, ValueError, IndexError):
-        return None, None
+    except (OSError, ValueError, IndexError):
+        return None, None, None, None
+    per_launch = table.get("kernels", {}).get(kname, {}).get("hbm_bytes_per_launch")
+    steps = table.get("steps_profiled", 3)          # r01 file: `--steps 2 --warmup 1` = 3 steps in the profiled process
+    total = sum(k["launches"] * k["hbm_bytes_per_launch"] for k in table.get("kernels", {}).values())
+    src = "%s [%s, measured at commit %s]" % (table.get("source"), os.path.basename(paths[-1]), table.get("commit", "23abb1c (round 1)"))
+    return per_launch, src, round(total / steps / 1e9, 1), table.get("commit", "23abb1c")
 
 
 def build_models(cfg, device, init_mode="ortho"):
@@ -437,7 +448,7 @@ def bench_biggan_deep(args, device, rank, world, local_rank, use_ddp):
             "roofline": None, "cpu_baseline": None}), flush=True)
 
 
-def cpu_baseline(cfg, name):
+def cpu_baseline(cfg, name, budget_s=25.0):
     """CPU oracle (restatement of the reference step, pinned to reference goldens) on this box's host cores."""
     from oracle import biggan_oracle as O, synth
     import ic_gan_amd.BigGAN as M
@@ -457,15 +468,16 @@ def cpu_baseline(cfg, name):
     samp = synth.CondSampler(cfg, dim_z, b, 3)
     x, y, f = synth.synth_batch(cfg, b, seed=4)
     times = []
-    t_end = time.time() + 25.0
+    t_end = time.time() + budget_s
     while len(times) < 3 and (not times or time.time() + times[-1] < t_end):
         t0 = time.time()
         O.train_step(gsd, dsd, ema_sd, cfg, og, od, x, y, f, samp, len(times) + 1, b)
         times.append(time.time() - t0)
     t = min(times)
     return {"value": round(b / t, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{name} shape, batch {b}, best of {len(times)} step(s) of oracle.biggan_oracle.train_step "
-                      f"(PyTorch CPU fp32), {t:.2f} s/step"}
+            "reference_unavailable_on_gpu_box": True,
+            "sample": f"{name} shape, batch {b}" + (" (full batch)" if name == "cfg1" else " (reduced batch, images/sec scale ~linearly)")
+                      + f", best of {len(times)} step(s) of oracle.biggan_oracle.train_step (PyTorch CPU fp32), {t:.2f} s/step"}
 
 
 def main():
@@ -488,7 +500,12 @@ def main():
     if args.cpu_baseline_only:          # child process of the N=1 run: bounded CPU sample, prints one JSON object
         cfg = dict(BASE_CFG)
         cfg.update(WORKLOADS[args.workload][0])
-        print("CPU_BASELINE " + json.dumps(cpu_baseline(cfg, args.workload)), flush=True)
+        res = cpu_baseline(cfg, args.workload)
+        if args.workload != "cfg1":          # cfg1 (the reference's CPU-runnable configuration) at its full batch of 8
+            c1 = dict(BASE_CFG)
+            c1.update(WORKLOADS["cfg1"][0])
+            res["cfg1_full_batch"] = cpu_baseline(c1, "cfg1", budget_s=8.0)
+        print("CPU_BASELINE " + json.dumps(res), flush=True)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -573,18 +590,29 @@ def main():
         if agg:
             variant, (flops, secs, n, exe, byt) = max(((k, v) for k, v in agg.items() if not k.startswith("composite:")),
                                                       key=lambda kv: kv[1][1])
-            ach = flops / secs / 1e12
-            traffic, traffic_src = measured_traffic(variant)
-            # `achieved` counts ALGORITHMIC FLOPs (the reference op graph: the 3x3 conv that follows a nearest x2
-            # upsample is counted on the upsampled tensor); `executed_tflops` is what the MFMA pipe really ran (the
-            # 4-phase form of those layers executes 16/36 of the algorithmic MACs), i.e. the hardware utilisation.
-            roof = {"bound": "mfma", "kernel": variant, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            traffic, traffic_src, step_hbm_gb, _ = measured_traffic(variant)
+            alg_tf, exe_tf = flops / secs / 1e12, exe / secs / 1e12
+            # Roofline of the dominant kernel = what the MFMA pipe EXECUTED / its HIP-event time / the fp32 MFMA peak.  The
+            # same time priced on the reference op graph's FLOPs (3x3 conv counted directly, on the upsampled tensor where
+            # the reference upsamples first) is reported as `algorithmic_tflops`; their ratio is the algebraic saving
+            # (Winograd F(4x4,3x3): 144/36, resample-fused 25-plane form: 144/25, 2x2-phase / 4x4-stride-2 forms: 36/16).
+            step_exe = sum(r[2] for r in timer.records) / args.steps         # entry-point level: no double counting
+            step_ms = elapsed / args.steps * 1e3
+            t_mfma = step_exe / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e3
+            t_hbm = (step_hbm_gb / PEAK_HBM_GBPS * 1e3) if step_hbm_gb else None
+            roof = {"bound": "mfma", "kernel": variant, "achieved": round(exe_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(exe_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(byt / n),
-                    "executed_tflops": round(exe / secs / 1e12, 2),
-                    "executed_frac": round(exe / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                    "algorithmic_tflops": round(alg_tf, 2), "algorithmic_speedup": round(alg_tf / exe_tf, 3),
                     "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
-                    "flops_per_launch_avg": round(flops / n / 1e9, 3),
+                    "executed_gflop_per_launch_avg": round(exe / n / 1e9, 3),
+                    # whole step against its own binding roof: executed conv/GEMM work at the MFMA peak vs measured HBM
+                    # traffic (all kernels, PMC passes of the same command) at 8 TB/s
+                    "step": {"executed_tflop": round(step_exe / 1e12, 2), "hbm_gb_measured": step_hbm_gb,
+                             "t_mfma_ms": round(t_mfma, 1), "t_hbm_ms": (round(t_hbm, 1) if t_hbm else None),
+                             "ms_per_step": round(step_ms, 2),
+                             "frac": round(max(t_mfma, t_hbm or 0.0) / step_ms, 4),
+                             "frac_if_serial": round((t_mfma + (t_hbm or 0.0)) / step_ms, 4)},
                     "all_conv_kernels": {k: {"algorithmic_tflops": round(v[0] / v[1] / 1e12, 2),
                                              "executed_tflops": round(v[3] / v[1] / 1e12, 2),
                                              "ms_per_step": round(v[1] / args.steps * 1e3, 2),
@@ -597,10 +625,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: IC-GAN BigGAN {cfg['resolution']}x{cfg['resolution']} ch={cfg['G_ch']}"
-                                   f" class_cond={cfg['class_cond']} instance_cond={cfg['instance_cond']} hier attn@64,"
+                                   f" class_cond={cfg['class_cond']} instance_cond={cfg['instance_cond']} hier attn@{cfg['G_attn']},"
                                    f" 1 D step + 1 G step + Adam x2 + EMA, fp32 exact MFMA",
                        "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
-                       "init": init, "sync_bn": bool(args.sync_bn), "winograd": not args.no_winograd,
+                       "rccl_world_size": (dist.get_world_size() if use_ddp else 1), "init": init, "sync_bn": bool(args.sync_bn), "winograd": not args.no_winograd,
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "losses_last_step": metrics},
             "roofline": roof,
         }

@@ -21,6 +21,9 @@
 #ifndef ICG_PLANES_BLOCKED
 #define ICG_PLANES_BLOCKED 1     // two-level accumulation in the Winograd-plane GEMMs (0: ablation build of tools/)
 #endif
+#ifndef ICG_PLANES_FLUSH_TILES
+#define ICG_PLANES_FLUSH_TILES 2 // K-tiles (of 16) per first-level chain
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -659,9 +662,11 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
     cur = nxt;
   };
   if (BLK) {
-    for (int kt = 0; kt < nk; kt += 2) {
+    for (int kt = 0; kt < nk; kt += ICG_PLANES_FLUSH_TILES) {
       tile_body(kt, std::true_type{});
-      if (kt + 1 < nk) tile_body(kt + 1, std::false_type{});
+#pragma unroll
+      for (int h = 1; h < ICG_PLANES_FLUSH_TILES; ++h)
+        if (kt + h < nk) tile_body(kt + h, std::false_type{});
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[j] += acc2[j];

@@ -119,6 +119,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, const float*
   float mean, invstd;
   if (training) {
     const double k = kshift ? (double)kshift[c] : 0.0;   // read before the running mean is overwritten
+    if (count <= 0.0) count = sums[2 * C];                // packed cross-replica payload [sum, sumsq, n] (icg_bn_sync_pack)
     const double m1 = sums[c] / count;
     double var = sums[C + c] / count - m1 * m1;
     if (var < 0.0) var = 0.0;
@@ -174,11 +175,34 @@ extern "C" int icg_bn_finalize(const double* sums, const float* shift_k, double 
                                const float* bias, int gb_rows, float gain_offset, int C, float* mean, float* invstd,
                                float* scale, float* shift, void* stream) {
   ICG_REQUIRE(C > 0 && mean && invstd && scale && shift && gb_rows >= 1);
-  if (training) ICG_REQUIRE(sums && count > 0);
+  if (training) ICG_REQUIRE(sums != nullptr);          // count <= 0: the element count is sums[2*C] (device side)
   else ICG_REQUIRE(running_mean && running_var);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)icg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, sums,
                      shift_k, count, running_mean, running_var, momentum, eps, training, gain, bias, gb_rows,
                      gain_offset, C, mean, invstd, scale, shift);
+  return icg_check_launch();
+}
+
+// Cross-replica BN payload: the per-replica sums are taken about each replica's own shift k (its running mean), so they are
+// moved to the common origin 0 in fp64 before the all-reduce, and the element count travels with them:
+//   payload = [ sum x (C) | sum x^2 (C) | n ],   sum x = S1 + n k,  sum x^2 = S2 + 2 k S1 + n k^2
+// (fp64: the cancellation in var = E[x^2] - E[x]^2 costs ~1e-16 * mean^2/var, far below fp32 resolution)
+__global__ void bn_sync_pack_kernel(const double* __restrict__ sums, const float* __restrict__ kshift, double n, int C,
+                                    double* __restrict__ payload) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) payload[2 * C] = n;
+  if (c >= C) return;
+  const double k = kshift ? (double)kshift[c] : 0.0;
+  const double s1 = sums[c], s2 = sums[C + c];
+  payload[c] = s1 + n * k;
+  payload[C + c] = s2 + 2.0 * k * s1 + n * k * k;
+}
+
+extern "C" int icg_bn_sync_pack(const double* sums, const float* shift_k, double local_count, int C, double* payload,
+                                void* stream) {
+  ICG_REQUIRE(sums && payload && C > 0 && local_count > 0);
+  hipLaunchKernelGGL(bn_sync_pack_kernel, dim3((unsigned)icg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, sums,
+                     shift_k, local_count, C, payload);
   return icg_check_launch();
 }
 
@@ -347,6 +371,7 @@ __global__ void bn_bwd_coefs_kernel(const float* __restrict__ sum_dy, const floa
   }
   float ca = 0.f, cb = 0.f;
   if (batch_stats) {
+    if (count <= 0.0) count = chan[2 * C];               // global element count kept on the device (cross-replica BN)
     ca = (float)((double)is * chan[c] / count);
     cb = (float)((double)is * (double)is * chan[C + c] / count);
   }
@@ -432,7 +457,7 @@ extern "C" int icg_bn_bwd_coefs(const float* sum_dy, const float* sum_dyx, const
                                 const float* invstd, double count, int batch_stats, int gb_rows, int B, int C,
                                 float* dgain, float* dbias, float* coefA, float* coefB, void* stream) {
   ICG_REQUIRE(sum_dy && sum_dyx && invstd && coefA && coefB && B > 0 && C > 0 && gb_rows >= 1);
-  if (batch_stats) ICG_REQUIRE(chan_sums && count > 0);
+  if (batch_stats) ICG_REQUIRE(chan_sums != nullptr);
   hipLaunchKernelGGL(bn_bwd_coefs_kernel, dim3((unsigned)icg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, sum_dy,
                      sum_dyx, chan_sums, invstd, count, batch_stats, gb_rows, B, C, dgain, dbias, coefA, coefB);
   return icg_check_launch();

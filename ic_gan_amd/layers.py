@@ -347,12 +347,27 @@ class GBlock(nn.Module):
 
     def forward(self, x, y):
         up = bool(self.upsample)
+        o1, o2 = self.bn1.bn_opt(), self.bn2.bn_opt()
+        if ops._sync_enabled(o1):
+            return self._forward_sync(x, y, up, o1, o2)
         g1, b1 = self.bn1.affine(y) if isinstance(self.bn1, ccbn) else (self.bn1.gain, self.bn1.bias)
         g2, b2 = self.bn2.affine(y) if isinstance(self.bn2, ccbn) else (self.bn2.gain, self.bn2.bias)
         # 1x1 shortcut commutes with nearest upsampling: run it at the input resolution
         sc = self.conv_sc(x) if self.learnable_sc else x
-        h = self.conv1(x, relu=True, upsample=up, bn=self.bn1.bn_opt(), gain=g1, beta=b1)
-        return self.conv2(h, relu=True, bn=self.bn2.bn_opt(), gain=g2, beta=b2, residual=sc, res_up=up)
+        h = self.conv1(x, relu=True, upsample=up, bn=o1, gain=g1, beta=b1)
+        return self.conv2(h, relu=True, bn=o2, gain=g2, beta=b2, residual=sc, res_up=up)
+
+    def _forward_sync(self, x, y, up, o1, o2):
+        """Cross-replica BN: same arithmetic, launch order chosen so that each statistic all-reduce (latency-bound, on
+        RCCL's stream) has independent kernels to hide behind -- bn1's behind the four conditioning projections, bn2's
+        behind the 1x1 shortcut convolution."""
+        st1 = ops.bn_stats_begin(x, o1)
+        g1, b1 = self.bn1.affine(y) if isinstance(self.bn1, ccbn) else (self.bn1.gain, self.bn1.bias)
+        g2, b2 = self.bn2.affine(y) if isinstance(self.bn2, ccbn) else (self.bn2.gain, self.bn2.bias)
+        h = self.conv1(x, relu=True, upsample=up, bn=o1, gain=g1, beta=b1, bn_stats=st1)
+        st2 = ops.bn_stats_begin(h, o2)
+        sc = self.conv_sc(x) if self.learnable_sc else x
+        return self.conv2(h, relu=True, bn=o2, gain=g2, beta=b2, residual=sc, res_up=up, bn_stats=st2)
 
 
 class DBlock(nn.Module):

@@ -279,6 +279,22 @@ class ConvOpt:
     res_up: bool = False
     bn: Optional[BNOpt] = None
     downsample: bool = False    # conv3x3 -> 2x2 average pool, run as one 4x4/stride-2 conv (needs sn.w_down)
+    bn_stats: object = None     # BNStats started ahead by bn_stats_begin (cross-replica BN: all-reduce in flight)
+
+
+@dataclass
+class BNStats:
+    """Training-mode batch statistics of one BN input, possibly still being all-reduced across replicas."""
+    x: torch.Tensor              # the channels-last tensor the statistics were taken of
+    sums: torch.Tensor           # double[2C] about `shift`, or the packed cross-replica payload double[2C+1] about 0
+    shift: Optional[torch.Tensor]
+    count: float                 # element count per channel; 0.0 = on the device, sums[2C] (cross-replica)
+    work: object = None          # pending torch.distributed work of the all-reduce
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()     # RCCL: the current stream waits for the collective's stream; gloo: host wait
+            self.work = None
 
 
 def _sync_enabled(bn: Optional[BNOpt]) -> bool:
@@ -312,8 +328,13 @@ class FusedConvFn(Function):
         count = float(B * Hs * Ws)
         bn = opt.bn
         gb_rows = 1
+        count_dev = None
         if bn is not None:
-            gain, beta, gb_rows, ssb, count, mean, invstd, scale, shift = _bn_forward_stats(x, bn, gain, beta)
+            if opt.bn_stats is not None:
+                x = opt.bn_stats.x            # the channels-last tensor the statistics were started on (same values)
+            gain, beta, gb_rows, ssb, count, count_dev, mean, invstd, scale, shift = _bn_forward_stats(x, bn, gain, beta,
+                                                                                                      opt.bn_stats)
+            opt.bn_stats = None
             flags |= L.ICG_PRE_AFFINE
         res = None
         fflags = flags
@@ -363,12 +384,12 @@ class FusedConvFn(Function):
         ctx.opt, ctx.flags, ctx.dims = opt, flags, (B, Cin, Hs, Ws, H, W, Cout, R, gb_rows, ssb, count)
         ctx.has = (bias is not None, residual is not None, gain is not None, beta is not None)
         ctx.weight_like = weight
-        ctx.save_for_backward(x, scale, shift, mean, invstd, gain)
+        ctx.save_for_backward(x, scale, shift, mean, invstd, gain, count_dev)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, scale, shift, mean, invstd, gain = ctx.saved_tensors
+        x, scale, shift, mean, invstd, gain, count_dev = ctx.saved_tensors
         opt, flags = ctx.opt, ctx.flags
         sn, bn = opt.sn, opt.bn
         B, Cin, Hs, Ws, H, W, Cout, R, gb_rows, ssb, count = ctx.dims
@@ -377,6 +398,7 @@ class FusedConvFn(Function):
         dout = _cl(dout)
         need = ctx.needs_input_grad
         dx = dweight = dbias = dres = dgain = dbeta = None
+        bn_state = None
         if need[0] or (bn is not None and (need[4] or need[5])):
             if ctx.down:
                 if (sn.w_wino_dgrad if sn.rs[1] else sn.w_down_dgrad) is None:
@@ -406,15 +428,16 @@ class FusedConvFn(Function):
                 else:
                     _conv_fprop(dout, sn.w_dgrad, None, None, da, None, None, 0, B, H, W, Cout, Cin, R, 0)
             if bn is not None:
-                dx, dgain, dbeta = _bn_backward(x, da, bn, gain, scale, shift, ssb, mean, invstd, gb_rows, count,
-                                                flags, has_gain, has_beta, (B, Cin, Hs, Ws))
+                # stages 1-2 now (+ the cross-replica all-reduce of the channel sums, asynchronous); stages 3-4 after the
+                # weight / bias gradients below, which do not depend on them and overlap the collective
+                bn_state = _bn_backward_begin(x, da, bn, gain, scale, shift, ssb, mean, invstd, gb_rows, count_dev, flags,
+                                              (B, Cin, Hs, Ws))
+                bn_flags = flags
             elif opt.relu or (opt.upsample and not ctx.phase):
                 dx = _empty_cl(B, Cin, Hs, Ws, dev)
                 L.call("icg_bn_bwd_apply", x, da, None, None, 0, None, None, None, B, Hs, Ws, Cin, flags, dx)
             else:
                 dx = da
-            if not need[0]:
-                dx = None
         if need[1] and (ctx.down or ctx.phase) and sn.rs[2]:
             # weight gradient of the resample-fused layer in the 25-plane domain: plain HWIO 3x3 result
             dw_hwio = _f32(9 * Cin * Cout, dev)
@@ -476,11 +499,43 @@ class FusedConvFn(Function):
                 L.call("icg_sumpool2_fwd", dout, dres, B, H, W, Cout)
             else:
                 dres = dout
+        if bn_state is not None:
+            dx, dgain, dbeta = _bn_backward_end(bn_state, x, da, bn, scale, shift, ssb, mean, invstd, gb_rows, count,
+                                                bn_flags, has_gain, has_beta, (B, Cin, Hs, Ws))
+        if not need[0]:
+            dx = None
         return dx, dweight, dbias, dres, dgain, dbeta, None
 
 
-def _bn_forward_stats(x, bn: BNOpt, gain, beta):
-    """Statistics + finalize shared by the fused and the stand-alone normalisation."""
+def bn_stats_begin(x, bn: BNOpt) -> Optional[BNStats]:
+    """Start the training-mode statistics of `x`.  With cross-replica BN (sync_bn) the packed payload [sum x | sum x^2 | n]
+    (icg_bn_sync_pack: common origin, count on the device) is all-reduced asynchronously: RCCL runs it on its own stream
+    behind an event on the current one, so every kernel launched between this call and the consumer's BNStats.wait()
+    overlaps the (latency-bound, <= 12 KB) collective.  Replaces the master/slave exchange of
+    sync_batchnorm/batchnorm.py:148-193.  Returns None in eval mode (running statistics)."""
+    if not bn.training:
+        return None
+    x = _cl(x)
+    B, C, Hs, Ws = x.shape
+    dev = x.device
+    rows = B * Hs * Ws
+    nb = L.query("icg_bn_workspace_bytes", rows, C)
+    ws = _bytes(nb, dev)
+    L.call("icg_bn_partial_stats", x, bn.running_mean, rows, C, ws, nb)
+    sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
+    L.call("icg_bn_reduce_partials", ws, rows, C, sums)
+    if not _sync_enabled(bn):
+        return BNStats(x, sums, bn.running_mean, float(rows))
+    payload = torch.empty(2 * C + 1, device=dev, dtype=torch.float64)
+    L.call("icg_bn_sync_pack", sums, bn.running_mean, float(rows), C, payload)
+    work = dist.all_reduce(payload, group=_group(bn), async_op=True)
+    return BNStats(x, payload, None, 0.0, work)
+
+
+def _bn_forward_stats(x, bn: BNOpt, gain, beta, stats: Optional[BNStats] = None):
+    """Statistics + finalize shared by the fused and the stand-alone normalisation.
+    -> (..., count, count_dev, ...): count is the host-side element count (0.0 under cross-replica BN, where the global count
+    stays on the device as the 1-element tensor count_dev)."""
     B, C, Hs, Ws = x.shape
     dev = x.device
     gb_rows = 1
@@ -493,38 +548,51 @@ def _bn_forward_stats(x, bn: BNOpt, gain, beta):
     scale, shift = _f32(gb_rows * C, dev), _f32(gb_rows * C, dev)
     ssb = C if gb_rows > 1 else 0
     count = float(B * Hs * Ws)
-    sums = None
+    sums = shift_k = count_dev = None
     if bn.training:
-        rows = B * Hs * Ws
-        nb = L.query("icg_bn_workspace_bytes", rows, C)
-        ws = _bytes(nb, dev)
-        L.call("icg_bn_partial_stats", x, bn.running_mean, rows, C, ws, nb)
-        sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
-        L.call("icg_bn_reduce_partials", ws, rows, C, sums)
-        if _sync_enabled(bn):
-            # equal per-replica batch (DDP): the global count needs no exchange and no host sync
-            dist.all_reduce(sums, group=_group(bn))
-            count = float(rows) * dist.get_world_size(_group(bn))
-    L.call("icg_bn_finalize", sums, bn.running_mean, count, bn.running_mean, bn.running_var, float(bn.momentum),
+        if stats is None:
+            stats = bn_stats_begin(x, bn)
+        elif stats.x.data_ptr() != x.data_ptr() or stats.x.shape != x.shape:
+            raise RuntimeError("bn_stats were started on a different tensor than the one being normalised")
+        stats.wait()
+        sums, shift_k, count = stats.sums, stats.shift, stats.count
+        if count <= 0.0:
+            count_dev = sums[2 * C:]
+    else:
+        shift_k = bn.running_mean
+    L.call("icg_bn_finalize", sums, shift_k, count, bn.running_mean, bn.running_var, float(bn.momentum),
            float(bn.eps), int(bn.training), gain, beta, gb_rows, float(bn.gain_offset), C, mean, invstd, scale, shift)
-    return gain, beta, gb_rows, ssb, count, mean, invstd, scale, shift
+    return gain, beta, gb_rows, ssb, count, count_dev, mean, invstd, scale, shift
 
 
-def _bn_backward(x, da, bn: BNOpt, gain, scale, shift, ssb, mean, invstd, gb_rows, count, flags, has_gain, has_beta,
-                 dims):
-    """Shared BN backward: returns dx, dgain, dbeta (see include/icgan_hip.h, stages 1-4)."""
+def _bn_backward_begin(x, da, bn: BNOpt, gain, scale, shift, ssb, mean, invstd, gb_rows, count_dev, flags, dims):
+    """Stages 1-2 of the BN backward (include/icgan_hip.h) and, under cross-replica BN, the start of the asynchronous
+    all-reduce of the per-channel sums; -> state for _bn_backward_end.  Work launched in between overlaps the collective."""
     B, C, Hs, Ws = dims
     dev = x.device
     nb = L.query("icg_bn_bwd_workspace_bytes", B, Hs, Ws, C)
     ws = _bytes(nb, dev)
     sd, sx = _f32(B * C, dev), _f32(B * C, dev)
     L.call("icg_bn_bwd_reduce", x, da, scale, shift, ssb, mean, B, Hs, Ws, C, flags, ws, nb, sd, sx)
-    chan = None
+    chan = work = None
     if bn.training:
-        chan = torch.empty(2 * C, device=dev, dtype=torch.float64)
+        chan = torch.empty(2 * C + 1, device=dev, dtype=torch.float64)
         L.call("icg_bn_bwd_channel_sums", sd, sx, gain, gb_rows, float(bn.gain_offset), invstd, B, C, chan)
-        if _sync_enabled(bn):
-            dist.all_reduce(chan, group=_group(bn))
+        if count_dev is not None:
+            chan[2 * C:].copy_(count_dev)            # global element count of the forward (device side)
+            if _sync_enabled(bn):
+                work = dist.all_reduce(chan[: 2 * C], group=_group(bn), async_op=True)
+    return sd, sx, chan, work
+
+
+def _bn_backward_end(state, x, da, bn: BNOpt, scale, shift, ssb, mean, invstd, gb_rows, count, flags, has_gain, has_beta,
+                     dims):
+    """Stages 3-4: -> dx, dgain, dbeta."""
+    sd, sx, chan, work = state
+    B, C, Hs, Ws = dims
+    dev = x.device
+    if work is not None:
+        work.wait()
     dgain = _f32(gb_rows * C, dev).view(gb_rows, C) if has_gain else None
     dbeta = _f32(gb_rows * C, dev).view(gb_rows, C) if has_beta else None
     coef_a, coef_b = _f32(C, dev), _f32(C, dev)
@@ -535,6 +603,13 @@ def _bn_backward(x, da, bn: BNOpt, gain, scale, shift, ssb, mean, invstd, gb_row
     return dx, dgain, dbeta
 
 
+def _bn_backward(x, da, bn: BNOpt, gain, scale, shift, ssb, mean, invstd, gb_rows, count, count_dev, flags, has_gain,
+                 has_beta, dims):
+    """Shared BN backward: returns dx, dgain, dbeta (see include/icgan_hip.h, stages 1-4)."""
+    st = _bn_backward_begin(x, da, bn, gain, scale, shift, ssb, mean, invstd, gb_rows, count_dev, flags, dims)
+    return _bn_backward_end(st, x, da, bn, scale, shift, ssb, mean, invstd, gb_rows, count, flags, has_gain, has_beta, dims)
+
+
 class NormActFn(Function):
     """Stand-alone  y = relu?(BN(x)*gain + bias)  (ccbn.forward / bn.forward called outside a fused block)."""
 
@@ -543,20 +618,20 @@ class NormActFn(Function):
         _require_gpu(x)
         x = _cl(x)
         B, C, H, W = x.shape
-        gain, beta, gb_rows, ssb, count, mean, invstd, scale, shift = _bn_forward_stats(x, bn, gain, beta)
+        gain, beta, gb_rows, ssb, count, count_dev, mean, invstd, scale, shift = _bn_forward_stats(x, bn, gain, beta)
         flags = L.ICG_PRE_AFFINE | (L.ICG_PRE_RELU if relu else 0)
         y = torch.empty_like(x)
         L.call("icg_bn_apply", x, scale, shift, ssb, B, H * W, C, flags, y)
         ctx.bn, ctx.meta = bn, (gb_rows, ssb, count, flags, gain is not None, beta is not None, (B, C, H, W))
-        ctx.save_for_backward(x, scale, shift, mean, invstd, gain)
+        ctx.save_for_backward(x, scale, shift, mean, invstd, gain, count_dev)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, scale, shift, mean, invstd, gain = ctx.saved_tensors
+        x, scale, shift, mean, invstd, gain, count_dev = ctx.saved_tensors
         gb_rows, ssb, count, flags, has_gain, has_beta, dims = ctx.meta
         dx, dgain, dbeta = _bn_backward(x, _cl(dy), ctx.bn, gain, scale, shift, ssb, mean, invstd, gb_rows, count,
-                                        flags, has_gain, has_beta, dims)
+                                        count_dev, flags, has_gain, has_beta, dims)
         return dx, dgain, dbeta, None, None
 
 
@@ -567,10 +642,10 @@ def norm_act(x, bn: BNOpt, gain, beta, relu=False):
 
 
 def fused_conv(x, weight, bias, sn: SNState, *, relu=False, upsample=False, residual=None, res_up=False,
-               bn: Optional[BNOpt] = None, gain=None, beta=None, downsample=False):
+               bn: Optional[BNOpt] = None, gain=None, beta=None, downsample=False, bn_stats: Optional[BNStats] = None):
     """conv(act(x)) with act = [BN affine] -> [ReLU] -> [nearest x2]; `gain`/`beta` are [B,C] (ccbn) or [C] (bn);
     downsample=True appends the 2x2 average pool (residual is then at the pooled resolution)."""
-    opt = ConvOpt(sn=sn, relu=relu, upsample=upsample, res_up=res_up, bn=bn, downsample=downsample)
+    opt = ConvOpt(sn=sn, relu=relu, upsample=upsample, res_up=res_up, bn=bn, downsample=downsample, bn_stats=bn_stats)
     if bn is not None:
         g2 = gain if gain is None or gain.dim() == 2 else gain.view(1, -1)
         b2 = beta if beta is None or beta.dim() == 2 else beta.view(1, -1)

@@ -265,6 +265,12 @@ int icg_bn_reduce_partials(const void* workspace, int64_t rows, int C, double* s
  * gain/bias (and scale/shift) are [gb_rows][C] (gb_rows in {1,B}); gain_offset is added to gain
  * (ccbn: 1 + gain(y)).  shift_k may alias running_mean.
  */
+/* Cross-replica BN (the all-reduce semantics of sync_batchnorm/batchnorm.py:148-193 re-expressed for one process per GPU):
+ * payload double[2*C + 1] = [sum x | sum x^2 | n], un-shifted (common origin) so that replicas with different running
+ * means can be summed; all-reduce(sum) it over the replicas, then call icg_bn_finalize(payload, NULL, 0.0, ...):
+ * count <= 0 means "the element count is sums[2*C]" (stays on the device: no host sync, unequal per-replica batches allowed).
+ * The same convention holds for icg_bn_bwd_coefs (count <= 0: chan_sums[2*C]). */
+int icg_bn_sync_pack(const double* sums, const float* shift_k, double local_count, int C, double* payload, void* stream);
 int icg_bn_finalize(const double* sums, const float* shift_k, double count, float* running_mean,
                     float* running_var, float momentum, float eps, int training, const float* gain,
                     const float* bias, int gb_rows, float gain_offset, int C, float* mean,

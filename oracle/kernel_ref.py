@@ -379,6 +379,8 @@ def icg_bn_finalize(sums, shift_k, count, running_mean, running_var, momentum, e
                     gain_offset, C, mean, invstd, scale, shift):
     if training:
         k = mem(shift_k)[:C].double() if shift_k is not None else torch.zeros(C, dtype=torch.float64)
+        if count <= 0:
+            count = float(sums[2 * C])          # packed cross-replica payload (icg_bn_sync_pack)
         m1 = sums[:C] / count
         var = (sums[C: 2 * C] / count - m1 * m1).clamp_min(0.0)
         mu = k + m1
@@ -397,6 +399,14 @@ def icg_bn_finalize(sums, shift_k, count, running_mean, running_var, momentum, e
     sc = invstd.view(1, C) * g
     mem(scale)[: gb_rows * C].copy_(sc.reshape(-1))
     mem(shift)[: gb_rows * C].copy_((be - mean.view(1, C) * sc).reshape(-1))
+
+
+def icg_bn_sync_pack(sums, shift_k, local_count, C, payload):
+    k = mem(shift_k)[:C].double() if shift_k is not None else torch.zeros(C, dtype=torch.float64)
+    s1, s2 = sums[:C], sums[C: 2 * C]
+    payload[:C] = s1 + local_count * k
+    payload[C: 2 * C] = s2 + 2.0 * k * s1 + local_count * k * k
+    payload[2 * C] = local_count
 
 
 def icg_bn_apply(x, scale, shift, ss_bstride, B, HW, C, flags, y):
@@ -454,6 +464,8 @@ def icg_bn_bwd_coefs(sum_dy, sum_dyx, chan_sums, invstd, count, batch_stats, gb_
     if dbias is not None:
         mem(dbias)[: gb_rows * C].copy_(db.float().reshape(-1))
     if batch_stats:
+        if count <= 0:
+            count = float(chan_sums[2 * C])
         coefA.copy_((invstd.double() * chan_sums[:C] / count).float())
         coefB.copy_((invstd.double() ** 2 * chan_sums[C: 2 * C] / count).float())
     else:

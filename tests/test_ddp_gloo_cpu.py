@@ -83,35 +83,44 @@ def _worker_step(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _worker_syncbn(rank, world, port, out):
+def _worker_syncbn(rank, world, port, out, split=(2, 2), skew=False):
     from torch.nn.parallel import DistributedDataParallel as DDP
     _init(rank, world, port)
     cfg = dict(CFG, sync_bn=True)
     _, G, _ = _models(cfg)
-    Gd = DDP(G)
+    if skew and rank == 1:
+        # replicas whose running means differ (broadcast_buffers=False, per-rank checkpoint loads: ADVICE r1): the packed
+        # payload is taken to a common origin before the all-reduce, so the normalisation must not depend on them
+        with torch.no_grad():
+            for m in G.modules():
+                if hasattr(m, "stored_mean"):
+                    m.stored_mean.add_(0.37)
+    Gd = DDP(G, broadcast_buffers=not skew)
     B = 4
     c = synth.CondSampler(cfg, G.dim_z, B, 9)()
     z, lab, fg = c
     wts = torch.from_numpy(__import__("numpy").random.RandomState(3).standard_normal((B, 3, 32, 32))).float()
-    sl = slice(rank * B // world, (rank + 1) * B // world)
+    lo = sum(split[:rank])
+    sl = slice(lo, lo + split[rank])          # possibly UNEQUAL shards: the element count travels in the payload
     Gd.train()
     img = Gd(z[sl], lab[sl], fg[sl])
     (img * wts[sl]).sum().backward()
     grads = torch.cat([p.grad.reshape(-1) for p in G.parameters()])
-    imgs = [torch.empty_like(img) for _ in range(world)]
-    dist.all_gather(imgs, img.detach().contiguous())
+    full = torch.zeros(B, *img.shape[1:])
+    full[sl] = img.detach()
+    dist.all_reduce(full)
     if rank == 0:
-        out["img"] = torch.cat(imgs, 0)
+        out["img"] = full
         out["grads"] = grads.clone()
         out["rm"] = G.blocks[0][0].bn1.stored_mean.clone()
         out["rv"] = G.output_layer[0].stored_var.clone()
     dist.destroy_process_group()
 
 
-def _spawn(fn):
+def _spawn(fn, *extra):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(fn, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(fn, args=(2, _free_port(), out) + extra, nprocs=2, join=True)
     return dict(out)
 
 
@@ -122,8 +131,9 @@ def test_ddp_step_keeps_replicas_identical():
 
 
 @pytest.mark.timeout(600)
-def test_syncbn_two_ranks_equal_one_process_on_full_batch(monkeypatch):
-    out = _spawn(_worker_syncbn)
+@pytest.mark.parametrize("split,skew", [((2, 2), False), ((3, 1), False), ((2, 2), True)])
+def test_syncbn_two_ranks_equal_one_process_on_full_batch(monkeypatch, split, skew):
+    out = _spawn(_worker_syncbn, split, skew)
     kernel_ref.install(monkeypatch)
     cfg = dict(CFG, sync_bn=False)
     _, G, _ = _models(cfg)
@@ -136,7 +146,7 @@ def test_syncbn_two_ranks_equal_one_process_on_full_batch(monkeypatch):
     ((img * wts).sum() / 2).backward()          # DDP averages the two ranks' gradients
     grads = torch.cat([p.grad.reshape(-1) for p in G.parameters()])
     assert torch.allclose(out["img"], img.detach(), rtol=1e-4, atol=1e-5)
-    assert torch.allclose(out["rm"], G.blocks[0][0].bn1.stored_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out["rm"], G.blocks[0][0].bn1.stored_mean, rtol=1e-5, atol=1e-6)      # rank 0's buffers
     assert torch.allclose(out["rv"], G.output_layer[0].stored_var, rtol=1e-5, atol=1e-6)
     rel = float((out["grads"] - grads).norm() / grads.norm())
     assert rel < 1e-4, rel
