@@ -4,7 +4,8 @@
 
 Autograd mirrors the reference plugin's scheme (bias_act.py:231-317): the first-order gradient is the same kernel
 with grad=1 fed by the saved input/output, the second-order gradient (R1 / path-length regularisers,
-training/loss.py:126-131,182-187) is grad=2.  fp32, contiguous tensors; no fallback implementation."""
+training/loss.py:126-131,182-187) is grad=2.  fp16 / fp32 / fp64 storage with the plugin's internal arithmetic type (fp32,
+fp64 for double: bias_act.cu:18-21); contiguous or channels-last tensors; no fallback implementation."""
 from __future__ import annotations
 
 import numpy as np
@@ -25,6 +26,9 @@ activation_funcs = {
     "softplus": (8, 0.0, 1.0, "y", True),
     "swish": (9, 0.0, float(np.sqrt(2)), "x", True),
 }
+
+
+_DTYPES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
 
 
 def _is_cl(t, dim):
@@ -51,20 +55,24 @@ def _kernel(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
         return y
     step_b = (1 if cl else int(np.prod(x.shape[dim + 1:]))) if b is not None else 1
     size_b = b.numel() if b is not None else 1
-    L.call("icg_bias_act", x, b, xref, yref, dy, y, n, step_b, size_b, grad, act_id, float(alpha), float(gain),
-           float(clamp))
+    if x.dtype == torch.float32:
+        L.call("icg_bias_act", x, b, xref, yref, dy, y, n, step_b, size_b, grad, act_id, float(alpha), float(gain),
+               float(clamp))
+    else:
+        L.call("icg_bias_act_typed", x, b, xref, yref, dy, y, n, step_b, size_b, grad, act_id, float(alpha), float(gain),
+               float(clamp), _DTYPES[x.dtype])
     return y
 
 
 def bias_act(x, b=None, dim=1, act="linear", alpha=None, gain=None, clamp=None, impl="hip"):
-    assert isinstance(x, torch.Tensor) and x.dtype == torch.float32, "fp32 only"
+    assert isinstance(x, torch.Tensor) and x.dtype in _DTYPES, "float16 / float32 / float64 storage"
     act_id, def_alpha, def_gain, ref, has2 = activation_funcs[act]
     alpha = float(alpha if alpha is not None else def_alpha)
     gain = float(gain if gain is not None else def_gain)
     clamp = float(clamp if clamp is not None else -1)
     if b is not None:
         assert b.ndim == 1 and 0 <= dim < x.ndim and b.shape[0] == x.shape[dim]
-        b = b.contiguous().float()
+        b = b.contiguous().to(x.dtype)       # the plugin requires b.dtype == x.dtype (bias_act.cpp:46); callers cast likewise
     return _BiasAct.apply(x, b, dim, act_id, alpha, gain, clamp, ref, has2)
 
 

@@ -3,7 +3,8 @@
 
 Zero-insert upsample -> pad/crop -> 2-D FIR -> decimate -> gain, per channel.  The backward is another
 upfirdn2d with up/down swapped, the filter flipped and the adjoint padding (reference 329-346), so arbitrary-order
-gradients work.  fp32 NCHW; separable 1-D filters are expanded to their outer product."""
+gradients work.  fp16 / fp32 / fp64 storage (fp32 / fp64 accumulation), NCHW or channels-last; separable 1-D filters are
+expanded to their outer product."""
 from __future__ import annotations
 
 import numpy as np
@@ -11,6 +12,9 @@ import torch
 
 from .. import _lib as L
 from .. import ops as _ops
+
+
+_DTYPES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
 
 
 def _parse_scaling(scaling):
@@ -76,6 +80,15 @@ def _run(x, f2, up, down, padding, flip, gain):
     out_w = (w * upx + px0 + px1 - fw + downx) // downx
     out_h = (h * upy + py0 + py1 - fh + downy) // downy
     assert out_w >= 1 and out_h >= 1
+    if x.dtype != torch.float32:
+        # fp16 / fp64 storage (upfirdn2d.cu:208-344 templates the kernels on the dtype; accumulation in fp32 / fp64)
+        vec = 8 if x.dtype == torch.float16 else 2
+        cl = c % vec == 0 and fh * fw <= 256 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+        y = torch.empty((n, c, out_h, out_w), device=x.device, dtype=x.dtype,
+                        memory_format=torch.channels_last if cl else torch.contiguous_format)
+        L.call("icg_upfirdn2d_typed", x if cl else x.contiguous(), f2, y, n, c, h, w, fh, fw, upx, upy, downx, downy, px0, px1,
+               py0, py1, int(bool(flip)), float(gain), out_h, out_w, _DTYPES[x.dtype], int(cl))
+        return y
     if c % 4 == 0 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):
         # channels-last in, channels-last out: no layout change between the NHWC convolutions and the FIR resampling
         y = torch.empty((n, c, out_h, out_w), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
@@ -110,7 +123,7 @@ class _Upfirdn2d(torch.autograd.Function):
 
 
 def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl="hip"):
-    assert isinstance(x, torch.Tensor) and x.ndim == 4 and x.dtype == torch.float32
+    assert isinstance(x, torch.Tensor) and x.ndim == 4 and x.dtype in _DTYPES
     if f is not None:
         assert f.dtype == torch.float32 and not f.requires_grad
     up, down, padding = _parse_scaling(up), _parse_scaling(down), _parse_padding(padding)

@@ -433,6 +433,20 @@ int icg_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int H,
                   int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1,
                   int flip, float gain, int outH, int outW, void* stream);
 
+/*
+ * Storage-typed forms of the two plugins (the reference templates them on the tensor dtype: bias_act.cu:155-167,
+ * upfirdn2d.cu:208-344): dtype 0 = fp32 (forwards to the entries above), 1 = fp16, 2 = fp64.  Arithmetic runs in the
+ * plugin's internal type -- fp32 for fp16 / fp32 storage, fp64 for fp64 (bias_act.cu:18-21) -- with one rounding into y.
+ * b has the dtype of x (bias_act.cpp:46); the filter f is always fp32 (upfirdn2d.cpp:27).
+ * channels_last != 0: x / y are [N][H][W][C] in memory (C % 8 == 0 for fp16, % 2 for fp64, % 4 for fp32).
+ */
+int icg_bias_act_typed(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y,
+                       int64_t n, int64_t step_b, int size_b, int grad, int act, float alpha, float gain, float clamp,
+                       int dtype, void* stream);
+int icg_upfirdn2d_typed(const void* x, const float* f, void* y, int N, int C, int H, int W, int fh, int fw, int upx,
+                        int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
+                        int outH, int outW, int dtype, int channels_last, void* stream);
+
 /* the same operation on channels-last data: x [N][H][W][C], y [N][outH][outW][C], C % 4 == 0 (what the NHWC
  * convolutions produce and consume: no layout change between conv, FIR resampling and bias_act) */
 int icg_upfirdn2d_nhwc(const float* x, const float* f, float* y, int N, int C, int H, int W, int fh, int fw,

@@ -712,8 +712,10 @@ _ACTS = {1: lambda x, a: x, 2: lambda x, a: F.relu(x), 3: lambda x, a: F.leaky_r
 
 
 def icg_bias_act(x, b, xref, yref, dy, y, n, step_b, size_b, grad, act, alpha, gain, clamp):
-    """grad 0 only follows _bias_act_ref (bias_act.py:177-207); grad 1/2 are derived by autograd from it."""
+    """grad 0 only follows _bias_act_ref (bias_act.py:177-207); grad 1/2 are derived by autograd from it.  Works in the dtype
+    of x (fp32 here; icg_bias_act_typed passes fp64 buffers for fp64 storage)."""
     xv = mem(x)[:n]
+    ct = xv.dtype
     idx = (torch.arange(n) // step_b) % size_b if b is not None else None
     bias = mem(b)[idx] if b is not None else 0.0
     up = mem(dy)[:n] if dy is not None else 1.0
@@ -734,7 +736,8 @@ def icg_bias_act(x, b, xref, yref, dy, y, n, step_b, size_b, grad, act, alpha, g
             mem(y)[:n].zero_()
             return
         yv = mem(yref)[:n] if yref is not None else None
-        slope = torch.ones(n) if act == 1 else torch.where(yv > 0, torch.ones(n), torch.full((n,), alpha if act == 3 else 0.0))
+        one = torch.ones(n, dtype=ct)
+        slope = one if act == 1 else torch.where(yv > 0, one, torch.full((n,), alpha if act == 3 else 0.0, dtype=ct))
         g = xv * slope * gain
         if clamp >= 0:
             g = torch.where(yv.abs() < clamp, g, torch.zeros_like(g))
@@ -745,13 +748,55 @@ def icg_bias_act(x, b, xref, yref, dy, y, n, step_b, size_b, grad, act, alpha, g
         o = fwd(xr)
         (g1,) = torch.autograd.grad(o.sum(), xr, create_graph=True)
         if grad == 1:
-            mem(y)[:n].copy_((xv.double() * g1 * up).detach().float())
+            mem(y)[:n].copy_((xv.double() * g1 * up).detach().to(ct))
         else:
             g2 = None
             if g1.requires_grad:
                 (g2,) = torch.autograd.grad(g1.sum(), xr, allow_unused=True)
             g2 = torch.zeros_like(xr) if g2 is None else g2
-            mem(y)[:n].copy_((xv.double() * g2 * up).detach().float())
+            mem(y)[:n].copy_((xv.double() * g2 * up).detach().to(ct))
+
+
+_DT = {0: torch.float32, 1: torch.float16, 2: torch.float64}
+
+
+def _up(t, dtype):
+    """storage dtype -> the plugin's internal compute type (bias_act.cu:18-21: half -> float)"""
+    if t is None:
+        return None
+    return t.double() if dtype == 2 else t.float()
+
+
+def icg_bias_act_typed(x, b, xref, yref, dy, y, n, step_b, size_b, grad, act, alpha, gain, clamp, dtype):
+    """fp16 / fp64 storage: compute in the internal type, round once into y (bias_act.cu:26-150)."""
+    if dtype == 0:
+        return icg_bias_act(x, b, xref, yref, dy, y, n, step_b, size_b, grad, act, alpha, gain, clamp)
+    assert x.dtype == _DT[dtype] and y.dtype == _DT[dtype]
+    if dtype == 2:          # fp64 storage = fp64 arithmetic: the same routine on the fp64 buffers
+        return icg_bias_act(x, b, xref, yref, dy, y, n, step_b, size_b, grad, act, alpha, gain, clamp)
+    tmp = torch.empty(n, dtype=torch.float32)
+    f = lambda t: None if t is None else mem(t)[: (size_b if t is b else n)].float()
+    icg_bias_act(f(x), f(b), f(xref), f(yref), f(dy), tmp, n, step_b, size_b, grad, act, alpha, gain, clamp)
+    mem(y)[:n].copy_(tmp.to(_DT[dtype]))
+
+
+def icg_upfirdn2d_typed(x, f, y, N, C, H, W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, outH,
+                        outW, dtype, channels_last):
+    """accumulate in the internal type, round once (upfirdn2d.cu:32-95); channels_last: x / y are [N][H][W][C] in memory"""
+    ct = torch.float64 if dtype == 2 else torch.float32
+    xin = mem(x)[: N * C * H * W]
+    xin = xin.view(N, H, W, C).permute(0, 3, 1, 2).contiguous() if channels_last else xin.view(N, C, H, W)
+    tmp = torch.empty(N * C * outH * outW, dtype=ct)
+    if dtype == 2:
+        icg_upfirdn2d(xin.double().contiguous(), f, tmp, N, C, H, W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1,
+                      flip, gain, outH, outW)
+    else:
+        icg_upfirdn2d(xin.float().contiguous(), f, tmp, N, C, H, W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1,
+                      flip, gain, outH, outW)
+    out = tmp.view(N, C, outH, outW)
+    if channels_last:
+        out = out.permute(0, 2, 3, 1).contiguous()
+    mem(y)[: N * C * outH * outW].copy_(out.reshape(-1).to(_DT[dtype]))
 
 
 def icg_upfirdn2d(x, f, y, N, C, H, W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, outH, outW):
@@ -760,7 +805,7 @@ def icg_upfirdn2d(x, f, y, N, C, H, W, fh, fw, upx, upy, downx, downy, padx0, pa
     xv = F.pad(xv, [0, upx - 1, 0, 0, 0, upy - 1]).reshape(N, C, H * upy, W * upx)
     xv = F.pad(xv, [max(padx0, 0), max(padx1, 0), max(pady0, 0), max(pady1, 0)])
     xv = xv[:, :, max(-pady0, 0): xv.shape[2] - max(-pady1, 0), max(-padx0, 0): xv.shape[3] - max(-padx1, 0)]
-    ff = mem(f)[: fh * fw].view(fh, fw) * gain
+    ff = mem(f)[: fh * fw].view(fh, fw).to(xv.dtype) * gain
     if not flip:
         ff = ff.flip([0, 1])
     out = F.conv2d(xv, ff[None, None].repeat(C, 1, 1, 1), groups=C)[:, :, ::downy, ::downx]

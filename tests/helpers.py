@@ -89,6 +89,24 @@ def check_group(gold, prefix, tensors, rtol, atol, what="", noise_floor=2e-3, ex
 
 GRAD_RTOL = 1.5e-2     # of the tensor rms; the goldens' own fp32-vs-fp64 conditioning is <= 3.5e-3 (B = 4 cases)
 STATE_RTOL = 5e-3
+COND_K = 4.0           # real-width cases: + COND_K x |fp32 reference - fp64 reference| per tensor (see conditioning_slack)
+
+
+def conditioning_slack(case, grad_prefix):
+    """Per-tensor absolute slack = COND_K x the distance between the reference's fp32 gradient and the SAME reference run
+    in fp64 (tests/golden/biggan_<case>_f64.npz, make_golden_real_widths.py::run_case_f64), maximum over the fingerprint
+    samples.  At the real widths with batch 2 the fp32 reference itself is up to 0.8 x (GRAD_RTOL * rms) away from the
+    exact gradient on the first generator layers (cfg3: blocks.0.0.conv1.weight 0.82, linear.bias 0.71); no fp32
+    implementation with another summation order can be held to less than a small multiple of that.  {} when the case has
+    no fp64 companion file (the small-width goldens: plain GRAD_RTOL)."""
+    path = os.path.join(GOLDEN_DIR, f"biggan_{case}_f64.npz")
+    if not os.path.exists(path):
+        return {}
+    g32, g64 = load_golden(case), np.load(path, allow_pickle=False)
+    names = json.loads(str(g32[grad_prefix + "names"]))
+    assert names == json.loads(str(g64[grad_prefix + "names"]))
+    d = np.abs(g32[grad_prefix + "samp"] - g64[grad_prefix + "samp"]).max(axis=1)
+    return {n: COND_K * float(d[i]) for i, n in enumerate(names)}
 
 
 def adam_slack(gold, grad_prefix, lr, steps, names):
