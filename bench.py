@@ -43,6 +43,11 @@ WORKLOADS = {
     "cfg3": (dict(resolution=256, G_ch=96, D_ch=96, class_cond=True, instance_cond=True, G_attn="64", D_attn="64"), 64),
     "cfg2": (dict(resolution=128, G_ch=96, D_ch=96, class_cond=False, instance_cond=True, G_attn="64", D_attn="64"), 64),
     "cfg1": (dict(resolution=64, G_ch=64, D_ch=64, class_cond=False, instance_cond=True, G_attn="32", D_attn="32"), 8),
+    # BASELINE.json configs[4]: IC-GAN BigGAN-deep 256x256 ch=128 bs=128/GPU, attention at 64 -- the instance-conditioned
+    # extension of ic_gan_amd/BigGANdeep.py (the reference's BigGANdeep.py cannot train IC-GAN) driven by the same
+    # train_fns.GAN_training_function step (1 D + 1 G update, Adam x2, EMA)
+    "cfg5": (dict(model="BigGANdeep", resolution=256, G_ch=128, D_ch=128, G_depth=2, D_depth=2, dim_z=128, shared_dim=128,
+                  class_cond=False, instance_cond=True, G_attn="64", D_attn="64", G_lr=5e-5, D_lr=2e-4), 128),
 }
 BASE_CFG = dict(dim_z=120, shared_dim=128, shared_dim_feat=512, G_shared=True, G_shared_feat=True, hier=True,
                 n_classes=1000, SN_eps=1e-6, BN_eps=1e-5, adam_eps=1e-6, G_lr=4e-5, D_lr=1e-4, G_B1=0.0, G_B2=0.999,
@@ -58,15 +63,20 @@ class KernelTimer:
     library (icg_gemm_last_variant), so they can be compared line by line with profiles/*_kernel_stats.csv."""
 
     # entry point -> (index of B in the argument list, kind)
-    SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"), "icg_conv2d_wino4_fprop": (8, "wino4"), "icg_conv2d_wino_wgrad": (6, "wino"), "icg_conv2d_wino4_wgrad": (6, "wino4"), "icg_conv2d_wino4_wgrad_from_v": (3, "from_v"),
+    SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"), "icg_conv2d_wino4_fprop": (8, "wino4"), "icg_conv2d_wino_wgrad": (6, "wino"), "icg_conv2d_wino4_wgrad": (6, "wino4"), "icg_conv2d_wino4_wgrad_from_v": (3, "from_v"), "icg_conv2d_wino4_wgrad_from_v_db": (4, "from_v"),
             "icg_conv2d_up_wino_fprop": (7, "rs_up"), "icg_conv2d_up_wino_dgrad": (3, "rs_up"), "icg_conv2d_up_wino_wgrad": (6, "rs_up"),
             "icg_conv2d_down_wino_fprop": (5, "rs_down"), "icg_conv2d_down_wino_dgrad": (3, "rs_down"), "icg_conv2d_down_wino_wgrad": (3, "rs_down"),
             "icg_conv2d_wgrad": (6, "conv"), "icg_conv2d_up_fprop": (7, "up"),
             "icg_conv2d_up_dgrad": (3, "up"), "icg_conv2d_up_wgrad": (6, "up"), "icg_conv2d_down_fprop": (5, "up"),
-            "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_wgrad": (3, "up")}
+            "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_wgrad": (3, "up"),
+            # StyleGAN2 (cfg4): general-geometry convolutions and the two HBM-bound plugins
+            "icg_conv2d_g_fprop": (4, "gconv"), "icg_conv2d_g_fprop_ws": (4, "gconv"), "icg_conv2d_tr2_fprop": (4, "tr2"),
+            "icg_conv2d_g_wgrad": (3, "gconv"), "icg_bias_act": (6, "bias_act"), "icg_bias_act_typed": (6, "bias_act"),
+            "icg_upfirdn2d": (3, "upfirdn2d"), "icg_upfirdn2d_nhwc": (3, "upfirdn2d"), "icg_upfirdn2d_typed": (3, "upfirdn2d")}
 
     def __init__(self):
         self.records = []      # (kernel name, algorithmic flops, executed flops, algorithmic bytes, start, end)
+        self.hbm_records = []  # (op name, algorithmic bytes, start, end) of the HBM-bound StyleGAN2 plugins
         self.enabled = False
 
     def install(self):
@@ -81,7 +91,32 @@ class KernelTimer:
             if not timer.enabled or name not in timer.SPEC:
                 return raw(name, *args)
             sl, mode = timer.SPEC[name]
-            if mode == "conv":
+            if mode in ("bias_act", "upfirdn2d"):          # HBM-bound plugins: algorithmic bytes / HIP-event time
+                if mode == "bias_act":
+                    n = args[sl]
+                    esz = {1: 2, 2: 8}.get(args[-1], 4) if name.endswith("typed") else 4
+                    byt = float(n) * esz * (2 + sum(1 for a in args[2:5] if a is not None))     # x, y (+ xref / yref / dy)
+                else:
+                    N, C, H, W = args[sl:sl + 4]
+                    oh, ow = args[sl + 16:sl + 18]
+                    esz = {1: 2, 2: 8}.get(args[-2], 4) if name.endswith("typed") else 4
+                    byt = float(N) * C * (H * W + oh * ow) * esz
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                raw(name, *args)
+                e.record()
+                timer.hbm_records.append((mode + " (" + name + ")", byt, s, e))
+                return
+            if mode == "gconv":      # out[b,oy,ox,co] = sum src(...)*w: one multiply-add per (output, Cin, tap)
+                B, Hin, Win, Cin, Hout, Wout, Cout, R = args[sl:sl + 8]
+                alg = exe = 2.0 * B * Hout * Wout * Cout * Cin * R * R
+                byt = 4.0 * (B * (Hin * Win * Cin + Hout * Wout * Cout) + Cout * Cin * R * R)
+            elif mode == "tr2":      # stride-2 transposed 3x3 in phase form: 16 tap slots per 4 outputs, 9 of them non-zero
+                B, Hin, Win, Cin, Hout, Wout, Cout = args[sl:sl + 7]
+                alg = 2.0 * B * Hout * Wout * Cout * Cin * 9 / 4
+                exe = 2.0 * B * Hout * Wout * Cout * Cin * 4
+                byt = 4.0 * (B * (Hin * Win * Cin + Hout * Wout * Cout) + 16 * Cout * Cin)
+            elif mode == "conv":
                 B, H, W, Cin, Cout, R = args[sl:sl + 6]
                 alg = exe = 2.0 * B * H * W * Cout * Cin * R * R
                 byt = 4.0 * (B * H * W * (Cin + Cout) + Cout * Cin * R * R)
@@ -169,6 +204,22 @@ class KernelTimer:
             a[0] += alg; a[1] += ms * 1e-3; a[2] += int(n); a[3] += flops; a[4] += byt
         return out
 
+    def hbm_roofline(self):
+        """roofline object of the HBM-bound op with the largest total time (None when the workload launched none)."""
+        agg = {}
+        for name, byt, s, e in self.hbm_records:
+            a = agg.setdefault(name, [0.0, 0.0, 0])
+            a[0] += byt; a[1] += s.elapsed_time(e) * 1e-3; a[2] += 1
+        if not agg:
+            return None
+        name, (byt, secs, n) = max(agg.items(), key=lambda kv: kv[1][1])
+        gbs = byt / secs / 1e9
+        return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": round(gbs / PEAK_HBM_GBPS, 4), "traffic": None, "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
+                "algorithmic_bytes_per_launch": round(byt / n),
+                "all_hbm_ops": {k: {"GB/s": round(v[0] / v[1] / 1e9, 1), "frac": round(v[0] / v[1] / 1e9 / PEAK_HBM_GBPS, 4),
+                                    "launches": v[2], "total_ms": round(v[1] * 1e3, 3)} for k, v in agg.items()}}
+
     def summary(self):
         agg = {}
         for kname, alg, exe, byt, s, e in self.records:
@@ -200,11 +251,50 @@ def measured_traffic(kname):
     return per_launch, src, round(total / steps / 1e9, 1), table.get("commit", "23abb1c")
 
 
+def assemble_roofline(timer, steps, elapsed, with_step_traffic=True):
+    """roofline object (see the module docstring) from the HIP-event records of the timed region; None without records."""
+    agg = timer.summary()
+    agg.update(timer.planes_summary())       # inner GEMMs of the composites (their time is part of the composite rows too)
+    cands = [(k, v) for k, v in agg.items() if not k.startswith("composite:")]
+    if not cands:
+        return None
+    variant, (flops, secs, n, exe, byt) = max(cands, key=lambda kv: kv[1][1])
+    traffic, traffic_src, step_hbm_gb, _ = measured_traffic(variant) if with_step_traffic else (None, None, None, None)
+    alg_tf, exe_tf = flops / secs / 1e12, exe / secs / 1e12
+    # Roofline of the dominant kernel = what the MFMA pipe EXECUTED / its HIP-event time / the fp32 MFMA peak.  The same
+    # time priced on the reference op graph's FLOPs (3x3 conv counted directly, on the upsampled tensor where the
+    # reference upsamples first) is `algorithmic_tflops`; their ratio is the algebraic saving (Winograd F(4x4,3x3): 144/36,
+    # resample-fused 25-plane form: 144/25, 2x2-phase / 4x4-stride-2 forms: 36/16).
+    step_exe = sum(r[2] for r in timer.records) / steps              # entry-point level: no double counting
+    step_ms = elapsed / steps * 1e3
+    t_mfma = step_exe / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e3
+    t_hbm = (step_hbm_gb / PEAK_HBM_GBPS * 1e3) if step_hbm_gb else None
+    return {"bound": "mfma", "kernel": variant, "achieved": round(exe_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(exe_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(byt / n),
+            "algorithmic_tflops": round(alg_tf, 2), "algorithmic_speedup": round(alg_tf / exe_tf, 3),
+            "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
+            "executed_gflop_per_launch_avg": round(exe / n / 1e9, 3),
+            # whole step against its own binding roof: executed conv/GEMM work at the MFMA peak vs measured HBM traffic
+            # (all kernels, PMC passes of the same command) at 8 TB/s
+            "step": {"executed_tflop": round(step_exe / 1e12, 3), "hbm_gb_measured": step_hbm_gb,
+                     "t_mfma_ms": round(t_mfma, 2), "t_hbm_ms": (round(t_hbm, 1) if t_hbm else None),
+                     "ms_per_step": round(step_ms, 2),
+                     "frac": round(max(t_mfma, t_hbm or 0.0) / step_ms, 4),
+                     "frac_if_serial": round((t_mfma + (t_hbm or 0.0)) / step_ms, 4)},
+            "all_conv_kernels": {k: {"algorithmic_tflops": round(v[0] / v[1] / 1e12, 2),
+                                     "executed_tflops": round(v[3] / v[1] / 1e12, 2),
+                                     "ms_per_step": round(v[1] / steps * 1e3, 2),
+                                     "avg_launch_ms": round(v[1] / v[2] * 1e3, 4),
+                                     "launches_per_step": v[2] // steps} for k, v in agg.items()}}
+
+
 def build_models(cfg, device, init_mode="ortho"):
-    import ic_gan_amd.BigGAN as M
+    import importlib
+    M = importlib.import_module("ic_gan_amd." + cfg.get("model", "BigGAN"))      # the reference's plugin seam (trainer.py:122)
     from ic_gan_amd import utils
     from ic_gan_amd.optim import FusedAdam
-    G = M.Generator(**{**cfg, "skip_init": True, "embedded_optimizers": False}).to(device)
+    G = M.Generator(**{**cfg, "skip_init": True, "embedded_optimizers": False, "no_optim": True}).to(device)
     D = M.Discriminator(**{**cfg, "skip_init": True, "embedded_optimizers": False}).to(device)
     try:                       # reference init (orthogonal) on the device: QR of up to 1536 x 13824 matrices
         if init_mode != "ortho":
@@ -298,12 +388,19 @@ def bench_stylegan2(args, device, rank, world, local_rank, use_ddp):
     def one_step():
         return step(img, real_c, real_h, torch.randn([n_ph * b, 512], device=device), gen_c, gen_h)
 
+    timer = KernelTimer()
+    timer.install()
     for _ in range(args.warmup):
         one_step()
     step.batch_idx = 0                        # the timed region starts at a cycle boundary
+    if args.steps % 16:
+        print(f"[bench] cfg4: --steps {args.steps} is not a multiple of 16 (the lazy-regularisation cycle: Greg every 4, Dreg "
+              f"every 16 iterations): the mean is not a whole-cycle average", file=sys.stderr)
     if use_ddp:
         dist.barrier()
     torch.cuda.synchronize()
+    timer.enabled = True
+    timer.planes(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -312,12 +409,14 @@ def bench_stylegan2(args, device, rank, world, local_rank, use_ddp):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timer.enabled = False
     if use_ddp:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         dist.destroy_process_group()
     if rank == 0:
+        roof = assemble_roofline(timer, args.steps, elapsed, with_step_traffic=False)
         print(json.dumps({
             "metric": "images/sec training iteration, IC-GAN StyleGAN2 256^2 (cfg4, secondary workload)",
             "value": round(b * world * args.steps / elapsed, 3), "unit": "images/sec", "n_gpus": world,
@@ -326,7 +425,11 @@ def bench_stylegan2(args, device, rank, world, local_rank, use_ddp):
             "config": {"workload": "cfg4: IC-GAN StyleGAN2 256x256 cfg=auto, h_dim 2048, fp32; Gmain+Dmain every iteration, "
                                    "Greg every 4, Dreg every 16 (steps should be a multiple of 16)",
                        "batch_per_gpu": b, "global_batch": b * world, "parallelism": f"dp{world}"},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            # dominant MFMA kernel of the iteration, and the dominant HBM-bound plugin (bias_act / upfirdn2d: algorithmic bytes
+            # of SURVEY 8(d) -- 8 B per element, 4 (in + out) B -- over HIP-event time, against the 8 TB/s HBM peak)
+            "roofline": roof, "roofline_hbm": timer.hbm_roofline(),
+            "cpu_baseline": (run_cpu_baseline_child("cfg4") if world == 1 and not args.no_cpu_baseline else None)}),
+            flush=True)
 
 
 def bench_sampling(args, device, rank, world):
@@ -343,17 +446,26 @@ def bench_sampling(args, device, rank, world):
     G.init = "N02"
     G.init_weights()
     G.eval()
+    from ic_gan_amd import layers as _layers
+    _layers.enable_sn_eval_cache(G)          # frozen sampling weights: W/sigma computed once (inference.load_model_inference does the same)
     sampler = conditioning_sampler(cfg, G.dim_z, b, device, seed=1000 + rank)
     if args.graph:
         G = inference.GraphedGenerator(G, b, class_cond=True, instance_cond=True, device=device, static_weights=True)
+    timer = KernelTimer()
+    if not args.graph:                 # (a HIP-graph replay has no per-launch events: roofline null there)
+        timer.install()
     for _ in range(args.warmup):
         inference.sample(G, sampler, cfg, class_cond=True, instance_cond=True, device=device)
     torch.cuda.synchronize()
+    timer.enabled = not args.graph
+    if not args.graph:
+        timer.planes(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img, _, _ = inference.sample(G, sampler, cfg, class_cond=True, instance_cond=True, device=device)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timer.enabled = False
     if rank == 0:
         print(json.dumps({
             "metric": "images/sec sampling, IC-GAN BigGAN 256^2 generator (secondary workload)",
@@ -362,90 +474,9 @@ def bench_sampling(args, device, rank, world):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "sample: cfg3 generator in eval mode, class + instance conditioning from the resident table",
                        "batch_per_gpu": b, "hip_graph": bool(args.graph), "finite": bool(torch.isfinite(img).all())},
-            "roofline": None, "cpu_baseline": None}), flush=True)
-
-
-def bench_biggan_deep(args, device, rank, world, local_rank, use_ddp):
-    """Secondary workload (BASELINE.json configs[4]): BigGAN-deep 256x256 ch=128, bs=128/GPU, class-conditional, attention
-    at 64.  The reference's IC-GAN step function cannot drive this model (its G_D has no feature arguments), so the step is
-    the plain BigGAN schedule it was written for: 1 D update (G forward without grad, D on fake||real, hinge) + 1 G update
-    (hinge) with Adam(beta1 = 0), toggle_grads on; no EMA."""
-    import ic_gan_amd.BigGANdeep as M
-    from ic_gan_amd import losses, utils
-    b = args.batch or 128
-    cfg = dict(G_ch=128, D_ch=128, G_depth=2, D_depth=2, dim_z=128, shared_dim=128, hier=True, G_shared=True,
-               resolution=256, G_attn="64", D_attn="64", n_classes=1000, SN_eps=1e-6, BN_eps=1e-5, adam_eps=1e-6,
-               G_lr=5e-5, D_lr=2e-4, G_B1=0.0, D_B1=0.0, G_B2=0.999, D_B2=0.999, G_init="N02", D_init="N02")
-    utils.seed_rng(rank)
-    G, D = M.Generator(**cfg).to(device), M.Discriminator(**cfg).to(device)
-    Gw, Dw = G, D
-    if use_ddp:
-        from torch.nn.parallel import DistributedDataParallel as DDP
-        Gw = DDP(G, device_ids=[local_rank], find_unused_parameters=True)
-        Dw = DDP(D, device_ids=[local_rank], find_unused_parameters=True)
-
-    class _GD(torch.nn.Module):            # G_D over the (possibly DDP-wrapped) modules, shared embedding from the bare G
-        def forward(self, z, gy, x=None, dy=None, train_G=False):
-            with torch.set_grad_enabled(train_G):
-                G_z = Gw(z, G.shared(gy))
-            if x is None:
-                return Dw(G_z, gy)
-            out = Dw(torch.cat([G_z, x], 0), torch.cat([gy, dy], 0))
-            return torch.split(out, [G_z.shape[0], x.shape[0]])
-
-    GD = _GD()
-    rs = np.random.RandomState(7 + rank)
-    x = torch.from_numpy(((rs.randint(0, 256, size=(b, 3, 256, 256)) / 255.0 - 0.5) * 2).astype(np.float32)).to(device)
-    x = x.contiguous(memory_format=torch.channels_last)
-    dy = torch.from_numpy(rs.randint(0, 1000, size=b).astype(np.int64)).to(device)
-
-    def one_step():
-        G.train(); D.train()
-        utils.toggle_grad(D, True); utils.toggle_grad(G, False)
-        D.optim.zero_grad()
-        z = torch.randn(b, 128, device=device)
-        gy = torch.randint(0, 1000, (b,), device=device)
-        D_fake, D_real = GD(z, gy, x, dy, train_G=False)
-        l_real, l_fake = losses.loss_hinge_dis(D_fake, D_real)
-        (l_real + l_fake).backward()
-        D.optim.step()
-        utils.toggle_grad(D, False); utils.toggle_grad(G, True)
-        G.optim.zero_grad()
-        z = torch.randn(b, 128, device=device)
-        gy = torch.randint(0, 1000, (b,), device=device)
-        loss = losses.loss_hinge_gen(GD(z, gy, train_G=True))
-        loss.backward()
-        G.optim.step()
-        return loss
-
-    for _ in range(args.warmup):
-        one_step()
-    if use_ddp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    torch.cuda.synchronize()
-    if use_ddp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_ddp:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps({
-            "metric": "images/sec G+D train step, BigGAN-deep 256^2 ch=128 bs=128/GPU (cfg5, secondary workload)",
-            "value": round(b * world * args.steps / elapsed, 3), "unit": "images/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg5: BigGAN-deep 256x256 ch=128 class-conditional, attention at 64, 1 D + 1 G update, fp32",
-                       "batch_per_gpu": b, "global_batch": b * world, "parallelism": f"dp{world}",
-                       "G_loss_last": float(loss)},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "roofline": (assemble_roofline(timer, args.steps, elapsed, with_step_traffic=False) if not args.graph else None),
+            "cpu_baseline": (run_cpu_baseline_child("sample") if world == 1 and not args.no_cpu_baseline else None)}),
+            flush=True)
 
 
 def cpu_baseline(cfg, name, budget_s=25.0):
@@ -480,12 +511,123 @@ def cpu_baseline(cfg, name, budget_s=25.0):
                       + f", best of {len(times)} step(s) of oracle.biggan_oracle.train_step (PyTorch CPU fp32), {t:.2f} s/step"}
 
 
+class _Patch:
+    def setattr(self, obj, name, val):
+        setattr(obj, name, val)
+
+
+def cpu_baseline_emulated(cfg, name, budget_s=25.0):
+    """CPU baseline for workloads without a stand-alone oracle module (cfg5: the instance-conditioned BigGAN-deep has no
+    reference model; cfg4: StyleGAN2): the product's host code with every C-ABI call served by oracle/kernel_ref.py -- the
+    plain-PyTorch CPU restatement of each kernel that the parity tests check the HIP kernels against (`kind` "port")."""
+    import importlib
+    from oracle import kernel_ref, synth
+    import ic_gan_amd.ops as ops
+    kernel_ref.install(_Patch())
+    ops.disable_winograd()                       # the CPU restatement of a direct convolution is one F.conv2d
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    if name == "cfg4":
+        return _cpu_baseline_stylegan2(budget_s)
+    from ic_gan_amd import train_fns, utils
+    from ic_gan_amd.optim import FusedAdam
+    M = importlib.import_module("ic_gan_amd." + cfg.get("model", "BigGAN"))
+    b = 2
+    G = M.Generator(**{**cfg, "skip_init": True, "no_optim": True})
+    D = M.Discriminator(**{**cfg, "skip_init": True})
+    G.load_state_dict(synth.synth_state(synth.spec_of(G.state_dict()), 11))
+    D.load_state_dict(synth.synth_state(synth.spec_of(D.state_dict()), 22))
+    G_ema = M.Generator(**{**cfg, "skip_init": True, "no_optim": True})
+    ema = utils.ema(G, G_ema, cfg["ema_decay"], cfg["ema_start"])
+    opt_d = FusedAdam(D.parameters(), lr=cfg["D_lr"], betas=(0.0, 0.999), eps=1e-6)
+    opt_g = FusedAdam(G.parameters(), lr=cfg["G_lr"], betas=(0.0, 0.999), eps=1e-6)
+    GD = M.G_D(G, D, optimizer_G=opt_g, optimizer_D=opt_d)
+    train = train_fns.GAN_training_function(G, D, GD, ema, {"itr": 1}, cfg, synth.CondSampler(cfg, G.dim_z, b, 3),
+                                            embedded_optimizers=False, device="cpu", batch_size=b)
+    x, y, f = synth.synth_batch(cfg, b, seed=4)
+    G.train(); D.train()
+    times, t_end = [], time.time() + budget_s
+    while len(times) < 3 and (not times or time.time() + times[-1] < t_end):
+        t0 = time.time()
+        train(x, y, f)
+        times.append(time.time() - t0)
+    t = min(times)
+    return {"value": round(b / t, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "reference_unavailable_on_gpu_box": True,
+            "sample": f"{name} shape, batch {b} (reduced batch), best of {len(times)} step(s) of the product host code over "
+                      f"oracle/kernel_ref.py (PyTorch CPU fp32 restatement of every kernel), {t:.2f} s/step"}
+
+
+def _cpu_baseline_stylegan2(budget_s):
+    import copy
+    from ic_gan_amd.stylegan2 import networks as N
+    from ic_gan_amd.stylegan2.training_step import TrainingStep
+    res, b = 256, 2
+    common = dict(channel_base=16384, channel_max=512, num_fp16_res=0, conv_clamp=None)
+    G = N.Generator(z_dim=512, c_dim=0, h_dim=2048, w_dim=512, img_resolution=res, img_channels=3,
+                    mapping_kwargs=dict(num_layers=2), synthesis_kwargs=common).train().requires_grad_(False)
+    D = N.Discriminator(c_dim=0, h_dim=2048, img_resolution=res, img_channels=3, mapping_kwargs=dict(num_layers=2),
+                        epilogue_kwargs=dict(mbstd_group_size=2), **common).train().requires_grad_(False)
+    adam = dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)
+    step = TrainingStep(G, D, copy.deepcopy(G).eval(), "cpu", batch_size=b, batch_gpu=b, num_gpus=1,
+                        loss_kwargs=dict(r1_gamma=0.0002 * res ** 2 / 16), G_opt_kwargs=adam, D_opt_kwargs=adam,
+                        ema_kimg=5.0, ema_rampup=0.05)
+    rs = np.random.RandomState(7)
+    img = torch.from_numpy((rs.randint(0, 256, size=(b, 3, res, res)) / 127.5 - 1).astype(np.float32))
+    unit = lambda n: torch.from_numpy((lambda h: h / np.linalg.norm(h, axis=1, keepdims=True))(rs.standard_normal((n, 2048)).astype(np.float32)))
+    n_ph = len(step.phases)
+    times, t_end = [], time.time() + budget_s
+    step.batch_idx = 1                           # iterations 1, 2, ...: Gmain + Dmain only (the lazy regularisers run every 4 / 16)
+    while len(times) < 3 and (not times or time.time() + times[-1] < t_end):
+        t0 = time.time()
+        step(img, torch.empty([b, 0]), unit(b), torch.randn([n_ph * b, 512]), torch.empty([n_ph * b, 0]), unit(n_ph * b))
+        times.append(time.time() - t0)
+    t = min(times)
+    return {"value": round(b / t, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "reference_unavailable_on_gpu_box": True,
+            "sample": f"cfg4 shape, batch {b} (reduced batch), best of {len(times)} Gmain + Dmain iteration(s) of the product host "
+                      f"code over oracle/kernel_ref.py (PyTorch CPU fp32 restatement of every kernel), {t:.2f} s/iteration"}
+
+
+def cpu_baseline_sampling(cfg, b=2):
+    """sampling engine: the oracle's eval-mode generator forward on the host cores"""
+    from oracle import biggan_oracle as O, synth
+    import ic_gan_amd.BigGAN as M
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    G = M.Generator(**{**cfg, "skip_init": True, "no_optim": True})
+    gsd = synth.synth_state(synth.spec_of(G.state_dict()), 11)
+    z, lab, fg = synth.CondSampler(cfg, G.dim_z, b, 3)()
+    times = []
+    with torch.no_grad():
+        for _ in range(3):
+            t0 = time.time()
+            O.generator_forward(gsd, cfg, z, lab, fg, False)
+            times.append(time.time() - t0)
+    t = min(times)
+    return {"value": round(b / t, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "reference_unavailable_on_gpu_box": True,
+            "sample": f"cfg3 generator, eval mode, batch {b}, best of 3 calls of oracle.biggan_oracle.generator_forward, {t:.2f} s/call"}
+
+
+def run_cpu_baseline_child(workload):
+    """the CPU leg runs in a separate process with a hard wall-clock bound: the default bench run must finish in minutes"""
+    import subprocess
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload],
+                             capture_output=True, text=True, timeout=240,
+                             env={**os.environ, "HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+        line = [l for l in res.stdout.splitlines() if l.startswith("CPU_BASELINE ")][-1]
+        return json.loads(line[len("CPU_BASELINE "):])
+    except Exception as exc:   # noqa: BLE001
+        return {"value": None, "unit": "images/sec", "cores": min(32, os.cpu_count() or 1), "kind": "port",
+                "sample": f"not completed within 240 s ({type(exc).__name__})"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS) + ["cfg4", "cfg5", "sample"])
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS) + ["cfg4", "sample"])
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -499,12 +641,17 @@ def main():
 
     if args.cpu_baseline_only:          # child process of the N=1 run: bounded CPU sample, prints one JSON object
         cfg = dict(BASE_CFG)
-        cfg.update(WORKLOADS[args.workload][0])
-        res = cpu_baseline(cfg, args.workload)
-        if args.workload != "cfg1":          # cfg1 (the reference's CPU-runnable configuration) at its full batch of 8
-            c1 = dict(BASE_CFG)
-            c1.update(WORKLOADS["cfg1"][0])
-            res["cfg1_full_batch"] = cpu_baseline(c1, "cfg1", budget_s=8.0)
+        cfg.update(WORKLOADS.get(args.workload, WORKLOADS["cfg3"])[0])
+        if args.workload in ("cfg4", "cfg5"):
+            res = cpu_baseline_emulated(cfg, args.workload)
+        elif args.workload == "sample":
+            res = cpu_baseline_sampling(cfg)
+        else:
+            res = cpu_baseline(cfg, args.workload)
+            if args.workload != "cfg1":      # cfg1 (the reference's CPU-runnable configuration) at its full batch of 8
+                c1 = dict(BASE_CFG)
+                c1.update(WORKLOADS["cfg1"][0])
+                res["cfg1_full_batch"] = cpu_baseline(c1, "cfg1", budget_s=8.0)
         print("CPU_BASELINE " + json.dumps(res), flush=True)
         return
 
@@ -529,8 +676,6 @@ def main():
         return bench_sampling(args, device, rank, world)
     if args.workload == "cfg4":
         return bench_stylegan2(args, device, rank, world, local_rank, use_ddp)
-    if args.workload == "cfg5":
-        return bench_biggan_deep(args, device, rank, world, local_rank, use_ddp)
     over, batch = WORKLOADS[args.workload]
     batch = args.batch or batch
     cfg = dict(BASE_CFG)
@@ -584,47 +729,15 @@ def main():
         elapsed = float(tt.item())
 
     if rank == 0:
-        agg = timer.summary()
-        agg.update(timer.planes_summary())       # inner GEMMs of the composites (their time is part of the composite rows too)
-        roof = None
-        if agg:
-            variant, (flops, secs, n, exe, byt) = max(((k, v) for k, v in agg.items() if not k.startswith("composite:")),
-                                                      key=lambda kv: kv[1][1])
-            traffic, traffic_src, step_hbm_gb, _ = measured_traffic(variant)
-            alg_tf, exe_tf = flops / secs / 1e12, exe / secs / 1e12
-            # Roofline of the dominant kernel = what the MFMA pipe EXECUTED / its HIP-event time / the fp32 MFMA peak.  The
-            # same time priced on the reference op graph's FLOPs (3x3 conv counted directly, on the upsampled tensor where
-            # the reference upsamples first) is reported as `algorithmic_tflops`; their ratio is the algebraic saving
-            # (Winograd F(4x4,3x3): 144/36, resample-fused 25-plane form: 144/25, 2x2-phase / 4x4-stride-2 forms: 36/16).
-            step_exe = sum(r[2] for r in timer.records) / args.steps         # entry-point level: no double counting
-            step_ms = elapsed / args.steps * 1e3
-            t_mfma = step_exe / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e3
-            t_hbm = (step_hbm_gb / PEAK_HBM_GBPS * 1e3) if step_hbm_gb else None
-            roof = {"bound": "mfma", "kernel": variant, "achieved": round(exe_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(exe_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(byt / n),
-                    "algorithmic_tflops": round(alg_tf, 2), "algorithmic_speedup": round(alg_tf / exe_tf, 3),
-                    "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
-                    "executed_gflop_per_launch_avg": round(exe / n / 1e9, 3),
-                    # whole step against its own binding roof: executed conv/GEMM work at the MFMA peak vs measured HBM
-                    # traffic (all kernels, PMC passes of the same command) at 8 TB/s
-                    "step": {"executed_tflop": round(step_exe / 1e12, 2), "hbm_gb_measured": step_hbm_gb,
-                             "t_mfma_ms": round(t_mfma, 1), "t_hbm_ms": (round(t_hbm, 1) if t_hbm else None),
-                             "ms_per_step": round(step_ms, 2),
-                             "frac": round(max(t_mfma, t_hbm or 0.0) / step_ms, 4),
-                             "frac_if_serial": round((t_mfma + (t_hbm or 0.0)) / step_ms, 4)},
-                    "all_conv_kernels": {k: {"algorithmic_tflops": round(v[0] / v[1] / 1e12, 2),
-                                             "executed_tflops": round(v[3] / v[1] / 1e12, 2),
-                                             "ms_per_step": round(v[1] / args.steps * 1e3, 2),
-                                             "avg_launch_ms": round(v[1] / v[2] * 1e3, 4),
-                                             "launches_per_step": v[2] // args.steps} for k, v in agg.items()}}
+        roof = assemble_roofline(timer, args.steps, elapsed, with_step_traffic=(args.workload == "cfg3"))
         out = {
             "metric": "images/sec G+D train step, IC-GAN BigGAN 256^2 bs=64/GPU" if args.workload == "cfg3"
-            else f"images/sec G+D train step, IC-GAN BigGAN ({args.workload})",
+            else ("images/sec G+D train step, IC-GAN BigGAN-deep 256^2 ch=128 bs=128/GPU (cfg5, secondary workload)"
+                  if args.workload == "cfg5" else f"images/sec G+D train step, IC-GAN BigGAN ({args.workload})"),
             "value": round(batch * world * args.steps / elapsed, 3), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: IC-GAN BigGAN {cfg['resolution']}x{cfg['resolution']} ch={cfg['G_ch']}"
+            "config": {"workload": f"{args.workload}: IC-GAN {cfg.get('model', 'BigGAN')} {cfg['resolution']}x{cfg['resolution']} ch={cfg['G_ch']}"
                                    f" class_cond={cfg['class_cond']} instance_cond={cfg['instance_cond']} hier attn@{cfg['G_attn']},"
                                    f" 1 D step + 1 G step + Adam x2 + EMA, fp32 exact MFMA",
                        "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
@@ -633,16 +746,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            import subprocess
-            try:     # separate process with a hard wall-clock bound: the default bench run must finish in minutes
-                res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload",
-                                      args.workload], capture_output=True, text=True, timeout=180,
-                                     env={**os.environ, "HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
-                line = [l for l in res.stdout.splitlines() if l.startswith("CPU_BASELINE ")][-1]
-                out["cpu_baseline"] = json.loads(line[len("CPU_BASELINE "):])
-            except Exception as exc:   # noqa: BLE001
-                out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": min(32, os.cpu_count() or 1),
-                                       "kind": "port", "sample": f"not completed within 180 s ({type(exc).__name__})"}
+            out["cpu_baseline"] = run_cpu_baseline_child(args.workload)
         print(json.dumps(out), flush=True)
     if use_ddp:
         dist.destroy_process_group()

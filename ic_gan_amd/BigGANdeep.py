@@ -5,7 +5,16 @@ channel-dropping skip in G, channel-concatenating skip in D, `G_depth` / `D_dept
 
 In the reference this model is class-conditional only (`Generator.forward(z, y)` with y the shared embedding, no instance
 features) and its `G_D` has no feature arguments, so `train_fns.GAN_training_function` (which always passes them) cannot
-drive it; it is provided for API completeness with the same constructor keywords, attribute names and state_dict keys.
+drive it.  That class-conditional form is kept bit-for-bit in API and state_dict (pinned by reference-generated
+goldens, tests/test_biggan_deep.py).
+
+INSTANCE CONDITIONING (BASELINE.json configs[4], "IC-GAN BigGANdeep") is added by analogy with BigGAN.py:350-358 (G's
+`shared_feat` linear on the 2048-d instance feature, concatenated with the class embedding into the conditioning vector of
+every ccbn), BigGAN.py:546-553,625-641 (D's projection head on class embedding ++ `linear_feat(feat)`) and BigGAN.py:655-711
+(`G_D.forward(z, gy, feats_g, x, dy, feats, ...)`): pass `instance_cond=True` (and `class_cond=False` for the label-free
+IC-GAN) and the module takes labels / features like ic_gan_amd.BigGAN and can be driven by train_fns.GAN_training_function.
+The reference has no such model, so this part has NO oracle: parity unpinned (state_dict names follow BigGAN.py's:
+`shared_feat.*`, `linear_feat.*`).
 
 Fusions used (ic_gan_amd/ops.py): every convolution takes its preceding [ccbn affine ->] ReLU [-> nearest x2] in the operand
 loader; G: conv2 after the upsample runs in 4-phase form, conv4 adds the (upsampled-on-read) skip in its epilogue; D: the
@@ -142,10 +151,18 @@ class Generator(nn.Module):
                  n_classes=1000, num_G_SVs=1, num_G_SV_itrs=1, G_shared=True, shared_dim=0, hier=False,
                  cross_replica=False, mybn=False, G_activation=nn.ReLU(inplace=False), G_lr=5e-5, G_B1=0.0, G_B2=0.999,
                  adam_eps=1e-8, BN_eps=1e-5, SN_eps=1e-12, G_mixed_precision=False, G_fp16=False, G_init="ortho",
-                 skip_init=False, no_optim=False, G_param="SN", norm_style="bn", sync_bn=False, **kwargs):
+                 skip_init=False, no_optim=False, G_param="SN", norm_style="bn", sync_bn=False, class_cond=True,
+                 instance_cond=False, G_shared_feat=True, shared_dim_feat=2048, **kwargs):
         super().__init__()
         if G_param != "SN":
             raise NotImplementedError("ic_gan_amd.BigGANdeep.Generator: G_param='SN' only")
+        if not class_cond and not instance_cond:
+            raise NotImplementedError("BigGANdeep.Generator needs class and / or instance conditioning")
+        if instance_cond and not (G_shared and hier):
+            raise NotImplementedError("instance conditioning of BigGANdeep is defined for G_shared=True, hier=True (the "
+                                      "shipped BigGAN-deep setting)")
+        self.class_cond, self.instance_cond = class_cond, instance_cond
+        self.G_shared_feat, self.shared_dim_feat = G_shared_feat, (shared_dim_feat if instance_cond else 0)
         if G_fp16 or G_mixed_precision:
             raise NotImplementedError("ic_gan_amd computes in fp32; fp16 modes are not implemented")
         self.ch, self.G_depth, self.dim_z, self.bottom_width = G_ch, G_depth, dim_z, bottom_width
@@ -162,12 +179,17 @@ class Generator(nn.Module):
         self.which_linear = functools.partial(layers.SNLinear, **sn_kw)
         self.which_embedding = nn.Embedding
         bn_linear = functools.partial(self.which_linear, bias=False) if self.G_shared else self.which_embedding
+        # width of the conditioning vector y: class embedding (++ instance embedding, BigGAN.py:350-358 by analogy)
+        self.cond_dim = (self.shared_dim if class_cond else 0) + self.shared_dim_feat
         self.which_bn = functools.partial(layers.ccbn, which_linear=bn_linear, cross_replica=self.cross_replica,
                                           mybn=self.mybn,
-                                          input_size=(self.shared_dim + self.dim_z if self.G_shared else self.n_classes),
+                                          input_size=(self.cond_dim + self.dim_z if self.G_shared else self.n_classes),
                                           norm_style=self.norm_style, eps=self.BN_eps, sync_bn=sync_bn)
-        self.shared = self.which_embedding(n_classes, self.shared_dim) if G_shared else layers.identity()
-        self.linear = self.which_linear(self.dim_z + self.shared_dim,
+        if class_cond:
+            self.shared = self.which_embedding(n_classes, self.shared_dim) if G_shared else layers.identity()
+        if instance_cond:
+            self.shared_feat = self.which_linear(2048, self.shared_dim_feat) if G_shared_feat else layers.identity()
+        self.linear = self.which_linear(self.dim_z + self.cond_dim,
                                         self.arch["in_channels"][0] * (self.bottom_width ** 2))
         stages = []
         for i in range(len(self.arch["out_channels"])):
@@ -199,28 +221,46 @@ class Generator(nn.Module):
         self.param_count = _init_module_weights(self, self.init)
         print("Param count for G" "s initialized parameters: %d" % self.param_count)
 
-    def forward(self, z, y):
-        """z [B, dim_z], y [B, shared_dim] (the class embedding `self.shared(labels)`) -> images (BigGANdeep.py:375-391)."""
-        layers.sn_prefetch([m for m in self.modules() if isinstance(m, layers.SN)])
-        if self.hier:
-            z = torch.cat([y, z], 1)
-            y = z
-        h = self.linear(z)
-        h = h.view(h.size(0), -1, self.bottom_width, self.bottom_width)
-        for stage in self.blocks:
-            for block in stage:
-                h = block(h, y)
-        return ops.TanhFn.apply(self.output_layer(h))
+    def get_condition_embeddings(self, cl=None, feat=None):
+        """class embedding ++ instance embedding (BigGAN.py:350-358)."""
+        parts = []
+        if cl is not None:
+            parts.append(self.shared(cl))
+        if feat is not None:
+            parts.append(self.shared_feat(feat))
+        return torch.cat(parts, dim=-1)
+
+    def forward(self, z, y=None, feats=None):
+        """Reference form (instance_cond=False): z [B, dim_z], y [B, shared_dim] = the class embedding `self.shared(labels)`
+        (BigGANdeep.py:375-391).  Instance-conditioned form: y = int64 labels [B] or None, feats [B, 2048] -> the embeddings
+        are computed here, as in BigGAN.py:364-386."""
+        sn_layers = [m for m in self.modules() if isinstance(m, layers.SN)]
+        layers.sn_prefetch(sn_layers)
+        try:
+            if self.instance_cond:
+                y = self.get_condition_embeddings(y if self.class_cond else None, feats)
+            if self.hier:
+                z = torch.cat([y, z], 1)
+                y = z
+            h = self.linear(z)
+            h = h.view(h.size(0), -1, self.bottom_width, self.bottom_width)
+            for stage in self.blocks:
+                for block in stage:
+                    h = block(h, y)
+            return ops.TanhFn.apply(self.output_layer(h))
+        finally:
+            layers.sn_drop_prefetched(sn_layers)
 
 
 class Discriminator(nn.Module):
     def __init__(self, D_ch=64, D_wide=True, D_depth=2, resolution=128, D_kernel_size=3, D_attn="64", n_classes=1000,
                  num_D_SVs=1, num_D_SV_itrs=1, D_activation=nn.ReLU(inplace=False), D_lr=2e-4, D_B1=0.0, D_B2=0.999,
                  adam_eps=1e-8, SN_eps=1e-12, output_dim=1, D_mixed_precision=False, D_fp16=False, D_init="ortho",
-                 skip_init=False, D_param="SN", **kwargs):
+                 skip_init=False, D_param="SN", class_cond=True, instance_cond=False, instance_sz=2048, **kwargs):
         super().__init__()
         if D_param != "SN":
             raise NotImplementedError("ic_gan_amd.BigGANdeep.Discriminator: D_param='SN' only")
+        self.class_cond, self.instance_cond = class_cond, instance_cond
         if D_fp16 or D_mixed_precision:
             raise NotImplementedError("ic_gan_amd computes in fp32; fp16 modes are not implemented")
         self.ch, self.D_wide, self.D_depth, self.resolution = D_ch, D_wide, D_depth, resolution
@@ -244,8 +284,16 @@ class Discriminator(nn.Module):
                 stage.append(layers.Attention(self.arch["out_channels"][i], self.which_conv))
             stages.append(nn.ModuleList(stage))
         self.blocks = nn.ModuleList(stages)
-        self.linear = self.which_linear(self.arch["out_channels"][-1], output_dim)
-        self.embed = self.which_embedding(self.n_classes, self.arch["out_channels"][-1])
+        top = self.arch["out_channels"][-1]
+        self.linear = self.which_linear(top, output_dim)
+        # projection head: class embedding, or (BigGAN.py:546-553 by analogy) class embedding ++ linear_feat(instance feature)
+        if class_cond and instance_cond:
+            self.linear_feat = self.which_linear(instance_sz, top // 2)
+            self.embed = self.which_embedding(self.n_classes, top // 2)
+        elif instance_cond:
+            self.linear_feat = self.which_linear(instance_sz, top)
+        else:
+            self.embed = self.which_embedding(self.n_classes, top)
         if not skip_init:
             self.init_weights()
         self.lr, self.B1, self.B2, self.adam_eps = D_lr, D_B1, D_B2, adam_eps
@@ -256,28 +304,58 @@ class Discriminator(nn.Module):
         self.param_count = _init_module_weights(self, self.init)
         print("Param count for D" "s initialized parameters: %d" % self.param_count)
 
-    def forward(self, x, y=None):
-        """x [N,3,R,R], y [N] int64 -> logits [N,1]  (BigGANdeep.py:673-688)."""
-        layers.sn_prefetch([m for m in self.modules() if isinstance(m, layers.SN)])
-        h = self.input_conv(x)
-        for stage in self.blocks:
-            for block in stage:
-                h = block(h)
-        h = ops.ReluSumPoolFn.apply(h)
-        out = self.linear(h)
-        return out + torch.sum(self.embed(y) * h, 1, keepdim=True)
+    def forward(self, x, y=None, feat=None):
+        """x [N,3,R,R], y [N] int64 (or None), feat [N,2048] (instance-conditioned form) -> logits [N,1]
+        (BigGANdeep.py:673-688; projection on class ++ instance embedding as BigGAN.py:625-641)."""
+        skip = set()
+        if (y is None or not self.class_cond) and hasattr(self, "embed"):
+            skip |= {id(m) for m in self.embed.modules()}
+        if feat is None and hasattr(self, "linear_feat"):
+            skip |= {id(m) for m in self.linear_feat.modules()}
+        sn_layers = [m for m in self.modules() if isinstance(m, layers.SN) and id(m) not in skip]
+        layers.sn_prefetch(sn_layers)
+        try:
+            h = self.input_conv(x)
+            for stage in self.blocks:
+                for block in stage:
+                    h = block(h)
+            h = ops.ReluSumPoolFn.apply(h)
+            out = self.linear(h)
+            parts = []
+            if self.class_cond and y is not None:
+                parts.append(self.embed(y))
+            if self.instance_cond and feat is not None:
+                parts.append(self.linear_feat(feat))
+            if not parts:
+                return out
+            proj = torch.cat(parts, dim=-1) if len(parts) > 1 else parts[0]
+            return out + torch.sum(proj * h, 1, keepdim=True)
+        finally:
+            layers.sn_drop_prefetched(sn_layers)
 
 
 class G_D(nn.Module):
-    """BigGANdeep.py:691-734."""
+    """BigGANdeep.py:691-734.  With an instance-conditioned generator the call signature is BigGAN.py's
+    `forward(z, gy, feats_g, x, dy, feats, train_G, return_G_z, split_D, policy, DA)` (BigGAN.py:655-711), which is what
+    train_fns.GAN_training_function passes positionally; otherwise the reference BigGAN-deep signature
+    `forward(z, gy, x, dy, train_G, return_G_z, split_D)`."""
 
-    def __init__(self, G, D):
+    def __init__(self, G, D, optimizer_G=None, optimizer_D=None):
         super().__init__()
         self.G, self.D = G, D
+        self.optimizer_G, self.optimizer_D = optimizer_G, optimizer_D
 
-    def forward(self, z, gy, x=None, dy=None, train_G=False, return_G_z=False, split_D=False):
+    def _bare(self, m):
+        return m.module if hasattr(m, "module") else m
+
+    def forward(self, z, gy, *args, **kwargs):
+        if getattr(self._bare(self.G), "instance_cond", False):
+            return self._forward_ic(z, gy, *args, **kwargs)
+        return self._forward_cc(z, gy, *args, **kwargs)
+
+    def _forward_cc(self, z, gy, x=None, dy=None, train_G=False, return_G_z=False, split_D=False):
         with torch.set_grad_enabled(train_G):
-            G_z = self.G(z, self.G.shared(gy))
+            G_z = self.G(z, self._bare(self.G).shared(gy))
         if split_D:
             D_fake = self.D(G_z, gy)
             if x is not None:
@@ -286,6 +364,25 @@ class G_D(nn.Module):
         D_input = torch.cat([G_z, x.contiguous(memory_format=torch.channels_last)], 0) if x is not None else G_z
         D_class = torch.cat([gy, dy], 0) if dy is not None else gy
         D_out = self.D(D_input, D_class)
+        if x is not None:
+            return torch.split(D_out, [G_z.shape[0], x.shape[0]])
+        return (D_out, G_z) if return_G_z else D_out
+
+    def _forward_ic(self, z, gy, feats_g=None, x=None, dy=None, feats=None, train_G=False, return_G_z=False, split_D=False,
+                    policy=False, DA=False):
+        if DA:
+            raise NotImplementedError("DiffAugment is disabled in every shipped IC-GAN config (SURVEY 2.1)")
+        with torch.set_grad_enabled(train_G):
+            G_z = self.G(z, gy, feats_g)
+        if split_D:
+            D_fake = self.D(G_z, gy, feats_g)
+            if x is not None:
+                return D_fake, self.D(x, dy, feats)
+            return (D_fake, G_z) if return_G_z else D_fake
+        D_input = torch.cat([G_z, x.contiguous(memory_format=torch.channels_last)], 0) if x is not None else G_z
+        D_class = (torch.cat([gy, dy], 0) if dy is not None else gy) if gy is not None else None
+        D_feats = (torch.cat([feats_g, feats], 0) if feats is not None else feats_g) if feats_g is not None else None
+        D_out = self.D(D_input, D_class, D_feats)
         if x is not None:
             return torch.split(D_out, [G_z.shape[0], x.shape[0]])
         return (D_out, G_z) if return_G_z else D_out

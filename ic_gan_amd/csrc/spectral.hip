@@ -8,16 +8,41 @@
 #include "icg_common.h"
 
 // part[yc][j] = sum_{i in row chunk yc} u[i] * w[i][j]
+// HBM-bound GEMV: a thread owns 4 consecutive columns (16-byte loads, a wavefront reads 1 KiB of a row per instruction) and
+// walks its row chunk four rows at a time (four independent loads in flight); scalar columns when cols % 4 != 0 (Cin = 3).
+#define SN_MAX_CHUNKS 64      // row chunks per layer: enough blocks to fill the chip on the 1536 x 13824 layers
 __device__ __forceinline__ void sn_uw_partial_body(int bx, int by, int gx, const float* __restrict__ w, const float* __restrict__ u,
                                                             int rows, int cols, int rows_per_chunk,
                                                             float* __restrict__ part) {
-  const int j = bx * 256 + threadIdx.x;
   const int yc = by;
-  if (j >= cols) return;
   const int i0 = yc * rows_per_chunk, i1 = min(rows, i0 + rows_per_chunk);
-  float s = 0.f;
-  for (int i = i0; i < i1; ++i) s = fmaf(u[i], w[(long)i * cols + j], s);
-  part[(long)yc * cols + j] = s;
+  if ((cols & 3) == 0) {
+    const int j = (bx * 256 + threadIdx.x) * 4;
+    if (j >= cols) return;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    int i = i0;
+    for (; i + 1 < i1; i += 2) {
+      const float4 a = *reinterpret_cast<const float4*>(w + (long)i * cols + j);
+      const float4 b = *reinterpret_cast<const float4*>(w + (long)(i + 1) * cols + j);
+      const float ua = u[i], ub = u[i + 1];
+      s0.x = fmaf(ua, a.x, s0.x); s0.y = fmaf(ua, a.y, s0.y); s0.z = fmaf(ua, a.z, s0.z); s0.w = fmaf(ua, a.w, s0.w);
+      s1.x = fmaf(ub, b.x, s1.x); s1.y = fmaf(ub, b.y, s1.y); s1.z = fmaf(ub, b.z, s1.z); s1.w = fmaf(ub, b.w, s1.w);
+    }
+    if (i < i1) {
+      const float4 a = *reinterpret_cast<const float4*>(w + (long)i * cols + j);
+      const float ua = u[i];
+      s0.x = fmaf(ua, a.x, s0.x); s0.y = fmaf(ua, a.y, s0.y); s0.z = fmaf(ua, a.z, s0.z); s0.w = fmaf(ua, a.w, s0.w);
+    }
+    *reinterpret_cast<float4*>(part + (long)yc * cols + j) = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    return;
+  }
+  for (int q = 0; q < 4; ++q) {            // the same block-to-column map (4 columns per thread slot), one at a time
+    const int j = (bx * 256 + threadIdx.x) * 4 + q;
+    if (j >= cols) return;
+    float s = 0.f;
+    for (int i = i0; i < i1; ++i) s = fmaf(u[i], w[(long)i * cols + j], s);
+    part[(long)yc * cols + j] = s;
+  }
 }
 __global__ __launch_bounds__(256) void sn_uw_partial_kernel(const float* __restrict__ w, const float* __restrict__ u,
                                                             int rows, int cols, int rows_per_chunk,
@@ -55,7 +80,7 @@ __global__ __launch_bounds__(1024) void sn_v_kernel(const float* __restrict__ pa
   sn_v_body(blockIdx.x, blockIdx.y, gridDim.x, part, ychunks, cols, eps, v);
 }
 
-// s[i] = sum_j w[i][j] v[j]; one wavefront per row
+// s[i] = sum_j w[i][j] v[j]; one wavefront per row, 16-byte loads (two in flight) when the row length allows
 __device__ __forceinline__ void sn_wv_body(int bx, int by, int gx, const float* __restrict__ w, const float* __restrict__ v, int rows,
                                                     int cols, float* __restrict__ s) {
   const int lane = threadIdx.x & 63;
@@ -63,7 +88,25 @@ __device__ __forceinline__ void sn_wv_body(int bx, int by, int gx, const float* 
   if (i >= rows) return;
   const float* wr = w + (long)i * cols;
   float acc = 0.f;
-  for (int j = lane; j < cols; j += 64) acc = fmaf(wr[j], v[j], acc);
+  if ((cols & 3) == 0) {
+    float acc2 = 0.f;
+    const int c4 = cols >> 2;
+    const float4* w4 = reinterpret_cast<const float4*>(wr);
+    const float4* v4 = reinterpret_cast<const float4*>(v);
+    int j = lane;
+    for (; j + 64 < c4; j += 128) {
+      const float4 a = w4[j], b = w4[j + 64], x = v4[j], y = v4[j + 64];
+      acc = fmaf(a.x, x.x, acc); acc = fmaf(a.y, x.y, acc); acc = fmaf(a.z, x.z, acc); acc = fmaf(a.w, x.w, acc);
+      acc2 = fmaf(b.x, y.x, acc2); acc2 = fmaf(b.y, y.y, acc2); acc2 = fmaf(b.z, y.z, acc2); acc2 = fmaf(b.w, y.w, acc2);
+    }
+    if (j < c4) {
+      const float4 a = w4[j], x = v4[j];
+      acc = fmaf(a.x, x.x, acc); acc = fmaf(a.y, x.y, acc); acc = fmaf(a.z, x.z, acc); acc = fmaf(a.w, x.w, acc);
+    }
+    acc += acc2;
+  } else {
+    for (int j = lane; j < cols; j += 64) acc = fmaf(wr[j], v[j], acc);
+  }
   acc = wave_sum(acc);
   if (lane == 0) s[i] = acc;
 }
@@ -244,9 +287,18 @@ __global__ __launch_bounds__(256) void sn_up_layouts_kernel(const float* __restr
   sn_up_layouts_body(blockIdx.x, blockIdx.y, gridDim.x, w, sigma, rows, Cin, wp, vd, vdn, wq);
 }
 
+// rows per chunk: 24 rows of the widest layer (13824 columns) = 1.3 MB streamed per block column; at least 16 rows per chunk
+static void sn_chunk_plan(int rows, int* ychunks, int* rpc) {
+  int yc = (int)icg_cdiv(rows, 24);
+  if (yc > SN_MAX_CHUNKS) yc = SN_MAX_CHUNKS;
+  if (yc < 1) yc = 1;
+  *rpc = (int)icg_cdiv(rows, yc);
+  *ychunks = (int)icg_cdiv(rows, *rpc);
+}
+
 extern "C" size_t icg_sn_scratch_bytes(int rows, int Cin, int R) {
   const long cols = (long)Cin * R * R;
-  return (size_t)(16 * cols + rows + 512) * sizeof(float);
+  return (size_t)(SN_MAX_CHUNKS * cols + rows + 512) * sizeof(float);
 }
 
 extern "C" int icg_sn_forward(const float* w, float* u, float* sv, int rows, int Cin, int R, float eps, int training,
@@ -259,12 +311,10 @@ extern "C" int icg_sn_forward(const float* w, float* u, float* sv, int rows, int
   const int cols = Cin * R * R;
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)scratch;
-  float* svec = part + 16L * cols;
-  int ychunks = (int)icg_cdiv(rows, 64);
-  if (ychunks > 16) ychunks = 16;
-  const int rpc = (int)icg_cdiv(rows, ychunks);
-  ychunks = (int)icg_cdiv(rows, rpc);
-  hipLaunchKernelGGL(sn_uw_partial_kernel, dim3((unsigned)icg_cdiv(cols, 256), ychunks), dim3(256), 0, st, w, u, rows,
+  float* svec = part + (long)SN_MAX_CHUNKS * cols;
+  int ychunks, rpc;
+  sn_chunk_plan(rows, &ychunks, &rpc);
+  hipLaunchKernelGGL(sn_uw_partial_kernel, dim3((unsigned)icg_cdiv(cols, 1024), ychunks), dim3(256), 0, st, w, u, rows,
                      cols, rpc, part);
   hipLaunchKernelGGL(sn_v_kernel, dim3(1), dim3(1024), 0, st, (const float*)part, ychunks, cols, eps, v_out);
   hipLaunchKernelGGL(sn_wv_kernel, dim3((unsigned)icg_cdiv(rows, 4)), dim3(256), 0, st, w, (const float*)v_out, rows,
@@ -298,7 +348,7 @@ struct SnPack {
 __global__ __launch_bounds__(256) void sn_uw_partial_multi_kernel(SnPack p) {
   const icg_sn_layer& L = p.l[blockIdx.z];
   const int cols = L.Cin * L.R * L.R;
-  if ((int)blockIdx.x * 256 >= cols || (int)blockIdx.y >= p.ychunks[blockIdx.z]) return;
+  if ((int)blockIdx.x * 1024 >= cols || (int)blockIdx.y >= p.ychunks[blockIdx.z]) return;
   sn_uw_partial_body(blockIdx.x, blockIdx.y, 0, L.w, L.u, L.rows, cols, p.rpc[blockIdx.z], (float*)L.scratch);
 }
 __global__ __launch_bounds__(1024) void sn_v_multi_kernel(SnPack p, float eps) {
@@ -310,12 +360,12 @@ __global__ __launch_bounds__(256) void sn_wv_multi_kernel(SnPack p) {
   const icg_sn_layer& L = p.l[blockIdx.z];
   const int cols = L.Cin * L.R * L.R;
   if ((int)blockIdx.x * 4 >= L.rows) return;
-  sn_wv_body(blockIdx.x, 0, 0, L.w, (const float*)L.v_out, L.rows, cols, (float*)L.scratch + 16L * cols);
+  sn_wv_body(blockIdx.x, 0, 0, L.w, (const float*)L.v_out, L.rows, cols, (float*)L.scratch + (long)SN_MAX_CHUNKS * cols);
 }
 __global__ __launch_bounds__(1024) void sn_u_multi_kernel(SnPack p, float eps, int training) {
   const icg_sn_layer& L = p.l[blockIdx.z];
   const int cols = L.Cin * L.R * L.R;
-  sn_u_body(0, 0, 1, (const float*)L.scratch + 16L * cols, L.rows, eps, training, L.u, L.sv, L.u_out, L.sigma_out);
+  sn_u_body(0, 0, 1, (const float*)L.scratch + (long)SN_MAX_CHUNKS * cols, L.rows, eps, training, L.u, L.sv, L.u_out, L.sigma_out);
 }
 __global__ __launch_bounds__(256) void sn_scale_multi_kernel(SnPack p) {
   const icg_sn_layer& L = p.l[blockIdx.z];
@@ -349,12 +399,10 @@ extern "C" int icg_sn_forward_multi(const icg_sn_layer* layers, int n, float eps
       if (lay && L.R != 3) return ICG_ERR_ARG;
       p.l[i] = L;
       const int cols = L.Cin * L.R * L.R;
-      int ychunks = (int)icg_cdiv(L.rows, 64);
-      if (ychunks > 16) ychunks = 16;
-      const int rpc = (int)icg_cdiv(L.rows, ychunks);
-      ychunks = (int)icg_cdiv(L.rows, rpc);
+      int ychunks, rpc;
+      sn_chunk_plan(L.rows, &ychunks, &rpc);
       p.ychunks[i] = ychunks; p.rpc[i] = rpc;
-      gx_uw = max(gx_uw, (unsigned)icg_cdiv(cols, 256));
+      gx_uw = max(gx_uw, (unsigned)icg_cdiv(cols, 1024));
       gy_uw = max(gy_uw, (unsigned)ychunks);
       gx_wv = max(gx_wv, (unsigned)icg_cdiv(L.rows, 4));
       long sb = icg_cdiv((long)L.rows * cols, 256);
@@ -441,14 +489,15 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ sigma,
                                                            const double* __restrict__ part, int nparts, int rows,
                                                            int Cin, int RR, float* __restrict__ dw, int accumulate) {
-  __shared__ double s_dot;
-  if (threadIdx.x == 0) {
+  __shared__ double s_red[4];
+  {   // every block re-reduces the per-block partial dots: all lanes, fixed order (deterministic)
     double d = 0.0;
-    for (int k = 0; k < nparts; ++k) d += part[k];
-    s_dot = d;
+    for (int k = threadIdx.x; k < nparts; k += 256) d += part[k];
+    d = wave_sum_d(d);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = d;
   }
   __syncthreads();
-  const float dot = (float)s_dot;
+  const float dot = (float)((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
   const float inv_sigma = 1.0f / sigma[0];
   const long total = (long)rows * Cin * RR;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -511,8 +560,9 @@ __global__ __launch_bounds__(256) void sn_bwd_gather_kernel(const float* __restr
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+#define SN_BWD_PARTS 2048     // blocks of the gather / dot pass (8 per CU: the pass is a latency-bound transpose at 1 per CU)
 extern "C" size_t icg_sn_backward_scratch_bytes(int rows, int Cin, int R) {
-  return 256 * sizeof(double) + (size_t)rows * Cin * R * R * sizeof(float);
+  return SN_BWD_PARTS * sizeof(double) + (size_t)rows * Cin * R * R * sizeof(float);
 }
 
 extern "C" int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* dw_up, const float* dw_down,
@@ -522,14 +572,14 @@ extern "C" int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const
   ICG_REQUIRE((dw_hwio || dw_ohwi || dw_up || dw_down) && w_ohwi && sigma && dw && scratch);
   if (dw_up || dw_down) ICG_REQUIRE(R == 3);
   ICG_REQUIRE(rows > 0 && Cin > 0 && R >= 1);
-  if (scratch_bytes < 256 * sizeof(double)) return ICG_ERR_WORKSPACE;
+  if (scratch_bytes < SN_BWD_PARTS * sizeof(double)) return ICG_ERR_WORKSPACE;
   const int RR = R * R;
   const long total = (long)rows * Cin * RR;
-  int nparts = (int)(icg_cdiv(total, 1024) > 256 ? 256 : icg_cdiv(total, 1024));
+  int nparts = (int)(icg_cdiv(total, 1024) > SN_BWD_PARTS ? SN_BWD_PARTS : icg_cdiv(total, 1024));
   hipStream_t st = (hipStream_t)stream;
   if ((dw_hwio || dw_up || dw_down) && scratch_bytes >= icg_sn_backward_scratch_bytes(rows, Cin, R)) {
     // two coalesced passes: transpose-gather into OHWI order (+ dot), then the correction in parameter order
-    float* g = reinterpret_cast<float*>(reinterpret_cast<double*>(scratch) + 256);
+    float* g = reinterpret_cast<float*>(reinterpret_cast<double*>(scratch) + SN_BWD_PARTS);
     hipLaunchKernelGGL(sn_bwd_gather_kernel, dim3(nparts), dim3(256), 0, st, dw_hwio, dw_ohwi, dw_up, dw_down, w_ohwi, rows,
                        Cin, RR, g, (double*)scratch);
     long blocks2 = icg_cdiv(total, 256);

@@ -744,45 +744,94 @@ __device__ __forceinline__ void w4_dy_up(const float4 l[2], float4 s[6]) {
 
 // DY[slot(i)*NP + slot(j)][t][c] = alpha (A d A^T)[i][j], one thread per (tile, channel quad);  UP = 0: d = the 4x4 tile of
 // dy [B][H][W][C];  UP = 1: d = the tile of the nearest-x2 upsampled dy [B][H/2][W/2][C] (2x2 loads)
+// db_part != NULL: the pass also produces the bias gradient's column sums of (unscaled) dy -- every pixel of dy is read exactly
+// once here, so the separate icg_colsum pass over dy (6.4 ms per cfg3 step in round 1) disappears.  Deterministic: per-thread
+// sums go through LDS, channel quad q is reduced by thread q over the block's threads in index order, and each block writes
+// one row [4*C4] of partials that wino_db_final_kernel sums in block order.
 template <int UP, int NP>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ DY, int B, int H,
-                                                       int W, int C4, float alpha) {
+                                                       int W, int C4, float alpha, float* __restrict__ db_part) {
   static_assert(!UP || NP == 5, "the upsampled tile has no component 2");
+  __shared__ float4 red[256];
   const int th = H >> 2, tw = W >> 2;
   const long T = (long)B * th * tw;
   const long total = T * C4, plane = T * C4;
   const long gstride = (long)gridDim.x * blockDim.x;
   constexpr int NL = UP ? 2 : 4;
   const int Hx = UP ? (H >> 1) : H, Wx = UP ? (W >> 1) : W;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
-    const int c4 = (int)(i % C4);
-    const long t = i / C4;
-    const int tx = (int)(t % tw);
-    const long t2 = t / tw;
-    const int ty = (int)(t2 % th);
-    const long b = t2 / th;
-    const float4* gp = reinterpret_cast<const float4*>(dy) + ((b * Hx + NL * ty) * Wx + NL * tx) * C4 + c4;
-    float4 E[NL][6];
+  float4 bsum[2] = {f4zero(), f4zero()};                      // running sums of channel quads tid and tid + 256 (C <= 2048)
+  for (long base = (long)blockIdx.x * blockDim.x; base < total; base += gstride) {
+    const long i = base + threadIdx.x;
+    float4 tsum = f4zero();
+    if (i < total) {
+      const int c4 = (int)(i % C4);
+      const long t = i / C4;
+      const int tx = (int)(t % tw);
+      const long t2 = t / tw;
+      const int ty = (int)(t2 % th);
+      const long b = t2 / th;
+      const float4* gp = reinterpret_cast<const float4*>(dy) + ((b * Hx + NL * ty) * Wx + NL * tx) * C4 + c4;
+      float4 E[NL][6];
 #pragma unroll
-    for (int r = 0; r < NL; ++r) {
-      float4 d[NL];
+      for (int r = 0; r < NL; ++r) {
+        float4 d[NL];
 #pragma unroll
-      for (int c = 0; c < NL; ++c) d[c] = f4s(gp[((long)r * Wx + c) * C4], alpha);
-      if constexpr (UP) w4_dy_up(d, E[r]); else w4_dy6(d, E[r]);
+        for (int c = 0; c < NL; ++c) {
+          const float4 raw = gp[((long)r * Wx + c) * C4];
+          tsum = f4add(tsum, raw);
+          d[c] = f4s(raw, alpha);
+        }
+        if constexpr (UP) w4_dy_up(d, E[r]); else w4_dy6(d, E[r]);
+      }
+      float4* op = reinterpret_cast<float4*>(DY) + t * C4 + c4;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (!w4_has<NP>(j)) continue;
+        float4 col[NL], o[6];
+#pragma unroll
+        for (int r = 0; r < NL; ++r) col[r] = E[r][j];
+        if constexpr (UP) w4_dy_up(col, o); else w4_dy6(col, o);
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+          if (w4_has<NP>(r)) op[(long)(w4_slot<NP>(r) * NP + w4_slot<NP>(j)) * plane] = o[r];
+      }
     }
-    float4* op = reinterpret_cast<float4*>(DY) + t * C4 + c4;
+    if (db_part) {                      // (uniform over the block: every thread takes the same number of iterations)
+      red[threadIdx.x] = tsum;
+      __syncthreads();
+      const int off = (int)(base % C4);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      if (!w4_has<NP>(j)) continue;
-      float4 col[NL], o[6];
-#pragma unroll
-      for (int r = 0; r < NL; ++r) col[r] = E[r][j];
-      if constexpr (UP) w4_dy_up(col, o); else w4_dy6(col, o);
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-        if (w4_has<NP>(r)) op[(long)(w4_slot<NP>(r) * NP + w4_slot<NP>(j)) * plane] = o[r];
+      for (int h = 0; h < 2; ++h) {
+        const int q = (int)threadIdx.x + 256 * h;
+        if (q < C4) {
+          float4 a = bsum[h];
+          for (int j = (q - off + C4) % C4; j < 256; j += C4) a = f4add(a, red[j]);
+          bsum[h] = a;
+        }
+      }
+      __syncthreads();
     }
   }
+  if (db_part) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = (int)threadIdx.x + 256 * h;
+      if (q < C4) reinterpret_cast<float4*>(db_part)[(long)blockIdx.x * C4 + q] = bsum[h];
+    }
+  }
+}
+
+// dbias[c] = sum over blocks of part[block][c]: one workgroup per channel, lanes stride over the blocks in fixed order
+__global__ __launch_bounds__(256) void wino_db_final_kernel(const float* __restrict__ part, int nblocks, int C,
+                                                            float* __restrict__ dbias) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  float a = 0.f;
+  for (int k = threadIdx.x; k < nblocks; k += 256) a += part[(long)k * C + c];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) dbias[c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __device__ __forceinline__ void w4_gt3(const float u[6], float g[3]) {
@@ -826,9 +875,15 @@ static size_t wino4_wgrad_bytes(int np, int B, int H, int W, int Cin, int Cout) 
 
 // shared driver: V = input transform of x (x_up: of the upsampled x), DY = transform of dy (dy_up: of the upsampled dy, scaled),
 // dU[xi] = V[xi]^T DY[xi], dw = G^T dU G.  H, W: full resolution.
+static long wino4_dy_blocks(long T, int Cout) {
+  long nb = icg_cdiv(T * (Cout / 4), 256);
+  return nb > 256 * 64 ? 256 * 64 : nb;
+}
+
 static int wino4_wgrad_run(const float* x, int x_up, const float* dy, int dy_up, float dy_alpha, float* dw, const float* scale,
                            const float* shift, int64_t ssb, int B, int H, int W, int Cin, int Cout, unsigned flags, int np,
-                           void* workspace, void* stream, const float* v_saved = nullptr) {
+                           void* workspace, void* stream, const float* v_saved = nullptr, float* dbias = nullptr,
+                           float* db_part = nullptr) {
   const long T = (long)B * (H / 4) * (W / 4), P = (long)np * np;
   ICG_REQUIRE(T * 36 < 0x7fffffffL);
   hipStream_t st = (hipStream_t)stream;
@@ -841,12 +896,13 @@ static int wino4_wgrad_run(const float* x, int x_up, const float* dy, int dy_up,
   const size_t gws_bytes = icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, (int)P);
   if (x) launch_wino4_input(st, x_up, np, x, scale, shift, (long)ssb, V, B, H, W, Cin, flags);
   else V = const_cast<float*>(v_saved);        // the forward pass's V, kept by the caller (icg_conv2d_wino4_wgrad_from_v)
-  long nb = icg_cdiv(T * (Cout / 4), 256);
-  if (nb > 256 * 64) nb = 256 * 64;
+  long nb = wino4_dy_blocks(T, Cout);
   const dim3 g((unsigned)nb), blk(256);
-  if (dy_up) hipLaunchKernelGGL((wino4_dy_kernel<1, 5>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha);
-  else if (np == 5) hipLaunchKernelGGL((wino4_dy_kernel<0, 5>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha);
-  else hipLaunchKernelGGL((wino4_dy_kernel<0, 6>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha);
+  if (dy_up) hipLaunchKernelGGL((wino4_dy_kernel<1, 5>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha, db_part);
+  else if (np == 5) hipLaunchKernelGGL((wino4_dy_kernel<0, 5>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha, db_part);
+  else hipLaunchKernelGGL((wino4_dy_kernel<0, 6>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha, db_part);
+  if (db_part)
+    hipLaunchKernelGGL(wino_db_final_kernel, dim3((unsigned)Cout), dim3(256), 0, st, (const float*)db_part, (int)nb, Cout, dbias);
   int rc;
   { PlanesScope ps(stream, (int)P, Cin, Cout, (double)T); rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, (int)P, gws, gws_bytes, stream); }
   if (rc != ICG_OK) return rc;
@@ -905,6 +961,25 @@ extern "C" size_t icg_conv2d_wino4_wgrad_from_v_workspace_bytes(int B, int H, in
   const size_t T = (size_t)B * (H / 4) * (W / 4), P = (size_t)planes;
   return wino_al(P * T * Cout * sizeof(float)) + wino_al(P * Cin * Cout * sizeof(float)) +
          wino_al(icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, planes));
+}
+
+// the same, and dbias [Cout] = column sums of dy (the gradient of the layer's bias) from the pass that reads dy anyway
+extern "C" size_t icg_conv2d_wino4_wgrad_from_v_db_workspace_bytes(int B, int H, int W, int Cin, int Cout, int planes) {
+  const long T = (long)B * (H / 4) * (W / 4);
+  return icg_conv2d_wino4_wgrad_from_v_workspace_bytes(B, H, W, Cin, Cout, planes) +
+         wino_al((size_t)wino4_dy_blocks(T, Cout) * Cout * sizeof(float));
+}
+
+extern "C" int icg_conv2d_wino4_wgrad_from_v_db(const float* V, const float* dy, float* dw, float* dbias, int B, int H, int W,
+                                                int Cin, int Cout, int planes, int dy_up, float dy_alpha, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(V && dy && dw && dbias && workspace && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  ICG_REQUIRE((H % 4 == 0) && (W % 4 == 0) && (Cin % 4 == 0) && (Cout % 4 == 0) && (planes == 36 || planes == 25));
+  ICG_REQUIRE((!dy_up || planes == 25) && Cout <= 2048);
+  if (workspace_bytes < icg_conv2d_wino4_wgrad_from_v_db_workspace_bytes(B, H, W, Cin, Cout, planes)) return ICG_ERR_WORKSPACE;
+  float* part = (float*)((char*)workspace + icg_conv2d_wino4_wgrad_from_v_workspace_bytes(B, H, W, Cin, Cout, planes));
+  return wino4_wgrad_run(nullptr, 0, dy, dy_up ? 1 : 0, dy_alpha, dw, nullptr, nullptr, 0, B, H, W, Cin, Cout, 0,
+                         planes == 25 ? 5 : 6, workspace, stream, V, dbias, part);
 }
 
 extern "C" int icg_conv2d_wino4_wgrad_from_v(const float* V, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,

@@ -8,7 +8,8 @@ Checkpoints are the reference's own files (`{G,G_ema,D,G_optim,D_optim,state_dic
 BigGAN_PyTorch/utils.py:1116-1167): a checkpoint written by the reference loads here and vice versa
 (tests/test_checkpoint.py runs both directions against files written by the reference).
 
-The StyleGAN2 branch (pickled network, inference/utils.py:395-403) is not part of this path and raises.
+The StyleGAN2 branch (inference/utils.py:395-403) reads the pickled `best-network-snapshot.pkl` through
+ic_gan_amd.stylegan2.legacy.load_network_pkl (no execution of the source text embedded in the pickle) and returns G_ema.
 """
 import torch
 
@@ -29,8 +30,8 @@ def sample(generator, sample_conditioning_func, config, class_cond=True, instanc
 
     `sample_conditioning_func()` yields z | (z, y) | (z, feats) | (z, y, feats) in that order
     (data_utils/utils.py:877-901)."""
-    if backbone != "biggan":
-        raise NotImplementedError("only the BigGAN backbone is served by this engine (backbone=%r)" % (backbone,))
+    if backbone not in ("biggan", "stylegan2"):
+        raise NotImplementedError("backbone must be 'biggan' or 'stylegan2' (got %r)" % (backbone,))
     if config.get("parallel", False):
         raise NotImplementedError("nn.DataParallel sampling is not supported; run one process per GPU")
     cond = sample_conditioning_func()
@@ -49,6 +50,12 @@ def sample(generator, sample_conditioning_func, config, class_cond=True, instanc
         if feats_ is not None:
             feats_ = feats_.to(device, non_blocking=True)
         z_ = z_.to(device, non_blocking=True).as_subclass(torch.Tensor)
+        if backbone == "stylegan2":          # inference/utils.py:243-262: one-hot / empty class vector, truncation, constant noise
+            n = z_.shape[0]
+            c = torch.empty([n, generator.c_dim], device=device) if y_ is None else torch.eye(config["n_classes"], device=device)[y_]
+            h = torch.empty([n, generator.h_dim], device=device) if feats_ is None else feats_
+            gen_samples = generator(z=z_, c=c, feats=h, truncation_psi=truncation_value, noise_mode="const")
+            return gen_samples, c, h
         gen_samples = generator(z_, y_, feats_)
     return gen_samples, y_, feats_
 
@@ -132,8 +139,17 @@ def _best_checkpoint(config):
 def load_model_inference(config, device="cuda"):
     """inference/utils.py:272-393 (BigGAN backbone): returns (generator, config) with `config` overwritten by the
     training-time configuration stored in the checkpoint, except for the caller-side keys."""
+    if config.get("model_backbone", "biggan") == "stylegan2":
+        # inference/utils.py:395-403: StyleGAN2 saves the entire network in a pickle
+        import os
+        from .stylegan2 import legacy
+        network_pkl = os.path.join(config["base_root"], config["experiment_name"], "best-network-snapshot.pkl")
+        print('Loading networks from "%s"...' % network_pkl)
+        with open(network_pkl, "rb") as f:
+            generator = legacy.load_network_pkl(f)["G_ema"].to(device)
+        return generator, config
     if config.get("model_backbone", "biggan") != "biggan":
-        raise NotImplementedError("only model_backbone='biggan' is served by this engine")
+        raise NotImplementedError("model_backbone must be 'biggan' or 'stylegan2'")
     from . import BigGAN as model
 
     if not config.get("experiment_name"):

@@ -183,6 +183,21 @@ def _conv_fprop(x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, 
 KEEP_WINOGRAD_V = True          # keep the forward pass's transformed input for the weight gradient (memory for one HBM pass)
 
 
+def _wgrad_from_v(v, dout, dw_hwio, B, H, W, Cin, Cout, planes, dy_up, dy_alpha, want_dbias):
+    """Weight gradient from the forward pass's V planes; when the layer's bias gradient is wanted as well it comes out of the
+    same pass over dy (icg_conv2d_wino4_wgrad_from_v_db) instead of a separate icg_colsum.  -> dbias or None"""
+    dev = dout.device
+    if want_dbias and Cout <= 2048:
+        dbias = _f32(Cout, dev)
+        nb = L.query("icg_conv2d_wino4_wgrad_from_v_db_workspace_bytes", B, H, W, Cin, Cout, planes)
+        L.call("icg_conv2d_wino4_wgrad_from_v_db", v, dout, dw_hwio, dbias, B, H, W, Cin, Cout, planes, dy_up, dy_alpha,
+               _bytes(nb, dev), nb)
+        return dbias
+    nb = L.query("icg_conv2d_wino4_wgrad_from_v_workspace_bytes", B, H, W, Cin, Cout, planes)
+    L.call("icg_conv2d_wino4_wgrad_from_v", v, dout, dw_hwio, B, H, W, Cin, Cout, planes, dy_up, dy_alpha, _bytes(nb, dev), nb)
+    return None
+
+
 def _saved_v(ws, planes, B, H, W, Cin):
     """the V = transform(act(x)) region the F(4x4,3x3) forward entries leave at the start of their workspace (H, W: full
     resolution); the view keeps the workspace alive until the backward pass has used it"""
@@ -443,9 +458,8 @@ class FusedConvFn(Function):
             dw_hwio = _f32(9 * Cin * Cout, dev)
             Hf, Wf = (Hs, Ws) if ctx.down else (H, W)                # full resolution of the layer
             if ctx.saved_v is not None and ctx.saved_v[1] == 25:
-                nb = L.query("icg_conv2d_wino4_wgrad_from_v_workspace_bytes", B, Hf, Wf, Cin, Cout, 25)
-                L.call("icg_conv2d_wino4_wgrad_from_v", ctx.saved_v[0], dout, dw_hwio, B, Hf, Wf, Cin, Cout, 25,
-                       1 if ctx.down else 0, 0.25 if ctx.down else 1.0, _bytes(nb, dev), nb)
+                dbias = _wgrad_from_v(ctx.saved_v[0], dout, dw_hwio, B, Hf, Wf, Cin, Cout, 25, 1 if ctx.down else 0,
+                                      0.25 if ctx.down else 1.0, has_bias and need[2])
                 ctx.saved_v = None
             elif ctx.down:
                 nb = L.query("icg_conv2d_rs_wino_wgrad_workspace_bytes", B, Hs, Ws, Cin, Cout)
@@ -472,9 +486,7 @@ class FusedConvFn(Function):
             dw_hwio = _f32(R * R * Cin * Cout, dev)
             wt = winograd_wgrad_tile(Cin, Cout, H, W, B) if sn.w_wino is not None else 0
             if wt == 4 and ctx.saved_v is not None and ctx.saved_v[1] == 36:
-                nb = L.query("icg_conv2d_wino4_wgrad_from_v_workspace_bytes", B, H, W, Cin, Cout, 36)
-                L.call("icg_conv2d_wino4_wgrad_from_v", ctx.saved_v[0], dout, dw_hwio, B, H, W, Cin, Cout, 36, 0, 1.0,
-                       _bytes(nb, dev), nb)
+                dbias = _wgrad_from_v(ctx.saved_v[0], dout, dw_hwio, B, H, W, Cin, Cout, 36, 0, 1.0, has_bias and need[2])
                 ctx.saved_v = None
             elif wt:
                 # wide 3x3 stride-1 layer: weight gradient through the Winograd domain (16/36 or 9/36 of the MACs)
@@ -487,7 +499,7 @@ class FusedConvFn(Function):
                 ws = _bytes(nb, dev)
                 L.call("icg_conv2d_wgrad", x, dout, dw_hwio, scale, shift, ssb, B, H, W, Cin, Cout, R, ctx.flags, ws, nb)
             dweight = _sn_backward(dw_hwio, None, sn, ctx.weight_like)
-        if has_bias and need[2]:
+        if has_bias and need[2] and dbias is None:
             rows = B * H * W
             nb = L.query("icg_colsum_workspace_bytes", rows, Cout)
             ws = _bytes(nb, dev)

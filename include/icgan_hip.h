@@ -219,6 +219,12 @@ int icg_conv2d_down_wino_wgrad(const float* x, const float* dy, float* dw, int B
 size_t icg_conv2d_wino4_wgrad_from_v_workspace_bytes(int B, int H, int W, int Cin, int Cout, int planes);
 int icg_conv2d_wino4_wgrad_from_v(const float* V, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
                                   int planes, int dy_up, float dy_alpha, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with dbias [Cout] = column sums of dy over all of its pixels (the gradient of the layer's bias, layers.py:144-153
+ * `F.conv2d(x, W, bias)`), produced by the dy-transform pass that reads dy anyway; deterministic two-stage reduction. */
+size_t icg_conv2d_wino4_wgrad_from_v_db_workspace_bytes(int B, int H, int W, int Cin, int Cout, int planes);
+int icg_conv2d_wino4_wgrad_from_v_db(const float* V, const float* dy, float* dw, float* dbias, int B, int H, int W, int Cin,
+                                     int Cout, int planes, int dy_up, float dy_alpha, void* workspace, size_t workspace_bytes,
+                                     void* stream);
 /* measurement hook (bench.py): with timing enabled every batched GEMM over Winograd planes (rocprofv3 name
  * icg_gemm_planes_kernel<AMODE, BMODE, TN>) is bracketed by HIP events on its launch stream.  drain() writes rows of
  * {amode, tn, planes, launches, total ms, total executed flops, total operand bytes} and returns the row count. */

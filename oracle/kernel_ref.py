@@ -180,6 +180,17 @@ def icg_conv2d_wino4_wgrad_from_v(V, dy, dw, B, H, W, Cin, Cout, planes, dy_up, 
     mem(dw)[: 9 * Cin * Cout].copy_(gw.reshape(-1).float())
 
 
+def icg_conv2d_wino4_wgrad_from_v_db_workspace_bytes(B, H, W, Cin, Cout, planes):
+    return 16
+
+
+def icg_conv2d_wino4_wgrad_from_v_db(V, dy, dw, dbias, B, H, W, Cin, Cout, planes, dy_up, dy_alpha, workspace, workspace_bytes):
+    """... and dbias = column sums of dy (dy at the pooled resolution when dy_up)"""
+    icg_conv2d_wino4_wgrad_from_v(V, dy, dw, B, H, W, Cin, Cout, planes, dy_up, dy_alpha, workspace, workspace_bytes)
+    hh, ww = (H // 2, W // 2) if dy_up else (H, W)
+    mem(dbias)[:Cout].copy_(_nhwc(dy, B, hh, ww, Cout).double().sum((0, 1, 2)).float())
+
+
 def icg_gemm_tn_batched_workspace_bytes(M, N, K, batch):
     return 16
 

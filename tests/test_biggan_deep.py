@@ -88,3 +88,57 @@ def test_steps_host_logic(name, emu):
 @pytest.mark.parametrize("name", CASES)
 def test_steps_hip(name):
     _steps(name, "cuda:0")
+
+
+# ---------------------------------------------------------------------------------- instance-conditioned extension
+IC_CFG = dict(G_ch=8, D_ch=8, G_depth=2, D_depth=2, dim_z=32, shared_dim=16, shared_dim_feat=24, hier=True, G_shared=True,
+              G_shared_feat=True, resolution=32, G_attn="16", D_attn="16", n_classes=10, SN_eps=1e-6, BN_eps=1e-5,
+              adam_eps=1e-6, G_lr=1e-3, D_lr=2e-3, G_B1=0.0, D_B1=0.0, G_B2=0.999, D_B2=0.999, toggle_grads=True,
+              num_D_steps=1, num_D_accumulations=2, num_G_accumulations=1, split_D=False, DiffAugment="", DA=False,
+              D_ortho=0.0, G_ortho=0.0, ema=True, skip_init=True)
+
+
+def _ic_step(dev, class_cond):
+    """BASELINE configs[4] "IC-GAN BigGANdeep": the instance-conditioned extension (no reference model exists: parity
+    unpinned) must be drivable by the reference's step function signature (train_fns.GAN_training_function passes
+    labels / features positionally as for BigGAN.py) and produce a finite, non-trivial update of every parameter."""
+    import ic_gan_amd.BigGANdeep as M
+    from ic_gan_amd import train_fns, utils
+    cfg = dict(IC_CFG, class_cond=class_cond, instance_cond=True)
+    G, D = M.Generator(**cfg), M.Discriminator(**cfg)
+    G.load_state_dict(synth.synth_state(synth.spec_of(G.state_dict()), 11))
+    D.load_state_dict(synth.synth_state(synth.spec_of(D.state_dict()), 22))
+    names = set(G.state_dict())
+    assert {"shared_feat.weight", "shared_feat.u0"} <= names and (("shared.weight" in names) == class_cond)
+    assert ("embed.weight" in D.state_dict()) == class_cond and "linear_feat.weight" in D.state_dict()
+    G, D = G.to(dev), D.to(dev)
+    G_ema = M.Generator(**{**cfg, "no_optim": True}).to(dev)
+    ema = utils.ema(G, G_ema, 0.9, 0)
+    GD = M.G_D(G, D)
+    gb = 2
+    samp = synth.CondSampler(cfg, cfg["dim_z"], gb, seed=7)
+    train = train_fns.GAN_training_function(G, D, GD, ema, {"itr": 1}, cfg, samp, embedded_optimizers=True, device=dev,
+                                            batch_size=gb)
+    x, y, f = synth.synth_batch(cfg, gb * cfg["num_D_accumulations"], seed=100)
+    before = {n: p.detach().clone() for n, p in list(G.named_parameters()) + list(D.named_parameters())}
+    G.train(); D.train()
+    m = train(x.to(dev), y.to(dev) if y is not None else None, f.to(dev))
+    assert all(np.isfinite(v) for v in m.values()), m
+    after = dict(list(G.named_parameters()) + list(D.named_parameters()))
+    moved = sum(int(not torch.equal(after[n].detach(), b)) for n, b in before.items())
+    assert moved == len(before), (moved, len(before))
+    with torch.no_grad():
+        z, lab, fg = (samp() + (None,))[:3] if class_cond else (samp()[0], None, samp()[1])
+        img = G_ema.eval()(z.to(dev), lab.to(dev) if lab is not None else None, fg.to(dev))
+    assert img.shape == (gb, 3, 32, 32) and torch.isfinite(img).all() and float(img.abs().max()) <= 1.0
+
+
+@pytest.mark.parametrize("class_cond", [False, True])
+def test_instance_conditioned_deep_step_host_logic(class_cond, emu):
+    _ic_step("cpu", class_cond)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("class_cond", [False, True])
+def test_instance_conditioned_deep_step_hip(class_cond):
+    _ic_step("cuda:0", class_cond)

@@ -421,6 +421,13 @@ def test_conv2d_winograd4_wgrad_from_saved_v(case, kind):
     a[2] = dw_ref
     getattr(R, name)(*a)
     close(p[0], dw_ref, rtol=5e-4, atol_rel=5e-4, what=f"wgrad from saved V vs re-transform {kind} {case}")
+    # ... and the variant that also emits the bias gradient (column sums of dy) from the dy-transform pass
+    nbd = L.query("icg_conv2d_wino4_wgrad_from_v_db_workspace_bytes", B, H, W, Cin, Cout, planes)
+    (p2, pb) = run_pair("icg_conv2d_wino4_wgrad_from_v_db", [v_cpu.clone(), dy, torch.empty(9 * Cin * Cout), torch.empty(Cout), B, H, W,
+                                                              Cin, Cout, planes, dy_up, alpha, torch.empty(nbd, dtype=torch.uint8), nbd],
+                        [2, 3])
+    assert torch.equal(p2[0].cpu(), p[0].cpu()), "the dbias variant must not change dw"
+    close(*pb, rtol=2e-5, atol_rel=2e-5, what=f"dbias from the dy transform {kind} {case}")
 
 
 GEMM_CASES = [
