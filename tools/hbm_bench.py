@@ -124,6 +124,23 @@ def main():
     xs = torch.randn(16, 64, 256, 256, device=dev)
     report("downsample2d-style 1x1 skip [16,64,256,256]->128", 4 * xs.numel() * 1.25,
            ev(lambda: UF.upfirdn2d(xs, f, down=2, padding=[1, 1, 1, 1])))
+    # ---- fp16 storage (the reference's num_fp16_res blocks): half the bytes per element, fp32 arithmetic
+    xs = cl(16, 64, 256, 256).half()
+    bias = torch.randn(64, device=dev).half()
+    report("bias_act lrelu fwd fp16 [16,64,256,256] nhwc", 4 * xs.numel(), ev(lambda: BA.bias_act(xs, bias, act="lrelu", clamp=256)))
+    xs = cl(16, 64, 257, 257).half()
+    report("upfirdn2d_nhwc fp16 blur after up-conv [16,64,257,257]->256", 2 * (xs.numel() + 16 * 64 * 256 * 256),
+           ev(lambda: UF.upfirdn2d(xs, f, padding=[1, 1, 1, 1], gain=4)))
+    # bias gradient out of the Winograd dy transform (replaces the colsum pass): the pass itself, with and without the sums
+    B, C, H = 64, 96, 256
+    dy = cl(B, C, H, H)
+    T = B * (H // 4) * (H // 4)
+    v = torch.empty(36 * T * C, device=dev)
+    dw, db = torch.empty(9 * C * C, device=dev), torch.empty(C, device=dev)
+    nb = L.query("icg_conv2d_wino4_wgrad_from_v_db_workspace_bytes", B, H, H, C, C, 36); ws = ops._bytes(nb, dev)
+    t1 = ev(lambda: L.call("icg_conv2d_wino4_wgrad_from_v", v, dy, dw, B, H, H, C, C, 36, 0, 1.0, ws, nb), 5, 2)
+    t2 = ev(lambda: L.call("icg_conv2d_wino4_wgrad_from_v_db", v, dy, dw, db, B, H, H, C, C, 36, 0, 1.0, ws, nb), 5, 2)
+    print(f"wino4 wgrad from V 96->96@256 B64: {t1 * 1e3:.3f} ms; with the bias-gradient sums in the dy transform: {t2 * 1e3:.3f} ms", flush=True)
 
 
 if __name__ == "__main__":
