@@ -356,7 +356,10 @@ def bench_stylegan2(args, device, rank, world, local_rank, use_ddp):
     res, b = 256, (args.batch or 16)
     torch.manual_seed(rank)
     np.random.seed(rank)
-    common = dict(channel_base=16384, channel_max=512, num_fp16_res=0, conv_clamp=None)
+    # --fp16: the reference's own cfg=auto block precision (train.py:297-310: num_fp16_res=4, conv_clamp=256): the 32x32 ... 256x256
+    # blocks store fp16 (bias_act / upfirdn2d / modulation glue move half the bytes), convolutions compute in fp32 on MFMA
+    common = dict(channel_base=16384, channel_max=512, num_fp16_res=(4 if args.fp16 else 0),
+                  conv_clamp=(256 if args.fp16 else None))
     G = N.Generator(z_dim=512, c_dim=0, h_dim=2048, w_dim=512, img_resolution=res, img_channels=3,
                     mapping_kwargs=dict(num_layers=2), synthesis_kwargs=common).train().requires_grad_(False).to(device)
     D = N.Discriminator(c_dim=0, h_dim=2048, img_resolution=res, img_channels=3, mapping_kwargs=dict(num_layers=2),
@@ -421,8 +424,8 @@ def bench_stylegan2(args, device, rank, world, local_rank, use_ddp):
             "metric": "images/sec training iteration, IC-GAN StyleGAN2 256^2 (cfg4, secondary workload)",
             "value": round(b * world * args.steps / elapsed, 3), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg4: IC-GAN StyleGAN2 256x256 cfg=auto, h_dim 2048, fp32; Gmain+Dmain every iteration, "
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("f16 storage / f32 arithmetic" if args.fp16 else "f32"), "data": "synthetic",
+            "config": {"workload": "cfg4: IC-GAN StyleGAN2 256x256 cfg=auto, h_dim 2048, " + ("fp16 blocks (num_fp16_res=4, conv_clamp=256), fp32 MFMA arithmetic" if args.fp16 else "fp32 (num_fp16_res=0)") + "; Gmain+Dmain every iteration, "
                                    "Greg every 4, Dreg every 16 (steps should be a multiple of 16)",
                        "batch_per_gpu": b, "global_batch": b * world, "parallelism": f"dp{world}"},
             # dominant MFMA kernel of the iteration, and the dominant HBM-bound plugin (bias_act / upfirdn2d: algorithmic bytes
@@ -637,6 +640,7 @@ def main():
     ap.add_argument("--no-winograd", action="store_true",
                     help="implicit-GEMM / phase / 4x4-stride-2 kernels only (ops.disable_winograd): the strict-parity route")
     ap.add_argument("--sync-bn", action="store_true", help="cross-replica BN statistics over RCCL (cfg3 variant)")
+    ap.add_argument("--fp16", action="store_true", help="cfg4: the reference's cfg=auto precision (num_fp16_res=4, conv_clamp=256)")
     args = ap.parse_args()
 
     if args.cpu_baseline_only:          # child process of the N=1 run: bounded CPU sample, prints one JSON object

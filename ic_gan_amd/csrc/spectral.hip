@@ -50,40 +50,57 @@ __global__ __launch_bounds__(256) void sn_uw_partial_kernel(const float* __restr
   sn_uw_partial_body(blockIdx.x, blockIdx.y, gridDim.x, w, u, rows, cols, rows_per_chunk, part);
 }
 
-// single block: t = sum_yc part ; v = t / max(||t||, eps)
-__device__ __forceinline__ void sn_v_body(int bx, int by, int gx, const float* __restrict__ part, int ychunks, int cols, float eps,
-                                                    float* __restrict__ v) {
-  __shared__ double red[16];
-  __shared__ float s_inv;
+// scratch layout of one layer (floats unless noted): part[SN_MAX_CHUNKS][cols] | t[cols] | s[rows] | (8-byte aligned) ssq[SN_VBLOCKS] doubles
+#define SN_VBLOCKS 64
+struct SnScratch { float* part; float* t; float* s; double* ssq; };
+__host__ __device__ __forceinline__ SnScratch sn_scratch(void* base, int rows, int cols) {
+  SnScratch r;
+  r.part = (float*)base;
+  r.t = r.part + (long)SN_MAX_CHUNKS * cols;
+  r.s = r.t + cols;
+  const long nf = (((long)SN_MAX_CHUNKS * cols + cols + rows + 1) / 2) * 2;
+  r.ssq = (double*)(r.part + nf);
+  return r;
+}
+
+// t[j] = sum_yc part[yc][j] (chunk order), ssq[block] = sum over the block's columns of t^2.  Many blocks: the single-block
+// form of round 1 walked 64 x 13824 partials with 1024 threads (~90 us of the 0.37 ms a 1536 x 13824 layer took).
+__device__ __forceinline__ void sn_vsum_body(int bx, int gx, const float* __restrict__ part, int ychunks, int cols,
+                                             float* __restrict__ t, double* __restrict__ ssq) {
+  __shared__ double red[4];
   double ss = 0.0;
-  for (int j = threadIdx.x; j < cols; j += 1024) {
-    float t = 0.f;
-    for (int y = 0; y < ychunks; ++y) t += part[(long)y * cols + j];
-    v[j] = t;
-    ss += (double)t * (double)t;
+  for (int j = bx * 256 + threadIdx.x; j < cols; j += gx * 256) {
+    float a = 0.f;
+    for (int y = 0; y < ychunks; ++y) a += part[(long)y * cols + j];
+    t[j] = a;
+    ss += (double)a * (double)a;
   }
   ss = wave_sum_d(ss);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int k = 0; k < 16; ++k) tot += red[k];
-    const float nrm = (float)sqrt(tot);
-    s_inv = 1.0f / fmaxf(nrm, eps);
-  }
-  __syncthreads();
-  const float inv = s_inv;
-  for (int j = threadIdx.x; j < cols; j += 1024) v[j] *= inv;
+  if (threadIdx.x == 0) ssq[bx] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ __launch_bounds__(1024) void sn_v_kernel(const float* __restrict__ part, int ychunks, int cols, float eps,
-                                                    float* __restrict__ v) {
-  sn_v_body(blockIdx.x, blockIdx.y, gridDim.x, part, ychunks, cols, eps, v);
+__global__ __launch_bounds__(256) void sn_vsum_kernel(const float* __restrict__ part, int ychunks, int cols,
+                                                      float* __restrict__ t, double* __restrict__ ssq) {
+  sn_vsum_body(blockIdx.x, gridDim.x, part, ychunks, cols, t, ssq);
 }
 
-// s[i] = sum_j w[i][j] v[j]; one wavefront per row, 16-byte loads (two in flight) when the row length allows
-__device__ __forceinline__ void sn_wv_body(int bx, int by, int gx, const float* __restrict__ w, const float* __restrict__ v, int rows,
-                                                    int cols, float* __restrict__ s) {
+// 1 / max(||t||, eps) from the block partials (every wavefront recomputes it: <= 64 doubles, fixed order)
+__device__ __forceinline__ float sn_inv_norm(const double* __restrict__ ssq, int nblk, float eps) {
   const int lane = threadIdx.x & 63;
+  double a = lane < nblk ? ssq[lane] : 0.0;
+  a = wave_sum_d(a);
+  return 1.0f / fmaxf((float)sqrt(a), eps);
+}
+
+// v = t / max(||t||, eps) (written by the blocks in a grid-stride sweep) and s[i] = sum_j w[i][j] v[j] = inv * sum_j w[i][j] t[j]:
+// one wavefront per row, 16-byte loads (two in flight) when the row length allows
+__device__ __forceinline__ void sn_wv_body(int bx, int gx, const float* __restrict__ w, const float* __restrict__ t,
+                                           const double* __restrict__ ssq, int nblk, float eps, int rows, int cols,
+                                           float* __restrict__ v_out, float* __restrict__ s) {
+  const int lane = threadIdx.x & 63;
+  const float inv = sn_inv_norm(ssq, nblk, eps);
+  for (int j = bx * 256 + threadIdx.x; j < cols; j += gx * 256) v_out[j] = t[j] * inv;
   const int i = bx * 4 + (threadIdx.x >> 6);
   if (i >= rows) return;
   const float* wr = w + (long)i * cols;
@@ -92,7 +109,7 @@ __device__ __forceinline__ void sn_wv_body(int bx, int by, int gx, const float* 
     float acc2 = 0.f;
     const int c4 = cols >> 2;
     const float4* w4 = reinterpret_cast<const float4*>(wr);
-    const float4* v4 = reinterpret_cast<const float4*>(v);
+    const float4* v4 = reinterpret_cast<const float4*>(t);
     int j = lane;
     for (; j + 64 < c4; j += 128) {
       const float4 a = w4[j], b = w4[j + 64], x = v4[j], y = v4[j + 64];
@@ -105,14 +122,15 @@ __device__ __forceinline__ void sn_wv_body(int bx, int by, int gx, const float* 
     }
     acc += acc2;
   } else {
-    for (int j = lane; j < cols; j += 64) acc = fmaf(wr[j], v[j], acc);
+    for (int j = lane; j < cols; j += 64) acc = fmaf(wr[j], t[j], acc);
   }
   acc = wave_sum(acc);
-  if (lane == 0) s[i] = acc;
+  if (lane == 0) s[i] = acc * inv;
 }
-__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ v, int rows,
-                                                    int cols, float* __restrict__ s) {
-  sn_wv_body(blockIdx.x, blockIdx.y, gridDim.x, w, v, rows, cols, s);
+__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ w, const float* __restrict__ t,
+                                                    const double* __restrict__ ssq, int nblk, float eps, int rows, int cols,
+                                                    float* __restrict__ v_out, float* __restrict__ s) {
+  sn_wv_body(blockIdx.x, gridDim.x, w, t, ssq, nblk, eps, rows, cols, v_out, s);
 }
 
 // single block: u' = s / max(||s||, eps); sigma = s . u'
@@ -288,6 +306,11 @@ __global__ __launch_bounds__(256) void sn_up_layouts_kernel(const float* __restr
 }
 
 // rows per chunk: 24 rows of the widest layer (13824 columns) = 1.3 MB streamed per block column; at least 16 rows per chunk
+static int sn_vblocks(int cols) {
+  const long b = icg_cdiv(cols, 256);
+  return (int)(b > SN_VBLOCKS ? SN_VBLOCKS : b);
+}
+
 static void sn_chunk_plan(int rows, int* ychunks, int* rpc) {
   int yc = (int)icg_cdiv(rows, 24);
   if (yc > SN_MAX_CHUNKS) yc = SN_MAX_CHUNKS;
@@ -298,7 +321,7 @@ static void sn_chunk_plan(int rows, int* ychunks, int* rpc) {
 
 extern "C" size_t icg_sn_scratch_bytes(int rows, int Cin, int R) {
   const long cols = (long)Cin * R * R;
-  return (size_t)(SN_MAX_CHUNKS * cols + rows + 512) * sizeof(float);
+  return (size_t)((long)SN_MAX_CHUNKS * cols + cols + rows + 2) * sizeof(float) + SN_VBLOCKS * sizeof(double) + 256;
 }
 
 extern "C" int icg_sn_forward(const float* w, float* u, float* sv, int rows, int Cin, int R, float eps, int training,
@@ -310,16 +333,16 @@ extern "C" int icg_sn_forward(const float* w, float* u, float* sv, int rows, int
   if (scratch_bytes < icg_sn_scratch_bytes(rows, Cin, R)) return ICG_ERR_WORKSPACE;
   const int cols = Cin * R * R;
   hipStream_t st = (hipStream_t)stream;
-  float* part = (float*)scratch;
-  float* svec = part + (long)SN_MAX_CHUNKS * cols;
+  const SnScratch sc = sn_scratch(scratch, rows, cols);
   int ychunks, rpc;
   sn_chunk_plan(rows, &ychunks, &rpc);
+  const int nblk = sn_vblocks(cols);
   hipLaunchKernelGGL(sn_uw_partial_kernel, dim3((unsigned)icg_cdiv(cols, 1024), ychunks), dim3(256), 0, st, w, u, rows,
-                     cols, rpc, part);
-  hipLaunchKernelGGL(sn_v_kernel, dim3(1), dim3(1024), 0, st, (const float*)part, ychunks, cols, eps, v_out);
-  hipLaunchKernelGGL(sn_wv_kernel, dim3((unsigned)icg_cdiv(rows, 4)), dim3(256), 0, st, w, (const float*)v_out, rows,
-                     cols, svec);
-  hipLaunchKernelGGL(sn_u_kernel, dim3(1), dim3(1024), 0, st, (const float*)svec, rows, eps, training, u, sv, u_out,
+                     cols, rpc, sc.part);
+  hipLaunchKernelGGL(sn_vsum_kernel, dim3(nblk), dim3(256), 0, st, (const float*)sc.part, ychunks, cols, sc.t, sc.ssq);
+  hipLaunchKernelGGL(sn_wv_kernel, dim3((unsigned)icg_cdiv(rows, 4)), dim3(256), 0, st, w, (const float*)sc.t,
+                     (const double*)sc.ssq, nblk, eps, rows, cols, v_out, sc.s);
+  hipLaunchKernelGGL(sn_u_kernel, dim3(1), dim3(1024), 0, st, (const float*)sc.s, rows, eps, training, u, sv, u_out,
                      sigma_out);
   const long total = (long)rows * cols;
   long blocks = icg_cdiv(total, 256);
@@ -341,7 +364,7 @@ extern "C" int icg_sn_forward(const float* w, float* u, float* sv, int rows, int
 // arithmetic in the same order as the single-layer path: results are bit-identical.
 struct SnPack {
   icg_sn_layer l[ICG_SN_PACK];
-  int ychunks[ICG_SN_PACK], rpc[ICG_SN_PACK];
+  int ychunks[ICG_SN_PACK], rpc[ICG_SN_PACK], vblocks[ICG_SN_PACK];
   int n;
 };
 
@@ -349,23 +372,28 @@ __global__ __launch_bounds__(256) void sn_uw_partial_multi_kernel(SnPack p) {
   const icg_sn_layer& L = p.l[blockIdx.z];
   const int cols = L.Cin * L.R * L.R;
   if ((int)blockIdx.x * 1024 >= cols || (int)blockIdx.y >= p.ychunks[blockIdx.z]) return;
-  sn_uw_partial_body(blockIdx.x, blockIdx.y, 0, L.w, L.u, L.rows, cols, p.rpc[blockIdx.z], (float*)L.scratch);
+  sn_uw_partial_body(blockIdx.x, blockIdx.y, 0, L.w, L.u, L.rows, cols, p.rpc[blockIdx.z], sn_scratch(L.scratch, L.rows, cols).part);
 }
-__global__ __launch_bounds__(1024) void sn_v_multi_kernel(SnPack p, float eps) {
+__global__ __launch_bounds__(256) void sn_vsum_multi_kernel(SnPack p) {
   const icg_sn_layer& L = p.l[blockIdx.z];
   const int cols = L.Cin * L.R * L.R;
-  sn_v_body(0, 0, 1, (const float*)L.scratch, p.ychunks[blockIdx.z], cols, eps, L.v_out);
+  const int nblk = p.vblocks[blockIdx.z];
+  if ((int)blockIdx.x >= nblk) return;
+  const SnScratch sc = sn_scratch(L.scratch, L.rows, cols);
+  sn_vsum_body(blockIdx.x, nblk, sc.part, p.ychunks[blockIdx.z], cols, sc.t, sc.ssq);
 }
-__global__ __launch_bounds__(256) void sn_wv_multi_kernel(SnPack p) {
+__global__ __launch_bounds__(256) void sn_wv_multi_kernel(SnPack p, float eps) {
   const icg_sn_layer& L = p.l[blockIdx.z];
   const int cols = L.Cin * L.R * L.R;
-  if ((int)blockIdx.x * 4 >= L.rows) return;
-  sn_wv_body(blockIdx.x, 0, 0, L.w, (const float*)L.v_out, L.rows, cols, (float*)L.scratch + (long)SN_MAX_CHUNKS * cols);
+  const int gx = (L.rows + 3) / 4;                         // the single-layer launch geometry
+  if ((int)blockIdx.x >= gx) return;
+  const SnScratch sc = sn_scratch(L.scratch, L.rows, cols);
+  sn_wv_body(blockIdx.x, gx, L.w, sc.t, sc.ssq, p.vblocks[blockIdx.z], eps, L.rows, cols, L.v_out, sc.s);
 }
 __global__ __launch_bounds__(1024) void sn_u_multi_kernel(SnPack p, float eps, int training) {
   const icg_sn_layer& L = p.l[blockIdx.z];
   const int cols = L.Cin * L.R * L.R;
-  sn_u_body(0, 0, 1, (const float*)L.scratch + (long)SN_MAX_CHUNKS * cols, L.rows, eps, training, L.u, L.sv, L.u_out, L.sigma_out);
+  sn_u_body(0, 0, 1, sn_scratch(L.scratch, L.rows, cols).s, L.rows, eps, training, L.u, L.sv, L.u_out, L.sigma_out);
 }
 __global__ __launch_bounds__(256) void sn_scale_multi_kernel(SnPack p) {
   const icg_sn_layer& L = p.l[blockIdx.z];
@@ -401,7 +429,7 @@ extern "C" int icg_sn_forward_multi(const icg_sn_layer* layers, int n, float eps
       const int cols = L.Cin * L.R * L.R;
       int ychunks, rpc;
       sn_chunk_plan(L.rows, &ychunks, &rpc);
-      p.ychunks[i] = ychunks; p.rpc[i] = rpc;
+      p.ychunks[i] = ychunks; p.rpc[i] = rpc; p.vblocks[i] = sn_vblocks(cols);
       gx_uw = max(gx_uw, (unsigned)icg_cdiv(cols, 1024));
       gy_uw = max(gy_uw, (unsigned)ychunks);
       gx_wv = max(gx_wv, (unsigned)icg_cdiv(L.rows, 4));
@@ -412,8 +440,8 @@ extern "C" int icg_sn_forward_multi(const icg_sn_layer* layers, int n, float eps
     }
     const unsigned nz = (unsigned)p.n;
     hipLaunchKernelGGL(sn_uw_partial_multi_kernel, dim3(gx_uw, gy_uw, nz), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(sn_v_multi_kernel, dim3(1, 1, nz), dim3(1024), 0, st, p, eps);
-    hipLaunchKernelGGL(sn_wv_multi_kernel, dim3(gx_wv, 1, nz), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(sn_vsum_multi_kernel, dim3(SN_VBLOCKS, 1, nz), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(sn_wv_multi_kernel, dim3(gx_wv, 1, nz), dim3(256), 0, st, p, eps);
     hipLaunchKernelGGL(sn_u_multi_kernel, dim3(1, 1, nz), dim3(1024), 0, st, p, eps, training);
     hipLaunchKernelGGL(sn_scale_multi_kernel, dim3(gx_sc, 1, nz), dim3(256), 0, st, p);
     if (gx_up) hipLaunchKernelGGL(sn_up_layouts_multi_kernel, dim3(gx_up, 1, nz), dim3(256), 0, st, p);

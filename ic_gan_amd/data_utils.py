@@ -63,7 +63,8 @@ def build_knn(feats, k_nn, device=None, block=4096):
     hence the list-of-lists return type.
 
     The N×N distance matrix is produced block-wise as one GEMM per block on `device`
-    (|a-b|² = |a|² + |b|² - 2 a·b, features are unit-norm in the reference so this is well conditioned).
+    (|a-b|² = |a|² + |b|² - 2 a·b, features are unit-norm in the reference so this is well conditioned).  On the GPU both
+    the GEMM and the top-(k+1) selection are the hand-written kernels of csrc/knn.hip (C-ABI icg_knn_l2).
 
     Returns (sample_nns: list[list[int]] of length N, radius: float64 ndarray [N]).
     """
@@ -72,17 +73,28 @@ def build_knn(feats, k_nn, device=None, block=4096):
         f = f.to(device)
     N = f.shape[0]
     k = min(int(k_nn) + 1, N)
-    sq = (f * f).sum(1)
-    nn_idx = torch.empty(N, k, dtype=torch.int64, device=f.device)
-    nn_d2 = torch.empty(N, k, dtype=torch.float32, device=f.device)
-    for s in range(0, N, block):
-        e = min(N, s + block)
-        d2 = sq[s:e, None] + sq[None, :] - 2.0 * (f[s:e] @ f.t())
-        d2.clamp_(min=0)
-        # the query is its own nearest hit by construction, not by rounding luck
-        d2[torch.arange(e - s, device=f.device), torch.arange(s, e, device=f.device)] = -1.0
-        v, i = torch.topk(d2, k, dim=1, largest=False, sorted=True)
-        nn_idx[s:e], nn_d2[s:e] = i, v.clamp_(min=0)
+    if f.is_cuda and k <= 64:
+        # hand-written path (csrc/knn.hip): inner products on the fp32 MFMA GEMM + one wavefront per query row keeping a
+        # lane-sorted running top-(k+1); replaces faiss-gpu's IndexFlatL2.search (datasets_common.py:720-731)
+        from . import _lib as L
+        f = f.contiguous()
+        nn_idx = torch.empty(N, k, dtype=torch.int64, device=f.device)
+        nn_d2 = torch.empty(N, k, dtype=torch.float32, device=f.device)
+        nb = L.query("icg_knn_l2_workspace_bytes", N, f.shape[1])
+        L.call("icg_knn_l2", f, N, f.shape[1], k, nn_idx, nn_d2, torch.empty(nb, dtype=torch.uint8, device=f.device), nb)
+    else:
+        # host tables (the reference's own placement: north_star keeps the sampler on the host) and k + 1 > 64: library ops
+        sq = (f * f).sum(1)
+        nn_idx = torch.empty(N, k, dtype=torch.int64, device=f.device)
+        nn_d2 = torch.empty(N, k, dtype=torch.float32, device=f.device)
+        for s in range(0, N, block):
+            e = min(N, s + block)
+            d2 = sq[s:e, None] + sq[None, :] - 2.0 * (f[s:e] @ f.t())
+            d2.clamp_(min=0)
+            # the query is its own nearest hit by construction, not by rounding luck
+            d2[torch.arange(e - s, device=f.device), torch.arange(s, e, device=f.device)] = -1.0
+            v, i = torch.topk(d2, k, dim=1, largest=False, sorted=True)
+            nn_idx[s:e], nn_d2[s:e] = i, v.clamp_(min=0)
     idx = nn_idx.cpu().numpy()
     radius = np.sqrt(nn_d2[:, -1].double().cpu().numpy())
     keep = idx != np.arange(N)[:, None]

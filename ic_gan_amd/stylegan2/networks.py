@@ -11,8 +11,10 @@ vector `h`), so `state_dict()` keys match the reference's pickled networks one-t
 What runs where: convolutions (plain, strided, transposed, modulated) -> icg_conv2d_g_fprop / icg_conv2d_g_wgrad;
 FIR resampling -> icg_upfirdn2d; bias + activation + clamp -> icg_bias_act; the small dense layers of the mapping /
 affine / epilogue heads -> library GEMMs (torch.addmm / matmul = hipBLASLt).  All operators have arbitrary-order
-gradients (R1 and path-length regularisation differentiate twice).  fp32 only: `num_fp16_res` must be 0 (the reference's
-fp16 blocks exist to feed tensor cores with half precision; this engine computes in exact fp32 on MFMA).
+gradients (R1 and path-length regularisation differentiate twice).  `num_fp16_res` / `conv_clamp` (the reference's
+`cfg=auto` uses 4 / 256, train.py:297-310): the highest-resolution blocks keep their activations in fp16 exactly where the
+reference does (networks.py:505-515, 581-600, 793-870) -- fp16 storage through bias_act / upfirdn2d / the modulation glue,
+fp16-rounded weights, exact-fp32 MFMA arithmetic inside the convolutions, one rounding per convolution output.
 """
 import numpy as np
 import torch
@@ -24,11 +26,6 @@ _DEF_GAIN = {name: spec[2] for name, spec in bias_act.activation_funcs.items()}
 
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
     return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
-
-
-def _no_fp16(use_fp16):
-    if use_fp16:
-        raise NotImplementedError("fp16 blocks are not supported by the fp32 engine: build the networks with num_fp16_res=0")
 
 
 class FullyConnectedLayer(torch.nn.Module):
@@ -72,8 +69,8 @@ class Conv2dLayer(torch.nn.Module):
                 self.bias = None
 
     def forward(self, x, gain=1):
-        x = conv2d_resample.conv2d_resample(x=x, w=self.weight * self.weight_gain, f=self.resample_filter, up=self.up,
-                                            down=self.down, padding=self.padding, flip_weight=(self.up == 1))
+        x = conv2d_resample.conv2d_resample(x=x, w=(self.weight * self.weight_gain).to(x.dtype), f=self.resample_filter,
+                                            up=self.up, down=self.down, padding=self.padding, flip_weight=(self.up == 1))
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return bias_act.bias_act(x, self.bias, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
 
@@ -185,11 +182,10 @@ class SynthesisBlock(torch.nn.Module):
                  resample_filter=[1, 3, 3, 1], conv_clamp=None, use_fp16=False, fp16_channels_last=False,
                  **layer_kwargs):
         assert architecture in ["orig", "skip", "resnet"]
-        _no_fp16(use_fp16)
         super().__init__()
         self.in_channels, self.w_dim, self.resolution = in_channels, w_dim, resolution
         self.img_channels, self.is_last, self.architecture = img_channels, is_last, architecture
-        self.use_fp16 = False
+        self.use_fp16 = use_fp16
         self.register_buffer("resample_filter", upfirdn2d.setup_filter(resample_filter))
         self.num_conv = self.num_torgb = 0
         if in_channels == 0:
@@ -211,10 +207,14 @@ class SynthesisBlock(torch.nn.Module):
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, **layer_kwargs):
         assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim
         w_iter = iter(ws.unbind(dim=1))
+        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32      # networks.py:581
         if fused_modconv is None:
             fused_modconv = not self.training
         if self.in_channels == 0:
-            x = self.const.unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+            x = self.const.to(dtype).unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+        else:
+            x = x.to(dtype)
+        if self.in_channels == 0:
             x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
         elif self.architecture == "resnet":
             y = self.skip(x, gain=np.sqrt(0.5))
@@ -228,7 +228,9 @@ class SynthesisBlock(torch.nn.Module):
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == "skip":
             y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv)
+            y = y.to(torch.float32)                  # the image accumulates in fp32 (networks.py:630)
             img = img + y if img is not None else y
+        assert x.dtype == dtype and (img is None or img.dtype == torch.float32)
         return x, img
 
 
@@ -236,18 +238,17 @@ class SynthesisNetwork(torch.nn.Module):
     def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0,
                  **block_kwargs):
         assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
-        if num_fp16_res != 0:
-            _no_fp16(True)
         super().__init__()
         self.w_dim, self.img_resolution, self.img_channels = w_dim, img_resolution, img_channels
         self.img_resolution_log2 = int(np.log2(img_resolution))
         self.block_resolutions = [2 ** i for i in range(2, self.img_resolution_log2 + 1)]
         channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)          # networks.py:665
         self.num_ws = 0
         for res in self.block_resolutions:
             block = SynthesisBlock(channels[res // 2] if res > 4 else 0, channels[res], w_dim=w_dim, resolution=res,
-                                   img_channels=img_channels, is_last=(res == img_resolution), use_fp16=False,
-                                   **block_kwargs)
+                                   img_channels=img_channels, is_last=(res == img_resolution),
+                                   use_fp16=(res >= fp16_resolution), **block_kwargs)
             self.num_ws += block.num_conv + (block.num_torgb if res == img_resolution else 0)
             setattr(self, f"b{res}", block)
 
@@ -286,10 +287,9 @@ class DiscriminatorBlock(torch.nn.Module):
                  use_fp16=False, fp16_channels_last=False, freeze_layers=0):
         assert in_channels in [0, tmp_channels]
         assert architecture in ["orig", "skip", "resnet"]
-        _no_fp16(use_fp16)
         super().__init__()
         self.in_channels, self.resolution, self.img_channels = in_channels, resolution, img_channels
-        self.first_layer_idx, self.architecture, self.use_fp16 = first_layer_idx, architecture, False
+        self.first_layer_idx, self.architecture, self.use_fp16 = first_layer_idx, architecture, use_fp16
         self.register_buffer("resample_filter", upfirdn2d.setup_filter(resample_filter))
         self.num_layers = 0
 
@@ -310,11 +310,14 @@ class DiscriminatorBlock(torch.nn.Module):
                                     trainable=trainable(), resample_filter=resample_filter)
 
     def forward(self, x, img, force_fp32=False):
+        dtype = torch.float16 if self.use_fp16 and not force_fp32 else torch.float32      # networks.py:854
         if x is not None:
             assert x.shape[1] == self.in_channels and x.shape[2] == self.resolution
+            x = x.to(dtype)
         if self.in_channels == 0 or self.architecture == "skip":
             assert img.shape[1] == self.img_channels and img.shape[2] == self.resolution
-            y = self.fromrgb(img.to(torch.float32))
+            img = img.to(dtype)
+            y = self.fromrgb(img)
             x = x + y if x is not None else y
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == "skip" else None
         if self.architecture == "resnet":
@@ -325,6 +328,7 @@ class DiscriminatorBlock(torch.nn.Module):
         else:
             x = self.conv0(x)
             x = self.conv1(x)
+        assert x.dtype == dtype
         return x, img
 
 
@@ -362,6 +366,7 @@ class DiscriminatorEpilogue(torch.nn.Module):
 
     def forward(self, x, img, cmap, force_fp32=False):
         assert x.shape[1] == self.in_channels and x.shape[2] == self.resolution
+        x = x.to(torch.float32)                      # the epilogue always runs in fp32 (networks.py:982-985)
         if self.architecture == "skip":
             x = x + self.fromrgb(img.to(torch.float32))
         if self.mbstd is not None:
@@ -379,13 +384,12 @@ class Discriminator(torch.nn.Module):
     def __init__(self, c_dim, h_dim, img_resolution, img_channels, architecture="resnet", channel_base=32768,
                  channel_max=512, num_fp16_res=0, conv_clamp=None, cmap_dim=None, block_kwargs={}, mapping_kwargs={},
                  epilogue_kwargs={}):
-        if num_fp16_res != 0:
-            _no_fp16(True)
         super().__init__()
         self.c_dim, self.h_dim, self.img_resolution, self.img_channels = c_dim, h_dim, img_resolution, img_channels
         self.img_resolution_log2 = int(np.log2(img_resolution))
         self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, 2, -1)]
         channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)          # networks.py:1045
         if cmap_dim is None:
             cmap_dim = channels[4]
         if c_dim == 0 and h_dim == 0:
@@ -394,8 +398,8 @@ class Discriminator(torch.nn.Module):
         cur_layer_idx = 0
         for res in self.block_resolutions:
             block = DiscriminatorBlock(channels[res] if res < img_resolution else 0, channels[res], channels[res // 2],
-                                       resolution=res, first_layer_idx=cur_layer_idx, use_fp16=False, **block_kwargs,
-                                       **common)
+                                       resolution=res, first_layer_idx=cur_layer_idx, use_fp16=(res >= fp16_resolution),
+                                       **block_kwargs, **common)
             setattr(self, f"b{res}", block)
             cur_layer_idx += block.num_layers
         if c_dim > 0 or h_dim > 0:

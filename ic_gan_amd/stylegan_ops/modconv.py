@@ -5,6 +5,7 @@ before and after the convolution" (the reference's fused_modconv=False branch, n
 uses); `fused_modconv=True` — a grouped convolution over per-sample weights in the reference, used in eval mode — is
 computed through the same branch: x*s -> conv(w) -> *d equals conv(w*s*d) exactly in real arithmetic and to fp32 rounding
 here, and needs no per-sample weight tensor [N, O, I, k, k] in HBM."""
+import numpy as np
 import torch
 
 from . import conv2d_resample, fma
@@ -15,8 +16,13 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     batch_size = int(x.shape[0])
     out_channels, in_channels, kh, kw = (int(s) for s in weight.shape)
     assert x.shape[1] == in_channels and tuple(styles.shape) == (batch_size, in_channels)
-    if x.dtype != torch.float32:
-        raise NotImplementedError("fp16 activations are not part of the fp32 hot path (use num_fp16_res=0)")
+    if x.dtype not in (torch.float32, torch.float16):
+        raise NotImplementedError("modulated_conv2d: fp32 or fp16 activations")
+
+    # fp16: pre-normalise weights and styles so that the modulated activations cannot overflow (networks.py:57-63)
+    if x.dtype == torch.float16 and demodulate:
+        weight = weight * (1 / np.sqrt(in_channels * kh * kw) / weight.norm(float("inf"), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float("inf"), dim=1, keepdim=True)
 
     dcoefs = None
     if demodulate:
@@ -24,13 +30,13 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
         wsq = weight.square().sum(dim=[2, 3])                              # [O, I]
         dcoefs = (styles.square() @ wsq.t() + 1e-8).rsqrt()                # [N, O]
 
-    x = x * styles.reshape(batch_size, -1, 1, 1)
-    x = conv2d_resample.conv2d_resample(x=x, w=weight, f=resample_filter, up=up, down=down, padding=padding,
+    x = x * styles.to(x.dtype).reshape(batch_size, -1, 1, 1)
+    x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding,
                                         flip_weight=flip_weight)
     if demodulate and noise is not None:
-        x = fma.fma(x, dcoefs.reshape(batch_size, -1, 1, 1), noise)
+        x = fma.fma(x, dcoefs.to(x.dtype).reshape(batch_size, -1, 1, 1), noise.to(x.dtype))
     elif demodulate:
-        x = x * dcoefs.reshape(batch_size, -1, 1, 1)
+        x = x * dcoefs.to(x.dtype).reshape(batch_size, -1, 1, 1)
     elif noise is not None:
-        x = x + noise
+        x = x + noise.to(x.dtype)
     return x

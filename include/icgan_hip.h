@@ -421,6 +421,17 @@ typedef struct {
 /* target = target*decay + source*(1-decay) */
 int icg_ema_multi(const icg_ema_tensor* tensors, int n, float decay, void* stream);
 
+/* ---- exact L2 k-NN build of the instance-feature table  (data_utils/datasets_common.py:695-769) ------ */
+/*
+ * For every row q of feats [N][D] (fp32): idx[q][0..k) = the k rows of the SAME table nearest in L2, ascending distance, ties to
+ * the lower index, the row itself forced first; d2[q][j] = squared distance (>= 0).  Callers pass k = k_nn + 1 and drop the
+ * query like the reference (datasets_common.py:720-740: faiss IndexFlatL2.search(feats, k_nn + 1)).  k <= 64.
+ * Inner products on the fp32 MFMA GEMM, selection = one wavefront per query row with a lane-sorted running top-k.
+ */
+size_t icg_knn_l2_workspace_bytes(int N, int D);
+int icg_knn_l2(const float* feats, int N, int D, int k, int64_t* idx, float* d2, void* workspace, size_t workspace_bytes,
+               void* stream);
+
 /* ---- StyleGAN2 custom ops (stylegan2_ada_pytorch/torch_utils/ops) ---------------------- */
 /*
  * bias_act: same contract as the reference plugin's bias_act(x,b,xref,yref,dy,grad,dim,act,alpha,

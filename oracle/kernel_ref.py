@@ -902,6 +902,21 @@ def icg_conv2d_g_wgrad(x, dy, dw, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride,
 
 
 # ---------------------------------------------------------------- host-logic test harness
+def icg_knn_l2_workspace_bytes(N, D):
+    return 16
+
+
+def icg_knn_l2(feats, N, D, k, idx, d2, workspace, workspace_bytes):
+    """exact L2 top-k of every row against the table (fp64 distances; stable sort = ties to the lower index; self first)"""
+    f = mem(feats)[: N * D].view(N, D).double()
+    sq = (f * f).sum(1)
+    dist = (sq[:, None] + sq[None, :] - 2.0 * (f @ f.t())).clamp_(min=0)
+    dist[torch.arange(N), torch.arange(N)] = -1.0
+    order = torch.sort(dist, dim=1, stable=True)
+    idx.view(-1)[: N * k].copy_(order.indices[:, :k].reshape(-1))
+    mem(d2)[: N * k].copy_(order.values[:, :k].clamp(min=0).float().reshape(-1))
+
+
 def install(monkeypatch):
     """Route ic_gan_amd._lib.call / query to this module (CPU host-logic tests only)."""
     import ic_gan_amd._lib as L

@@ -89,7 +89,7 @@ def run(name, cfg):
             p.grad = None
         torch.manual_seed(100 + pi)
         L.accumulate_gradients(phase=phase, real_img=img, real_c=rc, real_h=rh, gen_z=z[:b], gen_c=gc[:b], gen_h=gh[:b],
-                               sync=True, gain=1)
+                               sync=True, gain=cfg.get("phase_gain", 1))
         mod.requires_grad_(False)
         grads = {n: (p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in mod.named_parameters()}
         for k, v in pack(grads).items():

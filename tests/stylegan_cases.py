@@ -70,6 +70,16 @@ SG2_NETS = {
                epilogue_kwargs=dict(mbstd_group_size=4)),
         batch=4),
 }
+# the reference's cfg=auto block precision (train.py:297-310: num_fp16_res=4, conv_clamp=256) scaled to a 32x32 net: the 16x16 and
+# 32x32 blocks of G and D store fp16
+SG2_NETS["ic_r32_fp16"] = dict(
+    G=dict(z_dim=32, c_dim=0, h_dim=24, w_dim=32, img_resolution=32, img_channels=3, mapping_kwargs=dict(num_layers=2),
+           synthesis_kwargs=dict(channel_base=512, channel_max=64, num_fp16_res=2, conv_clamp=256)),
+    D=dict(c_dim=0, h_dim=24, img_resolution=32, img_channels=3, channel_base=512, channel_max=64, num_fp16_res=2,
+           conv_clamp=256, mapping_kwargs=dict(num_layers=2), epilogue_kwargs=dict(mbstd_group_size=2)),
+    # loss gain of the per-phase gradient comparison: at gain 1 the gradients inside the fp16 blocks of this synthetic net are
+    # ~1e-6, i.e. at fp16's subnormal step (6e-8), and both implementations return quantisation noise there
+    batch=4, phase_gain=1024.0)
 SG2_LOSS = dict(style_mixing_prob=0, r1_gamma=1.0, pl_batch_shrink=2, pl_decay=0.01, pl_weight=2)
 SG2_OPT = dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)
 

@@ -588,7 +588,7 @@ def test_sn_forward_backward(rows, Cin, taps):
         wupd = to(torch.empty(16 * rows * Cin)) if taps == 3 else None
         wdn = to(torch.empty(16 * rows * Cin)) if taps == 3 else None
         wdnd = to(torch.empty(16 * rows * Cin)) if taps == 3 else None
-        nb = L.query("icg_sn_scratch_bytes", rows, Cin, taps)
+        nb = max(L.query("icg_sn_scratch_bytes", rows, Cin, taps), L.query("icg_sn_backward_scratch_bytes", rows, Cin, taps))
         sc = to(torch.empty(max(nb, 4096), dtype=torch.uint8))
         fn("icg_sn_forward", ww, uu, sv, rows, Cin, taps, 1e-6, 1, v, uo, sg, wo, wd, wup, wupd, wdn, wdnd, sc,
            sc.numel())
@@ -774,7 +774,8 @@ def test_sn_backward_coalesced_path(rows, Cin, taps):
     R.icg_sn_backward(hw, oh, up, dn, wo, uo, v, sg, rows, Cin, taps, ref, 0, torch.empty(4096, dtype=torch.uint8), 4096)
     c = lambda t: None if t is None else t.cuda()
     outs = []
-    for nb in (256 * 8, L.query("icg_sn_backward_scratch_bytes", rows, Cin, taps)):
+    full = L.query("icg_sn_backward_scratch_bytes", rows, Cin, taps)
+    for nb in (full - rows * Cin * taps * taps * 4, full):       # partial-dot slots only (direct gather) | + the transposed copy
         dw = torch.empty(rows, Cin, taps, taps, device="cuda")
         sc = torch.empty(nb, dtype=torch.uint8, device="cuda")
         L.call("icg_sn_backward", c(hw), c(oh), c(up), c(dn), c(wo), c(uo), c(v), c(sg), rows, Cin, taps, dw, 0, sc, nb)
@@ -902,3 +903,50 @@ def test_conv2d_winograd4(case):
     out = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
     (pair,) = run_pair("icg_conv2d_wino4_fprop", [x, U, bvec, r, out, sc, sh, ssb, B, H, W, Cin, Cout, rflags, 1.0, ws, nb], [4])
     close(*pair, rtol=2e-4, atol_rel=2e-4, what=f"winograd4 fprop {case}")
+
+
+# ------------------------------------------------------------------------------------------------ kNN build
+@pytest.mark.parametrize("N,D,k", [(300, 64, 7), (1000, 2048, 51), (64, 16, 64), (5, 8, 3), (257, 130, 1)])
+def test_knn_l2(N, D, k):
+    """exact L2 top-k of every row against the table (csrc/knn.hip) against the fp64 distance matrix: the query first, k distinct
+    neighbours in ascending exact distance, none closer missed -- all up to the fp32 rounding of the Gram-matrix distances
+    (2e-6 absolute on unit-norm rows; two neighbours closer together than that may swap, as in faiss)."""
+    L = _L()
+    f = rnd(N, D, seed=3)
+    f = f / f.norm(dim=1, keepdim=True)
+    idx, d2 = torch.empty(N, k, dtype=torch.int64, device="cuda"), torch.empty(N, k, device="cuda")
+    nb = L.query("icg_knn_l2_workspace_bytes", N, D)
+    L.call("icg_knn_l2", f.cuda(), N, D, k, idx, d2, torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda"), nb)
+    idx, d2 = idx.cpu(), d2.cpu().double()
+    f64 = f.double()
+    sq = (f64 * f64).sum(1)
+    dist = (sq[:, None] + sq[None, :] - 2.0 * (f64 @ f64.t())).clamp_(min=0)
+    dist[torch.arange(N), torch.arange(N)] = -1.0
+    tol = 2e-6
+    assert torch.equal(idx[:, 0], torch.arange(N)), "the query row must rank first"
+    assert all(len(set(r.tolist())) == k for r in idx), "duplicate neighbours"
+    dg = dist.gather(1, idx)
+    assert bool((dg[:, 1:] >= dg[:, :-1] - tol).all()), "neighbours not in ascending distance"
+    kth = dist.sort(1).values[:, k - 1]
+    assert bool((dg[:, -1] <= kth + tol).all()), "a closer row was missed"
+    assert float((d2 - dg.clamp(min=0)).abs().max()) <= tol, float((d2 - dg.clamp(min=0)).abs().max())
+
+
+def test_knn_l2_ties_and_duplicates():
+    """identical rows: mutual distances are 0 up to the fp32 rounding of |a|^2 + |b|^2 - 2 a.b (as in faiss) -> the query itself
+    is forced first, the rest of the duplicate group follows at ~0, rows stay sorted"""
+    L = _L()
+    N, D, k = 40, 32, 6
+    f = rnd(N, D, seed=5)
+    f[3:11] = f[3]
+    f = f.cuda()
+    idx, d2 = torch.empty(N, k, dtype=torch.int64, device="cuda"), torch.empty(N, k, device="cuda")
+    nb = L.query("icg_knn_l2_workspace_bytes", N, D)
+    L.call("icg_knn_l2", f, N, D, k, idx, d2, torch.empty(nb, dtype=torch.uint8, device="cuda"), nb)
+    idx, d2 = idx.cpu(), d2.cpu()
+    assert all(int(idx[i, 0]) == i for i in range(N))
+    for q in range(3, 11):
+        got = idx[q, 1:].tolist()
+        assert len(set(got)) == k - 1 and all(3 <= j < 11 and j != q for j in got), (q, idx[q].tolist())
+        assert float(d2[q, 1:].abs().max()) < 1e-5
+    assert bool((d2[:, 1:] >= d2[:, :-1]).all())
