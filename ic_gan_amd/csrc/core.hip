@@ -1,7 +1,9 @@
 // Library-wide helpers of libicgan_hip.so (error reporting, version).
 #include "icg_common.h"
 
-int g_icg_last_hip_error = 0;
+// per calling thread: the hipError_t behind the last ICG_ERR_LAUNCH this thread received (no cross-thread races; a caller reads
+// it right after the failing call, on the same thread)
+thread_local int g_icg_last_hip_error = 0;
 
 extern "C" const char* icg_strerror(int code) {
   switch (code) {

@@ -6,7 +6,7 @@
 
 #include "../../include/icgan_hip.h"
 
-extern int g_icg_last_hip_error;
+extern thread_local int g_icg_last_hip_error;
 
 static inline int icg_check_launch() {
   hipError_t e = hipGetLastError();

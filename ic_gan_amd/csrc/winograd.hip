@@ -8,6 +8,8 @@
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
 #include "icg_common.h"
 #include <vector>
+#include <atomic>
+#include <mutex>
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -207,11 +209,13 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
 void icg_gemm_mark_planes(int on);       // gemm_conv.hip: launch the following GEMMs as icg_gemm_planes_kernel (profile name)
 extern "C" int icg_gemm_last_variant(int* out4);
 
-// measurement hook for bench.py: HIP events on the launch stream around every plane-GEMM launch (off by default; the
-// record list is process-global and unsynchronised: enable it from the one thread that launches the work, as bench.py does)
+// measurement hook for bench.py: HIP events on the launch stream around every plane-GEMM launch.  Off by default -- the
+// product path then pays one relaxed atomic load per plane-GEMM call and touches no shared state; when enabled, the record
+// list is appended under a mutex, so launches from several threads are safe (their rows simply interleave).
 struct PlanesRecord { hipEvent_t e0, e1; int amode, tn, planes; double flops, bytes; };
 static std::vector<PlanesRecord> g_planes_records;
-static bool g_planes_timing = false;
+static std::mutex g_planes_mutex;
+static std::atomic<bool> g_planes_timing{false};
 
 struct PlanesScope {
   hipStream_t st;
@@ -222,7 +226,7 @@ struct PlanesScope {
   PlanesScope(void* stream, int planes_, double M, double N, double K)
       : st((hipStream_t)stream), planes(planes_), flops(2.0 * planes_ * M * N * K), bytes(4.0 * planes_ * (M * K + K * N + M * N)) {
     icg_gemm_mark_planes(1);
-    if (g_planes_timing && hipEventCreate(&e0) == hipSuccess) hipEventRecord(e0, st);
+    if (g_planes_timing.load(std::memory_order_relaxed) && hipEventCreate(&e0) == hipSuccess) hipEventRecord(e0, st);
   }
   ~PlanesScope() {
     icg_gemm_mark_planes(0);
@@ -233,6 +237,7 @@ struct PlanesScope {
       r.amode = v[0]; r.tn = v[2];
       if (hipEventCreate(&r.e1) == hipSuccess) {
         hipEventRecord(r.e1, st);
+        std::lock_guard<std::mutex> lock(g_planes_mutex);
         g_planes_records.push_back(r);
       }
     }
@@ -240,9 +245,10 @@ struct PlanesScope {
 };
 
 extern "C" int icg_planes_timing(int enable) {
+  std::lock_guard<std::mutex> lock(g_planes_mutex);
   for (auto& r : g_planes_records) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   g_planes_records.clear();
-  g_planes_timing = enable != 0;
+  g_planes_timing.store(enable != 0);
   return ICG_OK;
 }
 
@@ -250,6 +256,7 @@ extern "C" int icg_planes_timing(int enable) {
 // returns the number of rows written (synchronises on the recorded events)
 extern "C" int icg_planes_timing_drain(double* out, int max_rows) {
   ICG_REQUIRE(out && max_rows > 0);
+  std::lock_guard<std::mutex> lock(g_planes_mutex);
   int rows = 0;
   for (auto& r : g_planes_records) {
     if (hipEventSynchronize(r.e1) != hipSuccess) continue;

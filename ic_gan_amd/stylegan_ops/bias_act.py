@@ -30,6 +30,12 @@ activation_funcs = {
 
 _DTYPES = {torch.float32: 0, torch.float16: 1, torch.float64: 2}
 
+# Gradient of a CLAMPED act='linear' bias_act (ToRGB with conv_clamp).  False (default): the true gradient -- zero where the
+# output was clamped -- which is what the reference's own `impl='ref'` path computes.  True: bit-compatible with the
+# reference's CUDA plugin path, which does not keep y for act='linear' (bias_act.py:262-266) and therefore passes the
+# gradient through unmasked.  Parity runs against a GPU-trained reference set this to True.
+REFERENCE_CLAMP_GRAD = False
+
 
 def _is_cl(t, dim):
     """4-D tensor stored channels-last (NHWC in memory) with the bias on the channel dim: handled in place, the kernel's
@@ -85,8 +91,9 @@ class _BiasAct(torch.autograd.Function):
         # y is also kept whenever a clamp is active: the clamp mask of the gradient needs it.  (The reference's CUDA
         # plugin drops y for act='linear' (bias_act.py:262-266) and therefore does not mask the gradient of a clamped
         # linear bias_act — e.g. ToRGB with conv_clamp; we follow its own `impl='ref'` semantics, the true gradient.)
+        keep_y = ("y" in ref) or (clamp >= 0 and not (REFERENCE_CLAMP_GRAD and act_id == 1))
         ctx.save_for_backward(x if ("x" in ref or has2) else None, b if ("x" in ref or has2) else None,
-                              y if ("y" in ref or clamp >= 0) else None)
+                              y if keep_y else None)
         ctx.has_b = b is not None
         return y
 

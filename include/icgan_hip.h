@@ -27,6 +27,10 @@ extern "C" {
 #define ICG_ERR_WORKSPACE (-3)/* workspace too small */
 
 const char* icg_strerror(int code);
+/* Library state, all of it: (1) this per-thread error slot, (2) the per-thread label of the last GEMM launch
+ * (icg_gemm_last_variant) and (3) the opt-in, mutex-guarded timing records of icg_planes_timing -- (2) and (3) are read only
+ * by bench.py.  No entry point's RESULT depends on any of them; everything else is passed in (buffers, workspaces, stream). */
+/* the hipError_t behind the last ICG_ERR_LAUNCH returned to the CALLING THREAD (thread-local) */
 int icg_last_hip_error(void);
 int icg_version(void);
 
@@ -227,7 +231,8 @@ int icg_conv2d_wino4_wgrad_from_v_db(const float* V, const float* dy, float* dw,
                                      void* stream);
 /* measurement hook (bench.py): with timing enabled every batched GEMM over Winograd planes (rocprofv3 name
  * icg_gemm_planes_kernel<AMODE, BMODE, TN>) is bracketed by HIP events on its launch stream.  drain() writes rows of
- * {amode, tn, planes, launches, total ms, total executed flops, total operand bytes} and returns the row count. */
+ * {amode, tn, planes, launches, total ms, total executed flops, total operand bytes} and returns the row count.
+ * Disabled (the default) the product path pays one relaxed atomic load per call; enabled, records are appended under a mutex. */
 int icg_planes_timing(int enable);
 int icg_planes_timing_drain(double* out, int max_rows);
 /* C[b] = A[b]^T B[b], A [K][M], B [K][N], long K: batched with deterministic split-K (strideC must be M*N) */
