@@ -3,7 +3,7 @@
 # a copy-kernel calibration of known size.  Output: gpurun_out/hbm_traffic.json (copy to profiles/).
 mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 cat > /tmp/calib.py <<'PY'
 import torch

@@ -34,6 +34,8 @@ def main():
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 2 "
                      "--warmup 1 --no-cpu-baseline --init N02`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
                      "MI355X_MICROARCH.md HBM section; tools/pmc_hbm.py",
+           "steps_profiled": int(os.environ.get("ICG_PMC_STEPS", "3")),       # --steps 2 --warmup 1
+           "commit": os.environ.get("ICG_PMC_COMMIT", "unknown"),
            "kernels": {}}
     for k in sorted(ft, key=lambda k: -ft[k]):
         if fc[k] == 0:
