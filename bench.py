@@ -65,10 +65,10 @@ class KernelTimer:
     # entry point -> (index of B in the argument list, kind)
     SPEC = {"icg_conv2d_fprop": (8, "conv"), "icg_conv2d_fprop_ws": (8, "conv"), "icg_conv2d_wino_fprop": (8, "wino"), "icg_conv2d_wino4_fprop": (8, "wino4"), "icg_conv2d_wino_wgrad": (6, "wino"), "icg_conv2d_wino4_wgrad": (6, "wino4"), "icg_conv2d_wino4_wgrad_from_v": (3, "from_v"), "icg_conv2d_wino4_wgrad_from_v_db": (4, "from_v"),
             "icg_conv2d_up_wino_fprop": (7, "rs_up"), "icg_conv2d_up_wino_dgrad": (3, "rs_up"), "icg_conv2d_up_wino_wgrad": (6, "rs_up"),
-            "icg_conv2d_down_wino_fprop": (5, "rs_down"), "icg_conv2d_down_wino_dgrad": (3, "rs_down"), "icg_conv2d_down_wino_wgrad": (3, "rs_down"),
+            "icg_conv2d_down_wino_fprop": (5, "rs_down"), "icg_conv2d_down_wino_dgrad": (3, "rs_down"), "icg_conv2d_down_wino_dgrad_relu": (4, "rs_down"), "icg_conv2d_down_wino_wgrad": (3, "rs_down"),
             "icg_conv2d_wgrad": (6, "conv"), "icg_conv2d_up_fprop": (7, "up"),
             "icg_conv2d_up_dgrad": (3, "up"), "icg_conv2d_up_wgrad": (6, "up"), "icg_conv2d_down_fprop": (5, "up"),
-            "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_wgrad": (3, "up"),
+            "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_dgrad_relu": (4, "up"), "icg_conv2d_down_wgrad": (3, "up"),
             # StyleGAN2 (cfg4): general-geometry convolutions and the two HBM-bound plugins
             "icg_conv2d_g_fprop": (4, "gconv"), "icg_conv2d_g_fprop_ws": (4, "gconv"), "icg_conv2d_tr2_fprop": (4, "tr2"),
             "icg_conv2d_g_wgrad": (3, "gconv"), "icg_bias_act": (6, "bias_act"), "icg_bias_act_typed": (6, "bias_act"),
@@ -151,7 +151,7 @@ class KernelTimer:
             if mode == "from_v":
                 kname = "composite: weight gradient from the saved V planes (wino4_dy_kernel + %d batched split-K icg_gemm_planes_kernel<1, 1, %d> GEMMs + reduce + wino4_dw_kernel)" % (args[sl + 5], last[2])
             elif mode in ("rs_up", "rs_down"):
-                kind = name.rsplit("_", 1)[1]
+                kind = (name[:-5] if name.endswith("_relu") else name).rsplit("_", 1)[1]
                 kname = "composite: %s-fused conv %s in the 25-plane F(4x4,3x3) domain (transforms + 25 batched icg_gemm_planes_kernel<%s, %d> GEMMs)" % (
                     "upsample" if mode == "rs_up" else "avgpool", kind, "1, 1" if kind == "wgrad" else "0, 0", last[2])
             elif mode in ("wino", "wino4"):     # three kernels behind one entry point: not comparable with a single rocprof row
@@ -639,6 +639,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="sample workload: replay the generator forward from a HIP graph")
     ap.add_argument("--no-winograd", action="store_true",
                     help="implicit-GEMM / phase / 4x4-stride-2 kernels only (ops.disable_winograd): the strict-parity route")
+    ap.add_argument("--no-fuse-relu-backward", action="store_true",
+                    help="ablation: ReLU backward of D's layers as a separate pass instead of the data-gradient epilogue")
     ap.add_argument("--sync-bn", action="store_true", help="cross-replica BN statistics over RCCL (cfg3 variant)")
     ap.add_argument("--fp16", action="store_true", help="cfg4: the reference's cfg=auto precision (num_fp16_res=4, conv_clamp=256)")
     args = ap.parse_args()
@@ -675,6 +677,9 @@ def main():
     if args.no_winograd:
         import ic_gan_amd.ops as _ops
         _ops.disable_winograd()
+    if args.no_fuse_relu_backward:
+        import ic_gan_amd.ops as _ops
+        _ops.FUSE_RELU_BACKWARD = False
 
     if args.workload == "sample":
         return bench_sampling(args, device, rank, world)

@@ -684,7 +684,7 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
     const long out_row = (p.phase_mode == 1) ? phase_row(m) : (long)m;
     if (out_row < 0) continue;
     long res_row = out_row;
-    if (p.res != nullptr && p.res_up) {
+    if (p.res != nullptr && p.res_up == 1) {
       const int w = m % p.W;
       const int t = m / p.W;
       const int h = t % p.H;
@@ -697,7 +697,10 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
       if (n < p.N) {
         float v = p.alpha * acc[j][r];
         if (p.bias != nullptr) v += p.bias[n];
-        if (p.res != nullptr) v += p.res[res_row * p.ldc + n];
+        if (p.res != nullptr) {
+          const float rv = p.res[res_row * p.ldc + n];
+          v = (p.res_up == 2) ? (rv > 0.f ? v : 0.f) : v + rv;     // 2: ICG_RES_RELU_MASK
+        }
         Cg[out_row * p.ldc + n] = v;
       }
     }
@@ -852,14 +855,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
     if (bias) v += bias[n];
     if (res) {
       long rr = i / N;
-      if (res_up) {
+      if (res_up == 1) {
         const int w = (int)(rr % W);
         const long t = rr / W;
         const int h = (int)(t % H);
         const long b = t / H;
         rr = (b * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1);
       }
-      v += res[rr * N + n];
+      const float rv = res[rr * N + n];
+      v = (res_up == 2) ? (rv > 0.f ? v : 0.f) : v + rv;
     }
     out[i] = v;
   }
@@ -940,7 +944,8 @@ static int conv2d_fprop_impl(const float* x, const float* w, const float* bias, 
   ICG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (R == 1 || R == 3));
   const int up = (flags & ICG_UPSAMPLE2X) ? 1 : 0;
   if (up) ICG_REQUIRE((H % 2 == 0) && (W % 2 == 0));
-  if (flags & ICG_RES_UPSAMPLE2X) ICG_REQUIRE(residual && (H % 2 == 0) && (W % 2 == 0));
+  if (flags & ICG_RES_UPSAMPLE2X) ICG_REQUIRE(residual && (H % 2 == 0) && (W % 2 == 0) && !(flags & ICG_RES_RELU_MASK));
+  if (flags & ICG_RES_RELU_MASK) ICG_REQUIRE(residual != nullptr);
   if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift);
   const long M = (long)B * H * W;
   ICG_REQUIRE(M < 0x7fffffffL);
@@ -970,7 +975,7 @@ static int conv2d_fprop_impl(const float* x, const float* w, const float* bias, 
   p.pre_affine = (flags & ICG_PRE_AFFINE) ? 1 : 0;
   p.pre_relu = (flags & ICG_PRE_RELU) ? 1 : 0;
   p.ldb = p.K; p.ldc = Cout;
-  p.bias = bias; p.res = residual; p.res_up = (flags & ICG_RES_UPSAMPLE2X) ? 1 : 0;
+  p.bias = bias; p.res = residual; p.res_up = icg_res_mode(flags);
   p.alpha = alpha;
   p.kchunk = 0;
   bool vec = (Cin % 4 == 0) && aligned16(x) && aligned16(w);
@@ -1225,8 +1230,8 @@ extern "C" int icg_conv2d_down_fprop(const float* x, const float* vdn, const flo
 
 // data gradient of the same layer: 4 phases of 2x2 taps scattering from the pooled gradient to full resolution
 //   da[b, 2hp+al, 2wp+be, ci] = sum_{u,v,co} dy[b, hp+al-1+u, wp+be-1+v, co] * wq[al][be][ci][u][v][co]
-extern "C" int icg_conv2d_down_dgrad(const float* dy, const float* wq, float* da, int B, int Hp, int Wp, int Cin,
-                                     int Cout, void* stream) {
+static int down_dgrad_impl(const float* dy, const float* wq, const float* relu_in, float* da, int B, int Hp, int Wp, int Cin,
+                           int Cout, void* stream) {
   ICG_REQUIRE(dy && wq && da && B > 0 && Hp > 0 && Wp > 0 && Cin > 0 && Cout > 0);
   const long M = (long)B * Hp * Wp;
   ICG_REQUIRE(M * 4 < 0x7fffffffL);
@@ -1237,11 +1242,23 @@ extern "C" int icg_conv2d_down_dgrad(const float* dy, const float* wq, float* da
   p.pad_h = 1; p.pad_w = 1; p.gs = 1; p.Hb = Hp; p.Wb = Wp;
   p.ldb = p.K; p.ldc = Cin;
   p.alpha = 1.f;
+  p.res = relu_in; p.res_up = relu_in ? 2 : 0;      // the output rows of the phase scatter index the mask as well
   p.kchunk = 0; p.phase_mode = 1; p.nsplit = 1;
   p.strideA = 0; p.strideB = (long)Cin * p.K; p.strideC = 0;
   const bool vec = (Cout % 4 == 0) && aligned16(dy) && aligned16(wq);
   const bool small = (M * Cout < 0x7fffffffL) && ((long)Cin * p.K < 0x7fffffffL);
   return launch_gemm<A_K, B_K>(p, vec, 4, (hipStream_t)stream, small);
+}
+
+extern "C" int icg_conv2d_down_dgrad(const float* dy, const float* wq, float* da, int B, int Hp, int Wp, int Cin,
+                                     int Cout, void* stream) {
+  return down_dgrad_impl(dy, wq, nullptr, da, B, Hp, Wp, Cin, Cout, stream);
+}
+
+extern "C" int icg_conv2d_down_dgrad_relu(const float* dy, const float* wq, const float* relu_in, float* dx, int B, int Hp,
+                                          int Wp, int Cin, int Cout, void* stream) {
+  ICG_REQUIRE(relu_in != nullptr);
+  return down_dgrad_impl(dy, wq, relu_in, dx, B, Hp, Wp, Cin, Cout, stream);
 }
 
 // weight gradient w.r.t. the 4x4 kernel, HWIO: dvdn[P][Q][ci][co] = sum act(x)[b,2hp-1+P,2wp-1+Q,ci] * dy[b,hp,wp,co]

@@ -22,6 +22,11 @@ static inline int icg_check_launch() {
     if (!(cond)) return ICG_ERR_ARG; \
   } while (0)
 
+// residual operand of an epilogue: 0 added as is, 1 added with nearest x2 upsampling on read, 2 not added: ReLU mask
+static inline int icg_res_mode(unsigned flags) {
+  return (flags & ICG_RES_RELU_MASK) ? 2 : ((flags & ICG_RES_UPSAMPLE2X) ? 1 : 0);
+}
+
 static inline int64_t icg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // 64-wide wavefront reductions (gfx950: wave = 64 lanes)

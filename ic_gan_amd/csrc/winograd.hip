@@ -12,6 +12,10 @@
 #include <mutex>
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// ICG_RES_RELU_MASK: v where the ReLU input r was positive, else 0
+__device__ __forceinline__ float4 f4relu_mask(float4 v, float4 r) {
+  return make_float4(r.x > 0.f ? v.x : 0.f, r.y > 0.f ? v.y : 0.f, r.z > 0.f ? v.z : 0.f, r.w > 0.f ? v.w : 0.f);
+}
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
 // V[xi][t][c] = (B^T d B)[xi],  d = act(x) on the 4x4 window of tile t (zero outside the image), xi = 4*i + j
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * c4);
     float4 rlow = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (res && res_up) rlow = reinterpret_cast<const float4*>(res)[((b * th + ty) * tw + tx) * C4 + c4];   // one source pixel per tile
+    if (res && res_up == 1) rlow = reinterpret_cast<const float4*>(res)[((b * th + ty) * tw + tx) * C4 + c4];   // one source pixel per tile
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const float4 o0 = f4add(f4add(s[a][0], s[a][1]), s[a][2]);
@@ -111,8 +115,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         const float4 o = c ? o1 : o0;
         float4 v = make_float4(alpha * o.x + bv.x, alpha * o.y + bv.y, alpha * o.z + bv.z, alpha * o.w + bv.w);
         if (res) {
-          const float4 r = res_up ? rlow : reinterpret_cast<const float4*>(res)[p0 + (long)c * C4];
-          v = f4add(v, r);
+          const float4 r = (res_up == 1) ? rlow : reinterpret_cast<const float4*>(res)[p0 + (long)c * C4];
+          v = (res_up == 2) ? f4relu_mask(v, r) : f4add(v, r);           // 2: ICG_RES_RELU_MASK
         }
         reinterpret_cast<float4*>(y)[p0 + (long)c * C4] = v;
       }
@@ -363,7 +367,7 @@ extern "C" int icg_conv2d_wino_fprop(const float* x, const float* U, const float
   nb = icg_cdiv(T * (Cout / 4), 256);
   if (nb > 256 * 64) nb = 256 * 64;
   hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)Mb, bias, residual,
-                     (flags & ICG_RES_UPSAMPLE2X) ? 1 : 0, alpha, out, B, H, W, Cout / 4);
+                     icg_res_mode(flags), alpha, out, B, H, W, Cout / 4);
   return icg_check_launch();
 }
 
@@ -547,8 +551,9 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
       for (int c = 0; c < NO; ++c) {
         float4 v = make_float4(alpha * o[c].x + bv.x, alpha * o[c].y + bv.y, alpha * o[c].z + bv.z, alpha * o[c].w + bv.w);
         if (res) {
-          const long rp = (!POOL && res_up) ? ((b * (H >> 1) + (oy >> 1)) * (W >> 1) + ((4 * tx + c) >> 1)) * C4 + c4 : p0 + (long)c * C4;
-          v = f4add(v, reinterpret_cast<const float4*>(res)[rp]);
+          const long rp = (!POOL && res_up == 1) ? ((b * (H >> 1) + (oy >> 1)) * (W >> 1) + ((4 * tx + c) >> 1)) * C4 + c4 : p0 + (long)c * C4;
+          const float4 r = reinterpret_cast<const float4*>(res)[rp];
+          v = (res_up == 2) ? f4relu_mask(v, r) : f4add(v, r);           // 2: ICG_RES_RELU_MASK
         }
         reinterpret_cast<float4*>(y)[p0 + (long)c * C4] = v;
       }
@@ -666,7 +671,8 @@ extern "C" int icg_conv2d_wino4_fprop(const float* x, const float* U, const floa
   ICG_REQUIRE((H % 4 == 0) && (W % 4 == 0) && (Cin % 4 == 0) && (Cout % 4 == 0) && !(flags & ICG_UPSAMPLE2X));
   if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift && (ss_bstride % 4 == 0));
   if (workspace_bytes < icg_conv2d_wino4_workspace_bytes(B, H, W, Cin, Cout)) return ICG_ERR_WORKSPACE;
-  return wino4_run(x, 0, U, bias, residual, (flags & ICG_RES_UPSAMPLE2X) ? 1 : 0, out, 0, scale, shift, ss_bstride, B, H, W, Cin,
+  if (flags & ICG_RES_RELU_MASK) ICG_REQUIRE(residual && !(flags & ICG_RES_UPSAMPLE2X));
+  return wino4_run(x, 0, U, bias, residual, icg_res_mode(flags), out, 0, scale, shift, ss_bstride, B, H, W, Cin,
                    Cout, flags, alpha, 6, workspace, stream);
 }
 
@@ -720,6 +726,15 @@ extern "C" int icg_conv2d_down_wino_dgrad(const float* dy, const float* U, float
   ICG_RS_REQUIRE(B, Hp, Wp, Cin, Cout);
   if (workspace_bytes < icg_conv2d_rs_wino_workspace_bytes(B, 2 * Hp, 2 * Wp, Cout, Cin)) return ICG_ERR_WORKSPACE;
   return wino4_run(dy, 1, U, nullptr, nullptr, 0, da, 0, nullptr, nullptr, 0, B, 2 * Hp, 2 * Wp, Cout, Cin, 0, 0.25f, 5, workspace,
+                   stream);
+}
+
+extern "C" int icg_conv2d_down_wino_dgrad_relu(const float* dy, const float* U, const float* relu_in, float* dx, int B, int Hp,
+                                               int Wp, int Cin, int Cout, void* workspace, size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(dy && U && relu_in && dx && workspace);
+  ICG_RS_REQUIRE(B, Hp, Wp, Cin, Cout);
+  if (workspace_bytes < icg_conv2d_rs_wino_workspace_bytes(B, 2 * Hp, 2 * Wp, Cout, Cin)) return ICG_ERR_WORKSPACE;
+  return wino4_run(dy, 1, U, nullptr, relu_in, 2, dx, 0, nullptr, nullptr, 0, B, 2 * Hp, 2 * Wp, Cout, Cin, 0, 0.25f, 5, workspace,
                    stream);
 }
 

@@ -180,6 +180,7 @@ def _conv_fprop(x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, 
         L.call("icg_conv2d_fprop", x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, flags, 1.0)
 
 
+FUSE_RELU_BACKWARD = True       # ReLU backward of a ReLU-only prologue in the data-gradient epilogue (ICG_RES_RELU_MASK)
 KEEP_WINOGRAD_V = True          # keep the forward pass's transformed input for the weight gradient (memory for one HBM pass)
 
 
@@ -415,16 +416,26 @@ class FusedConvFn(Function):
         dx = dweight = dbias = dres = dgain = dbeta = None
         bn_state = None
         if need[0] or (bn is not None and (need[4] or need[5])):
+            # ReLU-only prologue (every D layer): its backward, dx = (x > 0) ? da : 0, runs in the epilogue of the data-gradient
+            # convolution (ICG_RES_RELU_MASK) -- da is never written and no separate pass reads x and da
+            mask = bn is None and opt.relu and not opt.upsample and FUSE_RELU_BACKWARD
             if ctx.down:
                 if (sn.w_wino_dgrad if sn.rs[1] else sn.w_down_dgrad) is None:
                     raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
                 da = _empty_cl(B, Cin, Hs, Ws, dev)          # full (input) resolution
                 if sn.rs[1]:
                     nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, Hs, Ws, Cout, Cin)
-                    L.call("icg_conv2d_down_wino_dgrad", dout, sn.w_wino_dgrad, da, B, H, W, Cin, Cout, _bytes(nb, dev), nb)
+                    if mask:
+                        L.call("icg_conv2d_down_wino_dgrad_relu", dout, sn.w_wino_dgrad, x, da, B, H, W, Cin, Cout,
+                               _bytes(nb, dev), nb)
+                    else:
+                        L.call("icg_conv2d_down_wino_dgrad", dout, sn.w_wino_dgrad, da, B, H, W, Cin, Cout, _bytes(nb, dev), nb)
+                elif mask:
+                    L.call("icg_conv2d_down_dgrad_relu", dout, sn.w_down_dgrad, x, da, B, H, W, Cin, Cout)
                 else:
                     L.call("icg_conv2d_down_dgrad", dout, sn.w_down_dgrad, da, B, H, W, Cin, Cout)
             elif ctx.phase:
+                mask = False
                 if (sn.w_wino_dgrad if sn.rs[1] else sn.w_up_dgrad) is None:
                     raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
                 da = _empty_cl(B, Cin, Hs, Ws, dev)          # already at source resolution (upsample adjoint folded)
@@ -438,16 +449,19 @@ class FusedConvFn(Function):
                 if sn.w_dgrad is None:
                     raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
                 da = _empty_cl(B, Cin, H, W, dev)
+                mres, mflag = (x, L.ICG_RES_RELU_MASK) if mask else (None, 0)
                 if sn.w_wino_dgrad is not None:
-                    _wino_fprop(dout, sn.w_wino_dgrad, None, None, da, None, None, 0, B, H, W, Cout, Cin, 0, sn.wino_m)
+                    _wino_fprop(dout, sn.w_wino_dgrad, None, mres, da, None, None, 0, B, H, W, Cout, Cin, mflag, sn.wino_m)
                 else:
-                    _conv_fprop(dout, sn.w_dgrad, None, None, da, None, None, 0, B, H, W, Cout, Cin, R, 0)
+                    _conv_fprop(dout, sn.w_dgrad, None, mres, da, None, None, 0, B, H, W, Cout, Cin, R, mflag)
             if bn is not None:
                 # stages 1-2 now (+ the cross-replica all-reduce of the channel sums, asynchronous); stages 3-4 after the
                 # weight / bias gradients below, which do not depend on them and overlap the collective
                 bn_state = _bn_backward_begin(x, da, bn, gain, scale, shift, ssb, mean, invstd, gb_rows, count_dev, flags,
                                               (B, Cin, Hs, Ws))
                 bn_flags = flags
+            elif mask:
+                dx = da
             elif opt.relu or (opt.upsample and not ctx.phase):
                 dx = _empty_cl(B, Cin, Hs, Ws, dev)
                 L.call("icg_bn_bwd_apply", x, da, None, None, 0, None, None, None, B, Hs, Ws, Cin, flags, dx)

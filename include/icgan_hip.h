@@ -39,6 +39,11 @@ int icg_version(void);
 #define ICG_PRE_AFFINE 2u     /* a = x*scale[b][c] + shift[b][c] (BN / ccbn apply)  */
 #define ICG_UPSAMPLE2X 4u     /* conv input is nearest-upsampled x2 on read         */
 #define ICG_RES_UPSAMPLE2X 8u /* residual is at half resolution, upsampled on read  */
+#define ICG_RES_RELU_MASK 16u /* `residual` is NOT added: it is the input r of the ReLU in front of the layer whose data gradient
+                               * this call computes, and out = (r > 0) ? value : 0 -- autograd's ReLU backward of
+                               * DBlock.forward (`self.activation(x)`, layers.py:587-600) folded into the epilogue of the
+                               * data-gradient convolution.  Accepted by icg_conv2d_fprop[_ws], icg_conv2d_wino_fprop and
+                               * icg_conv2d_wino4_fprop; excludes ICG_RES_UPSAMPLE2X. */
 
 /*
  * Fused implicit-GEMM convolution, stride 1, pad R/2, R in {1,3}; also every Linear
@@ -112,6 +117,10 @@ int icg_conv2d_down_fprop(const float* x, const float* vdn, const float* bias, c
                           int B, int Hp, int Wp, int Cin, int Cout, unsigned flags, void* stream);
 int icg_conv2d_down_dgrad(const float* dy, const float* wq, float* da, int B, int Hp, int Wp, int Cin, int Cout,
                           void* stream);
+/* down_dgrad with the ReLU backward of the layer's prologue in the epilogue: dx = (relu_in > 0) ? da : 0, relu_in = the
+ * layer's input x [B][2Hp][2Wp][Cin] (see ICG_RES_RELU_MASK) */
+int icg_conv2d_down_dgrad_relu(const float* dy, const float* wq, const float* relu_in, float* dx, int B, int Hp, int Wp,
+                               int Cin, int Cout, void* stream);
 size_t icg_conv2d_down_wgrad_workspace_bytes(int B, int Hp, int Wp, int Cin, int Cout);
 int icg_conv2d_down_wgrad(const float* x, const float* dy, float* dvdn, int B, int Hp, int Wp, int Cin, int Cout,
                           unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
@@ -213,6 +222,9 @@ int icg_conv2d_down_wino_fprop(const float* x, const float* U, const float* bias
                                size_t workspace_bytes, void* stream);
 int icg_conv2d_down_wino_dgrad(const float* dy, const float* U, float* da, int B, int Hp, int Wp, int Cin, int Cout,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* ... with the ReLU backward of the layer's prologue in the output transform (see icg_conv2d_down_dgrad_relu) */
+int icg_conv2d_down_wino_dgrad_relu(const float* dy, const float* U, const float* relu_in, float* dx, int B, int Hp, int Wp,
+                                    int Cin, int Cout, void* workspace, size_t workspace_bytes, void* stream);
 int icg_conv2d_down_wino_wgrad(const float* x, const float* dy, float* dw, int B, int Hp, int Wp, int Cin, int Cout,
                                unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
 /* Weight gradient from the V planes the FORWARD pass of the same layer left in its workspace: icg_conv2d_wino4_fprop,

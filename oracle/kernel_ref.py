@@ -17,7 +17,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-PRE_RELU, PRE_AFFINE, UPSAMPLE2X, RES_UPSAMPLE2X = 1, 2, 4, 8
+PRE_RELU, PRE_AFFINE, UPSAMPLE2X, RES_UPSAMPLE2X, RES_RELU_MASK = 1, 2, 4, 8, 16
 
 
 def mem(t: torch.Tensor) -> torch.Tensor:
@@ -55,7 +55,11 @@ def icg_conv2d_fprop(x, w, bias, residual, out, scale, shift, ss_bstride, B, H, 
     y = F.conv2d(a, wt, None, 1, R // 2) * alpha
     if bias is not None:
         y = y + mem(bias)[:Cout].view(1, -1, 1, 1)
-    if residual is not None:
+    if flags & RES_RELU_MASK:
+        assert residual is not None and not flags & RES_UPSAMPLE2X
+        r = _nhwc(residual, B, H, W, Cout).permute(0, 3, 1, 2)
+        y = torch.where(r > 0, y, torch.zeros_like(y))
+    elif residual is not None:
         if flags & RES_UPSAMPLE2X:
             r = _nhwc(residual, B, H // 2, W // 2, Cout).permute(0, 3, 1, 2)
             r = F.interpolate(r, scale_factor=2)
@@ -277,6 +281,16 @@ def icg_conv2d_down_dgrad(dy, wq, da, B, Hp, Wp, Cin, Cout):
     mem(da)[: B * 4 * Hp * Wp * Cin].copy_(r.permute(0, 2, 3, 1).reshape(-1))
 
 
+def _relu_mask_inplace(dx, relu_in, n):
+    d, r = mem(dx)[:n], mem(relu_in)[:n]
+    d.copy_(torch.where(r > 0, d, torch.zeros_like(d)))
+
+
+def icg_conv2d_down_dgrad_relu(dy, wq, relu_in, dx, B, Hp, Wp, Cin, Cout):
+    icg_conv2d_down_dgrad(dy, wq, dx, B, Hp, Wp, Cin, Cout)
+    _relu_mask_inplace(dx, relu_in, B * 4 * Hp * Wp * Cin)
+
+
 def icg_conv2d_down_wgrad_workspace_bytes(B, Hp, Wp, Cin, Cout):
     return 16
 
@@ -348,6 +362,11 @@ def icg_conv2d_down_wino_dgrad(dy, U, da, B, Hp, Wp, Cin, Cout, workspace, works
     g = F.interpolate(_nhwc(dy, B, Hp, Wp, Cout).permute(0, 3, 1, 2), scale_factor=2) * 0.25
     r = F.conv2d(g, wd.permute(0, 3, 1, 2), None, 1, 1)
     mem(da)[: B * 4 * Hp * Wp * Cin].copy_(r.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_conv2d_down_wino_dgrad_relu(dy, U, relu_in, dx, B, Hp, Wp, Cin, Cout, workspace, workspace_bytes):
+    icg_conv2d_down_wino_dgrad(dy, U, dx, B, Hp, Wp, Cin, Cout, workspace, workspace_bytes)
+    _relu_mask_inplace(dx, relu_in, B * 4 * Hp * Wp * Cin)
 
 
 def icg_conv2d_down_wino_wgrad(x, dy, dw, B, Hp, Wp, Cin, Cout, flags, workspace, workspace_bytes):

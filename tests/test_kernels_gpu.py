@@ -10,7 +10,7 @@ from oracle import kernel_ref as R
 
 pytestmark = pytest.mark.gpu
 
-PRE_RELU, PRE_AFFINE, UP, RES_UP = 1, 2, 4, 8
+PRE_RELU, PRE_AFFINE, UP, RES_UP, RES_MASK = 1, 2, 4, 8, 16
 
 
 def _L():
@@ -59,8 +59,10 @@ def run_pair(name, args, outs):
 
 # ------------------------------------------------------------------------------------------------ conv / linear
 CONV_CASES = [
-    # B, H, W, Cin, Cout, R, flags, residual(0 none / 1 same / 2 half-res), bias
+    # B, H, W, Cin, Cout, R, flags, residual(0 none / 1 same / 2 half-res / 3 ReLU mask: ICG_RES_RELU_MASK), bias
     (2, 8, 8, 32, 32, 3, 0, 0, True),
+    (2, 8, 8, 32, 48, 3, 0, 3, False),                   # data gradient of a ReLU-prologue layer: mask in the epilogue
+    (1, 5, 7, 24, 20, 1, 0, 3, False),                   # ... 1x1, ragged N
     (2, 8, 8, 8, 16, 3, PRE_RELU, 1, True),              # K-tile straddles taps (Cin = 8)
     (1, 16, 16, 3, 96, 3, 0, 0, True),                   # RGB stem: thin-input direct kernels (narrow_conv.hip)
     (2, 9, 7, 3, 40, 3, 0, 0, False),                    # ... LP = 16 with 10 active lanes, odd sizes
@@ -103,6 +105,9 @@ def _conv_inputs(case, seed):
     elif res == 2:
         r = cl(B, Cout, H // 2, W // 2, seed=seed + 3)
         rflags |= RES_UP
+    elif res == 3:
+        r = cl(B, Cout, H, W, seed=seed + 3)
+        rflags |= RES_MASK
     sc = sh = None
     ssb = 0
     if flags & PRE_AFFINE:
@@ -284,6 +289,10 @@ def test_conv2d_down_fused_triplet(case):
     ref = torch.nn.grad.conv2d_input((B, Cin, H, W), wn, up_dy, padding=1)
     close(p[0], ref.contiguous(memory_format=torch.channels_last), rtol=1e-4, atol_rel=2e-5,
           what=f"down_dgrad vs direct {case}")
+    dx = torch.empty(B, Cin, H, W).contiguous(memory_format=torch.channels_last)
+    (pm,) = run_pair("icg_conv2d_down_dgrad_relu", [dy, wq, x, dx, B, Hp, Wp, Cin, Cout], [3])
+    close(*pm, what=f"down_dgrad_relu {case}")
+    close(pm[0], torch.where(x > 0, p[0].cpu(), torch.zeros(())), rtol=0, atol_rel=0, what="down_dgrad_relu == mask(down_dgrad), bitwise")
     nb = L.query("icg_conv2d_down_wgrad_workspace_bytes", B, Hp, Wp, Cin, Cout)
     ws = torch.empty(max(nb, 16), dtype=torch.uint8)
     (p,) = run_pair("icg_conv2d_down_wgrad", [x, dy, torch.empty(16 * Cin * Cout), B, Hp, Wp, Cin, Cout, flags, ws, nb],
@@ -361,6 +370,10 @@ def test_conv2d_down_winograd_triplet(case, has_res):
     nbd = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cout, Cin)
     (p,) = run_pair("icg_conv2d_down_wino_dgrad", [dy, Ud, da, B, Hp, Wp, Cin, Cout, torch.empty(nbd, dtype=torch.uint8), nbd], [2])
     close(*p, rtol=2e-4, atol_rel=2e-4, what=f"down_wino_dgrad {case}")
+    dx = torch.empty(B, Cin, H, W).contiguous(memory_format=torch.channels_last)
+    (pm,) = run_pair("icg_conv2d_down_wino_dgrad_relu", [dy, Ud, x, dx, B, Hp, Wp, Cin, Cout, torch.empty(nbd, dtype=torch.uint8), nbd], [3])
+    close(*pm, rtol=2e-4, atol_rel=2e-4, what=f"down_wino_dgrad_relu {case}")
+    close(pm[0], torch.where(x > 0, p[0].cpu(), torch.zeros(())), rtol=0, atol_rel=0, what="down_wino_dgrad_relu == mask(down_wino_dgrad), bitwise")
     nbw = L.query("icg_conv2d_rs_wino_wgrad_workspace_bytes", B, H, W, Cin, Cout)
     (p,) = run_pair("icg_conv2d_down_wino_wgrad", [x, dy, torch.empty(9 * Cin * Cout), B, Hp, Wp, Cin, Cout, flags,
                                                    torch.empty(nbw, dtype=torch.uint8), nbw], [2])
@@ -791,6 +804,7 @@ def test_sn_backward_coalesced_path(rows, Cin, taps):
     (2, 16, 16, 256, 256, 3, PRE_RELU, 2, True),           # half-resolution residual in the split-K epilogue
     (3, 4, 4, 512, 40, 1, 0, 0, False),                    # 1x1: slice = channel range
     (2, 8, 8, 80, 64, 3, 0, 0, True),                      # 45 K-tiles in 2 slices: the boundary falls inside a tap sequence
+    (2, 8, 8, 128, 64, 3, 0, 3, False),                    # ReLU mask applied by the split-K epilogue
 ])
 def test_conv2d_fprop_split_k(case):
     """icg_conv2d_fprop_ws (K cut into concurrent slices + deterministic slab reduction) against the CPU reference."""
@@ -817,6 +831,7 @@ def test_conv2d_fprop_split_k(case):
     (2, 16, 16, 64, 48, PRE_AFFINE | PRE_RELU, 2, True),     # GBlock conv2: BN + ReLU prologue, upsampled skip
     (1, 6, 10, 16, 40, PRE_RELU, 1, False),                 # DBlock conv1-like, ragged N, non-square
     (3, 4, 4, 256, 256, 0, 0, True),
+    (2, 6, 6, 32, 48, 0, 3, False),                         # ReLU mask in the output transform
 ])
 def test_conv2d_winograd(case):
     """Winograd F(2x2,3x3) forward (weight transform + input transform + 16 GEMMs + output transform) vs the direct conv."""
@@ -890,6 +905,7 @@ def test_gemm_tn_batched_split_k():
     (2, 16, 16, 64, 48, PRE_AFFINE | PRE_RELU, 2, True),
     (1, 8, 12, 16, 40, PRE_RELU, 1, False),
     (3, 4, 4, 256, 256, 0, 0, True),
+    (2, 8, 12, 48, 32, 0, 3, False),                        # ReLU mask in the output transform (D data gradients)
 ])
 def test_conv2d_winograd4(case):
     """Winograd F(4x4,3x3) forward vs the direct convolution (tolerance 2e-4 of max|ref|: fp32 transforms with entries up to 8)."""

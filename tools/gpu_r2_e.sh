@@ -4,7 +4,7 @@
 mkdir -p gpurun_out/prof
 export PYTHONDONTWRITEBYTECODE=1
 R=$PWD
-export ICG_PMC_STEPS=3 ICG_PMC_COMMIT=$(cat $R/gpurun_out/.commit 2>/dev/null || echo unknown)
+export ICG_PMC_STEPS=3 ICG_PMC_COMMIT=${ICG_PMC_COMMIT:-unknown}
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof4
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof4 -o bench -- python $R/bench.py --workload cfg4 --steps 16 --warmup 4 --no-cpu-baseline > $R/gpurun_out/prof/rocprof_cfg4.log 2>&1
 find /tmp/prof4 -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/prof/r02_bench_cfg4_kernel_stats.csv \;
