@@ -148,20 +148,21 @@ class KernelTimer:
             raw(name, *args)
             e.record()
             query(last)
+            pk = "icg_gemm_planes1_kernel" if last[3] == 4 else "icg_gemm_planes_kernel"     # single- / two-level chains
             if mode == "from_v":
-                kname = "composite: weight gradient from the saved V planes (wino4_dy_kernel + %d batched split-K icg_gemm_planes_kernel<1, 1, %d> GEMMs + reduce + wino4_dw_kernel)" % (args[sl + 5], last[2])
+                kname = "composite: weight gradient from the saved V planes (wino4_dy_kernel + %d batched split-K %s<1, 1, %d> GEMMs + reduce + wino4_dw_kernel)" % (args[sl + 5], pk, last[2])
             elif mode in ("rs_up", "rs_down"):
                 kind = (name[:-5] if name.endswith("_relu") else name).rsplit("_", 1)[1]
-                kname = "composite: %s-fused conv %s in the 25-plane F(4x4,3x3) domain (transforms + 25 batched icg_gemm_planes_kernel<%s, %d> GEMMs)" % (
-                    "upsample" if mode == "rs_up" else "avgpool", kind, "1, 1" if kind == "wgrad" else "0, 0", last[2])
+                kname = "composite: %s-fused conv %s in the 25-plane F(4x4,3x3) domain (transforms + 25 batched %s<%s, %d> GEMMs)" % (
+                    "upsample" if mode == "rs_up" else "avgpool", kind, pk, "1, 1" if kind == "wgrad" else "0, 0", last[2])
             elif mode in ("wino", "wino4"):     # three kernels behind one entry point: not comparable with a single rocprof row
-                kname = (("composite: wino4_input_kernel + wino4_dy_kernel + icg_gemm_planes_kernel<1, 1, %d> (36 batched split-K GEMMs) + reduce + wino4_dw_kernel" % last[2]
+                kname = (("composite: wino4_input_kernel + wino4_dy_kernel + %s<1, 1, %d> (36 batched split-K GEMMs) + reduce + wino4_dw_kernel" % (pk, last[2])
                           if mode == "wino4" else
-                          "composite: wino_input_kernel + wino_dy_kernel + icg_gemm_planes_kernel<1, 1, %d> (16 batched split-K GEMMs) + reduce + wino_dw_kernel" % last[2])
+                          "composite: wino_input_kernel + wino_dy_kernel + %s<1, 1, %d> (16 batched split-K GEMMs) + reduce + wino_dw_kernel" % (pk, last[2]))
                          if name.endswith("wgrad") else
-                         ("composite: wino4_input_kernel + icg_gemm_planes_kernel<0, 0, %d> (36 batched GEMMs) + wino4_output_kernel" % last[2]
+                         ("composite: wino4_input_kernel + %s<0, 0, %d> (36 batched GEMMs) + wino4_output_kernel" % (pk, last[2])
                           if mode == "wino4" else
-                          "composite: wino_input_kernel + icg_gemm_planes_kernel<0, 0, %d> (16 batched GEMMs) + wino_output_kernel" % last[2]))
+                          "composite: wino_input_kernel + %s<0, 0, %d> (16 batched GEMMs) + wino_output_kernel" % (pk, last[2])))
             elif last[0] == -4:      # thin-input 3x3 kernels (narrow_conv.hip): {-4, fprop/wgrad, Cout, Cin}
                 lp = 4
                 while lp < last[2] // 4:
@@ -200,7 +201,8 @@ class KernelTimer:
             mode = "1, 1" if int(amode) == 1 else "0, 0"
             # executed MACs -> MACs of the reference op graph: 36 of 144 (F(4x4,3x3)), 25 of 144 (resample-fused), 16 of 36 (F(2x2,3x3))
             alg = flops * {36: 144 / 36, 25: 144 / 25, 16: 36 / 16}.get(int(planes), 1.0)
-            a = out.setdefault("void icg_gemm_planes_kernel<%s, %d>(GemmP)" % (mode, int(tn)), [0.0, 0.0, 0, 0.0, 0.0])
+            kern = "icg_gemm_planes1_kernel" if int(tn) >= 10 else "icg_gemm_planes_kernel"      # single- / two-level chains
+            a = out.setdefault("void %s<%s, %d>(GemmP)" % (kern, mode, int(tn) % 10), [0.0, 0.0, 0, 0.0, 0.0])
             a[0] += alg; a[1] += ms * 1e-3; a[2] += int(n); a[3] += flops; a[4] += byt
         return out
 

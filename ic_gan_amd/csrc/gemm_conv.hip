@@ -74,13 +74,18 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 // 3.5e-6 -> 1.2e-6 per layer at C = 384).  Every 2 K-tiles (32 k-values) the first MFMA of the pair starts a fresh chain
 // from C = 0 and the finished chain is added into a second accumulator set by VALU adds that sit in the shadow of the
 // preceding MFMA (their operands were produced TN MFMAs earlier: no dependency stall).  Cost: 16*TN more registers.
-template <int AMODE, int BMODE, int TN, int PATH, int BLK = 0>
+template <int AMODE, int BMODE, int TN, int PATH, int BLK = 0, int PLANES = 0>
 __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
   // PATH 3 = PATH 2 with the BN/ccbn affine prologue compiled in (PATH 2 itself has none): keeps the hot loop
   // free of uniform branches so that the scheduler can interleave the staging work with the MFMAs
   constexpr bool VEC = PATH >= 1;
   constexpr bool FAST = PATH >= 2;
   constexpr bool FAST_AFFINE = PATH == 3;
+  // PLAIN: the batched GEMMs over Winograd planes (A [M][K], B [N][K], H = W = R = 1, no prologue, no split-K): the loader
+  // keeps one row offset per staged row instead of the convolution gather state (image base, pixel coordinates, tap tracker,
+  // validity flags) -- ~12 fewer live VGPRs and no per-tile address arithmetic beyond one add.  Rows >= M / >= N are clamped
+  // to the last row, not zeroed: they only feed outputs the epilogue masks.
+  constexpr bool PLAIN = (PLANES != 0) && AMODE == A_K && BMODE == B_K && PATH == 2;
   constexpr int BM = 128, BN = 32 * TN, BK = 16;
   constexpr int LDA = (AMODE == A_K) ? BM + 1 : BM + 4;
   constexpr int LDB = (BMODE == B_K) ? BN + 1 : BN + 4;
@@ -187,10 +192,20 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
     f_tr = tap0 / p.R;
     f_ts = tap0 - f_tr * p.R;
   }
+  unsigned pl_a[2] = {0u, 0u}, pl_b[2] = {0u, 0u};   // PLAIN: row offset + 4 * kq of this thread's two A / B rows
+  if (PLAIN) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = min(m0 + arow + 64 * i, p.M - 1);
+      const int n = min(n0 + min(arow + 64 * i, BN - 1), p.N - 1);
+      pl_a[i] = (unsigned)m * (unsigned)p.K + 4u * (unsigned)kq;
+      pl_b[i] = (unsigned)n * (unsigned)p.ldb + 4u * (unsigned)kq;
+    }
+  }
   unsigned f_mtap_c = 0;                      // A_M: channel of this thread's 4 columns
   int f_mr = 0, f_ms = 0;
   bool f_mok = false;
-  if (FAST) {
+  if (FAST && !PLAIN) {
     if (AMODE == A_K) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -221,7 +236,9 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
   // into one MFMA shadow; `last` advances the tap tracker
   unsigned f_idx[2], f_so[2];
   auto addr_A_fast = [&](int k0, int i, bool last) {
-    if (AMODE == A_K) {
+    if (PLAIN) {
+      f_idx[i] = pl_a[i] + (unsigned)min(k0, p.K - BK);      // the pipeline over-fetches one tile past the end: clamp
+    } else if (AMODE == A_K) {
       const unsigned c = (unsigned)(f_c0 + 4 * kq);
       const int hi = f_h[i] * gs + f_tr - pad_h, wi = f_w[i] * gs + f_ts - pad_w;
       // (f_c0 < Cin fails only on the tile the pipeline over-fetches past the end of K)
@@ -274,7 +291,11 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
   };
 
   auto load_B_fast = [&](int k0) {
-    if (BMODE == B_K) {
+    if (PLAIN) {
+      const unsigned kc = (unsigned)min(k0, p.K - BK);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) rb[i] = ld4(Bg + (pl_b[i] + kc));
+    } else if (BMODE == B_K) {
       // tap-minor K order (see addr_A_fast): tile -> (16-channel slice f_bc0, tap f_btap); the weight matrix keeps its
       // [N][tap][Cin] layout, only the order in which its K-tiles are visited changes.  Clamp: the pipeline over-fetches
       // one tile past the end.
@@ -439,6 +460,7 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
 
   float4 sv[2];
   auto prep_A_row = [&](int i) {
+    if (PLAIN) { sv[i] = ra[i]; return; }
     float4 v = act4(ra[i], rsc[i], rsh[i]);
     if (FAST && !f_ok[i]) v = zero4();
     sv[i] = v;
@@ -458,8 +480,8 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
   };
   auto store_A_row = [&](int buf, int i) {
     float* as = As[buf];
-    float4 v = act4(ra[i], rsc[i], rsh[i]);
-    if (FAST && !f_ok[i]) v = zero4();
+    float4 v = PLAIN ? ra[i] : act4(ra[i], rsc[i], rsh[i]);
+    if (FAST && !PLAIN && !f_ok[i]) v = zero4();
     if (AMODE == A_K) {
       const int row = arow + 64 * i;
       as[(4 * kq + 0) * LDA + row] = v.x;
@@ -716,7 +738,22 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
 // them from the convolutions that run on the kernel directly (only the fast loader is instantiated)
 template <int AMODE, int BMODE, int TN>
 __global__ __launch_bounds__(256) void icg_gemm_planes_kernel(GemmP p) {
-  icg_gemm_body<AMODE, BMODE, TN, 2, ICG_PLANES_BLOCKED>(p);
+  icg_gemm_body<AMODE, BMODE, TN, 2, ICG_PLANES_BLOCKED, 1>(p);
+}
+// ... with single-level accumulation, for plane GEMMs whose chains are short anyway (K <= planes_1level_max_k(): the
+// rounding of a K-long chain grows with K, and at K <= 192 the second level buys < 2x -- 1.7e-6 / 2.3e-6 against 1.2e-6 per
+// layer at 96 / 192 channels, profiles/r02_wino_microbench.txt -- while costing the 128-column kernel a wave per SIMD)
+template <int AMODE, int BMODE, int TN>
+__global__ __launch_bounds__(256) void icg_gemm_planes1_kernel(GemmP p) {
+  icg_gemm_body<AMODE, BMODE, TN, 2, 0, 1>(p);
+}
+
+#ifndef ICG_PLANES_1LEVEL_MAX_K
+#define ICG_PLANES_1LEVEL_MAX_K 0
+#endif
+static int planes_1level_max_k() {     // ICG_PLANES_1LEVEL_MAX_K in the environment: measurement override, read once
+  static const int v = []() { const char* e = getenv("ICG_PLANES_1LEVEL_MAX_K"); return e ? atoi(e) : ICG_PLANES_1LEVEL_MAX_K; }();
+  return v;
 }
 
 static thread_local int g_gemm_planes = 0;
@@ -801,7 +838,15 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
   }
   if (path == 2 && p.pre_affine) path = 3;
   g_last_variant[0] = AMODE; g_last_variant[1] = BMODE; g_last_variant[2] = tn; g_last_variant[3] = path;
-  if (path == 2 && g_gemm_planes) {
+  if (path == 2 && g_gemm_planes && p.K <= planes_1level_max_k()) {
+    g_last_variant[3] = 4;       // plane GEMM, single-level chains
+    switch (tn) {
+      case 1: hipLaunchKernelGGL((icg_gemm_planes1_kernel<AMODE, BMODE, 1>), grid, block, 0, st, p); break;
+      case 2: hipLaunchKernelGGL((icg_gemm_planes1_kernel<AMODE, BMODE, 2>), grid, block, 0, st, p); break;
+      case 3: hipLaunchKernelGGL((icg_gemm_planes1_kernel<AMODE, BMODE, 3>), grid, block, 0, st, p); break;
+      default: hipLaunchKernelGGL((icg_gemm_planes1_kernel<AMODE, BMODE, 4>), grid, block, 0, st, p); break;
+    }
+  } else if (path == 2 && g_gemm_planes) {
     switch (tn) {
       case 1: hipLaunchKernelGGL((icg_gemm_planes_kernel<AMODE, BMODE, 1>), grid, block, 0, st, p); break;
       case 2: hipLaunchKernelGGL((icg_gemm_planes_kernel<AMODE, BMODE, 2>), grid, block, 0, st, p); break;

@@ -216,7 +216,7 @@ extern "C" int icg_gemm_last_variant(int* out4);
 // measurement hook for bench.py: HIP events on the launch stream around every plane-GEMM launch.  Off by default -- the
 // product path then pays one relaxed atomic load per plane-GEMM call and touches no shared state; when enabled, the record
 // list is appended under a mutex, so launches from several threads are safe (their rows simply interleave).
-struct PlanesRecord { hipEvent_t e0, e1; int amode, tn, planes; double flops, bytes; };
+struct PlanesRecord { hipEvent_t e0, e1; int amode, tn, planes, levels; double flops, bytes; };
 static std::vector<PlanesRecord> g_planes_records;
 static std::mutex g_planes_mutex;
 static std::atomic<bool> g_planes_timing{false};
@@ -235,10 +235,10 @@ struct PlanesScope {
   ~PlanesScope() {
     icg_gemm_mark_planes(0);
     if (e0) {
-      PlanesRecord r{e0, nullptr, 0, 0, planes, flops, bytes};
+      PlanesRecord r{e0, nullptr, 0, 0, planes, 2, flops, bytes};
       int v[4] = {0, 0, 0, 0};
       icg_gemm_last_variant(v);
-      r.amode = v[0]; r.tn = v[2];
+      r.amode = v[0]; r.tn = v[2]; r.levels = (v[3] == 4) ? 1 : 2;
       if (hipEventCreate(&r.e1) == hipSuccess) {
         hipEventRecord(r.e1, st);
         std::lock_guard<std::mutex> lock(g_planes_mutex);
@@ -256,7 +256,8 @@ extern "C" int icg_planes_timing(int enable) {
   return ICG_OK;
 }
 
-// out[i] = {amode, tn, planes, launches, total ms, total executed flops, total operand bytes} per distinct (amode, tn, planes);
+// out[i] = {amode, tn + 10 * (levels == 1), planes, launches, total ms, total executed flops, total operand bytes} per distinct
+// (amode, tn, levels, planes) -- levels: accumulation levels of the kernel that ran (icg_gemm_planes1_kernel / icg_gemm_planes_kernel);
 // returns the number of rows written (synchronises on the recorded events)
 extern "C" int icg_planes_timing_drain(double* out, int max_rows) {
   ICG_REQUIRE(out && max_rows > 0);
@@ -268,10 +269,10 @@ extern "C" int icg_planes_timing_drain(double* out, int max_rows) {
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
     int k = 0;
     for (; k < rows; ++k)
-      if ((int)out[7 * k] == r.amode && (int)out[7 * k + 1] == r.tn && (int)out[7 * k + 2] == r.planes) break;
+      if ((int)out[7 * k] == r.amode && (int)out[7 * k + 1] == r.tn + (r.levels == 1 ? 10 : 0) && (int)out[7 * k + 2] == r.planes) break;
     if (k == rows) {
       if (rows == max_rows) continue;
-      out[7 * k] = r.amode; out[7 * k + 1] = r.tn; out[7 * k + 2] = r.planes;
+      out[7 * k] = r.amode; out[7 * k + 1] = r.tn + (r.levels == 1 ? 10 : 0); out[7 * k + 2] = r.planes;
       out[7 * k + 3] = out[7 * k + 4] = out[7 * k + 5] = out[7 * k + 6] = 0.0;
       ++rows;
     }

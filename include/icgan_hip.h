@@ -243,7 +243,8 @@ int icg_conv2d_wino4_wgrad_from_v_db(const float* V, const float* dy, float* dw,
                                      void* stream);
 /* measurement hook (bench.py): with timing enabled every batched GEMM over Winograd planes (rocprofv3 name
  * icg_gemm_planes_kernel<AMODE, BMODE, TN>) is bracketed by HIP events on its launch stream.  drain() writes rows of
- * {amode, tn, planes, launches, total ms, total executed flops, total operand bytes} and returns the row count.
+ * {amode, tn (+ 10 when the single-level kernel icg_gemm_planes1_kernel ran), planes, launches, total ms, total executed
+ * flops, total operand bytes} and returns the row count.
  * Disabled (the default) the product path pays one relaxed atomic load per call; enabled, records are appended under a mutex. */
 int icg_planes_timing(int enable);
 int icg_planes_timing_drain(double* out, int max_rows);
