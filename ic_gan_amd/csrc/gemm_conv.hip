@@ -62,6 +62,7 @@ struct GemmP {
   int vec_b;                       // PATH 1 only: 16-byte loads allowed on the B operand (A is vectorised)
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
@@ -86,6 +87,9 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
   // validity flags) -- ~12 fewer live VGPRs and no per-tile address arithmetic beyond one add.  Rows >= M / >= N are clamped
   // to the last row, not zeroed: they only feed outputs the epilogue masks.
   constexpr bool PLAIN = (PLANES != 0) && AMODE == A_K && BMODE == B_K && PATH == 2;
+  // PLAIN_M: the same for the weight-gradient plane GEMMs (A [K][M], B [K][N], K = tiles of a split-K slice): row index
+  // k0 + krow + 8 i clamped into the slice, A rows past its end zeroed (B rows there are then irrelevant)
+  constexpr bool PLAIN_M = (PLANES != 0) && AMODE == A_M && BMODE == B_N && PATH == 2;
   constexpr int BM = 128, BN = 32 * TN, BK = 16;
   constexpr int LDA = (AMODE == A_K) ? BM + 1 : BM + 4;
   constexpr int LDB = (BMODE == B_K) ? BN + 1 : BN + 4;
@@ -202,10 +206,15 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
       pl_b[i] = (unsigned)n * (unsigned)p.ldb + 4u * (unsigned)kq;
     }
   }
+  unsigned pm_a = 0u, pm_b = 0u;               // PLAIN_M: first of this thread's 4 columns of A / B (clamped into the matrix)
+  if (PLAIN_M) {
+    pm_a = (unsigned)min(m0 + 4 * mq, max(p.M - 4, 0));
+    pm_b = (unsigned)min(n0 + min(4 * mq, BN - 4), max(p.N - 4, 0));
+  }
   unsigned f_mtap_c = 0;                      // A_M: channel of this thread's 4 columns
   int f_mr = 0, f_ms = 0;
   bool f_mok = false;
-  if (FAST && !PLAIN) {
+  if (FAST && !PLAIN && !PLAIN_M) {
     if (AMODE == A_K) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -238,6 +247,10 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
   auto addr_A_fast = [&](int k0, int i, bool last) {
     if (PLAIN) {
       f_idx[i] = pl_a[i] + (unsigned)min(k0, p.K - BK);      // the pipeline over-fetches one tile past the end: clamp
+    } else if (PLAIN_M) {
+      const int kp = k0 + krow + 8 * i;
+      f_ok[i] = kp < kend;
+      f_idx[i] = (unsigned)min(kp, kend - 1) * (unsigned)Cin + pm_a;
     } else if (AMODE == A_K) {
       const unsigned c = (unsigned)(f_c0 + 4 * kq);
       const int hi = f_h[i] * gs + f_tr - pad_h, wi = f_w[i] * gs + f_ts - pad_w;
@@ -295,6 +308,10 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
       const unsigned kc = (unsigned)min(k0, p.K - BK);
 #pragma unroll
       for (int i = 0; i < 2; ++i) rb[i] = ld4(Bg + (pl_b[i] + kc));
+    } else if (PLAIN_M) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        rb[i] = ld4(Bg + ((unsigned)min(k0 + krow + 8 * i, kend - 1) * (unsigned)p.ldb + pm_b));   // A is zero past kend
     } else if (BMODE == B_K) {
       // tap-minor K order (see addr_A_fast): tile -> (16-channel slice f_bc0, tap f_btap); the weight matrix keeps its
       // [N][tap][Cin] layout, only the order in which its K-tiles are visited changes.  Clamp: the pipeline over-fetches
@@ -461,6 +478,7 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
   float4 sv[2];
   auto prep_A_row = [&](int i) {
     if (PLAIN) { sv[i] = ra[i]; return; }
+    if (PLAIN_M) { sv[i] = f_ok[i] ? ra[i] : zero4(); return; }
     float4 v = act4(ra[i], rsc[i], rsh[i]);
     if (FAST && !f_ok[i]) v = zero4();
     sv[i] = v;
@@ -480,7 +498,7 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
   };
   auto store_A_row = [&](int buf, int i) {
     float* as = As[buf];
-    float4 v = PLAIN ? ra[i] : act4(ra[i], rsc[i], rsh[i]);
+    float4 v = (PLAIN || PLAIN_M) ? ra[i] : act4(ra[i], rsc[i], rsh[i]);
     if (FAST && !PLAIN && !f_ok[i]) v = zero4();
     if (AMODE == A_K) {
       const int row = arow + 64 * i;
@@ -636,10 +654,17 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
         if (FLUSH && t == 0) {
           // fold the finished chain into the second level, restart from C = 0 (inline constant: no register zeroing)
           asm volatile("" : "+a"(acc[j]));    // ... and the accumulator -> VGPR copies must not be hoisted to the loop head
-          acc2[j] += acc[j];
-          // pin the adds HERE: they are pure, their result is not read before the next flush, and instruction selection would
-          // otherwise sink them to the end of the loop body, keeping all 16*TN accumulator copies live in VGPRs meanwhile
-          asm volatile("" : "+v"(acc2[j]));
+          // 8 packed adds (v_pk_add_f32) per column tile, written as asm: the vector add is otherwise legalised into 13 scalar
+          // + 1.5 packed adds per tile, and -- being pure, with a result nobody reads before the next flush -- sunk to the
+          // end of the loop body, which keeps all 16*TN accumulator copies live in VGPRs meanwhile
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            f32x2 a2 = {acc[j][2 * r], acc[j][2 * r + 1]};
+            f32x2 b2 = {acc2[j][2 * r], acc2[j][2 * r + 1]};
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(b2) : "v"(a2));
+            acc2[j][2 * r] = b2.x;
+            acc2[j][2 * r + 1] = b2.y;
+          }
           f32x16 zero;
 #pragma unroll
           for (int r = 0; r < 16; ++r) zero[r] = 0.f;
@@ -647,8 +672,13 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
         } else {
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1], fb[t & 1][j], acc[j], 0, 0, 0);
         }
+        // operand fragments of the next k-step: A with the first MFMA, B as PAIRS of column tiles (adjacent loads 32 dwords
+        // apart merge into one ds_read2_b32: 8 + 8*ceil(TN/2) LDS instructions per tile instead of 8 + 8*TN)
         if (j == 0) fa[wrap ? 0 : pn] = fas[0];
-        fb[wrap ? 0 : pn][j] = fbs[32 * j];
+        if ((j & 1) == 0) {
+          fb[wrap ? 0 : pn][j] = fbs[32 * j];
+          if (j + 1 < TN) fb[wrap ? 0 : pn][j + 1] = fbs[32 * (j + 1)];
+        }
         // 12 staging pieces over the 8*TN MFMA gaps (PPG pieces per gap; 1 for TN >= 2)
         constexpr int PPG = (8 * TN >= 12) ? 1 : 2;
         const int m = t * TN + j;
