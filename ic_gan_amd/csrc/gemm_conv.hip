@@ -766,8 +766,11 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
 
 // the same code under a second name for the batched GEMMs over Winograd planes (winograd.hip), so that a profile separates
 // them from the convolutions that run on the kernel directly (only the fast loader is instantiated)
+#ifndef ICG_PLANES_TN4_MIN_WAVES
+#define ICG_PLANES_TN4_MIN_WAVES 1     // (3: ablation build LB3 of tools/build_dbg.sh -- 168 registers with ~25 spilled dwords)
+#endif
 template <int AMODE, int BMODE, int TN>
-__global__ __launch_bounds__(256) void icg_gemm_planes_kernel(GemmP p) {
+__global__ __launch_bounds__(256, (TN == 4 ? ICG_PLANES_TN4_MIN_WAVES : 1)) void icg_gemm_planes_kernel(GemmP p) {
   icg_gemm_body<AMODE, BMODE, TN, 2, ICG_PLANES_BLOCKED, 1>(p);
 }
 // ... with single-level accumulation, for plane GEMMs whose chains are short anyway (K <= planes_1level_max_k(): the

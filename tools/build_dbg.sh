@@ -1,6 +1,7 @@
 #!/bin/bash
 # Ablation builds of libicgan_hip.so (tools only, never the product): tools/libdbg_<NAME>.so, selected by tools/*.py through ICG_LIB.
-#   NOBLK : plane GEMMs with single-level accumulation (-DICG_PLANES_BLOCKED=0);  F1 / F4: first-level chains of 1 / 4 K-tiles
+#   NOBLK : plane GEMMs with single-level accumulation (-DICG_PLANES_BLOCKED=0);  F1 / F4: first-level chains of 1 / 4 K-tiles;
+#   LB3 : 128-column two-level plane GEMM forced to 3 waves per SIMD (spills)
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 SRC="$HERE/../ic_gan_amd/csrc"
@@ -20,6 +21,7 @@ for v in "$@"; do
     NOBLK) build_variant NOBLK -DICG_PLANES_BLOCKED=0 gemm_conv ;;
     F1) build_variant F1 -DICG_PLANES_FLUSH_TILES=1 gemm_conv ;;
     F4) build_variant F4 -DICG_PLANES_FLUSH_TILES=4 gemm_conv ;;
+    LB3) build_variant LB3 -DICG_PLANES_TN4_MIN_WAVES=3 gemm_conv ;;
     *) echo "unknown variant $v"; exit 1 ;;
   esac
 done
