@@ -82,8 +82,9 @@ def main():
         img = Gd(z[sl].to(dev), lab[sl].to(dev), fg[sl].to(dev))
         (img * wts[sl].to(dev)).sum().backward()
         grads = torch.cat([p.grad.reshape(-1) for p in G.parameters()])
-        imgs = [torch.empty_like(img) for _ in range(world)]
-        dist.all_gather(imgs, img.detach().contiguous())
+        src = img.detach().contiguous()                  # the generator returns channels-last strides; collectives want dense NCHW
+        imgs = [torch.empty(tuple(src.shape), device=dev, dtype=src.dtype) for _ in range(world)]
+        dist.all_gather(imgs, src)
         if rank == 0:
             torch.save({"img": torch.cat(imgs, 0).cpu(), "grads": grads.cpu(), "world": world,
                         "rm": G.blocks[0][0].bn1.stored_mean.cpu(), "rv": G.output_layer[0].stored_var.cpu()}, out_path)
