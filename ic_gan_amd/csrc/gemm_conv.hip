@@ -21,6 +21,9 @@
 #ifndef ICG_PLANES_BLOCKED
 #define ICG_PLANES_BLOCKED 1     // two-level accumulation in the Winograd-plane GEMMs (0: ablation build of tools/)
 #endif
+#ifndef ICG_PLANES_PERSISTENT
+#define ICG_PLANES_PERSISTENT 1  // forward plane GEMMs on icg_planes_body (0: one output tile per workgroup; ablation build)
+#endif
 #ifndef ICG_PLANES_FLUSH_TILES
 #define ICG_PLANES_FLUSH_TILES 2 // K-tiles (of 16) per first-level chain
 #endif
@@ -60,6 +63,8 @@ struct GemmP {
   int bsplit;                      // > 0: batched split-K, slices per batch (see kernel head)
   int zmask;                       // generic A_K paths only: source is zero-inserted by (zmask+1): hi, wi must be multiples
   int vec_b;                       // PATH 1 only: 16-byte loads allowed on the B operand (A is vectorised)
+  // persistent plane GEMM (icg_planes_body): output tiles per plane, planes, consecutive output tiles per workgroup
+  int pt_tiles, pt_z, pt_run;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -759,6 +764,228 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
   }
 }
 
+
+// ---- persistent plane GEMM ----------------------------------------------------------------------------------------------
+// The forward / data-gradient GEMMs over Winograd planes are C[z] = A[z] B[z]^T with A [M][K], B [N][K] (K = Cin contiguous)
+// and a SHORT K (96 ... 1536: 6 ... 96 K-tiles per 128 x 32*TN output tile), so a workgroup that computes one output tile spends
+// a large part of its life in the pipeline fill (two K-tiles of HBM latency before the first MFMA) and in the epilogue, with
+// only 2-3 workgroups per CU to cover for it.  Here a workgroup owns a RUN of p.pt_run consecutive output tiles of the
+// (plane, m-tile, n-tile) order and treats their K-tiles as ONE stream: the global loads run two K-tiles ahead of the MFMAs
+// straight across output-tile boundaries (the loads for the next tile's first K-tiles are in flight while this tile's last
+// MFMAs and its epilogue run), the LDS ring and the operand-fragment prefetch never drain.  Same thread -> data mapping, LDS
+// layout, MFMA order, two-level accumulation and staging schedule as icg_gemm_body's fast path, so results are bit-identical to
+// it; the loader state is one row offset per staged row (rows >= M / >= N are clamped: they only feed masked outputs).
+template <int TN, int BLK>
+__device__ __forceinline__ void icg_planes_body(const GemmP& p) {
+  constexpr int BM = 128, BN = 32 * TN, BK = 16, LDA = BM + 1, LDB = BN + 1, NBUF = 3;
+  __shared__ __attribute__((aligned(16))) float As[NBUF][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF][BK * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int kq = tid & 3, arow = tid >> 2;
+  const int nk = p.K / BK;
+
+  // this workgroup's run [first, last) of the XCD-contiguous tile order (see icg_gemm_body)
+  const unsigned tot = (unsigned)p.pt_tiles * (unsigned)p.pt_z, lin = blockIdx.x;
+  unsigned first, last;
+  if (p.swz) {
+    const unsigned q = tot >> 3, r = tot & 7u, xcd = lin & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const unsigned cnt = q + (xcd < r ? 1u : 0u);
+    first = base + (lin >> 3) * (unsigned)p.pt_run;
+    last = min(first + (unsigned)p.pt_run, base + cnt);
+  } else {
+    first = lin * (unsigned)p.pt_run;
+    last = min(first + (unsigned)p.pt_run, tot);
+  }
+  if (first >= last) return;
+
+  // ---- load stream: position (tile ld_v, K offset ld_k); two K-tiles ahead of the MFMAs
+  unsigned ld_v = first;
+  int ld_k = 0;
+  const float* Agl;
+  const float* Bgl;
+  unsigned oa[2], ob[2];
+  auto stream_tile = [&](unsigned v) {     // operand bases and this thread's row offsets of output tile v
+    const unsigned zz = v / (unsigned)p.pt_tiles, tile = v - zz * (unsigned)p.pt_tiles;
+    const int nt = (int)(tile % (unsigned)p.ntiles_n), mt = (int)(tile / (unsigned)p.ntiles_n);
+    Agl = p.A + (long)zz * p.strideA;
+    Bgl = p.B + (long)zz * p.strideB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = min(mt * BM + arow + 64 * i, p.M - 1);
+      const int n = min(nt * BN + min(arow + 64 * i, BN - 1), p.N - 1);
+      oa[i] = (unsigned)m * (unsigned)p.K + 4u * (unsigned)kq;
+      ob[i] = (unsigned)n * (unsigned)p.ldb + 4u * (unsigned)kq;
+    }
+  };
+  auto stream_advance = [&]() {            // next K-tile of the stream; past the end of the run it stays on the last one
+    ld_k += BK;
+    if (ld_k == p.K) {
+      if (ld_v + 1 < last) { ++ld_v; ld_k = 0; stream_tile(ld_v); }
+      else ld_k = p.K - BK;
+    }
+  };
+  float4 ra[2], rb[2];
+  auto issue_A = [&](int i) { ra[i] = ld4(Agl + (oa[i] + (unsigned)ld_k)); };
+  auto issue_B = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rb[i] = ld4(Bgl + (ob[i] + (unsigned)ld_k));
+  };
+  auto write_A_row = [&](int buf, int i) {
+    float* as = As[buf];
+    const int row = arow + 64 * i;
+    as[(4 * kq + 0) * LDA + row] = ra[i].x;
+    as[(4 * kq + 1) * LDA + row] = ra[i].y;
+    as[(4 * kq + 2) * LDA + row] = ra[i].z;
+    as[(4 * kq + 3) * LDA + row] = ra[i].w;
+  };
+  auto write_B_row = [&](int buf, int i) {
+    float* bs = Bs[buf];
+    const int nl = arow + 64 * i;
+    if (BN == 128 || nl < BN) {
+      bs[(4 * kq + 0) * LDB + nl] = rb[i].x;
+      bs[(4 * kq + 1) * LDB + nl] = rb[i].y;
+      bs[(4 * kq + 2) * LDB + nl] = rb[i].z;
+      bs[(4 * kq + 3) * LDB + nl] = rb[i].w;
+    }
+  };
+
+  f32x16 acc[TN];
+  f32x16 acc2[BLK ? TN : 1];
+  float fa[2], fb[2][TN];
+
+  // pipeline fill: K-tile 0 of the first output tile into ring slot 0, K-tile 1 into the registers, fragments of k-step 0
+  stream_tile(ld_v);
+  issue_A(0); issue_A(1); issue_B();
+  write_A_row(0, 0); write_A_row(0, 1); write_B_row(0, 0); write_B_row(0, 1);
+  stream_advance();
+  issue_A(0); issue_A(1); issue_B();
+  __syncthreads();
+  fa[0] = As[0][32 * wv + li + lh * LDA];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) fb[0][j] = Bs[0][li + lh * LDB + 32 * j];
+  int cur = 0;
+
+  // one K-tile (see icg_gemm_body's tile_body: identical MFMA order and staging schedule)
+  // MODE 0: plain K-tile; 1: its first k-step folds the finished chains into the second level and starts fresh ones (BLK);
+  // 2: first K-tile of an output tile: fresh chains, (BLK) second level cleared
+  auto tile_body = [&](auto mode_c) {
+    constexpr int MODE = decltype(mode_c)::value;
+    const int nxt = (cur == NBUF - 1) ? 0 : cur + 1;
+    const float* as = As[cur] + 32 * wv + li + lh * LDA;
+    const float* bs = Bs[cur] + li + lh * LDB;
+    const float* asn = As[nxt] + 32 * wv + li + lh * LDA;
+    const float* bsn = Bs[nxt] + li + lh * LDB;
+#pragma unroll
+    for (int t = 0; t < BK / 2; ++t) {
+      const int pn = (t + 1) & 1;
+      const bool wrap = (t + 1 == BK / 2);
+      const float* fas = wrap ? asn : as + (2 * t + 2) * LDA;
+      const float* fbs = wrap ? bsn : bs + (2 * t + 2) * LDB;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (MODE == 2 && t == 0) {
+          if (BLK) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+            asm volatile("" : "+v"(acc2[j]));
+          }
+          f32x16 zero;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1], fb[t & 1][j], zero, 0, 0, 0);
+        } else if (MODE == 1 && t == 0) {
+          asm volatile("" : "+a"(acc[j]));
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            f32x2 a2 = {acc[j][2 * r], acc[j][2 * r + 1]};
+            f32x2 b2 = {acc2[j][2 * r], acc2[j][2 * r + 1]};
+            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(b2) : "v"(a2));
+            acc2[j][2 * r] = b2.x;
+            acc2[j][2 * r + 1] = b2.y;
+          }
+          f32x16 zero;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1], fb[t & 1][j], zero, 0, 0, 0);
+        } else {
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1], fb[t & 1][j], acc[j], 0, 0, 0);
+        }
+        if (j == 0) fa[wrap ? 0 : pn] = fas[0];
+        if ((j & 1) == 0) {
+          fb[wrap ? 0 : pn][j] = fbs[32 * j];
+          if (j + 1 < TN) fb[wrap ? 0 : pn][j + 1] = fbs[32 * (j + 1)];
+        }
+        constexpr int PPG = (8 * TN >= 12) ? 1 : 2;
+        const int m = t * TN + j;
+#pragma unroll
+        for (int q = m * PPG; q < (m + 1) * PPG; ++q) {
+          if (q == 1) write_A_row(nxt, 0);
+          if (q == 3) write_A_row(nxt, 1);
+          if (q == 4) write_B_row(nxt, 0);
+          if (q == 5) write_B_row(nxt, 1);
+          if (q == 6) {
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+          }
+          if (q == 7) stream_advance();
+          if (q == 8) issue_A(0);
+          if (q == 10) issue_A(1);
+          if (q == 11) issue_B();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    cur = nxt;
+  };
+
+  for (unsigned v = first; v < last; ++v) {
+    typedef std::integral_constant<int, 0> Plain;
+    typedef std::integral_constant<int, 1> Flush;
+    typedef std::integral_constant<int, 2> Start;
+    tile_body(Start{});
+    if (BLK) {
+#pragma unroll
+      for (int h = 1; h < ICG_PLANES_FLUSH_TILES; ++h)
+        if (h < nk) tile_body(Plain{});
+      for (int kt = ICG_PLANES_FLUSH_TILES; kt < nk; kt += ICG_PLANES_FLUSH_TILES) {
+        tile_body(Flush{});
+#pragma unroll
+        for (int h = 1; h < ICG_PLANES_FLUSH_TILES; ++h)
+          if (kt + h < nk) tile_body(Plain{});
+      }
+    } else {
+      for (int kt = 1; kt < nk; ++kt) tile_body(Plain{});
+    }
+    // epilogue of output tile v (the loads of the next tile's first two K-tiles are in flight meanwhile, so the staging and
+    // fragment registers stay live: one column tile at a time, 16 accumulator copies in VGPRs, pinned against hoisting)
+    const unsigned zz = v / (unsigned)p.pt_tiles, tile = v - zz * (unsigned)p.pt_tiles;
+    const int n0 = (int)(tile % (unsigned)p.ntiles_n) * BN, m0 = (int)(tile / (unsigned)p.ntiles_n) * BM;
+    float* __restrict__ Cg = p.C + (long)zz * p.strideC + (long)(m0 + 32 * wv + 4 * lh) * p.ldc + (n0 + li);
+    const int mrem = p.M - (m0 + 32 * wv + 4 * lh), nrem = p.N - (n0 + li);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      asm volatile("" : "+a"(acc[j]));
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {         // two accumulator copies in flight, (BLK) folded into the second level in place
+        f32x2 c2 = {acc[j][2 * r], acc[j][2 * r + 1]};
+        if (BLK) {
+          f32x2 b2 = {acc2[j][2 * r], acc2[j][2 * r + 1]};
+          asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(c2) : "v"(b2));
+        } else {
+          asm volatile("" : "+v"(c2));
+        }
+        if (32 * j < nrem) {
+          const int row0 = ((2 * r) & 3) + 8 * ((2 * r) >> 2);
+          if (row0 < mrem) Cg[(long)row0 * p.ldc + 32 * j] = p.alpha * c2.x;
+          if (row0 + 1 < mrem) Cg[(long)(row0 + 1) * p.ldc + 32 * j] = p.alpha * c2.y;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <int AMODE, int BMODE, int TN, int PATH>
 __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
   icg_gemm_body<AMODE, BMODE, TN, PATH>(p);
@@ -771,14 +998,16 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
 #endif
 template <int AMODE, int BMODE, int TN>
 __global__ __launch_bounds__(256, (TN == 4 ? ICG_PLANES_TN4_MIN_WAVES : 1)) void icg_gemm_planes_kernel(GemmP p) {
-  icg_gemm_body<AMODE, BMODE, TN, 2, ICG_PLANES_BLOCKED, 1>(p);
+  if constexpr (AMODE == A_K && BMODE == B_K && ICG_PLANES_PERSISTENT) icg_planes_body<TN, ICG_PLANES_BLOCKED>(p);   // 1-D grid
+  else icg_gemm_body<AMODE, BMODE, TN, 2, ICG_PLANES_BLOCKED, 1>(p);
 }
 // ... with single-level accumulation, for plane GEMMs whose chains are short anyway (K <= planes_1level_max_k(): the
 // rounding of a K-long chain grows with K, and at K <= 192 the second level buys < 2x -- 1.7e-6 / 2.3e-6 against 1.2e-6 per
 // layer at 96 / 192 channels, profiles/r02_wino_microbench.txt -- while costing the 128-column kernel a wave per SIMD)
 template <int AMODE, int BMODE, int TN>
 __global__ __launch_bounds__(256) void icg_gemm_planes1_kernel(GemmP p) {
-  icg_gemm_body<AMODE, BMODE, TN, 2, 0, 1>(p);
+  if constexpr (AMODE == A_K && BMODE == B_K && ICG_PLANES_PERSISTENT) icg_planes_body<TN, 0>(p);
+  else icg_gemm_body<AMODE, BMODE, TN, 2, 0, 1>(p);
 }
 
 #ifndef ICG_PLANES_1LEVEL_MAX_K
@@ -871,6 +1100,19 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
   }
   if (path == 2 && p.pre_affine) path = 3;
   g_last_variant[0] = AMODE; g_last_variant[1] = BMODE; g_last_variant[2] = tn; g_last_variant[3] = path;
+  if (path == 2 && g_gemm_planes && AMODE == A_K && BMODE == B_K && ICG_PLANES_PERSISTENT) {
+    // persistent plane GEMM (icg_planes_body): 1-D grid, every workgroup owns a run of consecutive output tiles sized for
+    // ~64 K-tiles of MFMA work, as long as the launch still queues several workgroups per CU
+    if (p.kchunk != 0 || p.bsplit != 0 || p.phase_mode != 0 || p.bias != nullptr || p.res != nullptr) return ICG_ERR_ARG;
+    const long tot = tiles * zdim;
+    const int nk = p.K / 16;
+    int run = (64 + nk - 1) / nk;
+    if (run > 16) run = 16;
+    while (run > 1 && tot / run < 2048) --run;
+    p.pt_tiles = (int)tiles; p.pt_z = zdim; p.pt_run = run;
+    const long per_xcd = icg_cdiv(icg_cdiv(tot, 8), run);
+    grid = p.swz ? dim3((unsigned)(8 * per_xcd), 1, 1) : dim3((unsigned)icg_cdiv(tot, run), 1, 1);
+  }
   if (path == 2 && g_gemm_planes && p.K <= planes_1level_max_k()) {
     g_last_variant[3] = 4;       // plane GEMM, single-level chains
     switch (tn) {

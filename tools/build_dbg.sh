@@ -21,6 +21,7 @@ for v in "$@"; do
     NOBLK) build_variant NOBLK -DICG_PLANES_BLOCKED=0 gemm_conv ;;
     F1) build_variant F1 -DICG_PLANES_FLUSH_TILES=1 gemm_conv ;;
     F4) build_variant F4 -DICG_PLANES_FLUSH_TILES=4 gemm_conv ;;
+    NOPERSIST) build_variant NOPERSIST -DICG_PLANES_PERSISTENT=0 gemm_conv ;;
     LB3) build_variant LB3 -DICG_PLANES_TN4_MIN_WAVES=3 gemm_conv ;;
     *) echo "unknown variant $v"; exit 1 ;;
   esac
