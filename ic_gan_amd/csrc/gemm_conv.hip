@@ -1106,8 +1106,9 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
     if (p.kchunk != 0 || p.bsplit != 0 || p.phase_mode != 0 || p.bias != nullptr || p.res != nullptr) return ICG_ERR_ARG;
     const long tot = tiles * zdim;
     const int nk = p.K / 16;
-    int run = (64 + nk - 1) / nk;
-    if (run > 16) run = 16;
+    static const int target = []() { const char* e = getenv("ICG_PLANES_RUN_KTILES"); return e ? atoi(e) : 64; }();   // (sweep knob)
+    int run = (target + nk - 1) / nk;
+    if (run > 32) run = 32;
     while (run > 1 && tot / run < 2048) --run;
     p.pt_tiles = (int)tiles; p.pt_z = zdim; p.pt_run = run;
     const long per_xcd = icg_cdiv(icg_cdiv(tot, 8), run);
