@@ -68,6 +68,10 @@ CONV_CASES = [
     (2, 9, 7, 3, 40, 3, 0, 0, False),                    # ... LP = 16 with 10 active lanes, odd sizes
     (1, 40, 5, 4, 256, 3, 0, 0, True),                   # ... LP = 64, two row segments, Cin = 4
     (2, 8, 8, 1, 16, 3, 0, 0, True),                     # ... single input channel
+    (2, 9, 7, 3, 64, 3, 0, 0, True),                     # RGB stem on the MFMA form (9 Cin <= 32, Cout % 32 == 0): odd sizes, ragged last tile
+    (1, 5, 33, 2, 32, 3, 0, 0, False),                   # ... two input channels, one column tile, odd width
+    (3, 16, 16, 3, 128, 3, 0, 0, True),                  # ... four column tiles (BigGAN-deep stem width)
+    (2, 12, 10, 1, 96, 3, 0, 0, True),                   # ... single input channel, three column tiles
     (1, 8, 8, 3, 96, 3, PRE_RELU, 0, True),              # prologue requested -> stays on the implicit-GEMM path
     (2, 16, 16, 96, 96, 3, PRE_AFFINE | PRE_RELU | UP, 2, True),   # GBlock conv1-like + half-res residual
     (2, 16, 16, 96, 96, 3, PRE_AFFINE | PRE_RELU, 2, True),
