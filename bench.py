@@ -164,10 +164,13 @@ class KernelTimer:
                           if mode == "wino4" else
                           "composite: wino_input_kernel + %s<0, 0, %d> (16 batched GEMMs) + wino_output_kernel" % (pk, last[2])))
             elif last[0] == -4:      # thin-input 3x3 kernels (narrow_conv.hip): {-4, fprop/wgrad, Cout, Cin}
-                lp = 4
-                while lp < last[2] // 4:
-                    lp *= 2
-                kname = "void thin_%s_kernel<%d, %d>" % ("wgrad" if last[1] else "fprop", last[3], lp)
+                if 9 * last[3] <= 32 and last[2] % 32 == 0 and last[2] <= 128:      # MFMA form (narrow_conv.hip: thin_mfma_ok)
+                    kname = "void thin_%s_mfma_kernel<%d, %d>" % ("wgrad" if last[1] else "fprop", last[3], last[2] // 32)
+                else:
+                    lp = 4
+                    while lp < last[2] // 4:
+                        lp *= 2
+                    kname = "void thin_%s_kernel<%d, %d>" % ("wgrad" if last[1] else "fprop", last[3], lp)
             elif last[0] == -3:      # skinny linear kernels (narrow_conv.hip): {-3, fprop/wgrad, Cout, Cin}
                 kname = "skinny_wgrad_kernel" if last[1] else "void skinny_fprop_kernel<8>"
             elif last[0] == -2:      # direct narrow-output kernels (narrow_conv.hip): {-2, fprop/wgrad, Cout, Cin}
