@@ -64,7 +64,7 @@ struct GemmP {
   int zmask;                       // generic A_K paths only: source is zero-inserted by (zmask+1): hi, wi must be multiples
   int vec_b;                       // PATH 1 only: 16-byte loads allowed on the B operand (A is vectorised)
   // persistent plane GEMM (icg_planes_body): output tiles per plane, planes, consecutive output tiles per workgroup
-  int pt_tiles, pt_z, pt_run;
+  int pt_tiles, pt_z, pt_run;      // (pt_run is informational: the grid size fixes the tiles per workgroup)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -769,8 +769,8 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
 // The forward / data-gradient GEMMs over Winograd planes are C[z] = A[z] B[z]^T with A [M][K], B [N][K] (K = Cin contiguous)
 // and a SHORT K (96 ... 1536: 6 ... 96 K-tiles per 128 x 32*TN output tile), so a workgroup that computes one output tile spends
 // a large part of its life in the pipeline fill (two K-tiles of HBM latency before the first MFMA) and in the epilogue, with
-// only 2-3 workgroups per CU to cover for it.  Here a workgroup owns a RUN of p.pt_run consecutive output tiles of the
-// (plane, m-tile, n-tile) order and treats their K-tiles as ONE stream: the global loads run two K-tiles ahead of the MFMAs
+// only 2-3 workgroups per CU to cover for it.  Here a workgroup owns several output tiles of the (plane, m-tile, n-tile) order
+// (grid-strided inside its XCD's range, ~pt_run of them) and treats their K-tiles as ONE stream: the global loads run two K-tiles ahead of the MFMAs
 // straight across output-tile boundaries (the loads for the next tile's first K-tiles are in flight while this tile's last
 // MFMAs and its epilogue run), the LDS ring and the operand-fragment prefetch never drain.  Same thread -> data mapping, LDS
 // layout, MFMA order, two-level accumulation and staging schedule as icg_gemm_body's fast path, so results are bit-identical to
@@ -784,18 +784,21 @@ __device__ __forceinline__ void icg_planes_body(const GemmP& p) {
   const int kq = tid & 3, arow = tid >> 2;
   const int nk = p.K / BK;
 
-  // this workgroup's run [first, last) of the XCD-contiguous tile order (see icg_gemm_body)
+  // this workgroup's output tiles: v = first, first + vstep, ... < last inside its XCD's contiguous range of the tile order (see
+  // icg_gemm_body).  The stride is the number of workgroups of the XCD, so the workgroups resident at any moment work on
+  // ADJACENT tiles, exactly like a one-tile-per-workgroup launch: they share the m-tile's A panel and the plane's B panel in L2.
   const unsigned tot = (unsigned)p.pt_tiles * (unsigned)p.pt_z, lin = blockIdx.x;
-  unsigned first, last;
+  unsigned first, last, vstep;
   if (p.swz) {
     const unsigned q = tot >> 3, r = tot & 7u, xcd = lin & 7u;
     const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const unsigned cnt = q + (xcd < r ? 1u : 0u);
-    first = base + (lin >> 3) * (unsigned)p.pt_run;
-    last = min(first + (unsigned)p.pt_run, base + cnt);
+    vstep = gridDim.x >> 3;
+    first = base + (lin >> 3);
+    last = base + q + (xcd < r ? 1u : 0u);
   } else {
-    first = lin * (unsigned)p.pt_run;
-    last = min(first + (unsigned)p.pt_run, tot);
+    vstep = gridDim.x;
+    first = lin;
+    last = tot;
   }
   if (first >= last) return;
 
@@ -821,7 +824,7 @@ __device__ __forceinline__ void icg_planes_body(const GemmP& p) {
   auto stream_advance = [&]() {            // next K-tile of the stream; past the end of the run it stays on the last one
     ld_k += BK;
     if (ld_k == p.K) {
-      if (ld_v + 1 < last) { ++ld_v; ld_k = 0; stream_tile(ld_v); }
+      if (ld_v + vstep < last) { ld_v += vstep; ld_k = 0; stream_tile(ld_v); }
       else ld_k = p.K - BK;
     }
   };
@@ -939,7 +942,7 @@ __device__ __forceinline__ void icg_planes_body(const GemmP& p) {
     cur = nxt;
   };
 
-  for (unsigned v = first; v < last; ++v) {
+  for (unsigned v = first; v < last; v += vstep) {
     typedef std::integral_constant<int, 0> Plain;
     typedef std::integral_constant<int, 1> Flush;
     typedef std::integral_constant<int, 2> Start;
