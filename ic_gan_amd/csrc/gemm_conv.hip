@@ -1014,12 +1014,12 @@ __global__ __launch_bounds__(256) void icg_gemm_planes1_kernel(GemmP p) {
 }
 
 #ifndef ICG_PLANES_1LEVEL_MAX_K
-#define ICG_PLANES_1LEVEL_MAX_K 0
+#define ICG_PLANES_1LEVEL_MAX_K 0      // K up to which plane GEMMs use the single-level kernel; 0 = never (ablation build L1_384:
+#endif                                 // 4-5 ms faster, but the ill-conditioned small test networks then exceed the strict tolerances)
+static constexpr int planes_1level_max_k() { return ICG_PLANES_1LEVEL_MAX_K; }
+#ifndef ICG_PLANES_RUN_KTILES
+#define ICG_PLANES_RUN_KTILES 64       // persistent plane GEMM: K-tiles of MFMA work per workgroup (measured flat between 16 and 256)
 #endif
-static int planes_1level_max_k() {     // ICG_PLANES_1LEVEL_MAX_K in the environment: measurement override, read once
-  static const int v = []() { const char* e = getenv("ICG_PLANES_1LEVEL_MAX_K"); return e ? atoi(e) : ICG_PLANES_1LEVEL_MAX_K; }();
-  return v;
-}
 
 static thread_local int g_gemm_planes = 0;
 void icg_gemm_mark_planes(int on) { g_gemm_planes = on; }
@@ -1109,8 +1109,7 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
     if (p.kchunk != 0 || p.bsplit != 0 || p.phase_mode != 0 || p.bias != nullptr || p.res != nullptr) return ICG_ERR_ARG;
     const long tot = tiles * zdim;
     const int nk = p.K / 16;
-    static const int target = []() { const char* e = getenv("ICG_PLANES_RUN_KTILES"); return e ? atoi(e) : 64; }();   // (sweep knob)
-    int run = (target + nk - 1) / nk;
+    int run = (ICG_PLANES_RUN_KTILES + nk - 1) / nk;
     if (run > 32) run = 32;
     while (run > 1 && tot / run < 2048) --run;
     p.pt_tiles = (int)tiles; p.pt_z = zdim; p.pt_run = run;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Ablation builds of libicgan_hip.so (tools only, never the product): tools/libdbg_<NAME>.so, selected by tools/*.py through ICG_LIB.
 #   NOBLK : plane GEMMs with single-level accumulation (-DICG_PLANES_BLOCKED=0);  F1 / F4: first-level chains of 1 / 4 K-tiles;
+#   L1_384 : plane GEMMs with K <= 384 on the single-level kernel;  NOPERSIST: one output tile per workgroup (generic body)
 #   LB3 : 128-column two-level plane GEMM forced to 3 waves per SIMD (spills)
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
@@ -21,6 +22,7 @@ for v in "$@"; do
     NOBLK) build_variant NOBLK -DICG_PLANES_BLOCKED=0 gemm_conv ;;
     F1) build_variant F1 -DICG_PLANES_FLUSH_TILES=1 gemm_conv ;;
     F4) build_variant F4 -DICG_PLANES_FLUSH_TILES=4 gemm_conv ;;
+    L1_384) build_variant L1_384 -DICG_PLANES_1LEVEL_MAX_K=384 gemm_conv ;;
     NOPERSIST) build_variant NOPERSIST -DICG_PLANES_PERSISTENT=0 gemm_conv ;;
     LB3) build_variant LB3 -DICG_PLANES_TN4_MIN_WAVES=3 gemm_conv ;;
     *) echo "unknown variant $v"; exit 1 ;;

@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 2, call G: plain-GEMM loader of the plane kernels; single-level chains for short-K plane GEMMs (threshold sweep)
+# (historical: ICG_PLANES_1LEVEL_MAX_K / ICG_PLANES_RUN_KTILES were environment overrides when this ran; they are compile-time
+# macros now -- tools/build_dbg.sh L1_384 builds the K <= 384 variant)
 mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
 timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_bench_shapes_gpu.py -m gpu -q -k "wino or winograd or gemm or bench" -p no:cacheprovider 2>&1 | tail -4

@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 2, call I: persistent plane GEMM (runs of output tiles per workgroup) vs one tile per workgroup
+# (historical: ICG_PLANES_1LEVEL_MAX_K / ICG_PLANES_RUN_KTILES were environment overrides when this ran; they are compile-time
+# macros now -- tools/build_dbg.sh L1_384 builds the K <= 384 variant)
 mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
 timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_bench_shapes_gpu.py -m gpu -q -x -k "wino or winograd or bench" -p no:cacheprovider 2>&1 | tail -6
