@@ -911,7 +911,7 @@ def test_gemm_tn_batched_split_k():
     (3, 4, 4, 256, 256, 0, 0, True),
     (2, 8, 12, 48, 32, 0, 3, False),                        # ReLU mask in the output transform (D data gradients)
     (16, 128, 128, 16, 24, 0, 0, True),                     # 4608 plane tiles of ONE K-tile: persistent workgroups cross an output-tile boundary every step
-    (4, 96, 160, 32, 40, PRE_RELU, 1, False),               # 8640 plane tiles of two K-tiles, ragged M tile (1500 rows) and N
+    (8, 100, 160, 32, 160, PRE_RELU, 1, False),             # 4536 plane tiles of two K-tiles, ragged last M tile (8000 rows) and N tile (128 + 32)
 ])
 def test_conv2d_winograd4(case):
     """Winograd F(4x4,3x3) forward vs the direct convolution (tolerance 2e-4 of max|ref|: fp32 transforms with entries up to 8)."""
