@@ -280,6 +280,223 @@ int icg_narrow_fprop(const float* x, const float* w, const float* bias, const fl
   return icg_check_launch();
 }
 
+// ---- MFMA form of the thin-input kernels (9 * CIN <= 32 and Cout = 32 * NT, NT <= 4: the from-RGB layer of every D) ----------
+// With K = 9 * CIN <= 32 the convolution is out[P][Cout] = Xcol[P][32] W^T[32][Cout] per 32-pixel tile: 16 k-steps of
+// v_mfma_f32_32x32x2_f32 per column tile instead of 27 packed FMAs per output quad, so both kernels become what they should be --
+// one HBM pass over the Cout-wide tensor (the 3-channel image stays in L1/L2).  Operand fragments come straight from global
+// memory: A[i = lane & 31][k = 2t + (lane >> 5)] is one image value per lane and k-step (zero for padding and for k >= 9 CIN),
+// B is the weight fragment held in registers (fprop) or one dy value per lane, k-step and column tile (wgrad: 128-byte rows).
+typedef float th_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CIN, int NT>
+__global__ __launch_bounds__(256) void thin_fprop_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                              const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                              int H, int W, float alpha) {
+  constexpr int KK = 9 * CIN, Cout = 32 * NT;
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  // weight fragments: B[k][j] = wgt[32 jt + j][k] (OHWI: [Cout][3][3][CIN] = [Cout][KK])
+  float wf[16][NT];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int k = 2 * t + lh;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) wf[t][jt] = (k < KK) ? wgt[(long)(32 * jt + li) * KK + k] : 0.f;
+  }
+  float bv[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) bv[jt] = bias ? bias[32 * jt + li] : 0.f;
+  const long P = (long)B * H * W;
+  const long ntile = (P + 31) / 32;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (long)gridDim.x * 4;
+  auto gather = [&](long tile, float (&af)[16]) {          // the A fragments of a 32-pixel tile
+    const long pa = min(tile * 32 + li, P - 1);            // this lane's pixel as the A-operand row (clamped: masked at the store)
+    const int w = (int)(pa % W);
+    const long t2 = pa / W;
+    const int h = (int)(t2 % H);
+    const float* xb = x + (t2 - h) * (long)W * CIN;          // image base
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int k = 2 * t + lh;
+      const int tap = k / CIN, c = k - tap * CIN;
+      const int r = tap / 3, sx = tap - 3 * r;
+      const int hi = h + r - 1, wi = w + sx - 1;
+      const bool ok = (k < KK) && ((unsigned)hi < (unsigned)H) && ((unsigned)wi < (unsigned)W);
+      const float v = xb[((long)(ok ? hi : h) * W + (ok ? wi : w)) * CIN + (k < KK ? c : 0)];
+      af[t] = ok ? v : 0.f;
+    }
+  };
+  float af[16], afn[16];
+  if (wave < ntile) gather(wave, af);
+  for (long tile = wave; tile < ntile; tile += nwave) {
+    gather(min(tile + nwave, ntile - 1), afn);             // next tile's operands in flight under this tile's MFMAs and stores
+    th_f32x16 acc[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], wf[t][jt], acc[jt], 0, 0, 0);
+    // C layout: column = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel of the tile)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long pp = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (pp < P) {
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) out[pp * Cout + 32 * jt + li] = alpha * acc[jt][r] + bv[jt];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) af[t] = afn[t];
+  }
+}
+
+// slab[block][k = tap * CIN + c][co] = sum over the block's image rows of x[pix + tap][c] * dy[pix][co]    (HWIO rows k < 9 CIN)
+// NARROW = 0: x is the CIN-channel image, dy the 32 NT-channel tensor (from-RGB weight gradient), rows k = (tap, c).
+// NARROW = 1: the roles are swapped (to-RGB weight gradient, CIN = its 1..3 OUTPUT channels): `x` is dy [.., CIN], `dy` is the
+// layer's 32 NT-channel input with the per-sample affine + ReLU prologue applied to the fragment, the tap shift changes sign
+// (dw[tap][ci][co] = sum_q act(x)[q][ci] * dy[q - tap][co]) and the slab is written as [tap][ci][co].
+template <int CIN, int NT, int NARROW>
+__global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ slabs, int B, int H, int W,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              long ssb, int affine, int relu) {
+  constexpr int KK = 9 * CIN, Cout = 32 * NT, U = 8;        // U k-steps (2 pixels each) of loads in flight ahead of their MFMAs
+  __shared__ float red[32 * Cout];
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5, wv = threadIdx.x >> 6;
+  // A[i][k]: row i = (tap, c) of the weight gradient, k = pixel
+  const int tap = li / CIN, c = li - tap * CIN;
+  const int sg = NARROW ? -1 : 1;
+  const int dr = sg * (tap / 3 - 1), ds = sg * (tap - 3 * (tap / 3) - 1);
+  const bool row_on = li < KK;
+  th_f32x16 acc[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+  const long rows = (long)B * H;
+  const int wsteps = (W + 1) / 2;                            // k-steps per image row
+  for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
+    const int h = (int)(row % H);
+    const int hi = h + dr;
+    const bool hok = row_on && ((unsigned)hi < (unsigned)H);
+    const float* xr = x + (row + (hok ? dr : 0)) * (long)W * CIN + c;     // row h + dr of the same image (clamped when masked)
+    const float* dr_ = dy + row * (long)W * Cout + li;
+    float psc[NT], psh[NT];                                  // NARROW: prologue coefficients of this lane's channels in this image
+    if (NARROW && affine) {
+      const long bimg = row / H;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) { psc[jt] = scale[bimg * ssb + 32 * jt + li]; psh[jt] = shift[bimg * ssb + 32 * jt + li]; }
+    }
+    float av[U], bfr[U][NT];
+    auto fetch = [&](int st, int u) {                        // operands of k-step st into slot u
+      const int wq = 2 * st + lh;                            // this lane's pixel column
+      const int wi = wq + ds;
+      const bool aok = hok && (wq < W) && ((unsigned)wi < (unsigned)W);
+      const float v = xr[(long)(aok ? wi : 0) * CIN];
+      av[u] = aok ? v : 0.f;
+      const bool bok = wq < W;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        float g = dr_[(long)(bok ? wq : 0) * Cout + 32 * jt];
+        if (NARROW) {
+          if (affine) g = fmaf(g, psc[jt], psh[jt]);
+          if (relu) g = fmaxf(g, 0.f);
+        }
+        bfr[u][jt] = bok ? g : 0.f;
+      }
+    };
+    for (int s0 = 0; s0 < wsteps; s0 += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (s0 + u < wsteps) fetch(s0 + u, u);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (s0 + u < wsteps) {
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bfr[u][jt], acc[jt], 0, 0, 0);
+        }
+    }
+  }
+  // combine the block's four wavefronts in fixed order, write the rows k < KK of the slab
+  float* slab = slabs + (long)blockIdx.x * KK * Cout;
+  for (int src = 1; src < 4; ++src) {
+    __syncthreads();
+    if (wv == src) {
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * lh) * Cout + 32 * jt + li] = acc[jt][r];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jt][r] += red[((r & 3) + 8 * (r >> 2) + 4 * lh) * Cout + 32 * jt + li];
+    }
+  }
+  if (wv == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (k < KK) {
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          if (NARROW) slab[((long)(k / CIN) * Cout + 32 * jt + li) * CIN + (k % CIN)] = acc[jt][r];
+          else slab[(long)k * Cout + 32 * jt + li] = acc[jt][r];
+        }
+      }
+    }
+  }
+}
+
+static bool thin_mfma_ok(int Cin, int Cout) { return 9 * Cin <= 32 && Cout % 32 == 0 && Cout <= 128; }
+
+template <int CIN>
+static void thin_mfma_launch(bool wgrad, int nt, dim3 grid, hipStream_t st, const float* x, const float* w_or_dy, const float* bias,
+                             float* out, int B, int H, int W, float alpha) {
+#define ICG_THM(NT_)                                                                                                            \
+  if (wgrad) hipLaunchKernelGGL((thin_wgrad_mfma_kernel<CIN, NT_, 0>), grid, dim3(256), 0, st, x, w_or_dy, out, B, H, W,         \
+                                (const float*)nullptr, (const float*)nullptr, 0L, 0, 0);                                        \
+  else hipLaunchKernelGGL((thin_fprop_mfma_kernel<CIN, NT_>), grid, dim3(256), 0, st, x, w_or_dy, bias, out, B, H, W, alpha)
+  switch (nt) {
+    case 1: ICG_THM(1); break;
+    case 2: ICG_THM(2); break;
+    case 3: ICG_THM(3); break;
+    default: ICG_THM(4); break;
+  }
+#undef ICG_THM
+}
+
+static void thin_mfma_dispatch(bool wgrad, int Cin, int nt, dim3 grid, hipStream_t st, const float* x, const float* w_or_dy,
+                               const float* bias, float* out, int B, int H, int W, float alpha) {
+  switch (Cin) {
+    case 1: thin_mfma_launch<1>(wgrad, nt, grid, st, x, w_or_dy, bias, out, B, H, W, alpha); break;
+    case 2: thin_mfma_launch<2>(wgrad, nt, grid, st, x, w_or_dy, bias, out, B, H, W, alpha); break;
+    default: thin_mfma_launch<3>(wgrad, nt, grid, st, x, w_or_dy, bias, out, B, H, W, alpha); break;
+  }
+}
+
+
+// to-RGB weight gradient on the same kernel (NARROW = 1): Cout in 1..3 output channels, Cin = 32 NT <= 128 input channels
+static bool narrow_wgrad_mfma_ok(int Cin, int Cout) { return Cout >= 1 && Cout <= 3 && Cin % 32 == 0 && Cin <= 128; }
+
+template <int NOUT>
+static void narrow_wgrad_mfma_launch(int nt, dim3 grid, hipStream_t st, const float* x, const float* dy, float* slabs, int B, int H,
+                                     int W, const float* scale, const float* shift, long ssb, int affine, int relu) {
+#define ICG_NWM(NT_) \
+  hipLaunchKernelGGL((thin_wgrad_mfma_kernel<NOUT, NT_, 1>), grid, dim3(256), 0, st, dy, x, slabs, B, H, W, scale, shift, ssb, affine, relu)
+  switch (nt) {
+    case 1: ICG_NWM(1); break;
+    case 2: ICG_NWM(2); break;
+    case 3: ICG_NWM(3); break;
+    default: ICG_NWM(4); break;
+  }
+#undef ICG_NWM
+}
+
 size_t icg_narrow_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   const int lp = narrow_lp(Cin);
   return (size_t)narrow_blocks(B, H, W, lp, 768) * 9 * Cin * Cout * sizeof(float);
@@ -305,8 +522,19 @@ static void narrow_wgrad_lp(int lp, dim3 grid, hipStream_t st, const float* x, c
 int icg_narrow_wgrad(const float* x, const float* dy, const float* scale, const float* shift, long ssb, float* dw,
                      void* workspace, int B, int H, int W, int Cin, int Cout, int affine, int relu, hipStream_t st) {
   const int lp = narrow_lp(Cin);
-  const int blocks = narrow_blocks(B, H, W, lp, 768);
+  int blocks = narrow_blocks(B, H, W, lp, 768);
   float* slabs = (float*)workspace;
+  if (narrow_wgrad_mfma_ok(Cin, Cout)) {
+    const long rows4 = ((long)B * H + 3) / 4;                 // one image row per wavefront and pass
+    if (blocks > rows4) blocks = (int)rows4;
+    const dim3 g((unsigned)blocks);
+    if (Cout == 1) narrow_wgrad_mfma_launch<1>(Cin / 32, g, st, x, dy, slabs, B, H, W, scale, shift, ssb, affine, relu);
+    else if (Cout == 2) narrow_wgrad_mfma_launch<2>(Cin / 32, g, st, x, dy, slabs, B, H, W, scale, shift, ssb, affine, relu);
+    else narrow_wgrad_mfma_launch<3>(Cin / 32, g, st, x, dy, slabs, B, H, W, scale, shift, ssb, affine, relu);
+    const long n = 9L * Cin * Cout;
+    hipLaunchKernelGGL(narrow_reduce_kernel, dim3((unsigned)icg_cdiv(n, 32)), dim3(256), 0, st, (const float*)slabs, dw, n, blocks);
+    return icg_check_launch();
+  }
   const dim3 grid((unsigned)blocks);
   switch (Cout) {
     case 1: narrow_wgrad_lp<1>(lp, grid, st, x, dy, scale, shift, ssb, slabs, B, H, W, Cin, affine, relu); break;
@@ -568,184 +796,6 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
     }
 }
 
-
-// ---- MFMA form of the thin-input kernels (9 * CIN <= 32 and Cout = 32 * NT, NT <= 4: the from-RGB layer of every D) ----------
-// With K = 9 * CIN <= 32 the convolution is out[P][Cout] = Xcol[P][32] W^T[32][Cout] per 32-pixel tile: 16 k-steps of
-// v_mfma_f32_32x32x2_f32 per column tile instead of 27 packed FMAs per output quad, so both kernels become what they should be --
-// one HBM pass over the Cout-wide tensor (the 3-channel image stays in L1/L2).  Operand fragments come straight from global
-// memory: A[i = lane & 31][k = 2t + (lane >> 5)] is one image value per lane and k-step (zero for padding and for k >= 9 CIN),
-// B is the weight fragment held in registers (fprop) or one dy value per lane, k-step and column tile (wgrad: 128-byte rows).
-typedef float th_f32x16 __attribute__((ext_vector_type(16)));
-
-template <int CIN, int NT>
-__global__ __launch_bounds__(256) void thin_fprop_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
-                                                              const float* __restrict__ bias, float* __restrict__ out, int B,
-                                                              int H, int W, float alpha) {
-  constexpr int KK = 9 * CIN, Cout = 32 * NT;
-  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
-  // weight fragments: B[k][j] = wgt[32 jt + j][k] (OHWI: [Cout][3][3][CIN] = [Cout][KK])
-  float wf[16][NT];
-#pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    const int k = 2 * t + lh;
-#pragma unroll
-    for (int jt = 0; jt < NT; ++jt) wf[t][jt] = (k < KK) ? wgt[(long)(32 * jt + li) * KK + k] : 0.f;
-  }
-  float bv[NT];
-#pragma unroll
-  for (int jt = 0; jt < NT; ++jt) bv[jt] = bias ? bias[32 * jt + li] : 0.f;
-  const long P = (long)B * H * W;
-  const long ntile = (P + 31) / 32;
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (long)gridDim.x * 4;
-  auto gather = [&](long tile, float (&af)[16]) {          // the A fragments of a 32-pixel tile
-    const long pa = min(tile * 32 + li, P - 1);            // this lane's pixel as the A-operand row (clamped: masked at the store)
-    const int w = (int)(pa % W);
-    const long t2 = pa / W;
-    const int h = (int)(t2 % H);
-    const float* xb = x + (t2 - h) * (long)W * CIN;          // image base
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int k = 2 * t + lh;
-      const int tap = k / CIN, c = k - tap * CIN;
-      const int r = tap / 3, sx = tap - 3 * r;
-      const int hi = h + r - 1, wi = w + sx - 1;
-      const bool ok = (k < KK) && ((unsigned)hi < (unsigned)H) && ((unsigned)wi < (unsigned)W);
-      const float v = xb[((long)(ok ? hi : h) * W + (ok ? wi : w)) * CIN + (k < KK ? c : 0)];
-      af[t] = ok ? v : 0.f;
-    }
-  };
-  float af[16], afn[16];
-  if (wave < ntile) gather(wave, af);
-  for (long tile = wave; tile < ntile; tile += nwave) {
-    gather(min(tile + nwave, ntile - 1), afn);             // next tile's operands in flight under this tile's MFMAs and stores
-    th_f32x16 acc[NT];
-#pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
-#pragma unroll
-    for (int t = 0; t < 16; ++t)
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], wf[t][jt], acc[jt], 0, 0, 0);
-    // C layout: column = lane & 31 (output channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel of the tile)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long pp = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (pp < P) {
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) out[pp * Cout + 32 * jt + li] = alpha * acc[jt][r] + bv[jt];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 16; ++t) af[t] = afn[t];
-  }
-}
-
-// slab[block][k = tap * CIN + c][co] = sum over the block's image rows of x[pix + tap][c] * dy[pix][co]    (HWIO rows k < 9 CIN)
-template <int CIN, int NT>
-__global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                              float* __restrict__ slabs, int B, int H, int W) {
-  constexpr int KK = 9 * CIN, Cout = 32 * NT, U = 4;        // U k-steps (2 pixels each) of loads in flight ahead of their MFMAs
-  __shared__ float red[32 * Cout];
-  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5, wv = threadIdx.x >> 6;
-  // A[i][k]: row i = (tap, c) of the weight gradient, k = pixel
-  const int tap = li / CIN, c = li - tap * CIN;
-  const int dr = tap / 3 - 1, ds = tap - 3 * (tap / 3) - 1;
-  const bool row_on = li < KK;
-  th_f32x16 acc[NT];
-#pragma unroll
-  for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
-  const long rows = (long)B * H;
-  const int wsteps = (W + 1) / 2;                            // k-steps per image row
-  for (long row = (long)blockIdx.x * 4 + wv; row < rows; row += (long)gridDim.x * 4) {
-    const int h = (int)(row % H);
-    const int hi = h + dr;
-    const bool hok = row_on && ((unsigned)hi < (unsigned)H);
-    const float* xr = x + (row + (hok ? dr : 0)) * (long)W * CIN + c;     // row h + dr of the same image (clamped when masked)
-    const float* dr_ = dy + row * (long)W * Cout + li;
-    float av[U], bfr[U][NT];
-    auto fetch = [&](int st, int u) {                        // operands of k-step st into slot u
-      const int wq = 2 * st + lh;                            // this lane's pixel column
-      const int wi = wq + ds;
-      const bool aok = hok && (wq < W) && ((unsigned)wi < (unsigned)W);
-      const float v = xr[(long)(aok ? wi : 0) * CIN];
-      av[u] = aok ? v : 0.f;
-      const bool bok = wq < W;
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt) {
-        const float g = dr_[(long)(bok ? wq : 0) * Cout + 32 * jt];
-        bfr[u][jt] = bok ? g : 0.f;
-      }
-    };
-    for (int s0 = 0; s0 < wsteps; s0 += U) {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (s0 + u < wsteps) fetch(s0 + u, u);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (s0 + u < wsteps) {
-#pragma unroll
-          for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bfr[u][jt], acc[jt], 0, 0, 0);
-        }
-    }
-  }
-  // combine the block's four wavefronts in fixed order, write the rows k < KK of the slab
-  float* slab = slabs + (long)blockIdx.x * KK * Cout;
-  for (int src = 1; src < 4; ++src) {
-    __syncthreads();
-    if (wv == src) {
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * lh) * Cout + 32 * jt + li] = acc[jt][r];
-    }
-    __syncthreads();
-    if (wv == 0) {
-#pragma unroll
-      for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[jt][r] += red[((r & 3) + 8 * (r >> 2) + 4 * lh) * Cout + 32 * jt + li];
-    }
-  }
-  if (wv == 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int k = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (k < KK) {
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) slab[(long)k * Cout + 32 * jt + li] = acc[jt][r];
-      }
-    }
-  }
-}
-
-static bool thin_mfma_ok(int Cin, int Cout) { return 9 * Cin <= 32 && Cout % 32 == 0 && Cout <= 128; }
-
-template <int CIN>
-static void thin_mfma_launch(bool wgrad, int nt, dim3 grid, hipStream_t st, const float* x, const float* w_or_dy, const float* bias,
-                             float* out, int B, int H, int W, float alpha) {
-#define ICG_THM(NT_)                                                                                                            \
-  if (wgrad) hipLaunchKernelGGL((thin_wgrad_mfma_kernel<CIN, NT_>), grid, dim3(256), 0, st, x, w_or_dy, out, B, H, W);            \
-  else hipLaunchKernelGGL((thin_fprop_mfma_kernel<CIN, NT_>), grid, dim3(256), 0, st, x, w_or_dy, bias, out, B, H, W, alpha)
-  switch (nt) {
-    case 1: ICG_THM(1); break;
-    case 2: ICG_THM(2); break;
-    case 3: ICG_THM(3); break;
-    default: ICG_THM(4); break;
-  }
-#undef ICG_THM
-}
-
-static void thin_mfma_dispatch(bool wgrad, int Cin, int nt, dim3 grid, hipStream_t st, const float* x, const float* w_or_dy,
-                               const float* bias, float* out, int B, int H, int W, float alpha) {
-  switch (Cin) {
-    case 1: thin_mfma_launch<1>(wgrad, nt, grid, st, x, w_or_dy, bias, out, B, H, W, alpha); break;
-    case 2: thin_mfma_launch<2>(wgrad, nt, grid, st, x, w_or_dy, bias, out, B, H, W, alpha); break;
-    default: thin_mfma_launch<3>(wgrad, nt, grid, st, x, w_or_dy, bias, out, B, H, W, alpha); break;
-  }
-}
 
 bool icg_thin_conv_ok(int Cin, int Cout, int R) { return R == 3 && Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && Cout >= 16 && Cout <= 256; }
 

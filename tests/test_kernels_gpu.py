@@ -93,6 +93,8 @@ CONV_CASES = [
     (1, 9, 9, 192, 4, 3, PRE_AFFINE | PRE_RELU, 0, True),  # LP = 64 with 48 active lanes, 4 outputs
     (2, 4, 6, 256, 2, 3, PRE_RELU, 0, True),             # LP = 64 full
     (2, 8, 8, 64, 3, 3, PRE_AFFINE, 0, False),           # LP = 16, affine without relu
+    (2, 9, 7, 32, 1, 3, PRE_RELU, 0, True),              # to-RGB weight gradient on the MFMA form: one output channel, odd sizes
+    (1, 6, 10, 128, 2, 3, PRE_AFFINE | PRE_RELU, 0, False),  # ... two output channels, four column tiles
 ]
 
 
