@@ -165,7 +165,7 @@ class KernelTimer:
                           "composite: wino_input_kernel + %s<0, 0, %d> (16 batched GEMMs) + wino_output_kernel" % (pk, last[2])))
             elif last[0] == -4:      # thin-input 3x3 kernels (narrow_conv.hip): {-4, fprop/wgrad, Cout, Cin}
                 if 9 * last[3] <= 32 and last[2] % 32 == 0 and last[2] <= 128:      # MFMA form (narrow_conv.hip: thin_mfma_ok)
-                    kname = "void thin_%s_mfma_kernel<%d, %d>" % ("wgrad" if last[1] else "fprop", last[3], last[2] // 32)
+                    kname = ("void thin_wgrad_mfma_kernel<%d, %d, 0>" if last[1] else "void thin_fprop_mfma_kernel<%d, %d>") % (last[3], last[2] // 32)
                 else:
                     lp = 4
                     while lp < last[2] // 4:
@@ -174,10 +174,13 @@ class KernelTimer:
             elif last[0] == -3:      # skinny linear kernels (narrow_conv.hip): {-3, fprop/wgrad, Cout, Cin}
                 kname = "skinny_wgrad_kernel" if last[1] else "void skinny_fprop_kernel<8>"
             elif last[0] == -2:      # direct narrow-output kernels (narrow_conv.hip): {-2, fprop/wgrad, Cout, Cin}
-                lp = 1
-                while lp < last[3] // 4:
-                    lp *= 2
-                kname = "void narrow_%s_kernel<%d, %d>" % ("wgrad" if last[1] else "fprop", last[2], lp)
+                if last[1] and last[2] <= 3 and last[3] % 32 == 0 and last[3] <= 128:   # wgrad on the MFMA thin kernel, roles swapped
+                    kname = "void thin_wgrad_mfma_kernel<%d, %d, 1>" % (last[2], last[3] // 32)
+                else:
+                    lp = 1
+                    while lp < last[3] // 4:
+                        lp *= 2
+                    kname = "void narrow_%s_kernel<%d, %d>" % ("wgrad" if last[1] else "fprop", last[2], lp)
             else:
                 kname = "void icg_gemm_kernel<%d, %d, %d, %d>(GemmP)" % tuple(last)
             timer.records.append((kname, alg, exe, byt, s, e))
