@@ -13,6 +13,7 @@
 
 #define NC_ROWS 32      // rows of a column segment (2 halo rows per segment are re-read)
 
+typedef float th_f32x16 __attribute__((ext_vector_type(16)));   // MFMA accumulator tile
 typedef float nc_v2 __attribute__((ext_vector_type(2)));      // v_pk_fma_f32: two fp32 FMAs per lane and issue slot
 __device__ __forceinline__ nc_v2 nc_lo(const float4& v) { return nc_v2{v.x, v.y}; }
 __device__ __forceinline__ nc_v2 nc_hi(const float4& v) { return nc_v2{v.z, v.w}; }
@@ -266,9 +267,136 @@ static void narrow_fprop_lp(int lp, dim3 grid, hipStream_t st, const float* x, c
 #undef ICG_NF
 }
 
+
+// ---- MFMA form of the narrow-OUTPUT forward (to-RGB, and the data gradient of from-RGB): NOUT <= 3, Cin = 32 NCT <= 128 --------
+// Per image row and 32-pixel tile one GEMM  T^T[(tap, o)][pixel] = sum_c W[(tap, o)][c] * act(x)[pixel][c]  (M = 9 NOUT <= 27
+// rows, K = Cin: Cin/2 MFMAs, the weight fragments live in registers), i.e. every pixel's contribution to the 9 output pixels
+// around it; the row of T goes into a three-row LDS window and the output row above is assembled from its 3x3 neighbourhood:
+// out[p][o] = alpha * sum_tap T[p + tap][(tap, o)] + bias[o].  A wavefront owns a 30-column chunk (tile = chunk + one halo
+// column each side) of a 32-row segment and walks down it, so x is read once (+ 2 halo rows per segment, 2 of 32 columns).
+// K order: lane half kk of k-step t = 4g + e holds channel 8g + 4kk + e, so a lane's operands of four k-steps are ONE 16-byte
+// load; the weight fragments are permuted the same way.  Prologue (per-sample affine + ReLU) on the loaded quads, zero padding
+// after it (halo pixels outside the image contribute zero fragments, rows outside leave a zero T row).
+template <int NOUT, int NCT>
+__global__ __launch_bounds__(256, (NCT <= 3 ? 3 : 2)) void narrow_fprop_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                                const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, long ssb,
+                                                                float* __restrict__ out, int B, int H, int W, int affine,
+                                                                int relu, float alpha) {
+  constexpr int Cin = 32 * NCT, NG = Cin / 8, MM = 9 * NOUT, TS = 29, CW = 30;
+  __shared__ float Tw[4][3][32 * TS];
+  __shared__ __attribute__((aligned(16))) float Pc[4][2][Cin];
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5, wv = threadIdx.x >> 6;
+  float* Ts = &Tw[wv][0][0];
+  // A fragments: row i = tap * NOUT + o of W, k-step (g, e) -> channel 8g + 4lh + e      (wgt: OHWI [NOUT][3][3][Cin])
+  float wf[NG][4];
+  {
+    const int tap = li / NOUT, o = li - tap * NOUT;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wf[g][e] = (li < MM) ? wgt[((long)o * 9 + tap) * Cin + 8 * g + 4 * lh + e] : 0.f;
+  }
+  const int cbs = (W + CW - 1) / CW, rss = (H + NC_ROWS - 1) / NC_ROWS;
+  const long units = (long)B * cbs * rss;
+  for (long u = (long)blockIdx.x * 4 + wv; u < units; u += (long)gridDim.x * 4) {
+    const int b = (int)(u / ((long)cbs * rss));
+    const int r2 = (int)(u - (long)b * cbs * rss);
+    const int hb = (r2 / cbs) * NC_ROWS, c0 = (r2 % cbs) * CW;
+    const int he = min(H, hb + NC_ROWS);
+    if (affine) {                                            // this image's prologue coefficients -> LDS (wave-private)
+      for (int c = lane; c < Cin; c += 64) { Pc[wv][0][c] = scale[(long)b * ssb + c]; Pc[wv][1][c] = shift[(long)b * ssb + c]; }
+    }
+    const int col = c0 - 1 + li;                             // this lane's pixel column as the B-operand column
+    const bool col_on = (unsigned)col < (unsigned)W;
+    for (int h = hb - 1; h <= he; ++h) {                     // T rows hb-1 .. he; output row h-1 once rows h-2 .. h are in the window
+      float* Trow = Ts + ((h + 3) % 3) * (32 * TS);
+      if ((unsigned)h < (unsigned)H) {
+        const float* xp = x + (((long)b * H + h) * W + (col_on ? col : 0)) * Cin + 4 * lh;
+        float4 v[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) v[g] = *reinterpret_cast<const float4*>(xp + 8 * g);
+        th_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          float4 a = v[g];
+          if (affine) {
+            const float4 sc = *reinterpret_cast<const float4*>(&Pc[wv][0][8 * g + 4 * lh]);
+            const float4 sh = *reinterpret_cast<const float4*>(&Pc[wv][1][8 * g + 4 * lh]);
+            a.x = fmaf(a.x, sc.x, sh.x); a.y = fmaf(a.y, sc.y, sh.y); a.z = fmaf(a.z, sc.z, sh.z); a.w = fmaf(a.w, sc.w, sh.w);
+          }
+          if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+          if (!col_on) a = make_float4(0.f, 0.f, 0.f, 0.f);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[g][0], a.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[g][1], a.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[g][2], a.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[g][3], a.w, acc, 0, 0, 0);
+        }
+        // C layout: column = lane & 31 = pixel of the tile, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = (tap, o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (i < MM) Trow[li * TS + i] = acc[r];
+        }
+      } else {
+        for (int k = lane; k < 32 * TS; k += 64) Trow[k] = 0.f;
+      }
+      const int ho = h - 1;
+      if (ho >= hb && ho < he) {                             // (wave-private LDS: program order is enough, no barrier)
+#pragma unroll
+        for (int it = 0; it < (CW * NOUT + 63) / 64; ++it) {
+          const int item = lane + 64 * it;
+          if (item < CW * NOUT) {
+            const int jo = 1 + item / NOUT, o = item - (item / NOUT) * NOUT;
+            const int oc = c0 - 1 + jo;
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+              const float* Tr = Ts + ((ho + r - 1 + 3) % 3) * (32 * TS);
+#pragma unroll
+              for (int sx = 0; sx < 3; ++sx) sum += Tr[(jo + sx - 1) * TS + (r * 3 + sx) * NOUT + o];
+            }
+            if (oc < W) out[(((long)b * H + ho) * W + oc) * NOUT + o] = alpha * sum + (bias ? bias[o] : 0.f);
+          }
+        }
+      }
+    }
+  }
+}
+
+static bool narrow_fprop_mfma_ok(int Cin, int Cout) { return Cout >= 1 && Cout <= 3 && Cin % 32 == 0 && Cin <= 128; }
+
+template <int NOUT>
+static void narrow_fprop_mfma_launch(int nct, dim3 grid, hipStream_t st, const float* x, const float* w, const float* bias,
+                                     const float* scale, const float* shift, long ssb, float* out, int B, int H, int W, int affine,
+                                     int relu, float alpha) {
+#define ICG_NFM(NCT_)                                                                                                          \
+  hipLaunchKernelGGL((narrow_fprop_mfma_kernel<NOUT, NCT_>), grid, dim3(256), 0, st, x, w, bias, scale, shift, ssb, out, B, H, W, \
+                     affine, relu, alpha)
+  switch (nct) {
+    case 1: ICG_NFM(1); break;
+    case 2: ICG_NFM(2); break;
+    case 3: ICG_NFM(3); break;
+    default: ICG_NFM(4); break;
+  }
+#undef ICG_NFM
+}
+
 int icg_narrow_fprop(const float* x, const float* w, const float* bias, const float* scale, const float* shift, long ssb,
                      float* out, int B, int H, int W, int Cin, int Cout, int affine, int relu, float alpha,
                      hipStream_t st) {
+  if (narrow_fprop_mfma_ok(Cin, Cout)) {
+    const long units = (long)B * icg_cdiv(W, 30) * icg_cdiv(H, NC_ROWS);
+    long blocks = icg_cdiv(units, 4);
+    if (blocks > 4096) blocks = 4096;
+    const dim3 g((unsigned)blocks);
+    if (Cout == 1) narrow_fprop_mfma_launch<1>(Cin / 32, g, st, x, w, bias, scale, shift, ssb, out, B, H, W, affine, relu, alpha);
+    else if (Cout == 2) narrow_fprop_mfma_launch<2>(Cin / 32, g, st, x, w, bias, scale, shift, ssb, out, B, H, W, affine, relu, alpha);
+    else narrow_fprop_mfma_launch<3>(Cin / 32, g, st, x, w, bias, scale, shift, ssb, out, B, H, W, affine, relu, alpha);
+    return icg_check_launch();
+  }
   const int lp = narrow_lp(Cin);
   const dim3 grid((unsigned)narrow_blocks(B, H, W, lp, 1 << 20));
   switch (Cout) {
@@ -286,7 +414,6 @@ int icg_narrow_fprop(const float* x, const float* w, const float* bias, const fl
 // one HBM pass over the Cout-wide tensor (the 3-channel image stays in L1/L2).  Operand fragments come straight from global
 // memory: A[i = lane & 31][k = 2t + (lane >> 5)] is one image value per lane and k-step (zero for padding and for k >= 9 CIN),
 // B is the weight fragment held in registers (fprop) or one dy value per lane, k-step and column tile (wgrad: 128-byte rows).
-typedef float th_f32x16 __attribute__((ext_vector_type(16)));
 
 template <int CIN, int NT>
 __global__ __launch_bounds__(256) void thin_fprop_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wgt,

@@ -94,6 +94,8 @@ CONV_CASES = [
     (2, 4, 6, 256, 2, 3, PRE_RELU, 0, True),             # LP = 64 full
     (2, 8, 8, 64, 3, 3, PRE_AFFINE, 0, False),           # LP = 16, affine without relu
     (2, 9, 7, 32, 1, 3, PRE_RELU, 0, True),              # to-RGB weight gradient on the MFMA form: one output channel, odd sizes
+    (1, 40, 70, 64, 3, 3, PRE_AFFINE | PRE_RELU, 0, True),  # to-RGB forward on the MFMA form: two row segments, three column chunks (30 + 30 + 10)
+    (2, 33, 31, 128, 2, 3, 0, 0, False),                 # ... four K groups, no prologue (data gradient of a from-RGB layer), ragged everything
     (1, 6, 10, 128, 2, 3, PRE_AFFINE | PRE_RELU, 0, False),  # ... two output channels, four column tiles
 ]
 
