@@ -174,8 +174,8 @@ class KernelTimer:
             elif last[0] == -3:      # skinny linear kernels (narrow_conv.hip): {-3, fprop/wgrad, Cout, Cin}
                 kname = "skinny_wgrad_kernel" if last[1] else "void skinny_fprop_kernel<8>"
             elif last[0] == -2:      # direct narrow-output kernels (narrow_conv.hip): {-2, fprop/wgrad, Cout, Cin}
-                if last[1] and last[2] <= 3 and last[3] % 32 == 0 and last[3] <= 128:   # wgrad on the MFMA thin kernel, roles swapped
-                    kname = "void thin_wgrad_mfma_kernel<%d, %d, 1>" % (last[2], last[3] // 32)
+                if last[2] <= 3 and last[3] % 32 == 0 and last[3] <= 128:      # MFMA forms (narrow_conv.hip: narrow_*_mfma_ok)
+                    kname = ("void thin_wgrad_mfma_kernel<%d, %d, 1>" if last[1] else "void narrow_fprop_mfma_kernel<%d, %d>") % (last[2], last[3] // 32)
                 else:
                     lp = 1
                     while lp < last[3] // 4:
