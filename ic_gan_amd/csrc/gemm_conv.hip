@@ -65,6 +65,8 @@ struct GemmP {
   int vec_b;                       // PATH 1 only: 16-byte loads allowed on the B operand (A is vectorised)
   // persistent plane GEMM (icg_planes_body): output tiles per plane, planes, consecutive output tiles per workgroup
   int pt_tiles, pt_z, pt_run;      // (pt_run is informational: the grid size fixes the tiles per workgroup)
+  int plain;                       // A [M][K] x B [N][K]^T batched GEMM outside the Winograd composites (attention Q K^T, dO V^T, kNN Gram):
+                                   // takes the persistent body too, with single-level chains as on the generic kernel
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1103,7 +1105,8 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
   }
   if (path == 2 && p.pre_affine) path = 3;
   g_last_variant[0] = AMODE; g_last_variant[1] = BMODE; g_last_variant[2] = tn; g_last_variant[3] = path;
-  if (path == 2 && g_gemm_planes && AMODE == A_K && BMODE == B_K && ICG_PLANES_PERSISTENT) {
+  const bool plain = p.plain != 0 && AMODE == A_K && BMODE == B_K && ICG_PLANES_PERSISTENT && !g_gemm_planes;
+  if (path == 2 && (g_gemm_planes || plain) && AMODE == A_K && BMODE == B_K && ICG_PLANES_PERSISTENT) {
     // persistent plane GEMM (icg_planes_body): 1-D grid, every workgroup owns a run of consecutive output tiles sized for
     // ~64 K-tiles of MFMA work, as long as the launch still queues several workgroups per CU
     if (p.kchunk != 0 || p.bsplit != 0 || p.phase_mode != 0 || p.bias != nullptr || p.res != nullptr) return ICG_ERR_ARG;
@@ -1116,7 +1119,7 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
     const long per_xcd = icg_cdiv(icg_cdiv(tot, 8), run);
     grid = p.swz ? dim3((unsigned)(8 * per_xcd), 1, 1) : dim3((unsigned)icg_cdiv(tot, run), 1, 1);
   }
-  if (path == 2 && g_gemm_planes && p.K <= planes_1level_max_k()) {
+  if (path == 2 && (plain || (g_gemm_planes && p.K <= planes_1level_max_k()))) {
     g_last_variant[3] = 4;       // plane GEMM, single-level chains
     switch (tn) {
       case 1: hipLaunchKernelGGL((icg_gemm_planes1_kernel<AMODE, BMODE, 1>), grid, block, 0, st, p); break;
@@ -1845,6 +1848,7 @@ extern "C" int icg_gemm_batched(const float* A, const float* B, float* C, int M,
   const bool small = ((long)M * K < 0x7fffffffL) && ((long)N * K < 0x7fffffffL);
   if (transA == 0 && transB == 1) {        // A [M][K], B [N][K]
     p.Cin = K; p.ldb = K;
+    p.plain = 1;
     return launch_gemm<A_K, B_K>(p, al && (K % 4 == 0), batch, st, small);
   } else if (transA == 0 && transB == 0) { // A [M][K], B [K][N]
     p.Cin = K; p.ldb = N;
