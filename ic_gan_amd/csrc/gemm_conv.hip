@@ -784,7 +784,7 @@ __device__ __forceinline__ void icg_planes_body(const GemmP& p) {
   __shared__ __attribute__((aligned(16))) float Bs[NBUF][BK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int kq = tid & 3, arow = tid >> 2;
-  const int nk = p.K / BK;
+  const int nk = (p.K + BK - 1) / BK;          // K % 4 == 0; the quads of the last K-tile past K are staged as zeros
 
   // this workgroup's output tiles: v = first, first + vstep, ... < last inside its XCD's contiguous range of the tile order (see
   // icg_gemm_body).  The stride is the number of workgroups of the XCD, so the workgroups resident at any moment work on
@@ -819,22 +819,30 @@ __device__ __forceinline__ void icg_planes_body(const GemmP& p) {
     for (int i = 0; i < 2; ++i) {
       const int m = min(mt * BM + arow + 64 * i, p.M - 1);
       const int n = min(nt * BN + min(arow + 64 * i, BN - 1), p.N - 1);
-      oa[i] = (unsigned)m * (unsigned)p.K + 4u * (unsigned)kq;
-      ob[i] = (unsigned)n * (unsigned)p.ldb + 4u * (unsigned)kq;
+      oa[i] = (unsigned)m * (unsigned)p.K;
+      ob[i] = (unsigned)n * (unsigned)p.ldb;
     }
   };
   auto stream_advance = [&]() {            // next K-tile of the stream; past the end of the run it stays on the last one
     ld_k += BK;
-    if (ld_k == p.K) {
+    if (ld_k >= p.K) {
       if (ld_v + vstep < last) { ld_v += vstep; ld_k = 0; stream_tile(ld_v); }
-      else ld_k = p.K - BK;
+      else ld_k = (nk - 1) * BK;
     }
   };
   float4 ra[2], rb[2];
-  auto issue_A = [&](int i) { ra[i] = ld4(Agl + (oa[i] + (unsigned)ld_k)); };
+  auto issue_A = [&](int i) {
+    const int kk = ld_k + 4 * kq;
+    const float4 v = ld4(Agl + (oa[i] + (unsigned)min(kk, p.K - 4)));
+    ra[i] = kk < p.K ? v : zero4();
+  };
   auto issue_B = [&]() {
+    const int kk = ld_k + 4 * kq;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) rb[i] = ld4(Bgl + (ob[i] + (unsigned)ld_k));
+    for (int i = 0; i < 2; ++i) {
+      const float4 v = ld4(Bgl + (ob[i] + (unsigned)min(kk, p.K - 4)));
+      rb[i] = kk < p.K ? v : zero4();
+    }
   };
   auto write_A_row = [&](int buf, int i) {
     float* as = As[buf];
@@ -1083,6 +1091,9 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
     p.vec_b = 0;
   }
   int path = vec ? 1 : 0;
+  const bool plain_body = AMODE == A_K && BMODE == B_K && ICG_PLANES_PERSISTENT && (g_gemm_planes || p.plain) && p.kchunk == 0 &&
+                          p.bsplit == 0 && p.phase_mode == 0 && p.bias == nullptr && p.res == nullptr;
+  if (vec && fast_ok && p.zmask == 0 && plain_body && p.K % 4 == 0 && p.K >= 4) path = 2;     // icg_planes_body masks the K tail
   if (vec && fast_ok && p.zmask == 0) {
     if (AMODE == A_K && (p.Cin % 16 == 0) && (p.kchunk == 0 || (BMODE == B_K && p.kchunk % 16 == 0))) path = 2;
     if (AMODE == A_M && p.lw >= 0 && p.lh >= 0) path = 2;
@@ -1111,7 +1122,7 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
     // ~64 K-tiles of MFMA work, as long as the launch still queues several workgroups per CU
     if (p.kchunk != 0 || p.bsplit != 0 || p.phase_mode != 0 || p.bias != nullptr || p.res != nullptr) return ICG_ERR_ARG;
     const long tot = tiles * zdim;
-    const int nk = p.K / 16;
+    const int nk = (p.K + 15) / 16;
     int run = (ICG_PLANES_RUN_KTILES + nk - 1) / nk;
     if (run > 32) run = 32;
     while (run > 1 && tot / run < 2048) --run;
