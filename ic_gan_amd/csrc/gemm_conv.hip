@@ -831,26 +831,26 @@ __device__ __forceinline__ void icg_planes_body(const GemmP& p) {
     }
   };
   float4 ra[2], rb[2];
+  bool kin = true;            // this thread's quad of the K-tile held in ra / rb lies inside K (applied when the quad is staged:
+                              // a select right after the load would make the wave wait for the data at issue time)
   auto issue_A = [&](int i) {
     const int kk = ld_k + 4 * kq;
-    const float4 v = ld4(Agl + (oa[i] + (unsigned)min(kk, p.K - 4)));
-    ra[i] = kk < p.K ? v : zero4();
+    ra[i] = ld4(Agl + (oa[i] + (unsigned)min(kk, p.K - 4)));
   };
   auto issue_B = [&]() {
     const int kk = ld_k + 4 * kq;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float4 v = ld4(Bgl + (ob[i] + (unsigned)min(kk, p.K - 4)));
-      rb[i] = kk < p.K ? v : zero4();
-    }
+    for (int i = 0; i < 2; ++i) rb[i] = ld4(Bgl + (ob[i] + (unsigned)min(kk, p.K - 4)));
+    kin = kk < p.K;           // (issue_B is the last load of a K-tile: the flag describes the tile now in the registers)
   };
   auto write_A_row = [&](int buf, int i) {
     float* as = As[buf];
     const int row = arow + 64 * i;
-    as[(4 * kq + 0) * LDA + row] = ra[i].x;
-    as[(4 * kq + 1) * LDA + row] = ra[i].y;
-    as[(4 * kq + 2) * LDA + row] = ra[i].z;
-    as[(4 * kq + 3) * LDA + row] = ra[i].w;
+    const float4 v = kin ? ra[i] : zero4();
+    as[(4 * kq + 0) * LDA + row] = v.x;
+    as[(4 * kq + 1) * LDA + row] = v.y;
+    as[(4 * kq + 2) * LDA + row] = v.z;
+    as[(4 * kq + 3) * LDA + row] = v.w;
   };
   auto write_B_row = [&](int buf, int i) {
     float* bs = Bs[buf];
