@@ -777,7 +777,8 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
 // MFMAs and its epilogue run), the LDS ring and the operand-fragment prefetch never drain.  Same thread -> data mapping, LDS
 // layout, MFMA order, two-level accumulation and staging schedule as icg_gemm_body's fast path, so results are bit-identical to
 // it; the loader state is one row offset per staged row (rows >= M / >= N are clamped: they only feed masked outputs).
-template <int TN, int BLK>
+// RAGGED: K % 16 != 0 (K % 4 == 0): the quads of the last K-tile past K are staged as zeros (costs the staging a select: own instantiation)
+template <int TN, int BLK, bool RAGGED = false>
 __device__ __forceinline__ void icg_planes_body(const GemmP& p) {
   constexpr int BM = 128, BN = 32 * TN, BK = 16, LDA = BM + 1, LDB = BN + 1, NBUF = 3;
   __shared__ __attribute__((aligned(16))) float As[NBUF][BK * LDA];
@@ -835,18 +836,18 @@ __device__ __forceinline__ void icg_planes_body(const GemmP& p) {
                               // a select right after the load would make the wave wait for the data at issue time)
   auto issue_A = [&](int i) {
     const int kk = ld_k + 4 * kq;
-    ra[i] = ld4(Agl + (oa[i] + (unsigned)min(kk, p.K - 4)));
+    ra[i] = ld4(Agl + (oa[i] + (unsigned)(RAGGED ? min(kk, p.K - 4) : kk)));
   };
   auto issue_B = [&]() {
     const int kk = ld_k + 4 * kq;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) rb[i] = ld4(Bgl + (ob[i] + (unsigned)min(kk, p.K - 4)));
-    kin = kk < p.K;           // (issue_B is the last load of a K-tile: the flag describes the tile now in the registers)
+    for (int i = 0; i < 2; ++i) rb[i] = ld4(Bgl + (ob[i] + (unsigned)(RAGGED ? min(kk, p.K - 4) : kk)));
+    if (RAGGED) kin = kk < p.K;           // (issue_B is the last load of a K-tile: the flag describes the tile now in the registers)
   };
   auto write_A_row = [&](int buf, int i) {
     float* as = As[buf];
     const int row = arow + 64 * i;
-    const float4 v = kin ? ra[i] : zero4();
+    const float4 v = (!RAGGED || kin) ? ra[i] : zero4();
     as[(4 * kq + 0) * LDA + row] = v.x;
     as[(4 * kq + 1) * LDA + row] = v.y;
     as[(4 * kq + 2) * LDA + row] = v.z;
@@ -1023,6 +1024,12 @@ __global__ __launch_bounds__(256) void icg_gemm_planes1_kernel(GemmP p) {
   else icg_gemm_body<AMODE, BMODE, TN, 2, 0, 1>(p);
 }
 
+// ... and for K % 16 != 0 (Winograd layers with Cin = 24, 40, ...; the D attention's d = 24): LEVELS as above
+template <int TN, int LEVELS>
+__global__ __launch_bounds__(256) void icg_gemm_planes_ragged_kernel(GemmP p) {
+  icg_planes_body<TN, (LEVELS == 2 ? ICG_PLANES_BLOCKED : 0), true>(p);
+}
+
 #ifndef ICG_PLANES_1LEVEL_MAX_K
 #define ICG_PLANES_1LEVEL_MAX_K 0      // K up to which plane GEMMs use the single-level kernel; 0 = never (ablation build L1_384:
 #endif                                 // 4-5 ms faster, but the ill-conditioned small test networks then exceed the strict tolerances)
@@ -1130,7 +1137,20 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
     const long per_xcd = icg_cdiv(icg_cdiv(tot, 8), run);
     grid = p.swz ? dim3((unsigned)(8 * per_xcd), 1, 1) : dim3((unsigned)icg_cdiv(tot, run), 1, 1);
   }
-  if (path == 2 && (plain || (g_gemm_planes && p.K <= planes_1level_max_k()))) {
+  const bool one_level = plain || (g_gemm_planes && p.K <= planes_1level_max_k());
+  if (path == 2 && plain_body && (p.K % 16) != 0) {
+    if (one_level) g_last_variant[3] = 4;
+#define ICG_RAG(TN_) \
+  if (one_level) hipLaunchKernelGGL((icg_gemm_planes_ragged_kernel<TN_, 1>), grid, block, 0, st, p); \
+  else hipLaunchKernelGGL((icg_gemm_planes_ragged_kernel<TN_, 2>), grid, block, 0, st, p)
+    switch (tn) {
+      case 1: ICG_RAG(1); break;
+      case 2: ICG_RAG(2); break;
+      case 3: ICG_RAG(3); break;
+      default: ICG_RAG(4); break;
+    }
+#undef ICG_RAG
+  } else if (path == 2 && one_level && (plain || g_gemm_planes)) {
     g_last_variant[3] = 4;       // plane GEMM, single-level chains
     switch (tn) {
       case 1: hipLaunchKernelGGL((icg_gemm_planes1_kernel<AMODE, BMODE, 1>), grid, block, 0, st, p); break;
