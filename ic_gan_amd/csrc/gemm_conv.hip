@@ -910,13 +910,27 @@ __device__ __forceinline__ void icg_planes_body(const GemmP& p) {
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1], fb[t & 1][j], zero, 0, 0, 0);
         } else if (MODE == 1 && t == 0) {
           asm volatile("" : "+a"(acc[j]));
+          if (TN == 3) {
+            // (96-column kernel only: at 128 columns the kernel runs two waves per SIMD either way and the packed adds are faster)
+            // accumulator -> VGPR -> add as ONE statement per value: left to the compiler, all 16 reads of the column tile are
+            // hoisted ahead of the first add (16 live copies: the 96-column kernel then needs 180 registers, without them it
+            // fits three waves per SIMD).  The MFMA that last wrote acc[j] is TN - 1 = 2 MFMAs (>= 128 cycles) back, far beyond
+            // the XDL-write -> accvgpr_read wait states the compiler would insert for its own copies.
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            f32x2 a2 = {acc[j][2 * r], acc[j][2 * r + 1]};
-            f32x2 b2 = {acc2[j][2 * r], acc2[j][2 * r + 1]};
-            asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(b2) : "v"(a2));
-            acc2[j][2 * r] = b2.x;
-            acc2[j][2 * r + 1] = b2.y;
+            for (int r = 0; r < 16; ++r) {
+              float b1 = acc2[j][r], t1;
+              asm volatile("v_accvgpr_read_b32 %1, %2\n\tv_add_f32 %0, %0, %1" : "+v"(b1), "=&v"(t1) : "a"(acc[j][r]));
+              acc2[j][r] = b1;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              f32x2 a2 = {acc[j][2 * r], acc[j][2 * r + 1]};
+              f32x2 b2 = {acc2[j][2 * r], acc2[j][2 * r + 1]};
+              asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(b2) : "v"(a2));
+              acc2[j][2 * r] = b2.x;
+              acc2[j][2 * r + 1] = b2.y;
+            }
           }
           f32x16 zero;
 #pragma unroll
@@ -1011,7 +1025,7 @@ __global__ __launch_bounds__(256) void icg_gemm_kernel(GemmP p) {
 #define ICG_PLANES_TN4_MIN_WAVES 1     // (3: ablation build LB3 of tools/build_dbg.sh -- 168 registers with ~25 spilled dwords)
 #endif
 template <int AMODE, int BMODE, int TN>
-__global__ __launch_bounds__(256, (TN == 4 ? ICG_PLANES_TN4_MIN_WAVES : 1)) void icg_gemm_planes_kernel(GemmP p) {
+__global__ __launch_bounds__(256, (TN == 4 ? ICG_PLANES_TN4_MIN_WAVES : (TN == 3 ? 3 : 1))) void icg_gemm_planes_kernel(GemmP p) {
   if constexpr (AMODE == A_K && BMODE == B_K && ICG_PLANES_PERSISTENT) icg_planes_body<TN, ICG_PLANES_BLOCKED>(p);   // 1-D grid
   else icg_gemm_body<AMODE, BMODE, TN, 2, ICG_PLANES_BLOCKED, 1>(p);
 }
