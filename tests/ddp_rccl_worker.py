@@ -42,9 +42,12 @@ def syncbn_inputs(cfg, dim_z):
 def main():
     mode, out_path = sys.argv[1], sys.argv[2]
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    backend = os.environ.get("ICG_TEST_BACKEND", "nccl")
+    if os.environ.get("ICG_TEST_SHARED_GPU") == "1":        # both ranks on GPU 0 (1-GPU box): RCCL refuses that, gloo moves the
+        local = 0                                            # CUDA tensors through the host -- same kernels, same DDP / SyncBN code
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
-    dist.init_process_group("nccl")
+    dist.init_process_group(backend)
     if mode == "step":
         from ic_gan_amd import train_fns, utils
         from ic_gan_amd.optim import FusedAdam

@@ -17,9 +17,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_workers(mode, n, tmp_path, port):
+def _run_workers(mode, n, tmp_path, port, shared_gpu=False):
     out = str(tmp_path / f"{mode}.pt")
     env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0", "PYTHONDONTWRITEBYTECODE": "1"}
+    if shared_gpu:
+        env.update(ICG_TEST_BACKEND="gloo", ICG_TEST_SHARED_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "ddp_rccl_worker.py"), mode, out]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
@@ -53,6 +55,37 @@ def test_syncbn_rccl_ranks_equal_one_process_on_concatenated_batch(tmp_path):
     assert torch.allclose(out["rv"], G.output_layer[0].stored_var.cpu(), rtol=1e-5, atol=1e-6)
     rel = float((out["grads"] - grads).norm() / grads.norm())
     assert rel < 1e-4, rel
+
+
+def _check_syncbn(out):
+    from tests import ddp_rccl_worker as W
+    cfg = dict(W.CFG, sync_bn=False)
+    _, G, _ = W.models(cfg, "cuda:0")
+    z, lab, fg, wts = W.syncbn_inputs(cfg, G.dim_z)
+    G.train()
+    img = G(z.cuda(), lab.cuda(), fg.cuda())
+    ((img * wts.cuda()).sum() / out["world"]).backward()          # DDP averages the ranks' gradients
+    grads = torch.cat([p.grad.reshape(-1) for p in G.parameters()]).cpu()
+    assert torch.allclose(out["img"], img.detach().cpu(), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(out["rm"], G.blocks[0][0].bn1.stored_mean.cpu(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out["rv"], G.output_layer[0].stored_var.cpu(), rtol=1e-5, atol=1e-6)
+    rel = float((out["grads"] - grads).norm() / grads.norm())
+    assert rel < 1e-4, rel
+
+
+def test_two_ranks_sharing_one_gpu_replicas_bit_identical(tmp_path):
+    """2 processes, both on GPU 0, gloo transport (RCCL does not allow two ranks per device): the production kernels under the
+    reference's DDP wiring with a real second rank -- buffer broadcast, bucketed gradient all-reduce, find_unused_parameters."""
+    out = _run_workers("step", 2, tmp_path, 29544, shared_gpu=True)
+    assert out["world"] == 2 and out["finite"] and out["identical"], out
+
+
+def test_two_ranks_sharing_one_gpu_syncbn_equals_one_process(tmp_path):
+    """... and cross-replica BN across the two processes (packed payload, asynchronous all-reduce, device-side count) against one
+    process on the concatenated batch."""
+    out = _run_workers("syncbn", 2, tmp_path, 29545, shared_gpu=True)
+    assert out["world"] == 2
+    _check_syncbn(out)
 
 
 def test_syncbn_path_single_rank_rccl_matches_local_statistics(monkeypatch):
