@@ -678,7 +678,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl")          # RCCL on ROCm
+        # RCCL on ROCm.  (ICG_BENCH_SHARED_GPU=1, tests only: all ranks on GPU 0 over gloo -- RCCL refuses two ranks per device --
+        # so that the N > 1 code path of this script can be exercised on a 1-GPU box; never a measurement)
+        shared = os.environ.get("ICG_BENCH_SHARED_GPU") == "1"
+        dist.init_process_group(backend="gloo" if shared else "nccl")
+        if shared:
+            local_rank = 0
     assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"

@@ -88,6 +88,27 @@ def test_two_ranks_sharing_one_gpu_syncbn_equals_one_process(tmp_path):
     _check_syncbn(out)
 
 
+@pytest.mark.parametrize("extra", [[], ["--sync-bn"]])
+def test_bench_script_two_ranks_sharing_one_gpu(extra):
+    """the N > 1 path of bench.py (DDP wrapping, barrier + synchronize bracket, MAX over ranks, whole-job value, rank-0 JSON line) run
+    as the driver launches it, with both ranks on GPU 0 over gloo (ICG_BENCH_SHARED_GPU: a test switch, not a measurement)."""
+    import json
+    env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0", "PYTHONDONTWRITEBYTECODE": "1", "ICG_BENCH_SHARED_GPU": "1"}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29546", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload",
+           "cfg1", "--init", "N02"] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
+    assert d["config"]["rccl_world_size"] == 2 and d["config"]["sync_bn"] == bool(extra)
+    assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-2 * d["value"]
+    assert all(v == v for v in d["config"]["losses_last_step"].values())          # finite losses
+    assert "cpu_baseline" not in d
+
+
 def test_syncbn_path_single_rank_rccl_matches_local_statistics(monkeypatch):
     """world_size 1 over RCCL with the cross-replica path forced on: pack kernel, async all-reduce (a no-op sum), device-side
     count in finalize / backward coefficients -- against the plain path on the same inputs (fp64 payload algebra: equal to
