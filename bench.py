@@ -111,11 +111,10 @@ class KernelTimer:
                 B, Hin, Win, Cin, Hout, Wout, Cout, R = args[sl:sl + 8]
                 alg = exe = 2.0 * B * Hout * Wout * Cout * Cin * R * R
                 byt = 4.0 * (B * (Hin * Win * Cin + Hout * Wout * Cout) + Cout * Cin * R * R)
-            elif mode == "tr2":      # stride-2 transposed 3x3 in phase form: 16 tap slots per 4 outputs, 9 of them non-zero (M = (Hin+1)(Win+1) rows per phase)
+            elif mode == "tr2":      # stride-2 transposed 3x3 in phase form: 16 tap slots per 4 outputs, 9 of them non-zero
                 B, Hin, Win, Cin, Hout, Wout, Cout = args[sl:sl + 7]
                 alg = 2.0 * B * Hout * Wout * Cout * Cin * 9 / 4
-                # fast path (Cin % 16 == 0): each phase walks only its non-zero tap slots (9 tap-GEMMs over the 4 phases), else all 16
-                exe = alg if Cin % 16 == 0 else 2.0 * B * Hout * Wout * Cout * Cin * 4
+                exe = 2.0 * B * Hout * Wout * Cout * Cin * 4
                 byt = 4.0 * (B * (Hin * Win * Cin + Hout * Wout * Cout) + 16 * Cout * Cin)
             elif mode == "conv":
                 B, H, W, Cin, Cout, R = args[sl:sl + 6]

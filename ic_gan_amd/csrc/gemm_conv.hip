@@ -65,8 +65,6 @@ struct GemmP {
   int vec_b;                       // PATH 1 only: 16-byte loads allowed on the B operand (A is vectorised)
   // persistent plane GEMM (icg_planes_body): output tiles per plane, planes, consecutive output tiles per workgroup
   int pt_tiles, pt_z, pt_run;      // (pt_run is informational: the grid size fixes the tiles per workgroup)
-  int phase_trim;                  // phase_mode 1 with R = 2 (stride-2 transposed 3x3): phase (al, be) walks only its (2-al) x (2-be)
-                                   // non-zero tap slots (fast path only)
   int plain;                       // A [M][K] x B [N][K]^T batched GEMM outside the Winograd composites (attention Q K^T, dO V^T, kNN Gram):
                                    // takes the persistent body too, with single-level chains as on the generic kernel
 };
@@ -144,14 +142,6 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
     kbeg = ksplit * p.kchunk;
     kend = min(p.K, kbeg + p.kchunk);
   }
-  // tap window the K loop walks: R x R, or -- phase_trim -- the (2 - al) x (2 - be) slots of this phase that carry a tap of the
-  // transposed 3x3 kernel (the other slots of its 2x2 phase kernel are zero weights: 9 instead of 16 tap-GEMMs over the 4 phases)
-  int Rh = p.R, Rw = p.R;
-  if (PATH >= 2 && AMODE == A_K && p.phase_mode == 1 && p.phase_trim) {
-    Rh = 2 - ph_a;
-    Rw = 2 - ph_b;
-    kend = Rh * Rw * p.Cin;
-  }
   const int gs = p.gs;
   const int Cin = p.Cin;
   // row of the (2H x 2W) grid that phase (ph_a, ph_b) of source pixel index q = (b, h, w) maps to
@@ -204,14 +194,14 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
   int f_h[2], f_w[2];
   bool f_rowok[2], f_ok[2];
   int f_tr = 0, f_ts = 0, f_c0 = 0;          // wave-uniform tap tracking (A_K)
-  int f_btr = 0, f_bts = 0, f_bc0 = 0;       // the same position, for the B operand (advanced by load_B_fast)
+  int f_btap = 0, f_bc0 = 0;                 // the same position, for the B operand (advanced by load_B_fast)
   if (FAST && AMODE == A_K && kbeg > 0) {    // split-K: K-tile kbeg/BK of the tap-minor order = (slice, tap)
     const int it0 = kbeg / 16, RRt = p.R * p.R;
     const int sl = it0 / RRt, tap0 = it0 - sl * RRt;
     f_c0 = f_bc0 = sl * 16;
+    f_btap = tap0;
     f_tr = tap0 / p.R;
     f_ts = tap0 - f_tr * p.R;
-    f_btr = f_tr; f_bts = f_ts;
   }
   unsigned pl_a[2] = {0u, 0u}, pl_b[2] = {0u, 0u};   // PLAIN: row offset + 4 * kq of this thread's two A / B rows
   if (PLAIN) {
@@ -283,9 +273,9 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
         // straddles a tap: Cin % BK == 0).  The R*R shifted re-reads of an activation element are then ~R*R K-tiles apart
         // (a few KB of footprint per workgroup) instead of a full Cin sweep apart (hundreds of KB), so they hit L1/L2
         // instead of going back to HBM: measured fetch traffic of the 3x3 layers drops accordingly.
-        if (++f_ts == Rw) {
+        if (++f_ts == p.R) {
           f_ts = 0;
-          if (++f_tr == Rh) { f_tr = 0; f_c0 += BK; }
+          if (++f_tr == p.R) { f_tr = 0; f_c0 += BK; }
         }
       }
     } else {
@@ -335,11 +325,8 @@ __device__ __forceinline__ void icg_gemm_body(const GemmP& p) {
       // one tile past the end.
       unsigned kg;
       if (AMODE == A_K) {
-        kg = (unsigned)(min((f_btr * p.R + f_bts) * Cin + f_bc0, p.K - BK) + 4 * kq);
-        if (++f_bts == Rw) {
-          f_bts = 0;
-          if (++f_btr == Rh) { f_btr = 0; f_bc0 += BK; }
-        }
+        kg = (unsigned)(min(f_btap * Cin + f_bc0, p.K - BK) + 4 * kq);
+        if (++f_btap == p.R * p.R) { f_btap = 0; f_bc0 += BK; }
       } else {
         kg = (unsigned)(min(k0, kend - BK) + 4 * kq);
       }
@@ -1713,7 +1700,6 @@ extern "C" int icg_conv2d_tr2_fprop(const float* x, const float* wp, const float
   p.strideA = 0; p.strideB = (long)Cout * p.K; p.strideC = 0;
   const bool vec = (Cin % 4 == 0) && aligned16(x) && aligned16(wp);
   const bool small = ((long)B * Hin * Win * Cin < 0x7fffffffL) && ((long)Cout * p.K < 0x7fffffffL);
-  p.phase_trim = (vec && small && Cin % 16 == 0) ? 1 : 0;     // exactly the condition under which launch_gemm takes PATH 2
   return launch_gemm<A_K, B_K>(p, vec, 4, (hipStream_t)stream, small);
 }
 
