@@ -181,6 +181,8 @@ class KernelTimer:
                     while lp < last[3] // 4:
                         lp *= 2
                     kname = "void narrow_%s_kernel<%d, %d>" % ("wgrad" if last[1] else "fprop", last[2], lp)
+            elif last[3] == 4:       # prologue-free 1x1 convolution on the persistent plain-GEMM body (single-level chains)
+                kname = "void icg_gemm_planes1_kernel<%d, %d, %d>(GemmP)" % (last[0], last[1], last[2])
             else:
                 kname = "void icg_gemm_kernel<%d, %d, %d, %d>(GemmP)" % tuple(last)
             timer.records.append((kname, alg, exe, byt, s, e))

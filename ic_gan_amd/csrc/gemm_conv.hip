@@ -1005,8 +1005,18 @@ __device__ __forceinline__ void icg_planes_body(const GemmP& p) {
         }
         if (32 * j < nrem) {
           const int row0 = ((2 * r) & 3) + 8 * ((2 * r) >> 2);
-          if (row0 < mrem) Cg[(long)row0 * p.ldc + 32 * j] = p.alpha * c2.x;
-          if (row0 + 1 < mrem) Cg[(long)(row0 + 1) * p.ldc + 32 * j] = p.alpha * c2.y;
+          float v0 = p.alpha * c2.x, v1 = p.alpha * c2.y;
+          if (p.bias != nullptr) {                           // 1x1 convolutions (plain = 2): bias, residual / ReLU mask as in
+            const float bv = p.bias[n0 + li + 32 * j];       // icg_gemm_body's epilogue; never set for the plane GEMMs
+            v0 += bv; v1 += bv;
+          }
+          if (p.res != nullptr) {
+            const float* rp = p.res + (Cg - p.C) + (long)row0 * p.ldc + 32 * j;
+            if (row0 < mrem) { const float rv = rp[0]; v0 = (p.res_up == 2) ? (rv > 0.f ? v0 : 0.f) : v0 + rv; }
+            if (row0 + 1 < mrem) { const float rv = rp[p.ldc]; v1 = (p.res_up == 2) ? (rv > 0.f ? v1 : 0.f) : v1 + rv; }
+          }
+          if (row0 < mrem) Cg[(long)row0 * p.ldc + 32 * j] = v0;
+          if (row0 + 1 < mrem) Cg[(long)(row0 + 1) * p.ldc + 32 * j] = v1;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1113,7 +1123,8 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
   }
   int path = vec ? 1 : 0;
   const bool plain_body = AMODE == A_K && BMODE == B_K && ICG_PLANES_PERSISTENT && (g_gemm_planes || p.plain) && p.kchunk == 0 &&
-                          p.bsplit == 0 && p.phase_mode == 0 && p.bias == nullptr && p.res == nullptr;
+                          p.bsplit == 0 && p.phase_mode == 0 && !p.pre_affine && !p.pre_relu && p.up == 0 && p.res_up != 1 &&
+                          ((p.bias == nullptr && p.res == nullptr) || p.plain == 2);
   if (vec && fast_ok && p.zmask == 0 && plain_body && p.K % 4 == 0 && p.K >= 4) path = 2;     // icg_planes_body masks the K tail
   if (vec && fast_ok && p.zmask == 0) {
     if (AMODE == A_K && (p.Cin % 16 == 0) && (p.kchunk == 0 || (BMODE == B_K && p.kchunk % 16 == 0))) path = 2;
@@ -1137,11 +1148,11 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
   }
   if (path == 2 && p.pre_affine) path = 3;
   g_last_variant[0] = AMODE; g_last_variant[1] = BMODE; g_last_variant[2] = tn; g_last_variant[3] = path;
-  const bool plain = p.plain != 0 && AMODE == A_K && BMODE == B_K && ICG_PLANES_PERSISTENT && !g_gemm_planes;
-  if (path == 2 && (g_gemm_planes || plain) && AMODE == A_K && BMODE == B_K && ICG_PLANES_PERSISTENT) {
+  const bool plain = p.plain != 0 && plain_body && !g_gemm_planes;
+  if (path == 2 && (g_gemm_planes || plain) && plain_body) {
     // persistent plane GEMM (icg_planes_body): 1-D grid, every workgroup owns a run of consecutive output tiles sized for
     // ~64 K-tiles of MFMA work, as long as the launch still queues several workgroups per CU
-    if (p.kchunk != 0 || p.bsplit != 0 || p.phase_mode != 0 || p.bias != nullptr || p.res != nullptr) return ICG_ERR_ARG;
+    if (!plain_body) return ICG_ERR_ARG;
     const long tot = tiles * zdim;
     const int nk = (p.K + 15) / 16;
     int run = (ICG_PLANES_RUN_KTILES + nk - 1) / nk;
@@ -1357,6 +1368,9 @@ static int conv2d_fprop_impl(const float* x, const float* w, const float* bias, 
     const int rc = launch_fprop_splitk(p, vec, (hipStream_t)stream, small, workspace, workspace_bytes);
     if (rc != -1) return rc;
   }
+  // 1x1 convolution without a prologue = a plain [M][Cin] x [Cout][Cin]^T GEMM: the persistent body with the bias / residual /
+  // ReLU-mask epilogue (the shortcut convolutions, the attention projections, every 1x1 data gradient of BigGAN-deep)
+  if (R == 1 && !up && !p.pre_affine && !p.pre_relu && p.res_up != 1) p.plain = 2;
   return launch_gemm<A_K, B_K>(p, vec, 1, (hipStream_t)stream, small);
 }
 
