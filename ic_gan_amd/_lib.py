@@ -37,6 +37,11 @@ class SnLayer(ctypes.Structure):          # icg_sn_layer
                 ("reserved", ctypes.c_int)]
 
 
+class WinoWeight(ctypes.Structure):        # icg_wino_weight
+    _fields_ = [("w", ctypes.c_void_p), ("U", ctypes.c_void_p), ("N", ctypes.c_int), ("K", ctypes.c_int), ("planes", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
 class EmaTensor(ctypes.Structure):
     _fields_ = [("target", ctypes.c_void_p), ("source", ctypes.c_void_p), ("numel", ctypes.c_int64)]
 

@@ -125,10 +125,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 }
 
 // U[xi][n][k] = (G g G^T)[xi] for g = w[n][.][.][k]   (w: [N][3][3][K], the OHWI or the dgrad layout)
-__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int N, int K) {
+// (blk, nblk: this block's index and the block count of ITS tensor -- the single-tensor kernel passes blockIdx.x / gridDim.x,
+// the batched one the position inside the tensor's block range)
+__device__ __forceinline__ void wino_weight_body(const float* __restrict__ w, float* __restrict__ U, int N, int K, unsigned blk,
+                                                 unsigned nblk) {
   const long total = (long)N * K;
-  const long gstride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+  const long gstride = (long)nblk * blockDim.x;
+  for (long i = (long)blk * blockDim.x + threadIdx.x; i < total; i += gstride) {
     const int k = (int)(i % K);
     const long n = i / K;
     float g[3][3];
@@ -152,6 +155,9 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
       U[(4 * r + 3) * total + i] = t[r][2];
     }
   }
+}
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int N, int K) {
+  wino_weight_body(w, U, N, K, blockIdx.x, gridDim.x);
 }
 
 // DY[xi][t][c] = (A dy A^T)[xi] on the 2x2 output tile t,  A = [1 0; 1 1; 1 -1; 0 -1]     (weight-gradient side)
@@ -573,10 +579,11 @@ __device__ __forceinline__ void w4_g6(const float g[3], float u[6]) {
 
 // U[slot(i)*NP + slot(j)][n][k] = (G g G^T)[i][j]
 template <int NP>
-__global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int N, int K) {
+__device__ __forceinline__ void wino4_weight_body(const float* __restrict__ w, float* __restrict__ U, int N, int K, unsigned blk,
+                                                  unsigned nblk) {
   const long total = (long)N * K;
-  const long gstride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+  const long gstride = (long)nblk * blockDim.x;
+  for (long i = (long)blk * blockDim.x + threadIdx.x; i < total; i += gstride) {
     const int k = (int)(i % K);
     const long n = i / K;
     float t[6][3];
@@ -599,6 +606,30 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restri
         if (w4_has<NP>(j)) U[(long)(w4_slot<NP>(r) * NP + w4_slot<NP>(j)) * total + i] = u[j];
     }
   }
+}
+template <int NP>
+__global__ __launch_bounds__(256) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int N, int K) {
+  wino4_weight_body<NP>(w, U, N, K, blockIdx.x, gridDim.x);
+}
+
+// all Winograd-domain weight copies of a network in one launch (same arithmetic per element as the single-tensor kernels)
+#define ICG_WW_MAX 64
+struct WinoWeightPack {
+  icg_wino_weight t[ICG_WW_MAX];
+  int blk_start[ICG_WW_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void wino_weight_multi_kernel(WinoWeightPack p) {
+  int lo = 0, hi = p.n - 1;
+  while (lo < hi) {                       // the tensor whose block range holds blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (p.blk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const icg_wino_weight& t = p.t[lo];
+  const unsigned blk = blockIdx.x - (unsigned)p.blk_start[lo], nblk = (unsigned)(p.blk_start[lo + 1] - p.blk_start[lo]);
+  if (t.planes == 36) wino4_weight_body<6>(t.w, t.U, t.N, t.K, blk, nblk);
+  else if (t.planes == 25) wino4_weight_body<5>(t.w, t.U, t.N, t.K, blk, nblk);
+  else wino_weight_body(t.w, t.U, t.N, t.K, blk, nblk);
 }
 
 static void launch_wino4_input(hipStream_t st, int up, int np, const float* x, const float* scale, const float* shift, long ssb,
@@ -637,6 +668,27 @@ extern "C" int icg_wino4r_weight_transform(const float* w, float* U, int N, int 
   long blocks = icg_cdiv((long)N * K, 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL((wino4_weight_kernel<5>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, U, N, K);
+  return icg_check_launch();
+}
+
+extern "C" int icg_wino_weight_transform_multi(const icg_wino_weight* items, int n, void* stream) {
+  ICG_REQUIRE(items && n > 0);
+  for (int base = 0; base < n; base += ICG_WW_MAX) {
+    WinoWeightPack p;
+    p.n = (n - base < ICG_WW_MAX) ? n - base : ICG_WW_MAX;
+    int blocks = 0;
+    for (int i = 0; i < p.n; ++i) {
+      const icg_wino_weight& t = items[base + i];
+      ICG_REQUIRE(t.w && t.U && t.N > 0 && t.K > 0 && (t.planes == 16 || t.planes == 25 || t.planes == 36));
+      p.t[i] = t;
+      p.blk_start[i] = blocks;
+      long b = icg_cdiv((long)t.N * t.K, 256);
+      if (b > 4096) b = 4096;
+      blocks += (int)b;
+    }
+    p.blk_start[p.n] = blocks;
+    hipLaunchKernelGGL(wino_weight_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  }
   return icg_check_launch();
 }
 

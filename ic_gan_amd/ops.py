@@ -116,6 +116,24 @@ def _sn_winograd(st: SNState):
         L.call(fn, st.w_dgrad, st.w_wino_dgrad, st.cin, st.rows)
 
 
+def _sn_winograd_many(states):
+    """`_sn_winograd` of many layers as ONE launch (icg_wino_weight_transform_multi; ~80 tiny launches per step otherwise)."""
+    import ctypes
+    jobs = []
+    for st in states:
+        planes = {5: 25, 4: 36}.get(st.wino_m, 16)
+        if st.w_wino is not None:
+            jobs.append((st.w_ohwi, st.w_wino, st.rows, st.cin, planes))
+        if st.w_wino_dgrad is not None:
+            jobs.append((st.w_dgrad, st.w_wino_dgrad, st.cin, st.rows, planes))
+    if not jobs:
+        return
+    arr = (L.WinoWeight * len(jobs))()
+    for i, (w, U, n, k, planes) in enumerate(jobs):
+        arr[i].w, arr[i].U, arr[i].N, arr[i].K, arr[i].planes = w.data_ptr(), U.data_ptr(), n, k, planes
+    L.call("icg_wino_weight_transform_multi", ctypes.cast(arr, ctypes.c_void_p), len(jobs))
+
+
 def sn_prepare(weight: torch.Tensor, u: torch.Tensor, sv: Optional[torch.Tensor], eps: float, training: bool,
                need_dgrad: bool, upsample: bool = False, downsample: bool = False, winograd: bool = False) -> SNState:
     """One power iteration (updates `u`/`sv` in place when training) and W/sigma in kernel layouts.
@@ -156,8 +174,7 @@ def sn_prepare_many(items, eps: float, training: bool):
     if training:
         for it in items:
             bump_version(it[1], it[2])
-    for st in states:
-        _sn_winograd(st)
+    _sn_winograd_many(states)
     return states
 
 

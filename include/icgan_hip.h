@@ -206,7 +206,15 @@ int icg_conv2d_wino4_wgrad(const float* x, const float* dy, float* dw, const flo
  * of the upsampling layer, Hp/Wp: pooled resolution of the downsampling layer; both must be even, Cin and Cout multiples
  * of 4.  Workspace queries take the FULL resolution (2Hs x 2Ws, 2Hp x 2Wp) and the (Cin, Cout) of the GEMM as called.
  */
-int icg_wino4r_weight_transform(const float* w, float* U, int N, int K, void* stream);    /* U [25][N][K] */
+int icg_wino4r_weight_transform(const float* w, float* U, int N, int K, void* stream);
+/* The Winograd-domain copies of many weights in one launch (planes = 16: icg_wino_weight_transform, 36: icg_wino4_..., 25:
+ * icg_wino4r_...; bit-identical to the single-tensor calls): a network's layers after their batched spectral-norm pass. */
+typedef struct {
+  const float* w;   /* [N][3][3][K] (OHWI or the data-gradient layout) */
+  float* U;         /* [planes][N][K] */
+  int N, K, planes, reserved;
+} icg_wino_weight;
+int icg_wino_weight_transform_multi(const icg_wino_weight* items, int n, void* stream);    /* U [25][N][K] */
 size_t icg_conv2d_rs_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 size_t icg_conv2d_rs_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int icg_conv2d_up_wino_fprop(const float* x, const float* U, const float* bias, float* out, const float* scale,

@@ -931,6 +931,28 @@ def test_conv2d_winograd4(case):
     close(*pair, rtol=2e-4, atol_rel=2e-4, what=f"winograd4 fprop {case}")
 
 
+def test_wino_weight_transform_multi_bit_identical():
+    """icg_wino_weight_transform_multi (all Winograd-domain weight copies of a network in one launch) == the single-tensor
+    transforms, bit for bit, for the three plane counts and more tensors than one descriptor pack holds."""
+    import ctypes
+    L = _L()
+    shapes = [(32, 16, 36), (40, 24, 25), (96, 96, 16), (8, 260, 36), (130, 12, 25)] * 15          # 75 tensors > 64 per pack
+    arr = (L.WinoWeight * len(shapes))()
+    ws, us, refs = [], [], []
+    fn = {16: "icg_wino_weight_transform", 25: "icg_wino4r_weight_transform", 36: "icg_wino4_weight_transform"}
+    for i, (n, k, planes) in enumerate(shapes):
+        w = rnd(n, 3, 3, k, seed=100 + i).cuda()
+        u = torch.full((planes * n * k,), float("nan"), device="cuda")
+        r = torch.empty(planes * n * k, device="cuda")
+        L.call(fn[planes], w, r, n, k)
+        arr[i].w, arr[i].U, arr[i].N, arr[i].K, arr[i].planes = w.data_ptr(), u.data_ptr(), n, k, planes
+        ws.append(w); us.append(u); refs.append(r)
+    L.call("icg_wino_weight_transform_multi", ctypes.cast(arr, ctypes.c_void_p), len(shapes))
+    torch.cuda.synchronize()
+    for i, (u, r) in enumerate(zip(us, refs)):
+        assert torch.equal(u, r), (i, shapes[i])
+
+
 # ------------------------------------------------------------------------------------------------ kNN build
 @pytest.mark.parametrize("N,D,k", [(300, 64, 7), (1000, 2048, 51), (64, 16, 64), (5, 8, 3), (257, 130, 1)])
 def test_knn_l2(N, D, k):
