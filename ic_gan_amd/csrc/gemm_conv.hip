@@ -1210,9 +1210,9 @@ int icg_narrow_wgrad(const float* x, const float* dy, const float* scale, const 
 // 3x3 convolutions with <= 4 input channels (narrow_conv.hip)
 bool icg_thin_conv_ok(int Cin, int Cout, int R);
 size_t icg_thin_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
-int icg_thin_fprop(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
+int icg_thin_fprop(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin, int Cout, int R,
                    float alpha, hipStream_t st);
-int icg_thin_wgrad(const float* x, const float* dy, float* dw, void* workspace, int B, int H, int W, int Cin, int Cout,
+int icg_thin_wgrad(const float* x, const float* dy, float* dw, void* workspace, int B, int H, int W, int Cin, int Cout, int R,
                    hipStream_t st);
 
 // skinny linear layers (batch rows x odd K; narrow_conv.hip)
@@ -1342,7 +1342,7 @@ static int conv2d_fprop_impl(const float* x, const float* w, const float* bias, 
   if (!up && !residual && !(flags & (ICG_PRE_AFFINE | ICG_PRE_RELU)) && icg_thin_conv_ok(Cin, Cout, R) && aligned16(out) &&
       (!bias || aligned16(bias)) && M * Cout < 0x7fffffffL) {
     g_last_variant[0] = -4; g_last_variant[1] = 0; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
-    return icg_thin_fprop(x, w, bias, out, B, H, W, Cin, Cout, alpha, (hipStream_t)stream);
+    return icg_thin_fprop(x, w, bias, out, B, H, W, Cin, Cout, R, alpha, (hipStream_t)stream);
   }
   if (!up && !residual && !(flags & (ICG_PRE_AFFINE | ICG_PRE_RELU)) && icg_skinny_ok(M, Cin, R)) {
     g_last_variant[0] = -3; g_last_variant[1] = 0; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
@@ -1434,7 +1434,7 @@ extern "C" int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
   if (!up && !(flags & (ICG_PRE_AFFINE | ICG_PRE_RELU)) && icg_thin_conv_ok(Cin, Cout, R) && aligned16(dy) && aligned16(dw)) {
     if (workspace == nullptr || workspace_bytes < icg_thin_wgrad_workspace_bytes(B, H, W, Cin, Cout)) return ICG_ERR_WORKSPACE;
     g_last_variant[0] = -4; g_last_variant[1] = 1; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
-    return icg_thin_wgrad(x, dy, dw, workspace, B, H, W, Cin, Cout, (hipStream_t)stream);
+    return icg_thin_wgrad(x, dy, dw, workspace, B, H, W, Cin, Cout, R, (hipStream_t)stream);
   }
   if (!up && !(flags & (ICG_PRE_AFFINE | ICG_PRE_RELU)) && (Cout % 4 == 0) && aligned16(dy) && aligned16(dw) &&
       icg_skinny_ok(K, Cin, R)) {

@@ -418,8 +418,9 @@ int icg_narrow_fprop(const float* x, const float* w, const float* bias, const fl
 template <int CIN, int NT>
 __global__ __launch_bounds__(256) void thin_fprop_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                               const float* __restrict__ bias, float* __restrict__ out, int B,
-                                                              int H, int W, float alpha) {
-  constexpr int KK = 9 * CIN, Cout = 32 * NT;
+                                                              int H, int W, float alpha, int R) {
+  constexpr int Cout = 32 * NT;
+  const int KK = R * R * CIN, PD = R >> 1;                 // R = 3, or 1 (the 1x1 shortcut of D's first block: K = CIN)
   const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   // weight fragments: B[k][j] = wgt[32 jt + j][k] (OHWI: [Cout][3][3][CIN] = [Cout][KK])
   float wf[16][NT];
@@ -445,8 +446,8 @@ __global__ __launch_bounds__(256) void thin_fprop_mfma_kernel(const float* __res
     for (int t = 0; t < 16; ++t) {
       const int k = 2 * t + lh;
       const int tap = k / CIN, c = k - tap * CIN;
-      const int r = tap / 3, sx = tap - 3 * r;
-      const int hi = h + r - 1, wi = w + sx - 1;
+      const int r = tap / R, sx = tap - R * r;
+      const int hi = h + r - PD, wi = w + sx - PD;
       const bool ok = (k < KK) && ((unsigned)hi < (unsigned)H) && ((unsigned)wi < (unsigned)W);
       const float v = xb[((long)(ok ? hi : h) * W + (ok ? wi : w)) * CIN + (k < KK ? c : 0)];
       af[t] = ok ? v : 0.f;
@@ -488,14 +489,15 @@ template <int CIN, int NT, int NARROW>
 __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                               float* __restrict__ slabs, int B, int H, int W,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
-                                                              long ssb, int affine, int relu) {
-  constexpr int KK = 9 * CIN, Cout = 32 * NT, U = 8;        // U k-steps (2 pixels each) of loads in flight ahead of their MFMAs
+                                                              long ssb, int affine, int relu, int R) {
+  constexpr int Cout = 32 * NT, U = 8;                      // U k-steps (2 pixels each) of loads in flight ahead of their MFMAs
+  const int KK = R * R * CIN, PD = R >> 1;
   __shared__ float red[32 * Cout];
   const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5, wv = threadIdx.x >> 6;
   // A[i][k]: row i = (tap, c) of the weight gradient, k = pixel
   const int tap = li / CIN, c = li - tap * CIN;
   const int sg = NARROW ? -1 : 1;
-  const int dr = sg * (tap / 3 - 1), ds = sg * (tap - 3 * (tap / 3) - 1);
+  const int dr = sg * (tap / R - PD), ds = sg * (tap - R * (tap / R) - PD);
   const bool row_on = li < KK;
   th_f32x16 acc[NT];
 #pragma unroll
@@ -579,15 +581,15 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
   }
 }
 
-static bool thin_mfma_ok(int Cin, int Cout) { return 9 * Cin <= 32 && Cout % 32 == 0 && Cout <= 128; }
+static bool thin_mfma_ok(int Cin, int Cout) { return 9 * Cin <= 32 && Cout % 32 == 0 && Cout <= 128; }     // (R = 1: K = Cin, also fits)
 
 template <int CIN>
 static void thin_mfma_launch(bool wgrad, int nt, dim3 grid, hipStream_t st, const float* x, const float* w_or_dy, const float* bias,
-                             float* out, int B, int H, int W, float alpha) {
+                             float* out, int B, int H, int W, float alpha, int R) {
 #define ICG_THM(NT_)                                                                                                            \
   if (wgrad) hipLaunchKernelGGL((thin_wgrad_mfma_kernel<CIN, NT_, 0>), grid, dim3(256), 0, st, x, w_or_dy, out, B, H, W,         \
-                                (const float*)nullptr, (const float*)nullptr, 0L, 0, 0);                                        \
-  else hipLaunchKernelGGL((thin_fprop_mfma_kernel<CIN, NT_>), grid, dim3(256), 0, st, x, w_or_dy, bias, out, B, H, W, alpha)
+                                (const float*)nullptr, (const float*)nullptr, 0L, 0, 0, R);                                     \
+  else hipLaunchKernelGGL((thin_fprop_mfma_kernel<CIN, NT_>), grid, dim3(256), 0, st, x, w_or_dy, bias, out, B, H, W, alpha, R)
   switch (nt) {
     case 1: ICG_THM(1); break;
     case 2: ICG_THM(2); break;
@@ -598,11 +600,11 @@ static void thin_mfma_launch(bool wgrad, int nt, dim3 grid, hipStream_t st, cons
 }
 
 static void thin_mfma_dispatch(bool wgrad, int Cin, int nt, dim3 grid, hipStream_t st, const float* x, const float* w_or_dy,
-                               const float* bias, float* out, int B, int H, int W, float alpha) {
+                               const float* bias, float* out, int B, int H, int W, float alpha, int R) {
   switch (Cin) {
-    case 1: thin_mfma_launch<1>(wgrad, nt, grid, st, x, w_or_dy, bias, out, B, H, W, alpha); break;
-    case 2: thin_mfma_launch<2>(wgrad, nt, grid, st, x, w_or_dy, bias, out, B, H, W, alpha); break;
-    default: thin_mfma_launch<3>(wgrad, nt, grid, st, x, w_or_dy, bias, out, B, H, W, alpha); break;
+    case 1: thin_mfma_launch<1>(wgrad, nt, grid, st, x, w_or_dy, bias, out, B, H, W, alpha, R); break;
+    case 2: thin_mfma_launch<2>(wgrad, nt, grid, st, x, w_or_dy, bias, out, B, H, W, alpha, R); break;
+    default: thin_mfma_launch<3>(wgrad, nt, grid, st, x, w_or_dy, bias, out, B, H, W, alpha, R); break;
   }
 }
 
@@ -614,7 +616,7 @@ template <int NOUT>
 static void narrow_wgrad_mfma_launch(int nt, dim3 grid, hipStream_t st, const float* x, const float* dy, float* slabs, int B, int H,
                                      int W, const float* scale, const float* shift, long ssb, int affine, int relu) {
 #define ICG_NWM(NT_) \
-  hipLaunchKernelGGL((thin_wgrad_mfma_kernel<NOUT, NT_, 1>), grid, dim3(256), 0, st, dy, x, slabs, B, H, W, scale, shift, ssb, affine, relu)
+  hipLaunchKernelGGL((thin_wgrad_mfma_kernel<NOUT, NT_, 1>), grid, dim3(256), 0, st, dy, x, slabs, B, H, W, scale, shift, ssb, affine, relu, 3)
   switch (nt) {
     case 1: ICG_NWM(1); break;
     case 2: ICG_NWM(2); break;
@@ -924,7 +926,10 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 }
 
 
-bool icg_thin_conv_ok(int Cin, int Cout, int R) { return R == 3 && Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && Cout >= 16 && Cout <= 256; }
+bool icg_thin_conv_ok(int Cin, int Cout, int R) {
+  if (R == 1) return Cin >= 1 && Cin <= 3 && thin_mfma_ok(Cin, Cout);       // 1x1: MFMA form only
+  return R == 3 && Cin >= 1 && Cin <= 4 && Cout % 4 == 0 && Cout >= 16 && Cout <= 256;
+}
 
 static int thin_lp(int Cout) {
   int lp = 4;
@@ -962,13 +967,13 @@ static void thin_dispatch(bool wgrad, int Cin, int lp, dim3 grid, hipStream_t st
   }
 }
 
-int icg_thin_fprop(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
+int icg_thin_fprop(const float* x, const float* w, const float* bias, float* out, int B, int H, int W, int Cin, int Cout, int R,
                    float alpha, hipStream_t st) {
-  if (thin_mfma_ok(Cin, Cout)) {
+  if (thin_mfma_ok(Cin, Cout) && Cin <= 3) {
     const long tiles = ((long)B * H * W + 31) / 32;
     long blocks = (tiles + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    thin_mfma_dispatch(false, Cin, Cout / 32, dim3((unsigned)blocks), st, x, w, bias, out, B, H, W, alpha);
+    thin_mfma_dispatch(false, Cin, Cout / 32, dim3((unsigned)blocks), st, x, w, bias, out, B, H, W, alpha, R);
     return icg_check_launch();
   }
   const int lp = thin_lp(Cout);
@@ -976,18 +981,18 @@ int icg_thin_fprop(const float* x, const float* w, const float* bias, float* out
   return icg_check_launch();
 }
 
-int icg_thin_wgrad(const float* x, const float* dy, float* dw, void* workspace, int B, int H, int W, int Cin, int Cout,
+int icg_thin_wgrad(const float* x, const float* dy, float* dw, void* workspace, int B, int H, int W, int Cin, int Cout, int R,
                    hipStream_t st) {
   const int lp = thin_lp(Cout);
   int blocks = narrow_blocks(B, H, W, lp, 768);
   float* slabs = (float*)workspace;
-  if (thin_mfma_ok(Cin, Cout)) {
+  if (thin_mfma_ok(Cin, Cout) && Cin <= 3) {
     const long rows4 = ((long)B * H + 3) / 4;                 // one image row per wavefront and pass
     if (blocks > rows4) blocks = (int)rows4;
-    thin_mfma_dispatch(true, Cin, Cout / 32, dim3((unsigned)blocks), st, x, dy, nullptr, slabs, B, H, W, 1.f);
+    thin_mfma_dispatch(true, Cin, Cout / 32, dim3((unsigned)blocks), st, x, dy, nullptr, slabs, B, H, W, 1.f, R);
   } else
   thin_dispatch(true, Cin, lp, dim3((unsigned)blocks), st, x, dy, nullptr, slabs, B, H, W, Cout, 1.f);
-  const long n = 9L * Cin * Cout;
+  const long n = (long)R * R * Cin * Cout;
   hipLaunchKernelGGL(narrow_reduce_kernel, dim3((unsigned)icg_cdiv(n, 32)), dim3(256), 0, st, (const float*)slabs, dw, n, blocks);
   return icg_check_launch();
 }

@@ -72,6 +72,8 @@ CONV_CASES = [
     (1, 5, 33, 2, 32, 3, 0, 0, False),                   # ... two input channels, one column tile, odd width
     (3, 16, 16, 3, 128, 3, 0, 0, True),                  # ... four column tiles (BigGAN-deep stem width)
     (2, 12, 10, 1, 96, 3, 0, 0, True),                   # ... single input channel, three column tiles
+    (2, 16, 16, 3, 96, 1, 0, 0, True),                   # 1x1 from-RGB shortcut (D block 0 conv_sc) on the same MFMA kernels: K = Cin
+    (1, 9, 7, 2, 32, 1, 0, 0, False),                    # ... two input channels, odd sizes
     (1, 8, 8, 3, 96, 3, PRE_RELU, 0, True),              # prologue requested -> stays on the implicit-GEMM path
     (2, 16, 16, 96, 96, 3, PRE_AFFINE | PRE_RELU | UP, 2, True),   # GBlock conv1-like + half-res residual
     (2, 16, 16, 96, 96, 3, PRE_AFFINE | PRE_RELU, 2, True),
