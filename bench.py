@@ -149,20 +149,26 @@ class KernelTimer:
             e.record()
             query(last)
             pk = "icg_gemm_planes1_kernel" if last[3] == 4 else "icg_gemm_planes_kernel"     # single- / two-level chains
+
+            def fwd_gemm():      # the forward / data-gradient plane GEMM that ran: second-generation kernel (pgemm.hip) or the first
+                if last[0] == 2:
+                    return "icg_pgemm_nn_kernel<%d, %d>" % (last[2], 1 if last[3] == 4 else 2)
+                return "%s<0, 0, %d>" % (pk, last[2])
             if mode == "from_v":
                 kname = "composite: weight gradient from the saved V planes (wino4_dy_kernel + %d batched split-K %s<1, 1, %d> GEMMs + reduce + wino4_dw_kernel)" % (args[sl + 5], pk, last[2])
             elif mode in ("rs_up", "rs_down"):
                 kind = (name[:-5] if name.endswith("_relu") else name).rsplit("_", 1)[1]
-                kname = "composite: %s-fused conv %s in the 25-plane F(4x4,3x3) domain (transforms + 25 batched %s<%s, %d> GEMMs)" % (
-                    "upsample" if mode == "rs_up" else "avgpool", kind, pk, "1, 1" if kind == "wgrad" else "0, 0", last[2])
+                kname = "composite: %s-fused conv %s in the 25-plane F(4x4,3x3) domain (transforms + 25 batched %s GEMMs)" % (
+                    "upsample" if mode == "rs_up" else "avgpool", kind,
+                    ("%s<1, 1, %d>" % (pk, last[2])) if kind == "wgrad" else fwd_gemm())
             elif mode in ("wino", "wino4"):     # three kernels behind one entry point: not comparable with a single rocprof row
                 kname = (("composite: wino4_input_kernel + wino4_dy_kernel + %s<1, 1, %d> (36 batched split-K GEMMs) + reduce + wino4_dw_kernel" % (pk, last[2])
                           if mode == "wino4" else
                           "composite: wino_input_kernel + wino_dy_kernel + %s<1, 1, %d> (16 batched split-K GEMMs) + reduce + wino_dw_kernel" % (pk, last[2]))
                          if name.endswith("wgrad") else
-                         ("composite: wino4_input_kernel + %s<0, 0, %d> (36 batched GEMMs) + wino4_output_kernel" % (pk, last[2])
+                         ("composite: wino4_input_kernel + %s (36 batched GEMMs) + wino4_output_kernel" % fwd_gemm()
                           if mode == "wino4" else
-                          "composite: wino_input_kernel + %s<0, 0, %d> (16 batched GEMMs) + wino_output_kernel" % (pk, last[2])))
+                          "composite: wino_input_kernel + %s (16 batched GEMMs) + wino_output_kernel" % fwd_gemm()))
             elif last[0] == -4:      # thin-input 3x3 kernels (narrow_conv.hip): {-4, fprop/wgrad, Cout, Cin}
                 if 9 * last[3] <= 32 and last[2] % 32 == 0 and last[2] <= 128:      # MFMA form (narrow_conv.hip: thin_mfma_ok)
                     kname = ("void thin_wgrad_mfma_kernel<%d, %d, 0>" if last[1] else "void thin_fprop_mfma_kernel<%d, %d>") % (last[3], last[2] // 32)
@@ -210,7 +216,10 @@ class KernelTimer:
             # executed MACs -> MACs of the reference op graph: 36 of 144 (F(4x4,3x3)), 25 of 144 (resample-fused), 16 of 36 (F(2x2,3x3))
             alg = flops * {36: 144 / 36, 25: 144 / 25, 16: 36 / 16}.get(int(planes), 1.0)
             kern = "icg_gemm_planes1_kernel" if int(tn) >= 10 else "icg_gemm_planes_kernel"      # single- / two-level chains
-            a = out.setdefault("void %s<%s, %d>(GemmP)" % (kern, mode, int(tn) % 10), [0.0, 0.0, 0, 0.0, 0.0])
+            kname = "void %s<%s, %d>(GemmP)" % (kern, mode, int(tn) % 10)
+            if int(amode) == 2:          # second-generation plane GEMM (pgemm.hip): <16-column tiles per wave, accumulation levels>
+                kname = "void icg_pgemm_nn_kernel<%d, %d>(PgemmP)" % (int(tn) % 10, 1 if int(tn) >= 10 else 2)
+            a = out.setdefault(kname, [0.0, 0.0, 0, 0.0, 0.0])
             a[0] += alg; a[1] += ms * 1e-3; a[2] += int(n); a[3] += flops; a[4] += byt
         return out
 

@@ -1065,6 +1065,10 @@ static constexpr int planes_1level_max_k() { return ICG_PLANES_1LEVEL_MAX_K; }
 static thread_local int g_gemm_planes = 0;
 void icg_gemm_mark_planes(int on) { g_gemm_planes = on; }
 
+// pgemm.hip; returns 1 when the shape is not one it takes
+int icg_pgemm_nn_launch(const float* A, const float* B, float* C, int M, int N, int K, long ldc, long sA, long sB, long sC,
+                        int planes, float alpha, int levels, hipStream_t st, int* tn_out);
+
 // deterministic second stage of split-K: out[i] = sum_z slab[z][i]
 __global__ void icg_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n,
                                          int splits) {
@@ -1149,6 +1153,20 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
   if (path == 2 && p.pre_affine) path = 3;
   g_last_variant[0] = AMODE; g_last_variant[1] = BMODE; g_last_variant[2] = tn; g_last_variant[3] = path;
   const bool plain = p.plain != 0 && plain_body && !g_gemm_planes;
+  if constexpr (AMODE == A_K && BMODE == B_K) {
+    // second-generation plane GEMM (pgemm.hip: LDS-DMA staging, 16-byte operand fragments, 8 waves per workgroup) for the
+    // Winograd-plane GEMMs it has a tile for (N a multiple of 128 or 96, K a multiple of 32); everything else stays below
+    if (path == 2 && g_gemm_planes && plain_body && p.bias == nullptr && p.res == nullptr && p.ldb == p.K) {
+      const int levels = (p.K <= planes_1level_max_k()) ? 1 : 2;
+      int nt2 = 0;
+      const int rc = icg_pgemm_nn_launch(p.A, p.B, p.C, p.M, p.N, p.K, p.ldc, p.strideA, p.strideB, p.strideC, zdim, p.alpha,
+                                         levels, st, &nt2);
+      if (rc != 1) {
+        g_last_variant[0] = 2; g_last_variant[1] = 0; g_last_variant[2] = nt2; g_last_variant[3] = (levels == 1) ? 4 : 2;
+        return rc;
+      }
+    }
+  }
   if (path == 2 && (g_gemm_planes || plain) && plain_body) {
     // persistent plane GEMM (icg_planes_body): 1-D grid, every workgroup owns a run of consecutive output tiles sized for
     // ~64 K-tiles of MFMA work, as long as the launch still queues several workgroups per CU

@@ -30,6 +30,15 @@ static inline int icg_res_mode(unsigned flags) {
 static inline int64_t icg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // 64-wide wavefront reductions (gfx950: wave = 64 lanes)
+// Ordering point for LDS data exchanged between the lanes of ONE wavefront (wave-private LDS regions): tells the compiler that
+// the LDS stores before it are visible to the LDS loads after it.  A wave executes in lockstep and the LDS queue is in order
+// per wave, so this costs nothing at run time -- it pins what the hardware already does against instruction scheduling.
+__device__ __forceinline__ void icg_wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

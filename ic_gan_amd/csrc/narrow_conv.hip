@@ -306,6 +306,7 @@ __global__ __launch_bounds__(256, (NCT <= 3 ? 3 : 2)) void narrow_fprop_mfma_ker
     const int he = min(H, hb + NC_ROWS);
     if (affine) {                                            // this image's prologue coefficients -> LDS (wave-private)
       for (int c = lane; c < Cin; c += 64) { Pc[wv][0][c] = scale[(long)b * ssb + c]; Pc[wv][1][c] = shift[(long)b * ssb + c]; }
+      icg_wave_lds_sync();                                   // other lanes of this wave read what this lane stored
     }
     const int col = c0 - 1 + li;                             // this lane's pixel column as the B-operand column
     const bool col_on = (unsigned)col < (unsigned)W;
@@ -343,8 +344,11 @@ __global__ __launch_bounds__(256, (NCT <= 3 ? 3 : 2)) void narrow_fprop_mfma_ker
       } else {
         for (int k = lane; k < 32 * TS; k += 64) Trow[k] = 0.f;
       }
+      // wave-private LDS exchange (T rows written by one set of lanes, read by others): no workgroup barrier is needed, but
+      // the store -> load order across lanes is stated to the compiler (release fence + wave barrier; both free at run time)
+      icg_wave_lds_sync();
       const int ho = h - 1;
-      if (ho >= hb && ho < he) {                             // (wave-private LDS: program order is enough, no barrier)
+      if (ho >= hb && ho < he) {
 #pragma unroll
         for (int it = 0; it < (CW * NOUT + 63) / 64; ++it) {
           const int item = lane + 64 * it;
@@ -362,6 +366,7 @@ __global__ __launch_bounds__(256, (NCT <= 3 ? 3 : 2)) void narrow_fprop_mfma_ker
           }
         }
       }
+      icg_wave_lds_sync();                                   // the next row's T stores reuse the window slot read above
     }
   }
 }

@@ -1,0 +1,222 @@
+// Plane GEMM, second generation: C[z] = alpha * A[z] B[z]^T for the batched GEMMs over Winograd planes (A [M][K] tiles x
+// channels, B [N][K] the Winograd-domain weights; K = Cin contiguous in both) -- the forward / data-gradient half of every
+// Winograd composite of winograd.hip, i.e. the kernels that dominate the IC-GAN BigGAN step (layers.py:144-153).
+//
+// Why a second kernel: the first-generation plane GEMM (icg_planes_body, gemm_conv.hip) stages both operands
+// global -> VGPR -> ds_write_b32 x 16 -> LDS and reads one ds_read_b32 per MFMA operand; with two-level accumulation it holds
+// 144 VGPR + 64 AGPR and runs at TWO waves per SIMD, which is what caps it at ~0.69 of the fp32 MFMA peak (single-level at three
+// waves: 0.76).  This kernel is built around the three things gfx950 offers for exactly that problem:
+//   * LDS-DMA (global_load_lds_dwordx4): operand tiles go HBM/L2 -> LDS without touching a VGPR and without a single
+//     ds_write; two DMA instructions per wave and K-tile replace 4 global loads + 16 LDS stores + their address arithmetic
+//   * ds_read_b128 operand fragments: with a permuted K order (a lane's four consecutive k-values are the operands of four
+//     successive k-steps of v_mfma_f32_16x16x4_f32) ONE 16-byte LDS read feeds four MFMAs: 6 LDS reads per 32 MFMAs instead of 40
+//   * 8 waves per workgroup, each owning a 32 x 64 (or 32 x 48) piece of the 128 x 128 (128 x 96) output tile: 32 (24) first-level
+//     + 32 (24) second-level accumulator registers per lane instead of 64 + 64, so the two-level kernel fits 4 waves per SIMD
+//     (two workgroups per CU) instead of 2
+// The LDS image the DMA writes is lane-linear (wave-uniform base + 16 B x lane), so the bank-conflict-free layout for the
+// 16-byte fragment reads is obtained by permuting the 16-byte chunks on the SOURCE side (which chunk of its row a lane
+// fetches) and applying the same involution to the read address (cdna_hip_programming.md rule 21).
+//
+// Pipeline: 3-slot LDS ring, ONE raw s_barrier per K-tile, DMA two K-tiles ahead, counted s_waitcnt vmcnt(N) (never 0 in the
+// loop).  The DMA is issued from inline asm: hipcc's own __builtin_amdgcn_global_load_lds makes the compiler drain vmcnt(0)
+// before every LDS read that follows (it cannot tell the ring slots apart), which serialises load and compute.
+#include "icg_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct PgemmP {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  long ldc;
+  long sA, sB, sC;        // per-plane strides (elements)
+  float alpha;
+  int tiles_n, tiles_mn;  // n-tiles per m-tile row, output tiles per plane
+  unsigned total;         // output tiles over all planes (= grid size)
+  int swz;                // XCD-aware tile order
+};
+
+// chunk permutation of the LDS image: the 16-byte chunk c (0..3) of row r sits at chunk position c ^ g(r), g = 0,0,3,3 by
+// (r >> 2) & 3.  With it the four 16-lane groups a ds_read_b128 is served in ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ... --
+// MI355X_MICROARCH.md, LDS) each touch 16 distinct 16-byte bank groups for the 16x16x4 operand pattern (lane l: row l & 15,
+// chunk l >> 4): conflict-free.
+__device__ __forceinline__ int pg_swz(int row) { return (row & 8) ? 3 : 0; }
+
+// one LDS-DMA instruction: every lane fetches 16 bytes from gbase + voff (bytes) and the wave's 1 KiB lands at LDS byte
+// address lds_dst + 16 * lane.  M0 carries the LDS address; it is compiler-reserved, so it is saved and restored inside the
+// statement (cdna_hip_programming.md 5.7).  Not visible to hipcc's s_waitcnt bookkeeping: counted by hand below.
+__device__ __forceinline__ void pg_dma16(const float* gbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(gbase), "s"(lds_dst)
+      : "memory");
+}
+
+// NT: 16-column MFMA tiles per wave (4: 128-column workgroup tile, 3: 96-column); LEVELS: accumulation levels (see gemm_conv.hip,
+// BLK: chains restart every 32 k-values and the finished chain is added into a second accumulator set)
+template <int NT, int LEVELS>
+__global__ __launch_bounds__(512, 4) void icg_pgemm_nn_kernel(PgemmP p) {
+  constexpr int BM = 128, BN = 32 * NT, BK = 16;
+  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, SLOT = A_BYTES + B_BYTES, NBUF = 3;
+  constexpr int B_CHUNKS = BN / 16;                 // DMA instructions (16 rows x 64 B = 1 KiB) per B tile; the A tile has 8
+  __shared__ __attribute__((aligned(1024))) char lds[NBUF * SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7, wave-uniform (SGPR)
+  const int wm = wv & 3, wn = wv >> 2;                              // wave tile: rows 32 wm .., columns 16 NT wn ..
+  const int r = lane & 15, kk = lane >> 4;
+
+  // ---- output tile (XCD-aware order, as icg_gemm_body: each XCD owns a contiguous range of the (plane, m-tile, n-tile) order)
+  unsigned t = blockIdx.x;
+  if (p.swz) {
+    const unsigned tot = p.total, q = tot >> 3, rr = tot & 7u, xcd = t & 7u;
+    t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
+  }
+  const int z = (int)(t / (unsigned)p.tiles_mn);
+  const int tile = (int)(t - (unsigned)z * (unsigned)p.tiles_mn);
+  const int nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const float* __restrict__ Ag = p.A + (long)z * p.sA;
+  const float* __restrict__ Bg = p.B + (long)z * p.sB;
+
+  // ---- DMA role of this lane: every wave fetches 16 rows of the A tile (1 KiB) and BN/8 rows of the B tile per K-tile; the
+  // lane's 16 bytes land at chunk position lane & 3 of row (lane >> 2) of the wave's piece
+  constexpr int BROWS = BN / 8;                                     // 16 (all 64 lanes) or 12 (lanes 0..47; the rest are masked off)
+  const int drowA = 16 * wv + (lane >> 2), drowB = BROWS * wv + (lane >> 2);
+  const unsigned voffA =
+      ((unsigned)min(m0 + drowA, p.M - 1) * (unsigned)p.K + 4u * (unsigned)((lane & 3) ^ pg_swz(drowA))) * 4u;
+  const unsigned voffB =
+      ((unsigned)min(n0 + min(drowB, BN - 1), p.N - 1) * (unsigned)p.K + 4u * (unsigned)((lane & 3) ^ pg_swz(drowB))) * 4u;
+  const bool dma_b_lane = (BROWS == 16) || ((lane >> 2) < BROWS);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned ldsA = lds_base + (unsigned)wv * 1024u, ldsB = lds_base + (unsigned)A_BYTES + (unsigned)wv * (BROWS * 64u);
+  const int nk = p.K / BK;                                          // even (K % 32 == 0)
+  auto issue = [&](int kt, unsigned slot_off) {                     // K-tile kt -> ring slot (past the end: the last tile again)
+    const int kc = min(kt, nk - 1) * BK;
+    pg_dma16(Ag + kc, voffA, ldsA + slot_off);
+    if (dma_b_lane) pg_dma16(Bg + kc, voffB, ldsB + slot_off);
+  };
+  auto next_slot = [](unsigned off) -> unsigned { return off == (unsigned)((NBUF - 1) * SLOT) ? 0u : off + (unsigned)SLOT; };
+
+  // ---- fragment addresses: lane (r, kk) reads the 16 bytes of chunk kk of row (tile base + r)
+  const int fo = r * 64 + ((kk ^ pg_swz(r)) * 16);
+  const char* fa = lds + fo + (32 * wm) * 64;
+  const char* fb = lds + fo + A_BYTES + (16 * NT * wn) * 64;
+
+  f32x4 acc[2][NT], acc2[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+  issue(0, 0u);
+  issue(1, (unsigned)SLOT);
+
+  // one K-tile from the ring slot at byte offset `cur`; FLUSH: fold the finished 32-deep chains into the second level and
+  // start fresh ones
+  auto tile_step = [&](int kt, unsigned cur, auto flush_c) {
+    constexpr bool FLUSH = decltype(flush_c)::value;
+    // K-tile kt has landed once at most the two DMAs of K-tile kt+1 are outstanding; this wave's LDS reads of K-tile kt-1 have
+    // all returned (their MFMAs were issued), so after the barrier that tile's slot may be overwritten
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(kt + 2, next_slot(next_slot(cur)));                       // into the slot K-tile kt-1 occupied
+    float4 a[2], b[NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(fa + cur + i * 1024);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float4*>(fb + cur + j * 1024);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float av = s == 0 ? a[i].x : (s == 1 ? a[i].y : (s == 2 ? a[i].z : a[i].w));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float bv = s == 0 ? b[j].x : (s == 1 ? b[j].y : (s == 2 ? b[j].z : b[j].w));
+          if (LEVELS == 2 && FLUSH && s == 0) {
+            acc2[i][j] += acc[i][j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  unsigned cur = 0u;
+  for (int kt = 0; kt < nk; kt += 2) {                              // flush period 2: the pair is the loop body
+    tile_step(kt, cur, std::true_type{});
+    cur = next_slot(cur);
+    tile_step(kt + 1, cur, std::false_type{});
+    cur = next_slot(cur);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the over-fetched tiles: nothing may land after the exit
+
+  // ---- epilogue.  C/D layout of 16x16x4: column = lane & 15, row = 4 (lane >> 4) + reg
+  float* __restrict__ Cg = p.C + (long)z * p.sC;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int mrow = m0 + 32 * wm + 16 * i + 4 * kk;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + 16 * NT * wn + 16 * j + r;
+      const f32x4 v = (LEVELS == 2) ? acc[i][j] + acc2[i][j] : acc[i][j];
+      if (n < p.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (mrow + e < p.M) Cg[(long)(mrow + e) * p.ldc + n] = p.alpha * v[e];
+      }
+    }
+  }
+}
+
+static bool pgemm_enabled() {      // measurement switch (ICG_PGEMM=0: first-generation plane GEMMs), read once per process
+  static const bool on = [] { const char* e = getenv("ICG_PGEMM"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+// -> ICG_OK when launched, 1 when the shape is not one this kernel takes (caller falls back to icg_planes_body)
+int icg_pgemm_nn_launch(const float* A, const float* B, float* C, int M, int N, int K, long ldc, long sA, long sB, long sC,
+                        int planes, float alpha, int levels, hipStream_t st, int* tn_out) {
+  if (!pgemm_enabled()) return 1;
+  const int nt = (N % 128 == 0) ? 4 : ((N % 96 == 0) ? 3 : 0);
+  if (nt == 0 || K % 32 != 0 || M < 1 || planes < 1) return 1;
+  if ((uintptr_t)A % 16 || (uintptr_t)B % 16 || sA % 4 || sB % 4) return 1;
+  if ((long)M * K >= (1L << 30) || (long)N * K >= (1L << 30)) return 1;        // 32-bit byte offsets inside a plane
+  PgemmP p{};
+  p.A = A; p.B = B; p.C = C;
+  p.M = M; p.N = N; p.K = K;
+  p.ldc = ldc; p.sA = sA; p.sB = sB; p.sC = sC;
+  p.alpha = alpha;
+  p.tiles_n = N / (32 * nt);
+  const long tiles_mn = icg_cdiv(M, 128) * p.tiles_n, total = tiles_mn * planes;
+  if (total <= 0 || total >= 0x7fffffffL) return 1;
+  p.tiles_mn = (int)tiles_mn;
+  p.total = (unsigned)total;
+  static const bool no_swz = [] { const char* e = getenv("ICG_NO_XCD_SWIZZLE"); return e && e[0] == '1'; }();
+  p.swz = (total >= 16 && !no_swz) ? 1 : 0;
+  dim3 grid((unsigned)total), block(512);
+  if (nt == 4) {
+    if (levels == 2) hipLaunchKernelGGL((icg_pgemm_nn_kernel<4, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((icg_pgemm_nn_kernel<4, 1>), grid, block, 0, st, p);
+  } else {
+    if (levels == 2) hipLaunchKernelGGL((icg_pgemm_nn_kernel<3, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((icg_pgemm_nn_kernel<3, 1>), grid, block, 0, st, p);
+  }
+  if (tn_out) *tn_out = nt;
+  return icg_check_launch();
+}

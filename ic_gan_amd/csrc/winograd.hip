@@ -286,6 +286,16 @@ extern "C" int icg_planes_timing_drain(double* out, int max_rows) {
   }
   return rows;
 }
+extern "C" int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int transA, int transB,
+                                int64_t strideA, int64_t strideB, int64_t strideC, int batch, float alpha, void* stream);
+
+extern "C" int icg_plane_gemm(const float* A, const float* B, float* C, int M, int N, int K, int planes, float alpha,
+                              void* stream) {
+  ICG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && planes > 0);
+  PlanesScope ps(stream, planes, M, N, K);
+  return icg_gemm_batched(A, B, C, M, N, K, 0, 1, (int64_t)M * K, (int64_t)N * K, (int64_t)M * N, planes, alpha, stream);
+}
+
 extern "C" size_t icg_gemm_tn_batched_workspace_bytes(int M, int N, int K, int batch);
 extern "C" int icg_gemm_tn_batched(const float* A, const float* B, float* C, int M, int N, int K, int64_t strideA,
                                    int64_t strideB, int64_t strideC, int batch, void* workspace, size_t workspace_bytes,

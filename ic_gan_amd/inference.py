@@ -83,12 +83,21 @@ class GraphedGenerator:
     def refresh(self):
         from . import layers
         was, layers.SN_EVAL_CACHE = layers.SN_EVAL_CACHE, bool(self.static_weights)
+        # the per-layer opt-in flags of the CALLER's generator are restored after the capture: the graph keeps the W/sigma
+        # buffers it baked in alive through self._pinned, while eval forwards of the module OUTSIDE the graph go back to
+        # whatever caching policy its owner chose (a module that is written through `.data` must not serve a stale cache)
+        sn_layers = [m for m in self._args[0].modules() if isinstance(m, layers.SN)]
+        flags = [getattr(m, "_sn_cache_ok", False) for m in sn_layers]
         if self.static_weights:
             layers.enable_sn_eval_cache(self._args[0], True)      # fixed checkpoint: W/sigma computed once, baked in
         try:
             self._capture(*self._args)
         finally:
             layers.SN_EVAL_CACHE = was
+            for m, f in zip(sn_layers, flags):
+                m._sn_cache_ok = f
+                if not f:
+                    m._sn_eval = None                              # (the graph's copy lives on in self._pinned)
 
     def _capture(self, generator, batch_size, class_cond, instance_cond, device, feature_dim):
         self.generator, self.batch_size = generator, batch_size

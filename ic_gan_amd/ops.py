@@ -364,7 +364,12 @@ class FusedConvFn(Function):
         count_dev = None
         if bn is not None:
             if opt.bn_stats is not None:
-                x = opt.bn_stats.x            # the channels-last tensor the statistics were started on (same values)
+                # the statistics must have been started on THIS input: same channels-last storage (the usual case: _cl was a
+                # no-op both times) or, when a layout copy was made on either side, the same logical tensor
+                sx = opt.bn_stats.x
+                if sx.shape != x.shape or (sx.data_ptr() != x.data_ptr() and not torch.equal(sx, x)):
+                    raise RuntimeError("bn_stats were started on a different tensor than the one being normalised")
+                x = sx                        # the channels-last tensor the statistics were started on (same values)
             gain, beta, gb_rows, ssb, count, count_dev, mean, invstd, scale, shift = _bn_forward_stats(x, bn, gain, beta,
                                                                                                       opt.bn_stats)
             opt.bn_stats = None

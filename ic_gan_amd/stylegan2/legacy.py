@@ -10,9 +10,11 @@ the reference's loader `exec`s that source text to rebuild the object (persisten
 source is NEVER executed: each persistent object becomes a stub holding (class_name, state); the top-level networks are then
 rebuilt as `ic_gan_amd.stylegan2.networks.<class_name>(*state._init_args, **state._init_kwargs)` (same constructor
 signatures) and every parameter / buffer of the stub tree is copied in by name (`load_state_dict(strict=True)`: the two
-implementations share the state_dict layout, tests/test_stylegan2.py).  The unpickler resolves only an allow-list of
-globals (torch tensor rebuild helpers, numpy arrays, collections, EasyDict, the persistence hook): a snapshot cannot run
-code here.
+implementations share the state_dict layout, tests/test_stylegan2.py).  The unpickler resolves only an EXACT
+(module, name) allow-list (the four torch tensor / parameter rebuild helpers, numpy array / dtype / scalar reconstruction,
+OrderedDict, EasyDict, the persistence hook), refuses dotted names, and routes the storage helper of plain-pickled tensors
+(`torch.storage._load_from_bytes`) through `torch.load(..., weights_only=True)`; tests/test_sg2_snapshot.py feeds it
+pickles that name `os.system` three different ways and checks that each is refused before anything is called.
 
 Not supported (raise): TensorFlow-era pickles (`dnnlib.tflib.network.Network`, legacy.py:31-41,80-89: conversion of the
 original TF StyleGAN2 weights, which IC-GAN never writes); `force_fp16` is honoured through the networks' own
@@ -77,6 +79,19 @@ class _TFNetworkStub(dict):
     pass
 
 
+def _load_storage_from_bytes(b):
+    """torch.storage._load_from_bytes is `torch.load(io.BytesIO(b), weights_only=False)` (torch 2.x): the helper plain-pickled
+    tensors use for their storage would hand the inner payload to the unrestricted unpickler.  Same bytes, restricted loader."""
+    return torch.load(io.BytesIO(b), weights_only=True)
+
+
+def _exact(module, names):
+    mod = __import__(module, fromlist=["_"])
+    return {(module, n): getattr(mod, n) for n in names if hasattr(mod, n)}
+
+
+# EXACT (module, name) pairs only.  No prefix rules: protocol-4 STACK_GLOBAL accepts dotted names, so a rule such as
+# "anything under torch.serialization." also resolves ("torch.serialization", "os.system") by attribute traversal.
 _ALLOWED = {
     ("torch_utils.persistence", "_reconstruct_persistent_obj"): _reconstruct_persistent_obj,
     ("dnnlib.util", "EasyDict"): EasyDict,
@@ -85,20 +100,27 @@ _ALLOWED = {
     ("collections", "OrderedDict"): __import__("collections").OrderedDict,
     ("builtins", "set"): set, ("builtins", "frozenset"): frozenset, ("builtins", "dict"): dict, ("builtins", "list"): list,
     ("builtins", "tuple"): tuple, ("builtins", "slice"): slice, ("builtins", "complex"): complex,
+    ("torch.storage", "_load_from_bytes"): _load_storage_from_bytes,
 }
-_ALLOWED_PREFIXES = ("torch._utils.", "torch.storage.", "torch.nn.parameter.", "torch.serialization.", "numpy.core.multiarray.",
-                     "numpy._core.multiarray.", "numpy.core.numeric.", "numpy._core.numeric.")
-_ALLOWED_NAMES = {("torch", n) for n in ("FloatStorage", "HalfStorage", "DoubleStorage", "LongStorage", "IntStorage", "BoolStorage",
-                                         "ByteStorage", "Size", "device", "float32", "float16", "float64", "int64", "int32", "bool",
-                                         "uint8", "Tensor")} | {("numpy", "ndarray"), ("numpy", "dtype")}
+_ALLOWED.update(_exact("torch._utils", ("_rebuild_tensor", "_rebuild_tensor_v2", "_rebuild_parameter",
+                                        "_rebuild_parameter_with_state")))
+_ALLOWED.update(_exact("torch", ("FloatStorage", "HalfStorage", "DoubleStorage", "LongStorage", "IntStorage", "BoolStorage",
+                                 "ByteStorage", "Size", "device", "float32", "float16", "float64", "int64", "int32", "bool",
+                                 "uint8", "Tensor")))
+_ALLOWED.update(_exact("numpy", ("ndarray", "dtype")))
+for _m in ("numpy.core.multiarray", "numpy._core.multiarray"):
+    try:
+        _ALLOWED.update(_exact(_m, ("_reconstruct", "scalar")))
+    except ImportError:
+        pass
 
 
 class _SnapshotUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        if (module, name) in _ALLOWED:
+        # exact pairs, resolved from the table above (never by importing what the pickle names); dotted names are refused
+        # outright -- they are attribute traversals (protocol >= 4), not globals
+        if "." not in name and (module, name) in _ALLOWED:
             return _ALLOWED[(module, name)]
-        if (module, name) in _ALLOWED_NAMES or (module + "." + name).startswith(_ALLOWED_PREFIXES):
-            return super().find_class(module, name)
         raise pickle.UnpicklingError("network snapshot references %s.%s, which this reader does not resolve" % (module, name))
 
 

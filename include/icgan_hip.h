@@ -272,6 +272,16 @@ int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int
                      float alpha, void* stream);
 
 /*
+ * The batched GEMM over Winograd planes on its own: C[z] = alpha * A[z] B[z]^T, A [planes][M][K] (tiles x channels),
+ * B [planes][N][K] (Winograd-domain weights), C [planes][M][N], all dense -- launched exactly as the Winograd composites
+ * (icg_conv2d_wino4_fprop, icg_conv2d_up_wino_fprop, ...) launch it, i.e. on the second-generation plane GEMM of
+ * csrc/pgemm.hip where that kernel has a tile (N a multiple of 128 or 96, K a multiple of 32) and on the first-generation
+ * kernels otherwise.  No reference counterpart (the reference calls cuDNN, layers.py:144-153); entry point of the kernel-level
+ * parity tests and of tools/pgemm_bench.py.
+ */
+int icg_plane_gemm(const float* A, const float* B, float* C, int M, int N, int K, int planes, float alpha, void* stream);
+
+/*
  * Measurement support (no reference counterpart): template arguments {AMODE, BMODE, TN, PATH} of the last
  * icg_gemm_kernel<AMODE, BMODE, TN, PATH> launched by the calling host thread through any of the conv / GEMM
  * entry points above ({-1,...} before the first launch; {-2, 0 fprop / 1 wgrad, Cout, Cin} when the direct

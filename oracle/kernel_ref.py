@@ -386,6 +386,10 @@ def icg_gemm_batched(A, Bm, C, M, N, K, transA, transB, strideA, strideB, stride
         c[z * strideC: z * strideC + M * N].copy_((alpha * (am @ bm)).reshape(-1))
 
 
+def icg_plane_gemm(A, Bm, C, M, N, K, planes, alpha):
+    icg_gemm_batched(A, Bm, C, M, N, K, 0, 1, M * K, N * K, M * N, planes, alpha)
+
+
 # ---------------------------------------------------------------- BN
 def icg_bn_workspace_bytes(rows, C):
     return 2 * C * 4

@@ -56,26 +56,30 @@ CASES = {
                         G_ch=8, D_ch=8), 4, 1, False),
 }
 NS = 64
+NS_GRAD = None      # samples per GRADIENT tensor (None = NS); make_golden_real_widths.py raises it to 4096, i.e. every gradient
+                    # of <= 4096 elements is stored in full and the large ones at 4096 strided positions
 
 
-def fingerprint(t):
+def fingerprint(t, ns=None):
+    ns = ns or NS
     t = t.detach().double().flatten()
     n = t.numel()
-    stride = max(n // NS, 1)
-    s = t[::stride][:NS]
-    samp = np.zeros(NS)
+    stride = max(n // ns, 1)
+    s = t[::stride][:ns]
+    samp = np.zeros(ns)
     samp[: s.numel()] = s.numpy()
     return float(t.sum()), float((t * t).sum()), samp
 
 
-def pack(d):
+def pack(d, ns=None):
+    ns = ns or NS
     names = list(d.keys())
-    fp = [fingerprint(d[k]) for k in names]
+    fp = [fingerprint(d[k], ns) for k in names]
     return dict(names=json.dumps(names), sum=np.array([f[0] for f in fp]),
-                sq=np.array([f[1] for f in fp]), samp=np.stack([f[2] for f in fp]) if fp else np.zeros((0, NS)))
+                sq=np.array([f[1] for f in fp]), samp=np.stack([f[2] for f in fp]) if fp else np.zeros((0, ns)))
 
 
-def run_case(name, over, gb, steps, full):
+def run_case(name, over, gb, steps, full, probe=True):
     cfg = dict(BASE)
     cfg.update(over)
     torch.manual_seed(0)
@@ -140,9 +144,9 @@ def run_case(name, over, gb, steps, full):
         m = train(x, y, f)
         losses.append([m["G_loss"], m["D_loss_real"], m["D_loss_fake"]])
         if s == 0:
-            for k, v in pack({n: p.grad for n, p in G.named_parameters() if p.grad is not None}).items():
+            for k, v in pack({n: p.grad for n, p in G.named_parameters() if p.grad is not None}, NS_GRAD).items():
                 out["step1/G_grad/" + k] = v
-            for k, v in pack({n: p.grad for n, p in D.named_parameters() if p.grad is not None}).items():
+            for k, v in pack({n: p.grad for n, p in D.named_parameters() if p.grad is not None}, NS_GRAD).items():
                 out["step1/D_grad/" + k] = v
         for k, v in pack(G.state_dict()).items():
             out[f"step{s + 1}/G_state/" + k] = v

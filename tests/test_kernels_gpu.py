@@ -471,6 +471,60 @@ def test_gemm_batched(case):
     close(*pair, what=f"gemm {case}")
 
 
+# the batched GEMM over Winograd planes as the composites launch it (icg_plane_gemm): second-generation kernel (csrc/pgemm.hip:
+# LDS-DMA staging, 16-byte fragments) where N % 128 == 0 or N % 96 == 0 and K % 32 == 0, first-generation kernels otherwise
+PLANE_GEMM_CASES = [
+    # M (tiles), N (Cout), K (Cin), planes
+    (256, 128, 32, 3),            # shortest K the DMA kernel takes: 2 K-tiles = prologue + over-fetch only
+    (128, 128, 64, 2),            # exactly one m-tile
+    (1, 128, 96, 2),              # a single row: 127 clamped rows per tile
+    (130, 256, 96, 5),            # ragged M (2 rows in the second m-tile), two n-tiles, odd plane count
+    (1000, 96, 96, 4),            # 96-column tile (12 B rows per wave, lanes 48..63 masked in the B DMA), ragged M
+    (384, 192, 192, 36),          # 96-column tile, two n-tiles, F(4x4,3x3) plane count
+    (257, 384, 128, 25),          # 128-column tile with three n-tiles, 25-plane count, K = 128 (8 K-tiles: not a multiple of 6)
+    (512, 768, 1536, 2),          # longest K of the product (96 K-tiles)
+    (4096, 128, 384, 16),         # > 16 workgroups per plane: XCD-aware order, several tiles per XCD
+    (300, 160, 96, 3),            # N takes neither tile -> first-generation persistent body
+    (300, 128, 48, 3),            # K % 32 != 0 -> first generation
+]
+
+
+@pytest.mark.parametrize("case", PLANE_GEMM_CASES)
+def test_plane_gemm(case):
+    M, N, K, planes = case
+    A = rnd(planes, M * K, seed=11, scale=1 / np.sqrt(K))
+    Bm = rnd(planes, N * K, seed=12)
+    C = torch.full((planes, M * N), float("nan"))
+    (pair,) = run_pair("icg_plane_gemm", [A, Bm, C, M, N, K, planes, 0.75], [2])
+    close(*pair, what=f"plane gemm {case}")
+    # against fp64: two-level accumulation keeps the chain error below the plain fp32 reference's own
+    ref64 = 0.75 * torch.bmm(A.view(planes, M, K).double(), Bm.view(planes, N, K).double().transpose(1, 2))
+    got = pair[0].cpu().double().view(planes, M, N)
+    rel = float((got - ref64).norm() / ref64.norm())
+    assert rel < 3e-6, rel
+
+
+def test_plane_gemm_is_deterministic_and_leaves_neighbours_alone():
+    """same launch twice -> bit-identical (no race between the DMA ring and the fragment reads shows up as run-to-run
+    differences); rows / planes beyond the problem are not written (ragged M, guard regions around C)."""
+    L = _L()
+    M, N, K, planes = 333, 256, 192, 7
+    A = rnd(planes, M * K, seed=21).cuda()
+    Bm = rnd(planes, N * K, seed=22).cuda()
+    guard = 4096
+    buf = torch.full((guard + planes * M * N + guard,), 7.5, device="cuda")
+    C = buf[guard: guard + planes * M * N]
+    outs = []
+    for _ in range(3):
+        C.fill_(float("nan"))
+        L.call("icg_plane_gemm", A, Bm, C, M, N, K, planes, 1.0)
+        torch.cuda.synchronize()
+        outs.append(C.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.isfinite(outs[0]).all()
+    assert bool((buf[:guard] == 7.5).all()) and bool((buf[guard + planes * M * N:] == 7.5).all())
+
+
 # ------------------------------------------------------------------------------------------------ batch norm
 BN_SHAPES = [(128, 8), (4096, 96), (70001, 192), (64, 1536), (100, 384), (3, 4), (20000, 32)]
 

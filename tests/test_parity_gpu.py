@@ -13,8 +13,8 @@ import torch
 
 from oracle import biggan_oracle as O
 from oracle import synth
-from tests.helpers import (CASES, GRAD_RTOL, REAL_CASES, STATE_RTOL, adam_slack, check_group, conditioning_slack, fingerprint,
-                           load_golden)
+from tests.helpers import (BENCH_CASES, CASES, GRAD_RTOL, REAL_CASES, STATE_RTOL, adam_slack, check_group, conditioning_slack,
+                           fingerprint, load_golden)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -48,7 +48,7 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("case", CASES + REAL_CASES)
+@pytest.mark.parametrize("case", CASES + REAL_CASES + BENCH_CASES)
 def test_forward_vs_golden(case):
     g = load_golden(case)
     cfg = g["cfg"]
@@ -126,6 +126,19 @@ def test_train_steps_vs_golden_real_widths(case, wino, monkeypatch):
     resample-fused layers) and the Winograd-free route (-1).  Gradient tolerance per tensor = GRAD_RTOL * rms + COND_K x the
     fp32 reference's own distance from its fp64 run (helpers.conditioning_slack): at cfg3 the Winograd-FREE route sits at
     1.6 x (GRAD_RTOL * rms) on blocks.0.0.conv1.weight where the reference itself is 0.82 x away from fp64."""
+    _train_steps_case(case, wino, monkeypatch)
+
+
+@pytest.mark.parametrize("wino", [-1, 0])
+@pytest.mark.parametrize("case", BENCH_CASES)
+def test_train_steps_vs_golden_bench_config(case, wino, monkeypatch):
+    """The configuration the metric is quoted on (cfg3: 256x256, ch 96, class + instance conditioning, attention at 64) at
+    B = 16 and at the benchmark's own B = 64, one full train() call against the UNMODIFIED reference run on the CPU
+    (tests/golden/make_golden_real_widths.py): losses, every gradient (4096 samples per tensor, tensors of <= 4096 elements in
+    full), every post-step tensor of G, D and G_ema -- at the batch sizes where BN statistics, split-K slice counts, persistent
+    tile runs and the attention maps take the routes the benchmark takes.  Production route (0) and Winograd-free route (-1).
+    B = 16 has an fp64 twin of the reference (conditioning slack as for the batch-2 cases); B = 64 has none (the fp64 graph
+    does not fit the build container) and is held to the plain GRAD_RTOL."""
     _train_steps_case(case, wino, monkeypatch)
 
 

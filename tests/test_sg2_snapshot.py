@@ -58,6 +58,53 @@ def test_snapshot_reader_never_resolves_foreign_globals(tmp_path):
         legacy.load_network_pkl(pickle.dumps([1, 2, 3]))
 
 
+def _stack_global_pickle(module, name, arg):
+    """protocol-4 pickle of `module.name(arg)` built by hand: STACK_GLOBAL takes ANY (module, dotted-name) pair, which is
+    how a prefix-based allow-list is bypassed (the name is resolved by attribute traversal from the module)."""
+    enc = lambda t: pickle.SHORT_BINUNICODE + bytes([len(t.encode())]) + t.encode()
+    return (pickle.PROTO + b"\x04" + enc(module) + enc(name) + pickle.STACK_GLOBAL + enc(arg) + pickle.TUPLE1 + pickle.REDUCE
+            + pickle.STOP)
+
+
+@pytest.mark.parametrize("module,name", [
+    ("torch.serialization", "os.system"),            # dotted name under a formerly allowed module prefix
+    ("torch._utils", "_import_dotted_name"),         # helper that imports whatever its argument names
+    ("torch.serialization", "load"),                 # the unrestricted loader itself
+    ("torch.storage", "os.system"),
+    ("numpy.core.multiarray", "os.system"),
+])
+def test_snapshot_reader_refuses_allow_list_bypasses(tmp_path, module, name):
+    from ic_gan_amd.stylegan2 import legacy
+    marker = tmp_path / "pwned"
+    blob = _stack_global_pickle(module, name, "touch %s" % marker)
+    with pytest.raises(pickle.UnpicklingError, match="does not resolve"):
+        legacy.load_network_pkl(blob)
+    assert not marker.exists()
+
+
+def test_snapshot_reader_storage_helper_uses_the_restricted_loader(tmp_path):
+    """`torch.storage._load_from_bytes` (what plain-pickled tensors call for their storage) is torch.load(weights_only=False)
+    in torch 2.x; the reader maps it to a weights_only=True load, so an inner payload naming a foreign global is refused too."""
+    from ic_gan_amd.stylegan2 import legacy
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("touch %s" % marker,))
+
+    inner = pickle.dumps(Evil(), protocol=2)
+    enc = lambda t: pickle.SHORT_BINUNICODE + bytes([len(t.encode())]) + t.encode()
+    blob = (pickle.PROTO + b"\x04" + enc("torch.storage") + enc("_load_from_bytes") + pickle.STACK_GLOBAL
+            + pickle.BINBYTES + len(inner).to_bytes(4, "little") + inner + pickle.TUPLE1 + pickle.REDUCE + pickle.STOP)
+    with pytest.raises(Exception):
+        legacy.load_network_pkl(blob)
+    assert not marker.exists()
+    # ... while a genuine plain-pickled tensor still loads through the same route
+    t = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    back = legacy._SnapshotUnpickler(__import__("io").BytesIO(pickle.dumps({"t": t}))).load()["t"]
+    assert torch.equal(back, t)
+
+
 @pytest.mark.gpu
 def test_snapshot_sample_matches_reference_generator():
     """load_model_inference(model_backbone='stylegan2') -> G_ema; inference.sample with truncation reproduces the image the
