@@ -154,17 +154,22 @@ class KernelTimer:
                 if last[0] == 2:
                     return "icg_pgemm_nn_kernel<%d, %d>" % (last[2], 1 if last[3] == 4 else 2)
                 return "%s<0, 0, %d>" % (pk, last[2])
+
+            def wg_gemm():       # ... and the weight-gradient one
+                if last[0] == 3:
+                    return "icg_pgemm_tn_kernel<%d, %d>" % (last[2], 1 if last[3] == 4 else 2)
+                return "%s<1, 1, %d>" % (pk, last[2])
             if mode == "from_v":
-                kname = "composite: weight gradient from the saved V planes (wino4_dy_kernel + %d batched split-K %s<1, 1, %d> GEMMs + reduce + wino4_dw_kernel)" % (args[sl + 5], pk, last[2])
+                kname = "composite: weight gradient from the saved V planes (wino4_dy_kernel + %d batched split-K %s GEMMs + reduce + wino4_dw_kernel)" % (args[sl + 5], wg_gemm())
             elif mode in ("rs_up", "rs_down"):
                 kind = (name[:-5] if name.endswith("_relu") else name).rsplit("_", 1)[1]
                 kname = "composite: %s-fused conv %s in the 25-plane F(4x4,3x3) domain (transforms + 25 batched %s GEMMs)" % (
                     "upsample" if mode == "rs_up" else "avgpool", kind,
-                    ("%s<1, 1, %d>" % (pk, last[2])) if kind == "wgrad" else fwd_gemm())
+                    wg_gemm() if kind == "wgrad" else fwd_gemm())
             elif mode in ("wino", "wino4"):     # three kernels behind one entry point: not comparable with a single rocprof row
-                kname = (("composite: wino4_input_kernel + wino4_dy_kernel + %s<1, 1, %d> (36 batched split-K GEMMs) + reduce + wino4_dw_kernel" % (pk, last[2])
+                kname = (("composite: wino4_input_kernel + wino4_dy_kernel + %s (36 batched split-K GEMMs) + reduce + wino4_dw_kernel" % wg_gemm()
                           if mode == "wino4" else
-                          "composite: wino_input_kernel + wino_dy_kernel + %s<1, 1, %d> (16 batched split-K GEMMs) + reduce + wino_dw_kernel" % (pk, last[2]))
+                          "composite: wino_input_kernel + wino_dy_kernel + %s (16 batched split-K GEMMs) + reduce + wino_dw_kernel" % wg_gemm())
                          if name.endswith("wgrad") else
                          ("composite: wino4_input_kernel + %s (36 batched GEMMs) + wino4_output_kernel" % fwd_gemm()
                           if mode == "wino4" else
@@ -219,6 +224,8 @@ class KernelTimer:
             kname = "void %s<%s, %d>(GemmP)" % (kern, mode, int(tn) % 10)
             if int(amode) == 2:          # second-generation plane GEMM (pgemm.hip): <16-column tiles per wave, accumulation levels>
                 kname = "void icg_pgemm_nn_kernel<%d, %d>(PgemmP)" % (int(tn) % 10, 1 if int(tn) >= 10 else 2)
+            elif int(amode) == 3:
+                kname = "void icg_pgemm_tn_kernel<%d, %d>(PgemmTnP)" % (int(tn) % 10, 1 if int(tn) >= 10 else 2)
             a = out.setdefault(kname, [0.0, 0.0, 0, 0.0, 0.0])
             a[0] += alg; a[1] += ms * 1e-3; a[2] += int(n); a[3] += flops; a[4] += byt
         return out

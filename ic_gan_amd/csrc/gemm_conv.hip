@@ -1068,6 +1068,8 @@ void icg_gemm_mark_planes(int on) { g_gemm_planes = on; }
 // pgemm.hip; returns 1 when the shape is not one it takes
 int icg_pgemm_nn_launch(const float* A, const float* B, float* C, int M, int N, int K, long ldc, long sA, long sB, long sC,
                         int planes, float alpha, int levels, hipStream_t st, int* tn_out);
+int icg_pgemm_tn_launch(const float* A, const float* B, float* C, int M, int N, int K, long sA, long sB, int planes, int kchunk,
+                        int slices, int levels, hipStream_t st, int* tn_out);
 
 // deterministic second stage of split-K: out[i] = sum_z slab[z][i]
 __global__ void icg_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n,
@@ -1888,6 +1890,25 @@ extern "C" int icg_gemm_tn_batched(const float* A, const float* B, float* C, int
   const bool vec = al && (M % 4 == 0) && (N % 4 == 0);
   const bool small = ((long)M * K < 0x7fffffffL) && ((long)N * K < 0x7fffffffL);
   hipStream_t st = (hipStream_t)stream;
+  if (g_gemm_planes && strideC == (int64_t)M * N) {
+    // second-generation weight-gradient plane GEMM (pgemm.hip): K-slices in multiples of 32 rows, same slab layout and reduction
+    const int kchunk2 = (int)(icg_cdiv(icg_cdiv(K, S > 1 ? S : 1), 32) * 32);
+    const int splits2 = (int)icg_cdiv(K, kchunk2);
+    int nt2 = 0;
+    const int rc2 = icg_pgemm_tn_launch(A, B, splits2 > 1 ? (float*)workspace : C, M, N, K, strideA, strideB, batch, kchunk2, splits2,
+                                        2, st, &nt2);
+    if (rc2 != 1) {
+      if (rc2 != ICG_OK) return rc2;
+      g_last_variant[0] = 3; g_last_variant[1] = 1; g_last_variant[2] = nt2; g_last_variant[3] = 2;
+      if (splits2 == 1) return ICG_OK;
+      const long n2 = (long)M * N;
+      long blocks2 = icg_cdiv(n2, 256);
+      if (blocks2 > 1024) blocks2 = 1024;
+      hipLaunchKernelGGL(splitk_reduce_batched_kernel, dim3((unsigned)blocks2, (unsigned)batch), dim3(256), 0, st,
+                         (const float*)workspace, C, n2, splits2);
+      return icg_check_launch();
+    }
+  }
   if (S <= 1) {
     p.C = C; p.strideC = strideC; p.kchunk = 0; p.bsplit = 0;
     return launch_gemm<A_M, B_N>(p, vec, batch, st, small);

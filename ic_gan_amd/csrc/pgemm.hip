@@ -184,6 +184,146 @@ __global__ __launch_bounds__(512, 4) void icg_pgemm_nn_kernel(PgemmP p) {
   }
 }
 
+// ---- weight-gradient plane GEMM: C[z][s] = A[z]^T B[z] over the K-slice s, A [K][M] (V planes: tiles x Cin), B [K][N] (transformed
+// dy: tiles x Cout), K = tiles (long; split into slices whose partial slabs a second kernel sums in fixed order).  Same pipeline
+// as above; the operands are M- / N-contiguous, so a K-tile's LDS image is [16 k][128 m] (512-byte rows, two per DMA
+// instruction) and an MFMA operand is one float per lane: lane (r, kk) of k-step s reads row 4 s + kk, column r.  The two
+// k-rows a 32-lane LDS group touches (kk = 0 / 1) differ by 128 floats = the same banks, so odd k-rows are stored with their
+// 16-byte chunks XOR 4 (columns XOR 16): source-side permutation again, applied to the read address as well.
+struct PgemmTnP {
+  const float* A;
+  const float* B;
+  float* C;               // slabs: [plane][slice][M][N]  (slices == 1: the result itself)
+  int M, N, K;
+  long sA, sB;            // per-plane strides (elements)
+  int kchunk, slices;     // K-rows per slice (multiple of 32), slices per plane
+  int tiles_n, tiles_mn;
+  unsigned total;         // tiles_mn * planes * slices
+  int swz;
+};
+
+template <int NT, int LEVELS>
+__global__ __launch_bounds__(512, 4) void icg_pgemm_tn_kernel(PgemmTnP p) {
+  constexpr int BM = 128, BN = 32 * NT, BK = 16;
+  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, SLOT = A_BYTES + B_BYTES, NBUF = 3;
+  constexpr int BCH = BN / 4;                                       // 16-byte chunks per B row: 32 or 24
+  __shared__ __attribute__((aligned(1024))) char lds[NBUF * SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv & 3, wn = wv >> 2;
+  const int r = lane & 15, kk = lane >> 4;
+
+  unsigned t = blockIdx.x;
+  if (p.swz) {
+    const unsigned tot = p.total, q = tot >> 3, rr = tot & 7u, xcd = t & 7u;
+    t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
+  }
+  const int zs = (int)(t / (unsigned)p.tiles_mn);                   // plane * slices + slice
+  const int tile = (int)(t - (unsigned)zs * (unsigned)p.tiles_mn);
+  const int z = zs / p.slices, sl = zs - z * p.slices;
+  const int nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int kbeg = sl * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+  const int nk = (kend - kbeg) / BK;                                // even
+  const float* __restrict__ Ag = p.A + (long)z * p.sA + (long)kbeg * p.M;
+  const float* __restrict__ Bg = p.B + (long)z * p.sB + (long)kbeg * p.N;
+
+  // DMA role: k-rows 2 wv, 2 wv + 1 of both tiles; columns beyond the matrix are clamped (they only feed masked outputs)
+  const int arow = 2 * wv + (lane >> 5), achunk = (lane & 31) ^ (4 * (arow & 1));
+  const unsigned voffA = ((unsigned)arow * (unsigned)p.M + (unsigned)min(m0 + 4 * achunk, p.M - 4)) * 4u;
+  const int bl = lane % BCH;
+  const int brow = 2 * wv + min(lane / BCH, 1), bchunk = bl ^ (4 * (brow & 1));
+  const unsigned voffB = ((unsigned)brow * (unsigned)p.N + (unsigned)min(n0 + 4 * bchunk, p.N - 4)) * 4u;
+  const bool dma_b_lane = (BCH == 32) || (lane < 2 * BCH);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned ldsA = lds_base + (unsigned)wv * 1024u, ldsB = lds_base + (unsigned)A_BYTES + (unsigned)wv * (2u * BN * 4u);
+  const long a_step = (long)BK * p.M, b_step = (long)BK * p.N;      // elements per K-tile
+  auto issue = [&](int kt, unsigned slot_off) {
+    const int kc = min(kt, nk - 1);
+    pg_dma16(Ag + kc * a_step, voffA, ldsA + slot_off);
+    if (dma_b_lane) pg_dma16(Bg + kc * b_step, voffB, ldsB + slot_off);
+  };
+  auto next_slot = [](unsigned off) -> unsigned { return off == (unsigned)((NBUF - 1) * SLOT) ? 0u : off + (unsigned)SLOT; };
+
+  // fragment addresses: k-step s reads row 4 s + kk (parity kk & 1), column (tile base + r) ^ 16 (kk & 1)
+  // (the XOR moves a lane between adjacent 16-column MFMA tiles, so every tile gets its own address register)
+  const int px = 16 * (kk & 1);
+  const char* fa[2];
+  const char* fb[NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) fa[i] = lds + kk * (BM * 4) + ((32 * wm + 16 * i + r) ^ px) * 4;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) fb[j] = lds + A_BYTES + kk * (BN * 4) + ((16 * NT * wn + 16 * j + r) ^ px) * 4;
+
+  f32x4 acc[2][NT], acc2[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+  issue(0, 0u);
+  issue(1, (unsigned)SLOT);
+
+  auto tile_step = [&](int kt, unsigned cur, auto flush_c) {
+    constexpr bool FLUSH = decltype(flush_c)::value;
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(kt + 2, next_slot(next_slot(cur)));
+    float a[4][2], b[4][NT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[s][i] = *reinterpret_cast<const float*>(fa[i] + cur + s * (4 * BM * 4));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[s][j] = *reinterpret_cast<const float*>(fb[j] + cur + s * (4 * BN * 4));
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (LEVELS == 2 && FLUSH && s == 0) {
+            acc2[i][j] += acc[i][j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][i], b[s][j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  unsigned cur = 0u;
+  for (int kt = 0; kt < nk; kt += 2) {
+    tile_step(kt, cur, std::true_type{});
+    cur = next_slot(cur);
+    tile_step(kt + 1, cur, std::false_type{});
+    cur = next_slot(cur);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* __restrict__ Cg = p.C + (long)zs * p.M * p.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int mrow = m0 + 32 * wm + 16 * i + 4 * kk;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + 16 * NT * wn + 16 * j + r;
+      const f32x4 v = (LEVELS == 2) ? acc[i][j] + acc2[i][j] : acc[i][j];
+      if (n < p.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (mrow + e < p.M) Cg[(long)(mrow + e) * p.N + n] = v[e];
+      }
+    }
+  }
+}
+
 static bool pgemm_enabled() {      // measurement switch (ICG_PGEMM=0: first-generation plane GEMMs), read once per process
   static const bool on = [] { const char* e = getenv("ICG_PGEMM"); return !(e && e[0] == '0'); }();
   return on;
@@ -216,6 +356,39 @@ int icg_pgemm_nn_launch(const float* A, const float* B, float* C, int M, int N, 
   } else {
     if (levels == 2) hipLaunchKernelGGL((icg_pgemm_nn_kernel<3, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((icg_pgemm_nn_kernel<3, 1>), grid, block, 0, st, p);
+  }
+  if (tn_out) *tn_out = nt;
+  return icg_check_launch();
+}
+
+// -> ICG_OK when launched, 1 when not applicable.  C: slabs [planes][slices][M][N]; kchunk: K-rows per slice
+int icg_pgemm_tn_launch(const float* A, const float* B, float* C, int M, int N, int K, long sA, long sB, int planes, int kchunk,
+                        int slices, int levels, hipStream_t st, int* tn_out) {
+  if (!pgemm_enabled()) return 1;
+  const int nt = (N % 128 == 0) ? 4 : ((N % 96 == 0) ? 3 : 0);
+  if (nt == 0 || M % 4 != 0 || M < 4 || K % 32 != 0 || kchunk % 32 != 0 || kchunk < 32 || planes < 1 || slices < 1) return 1;
+  if ((long)(slices - 1) * kchunk >= K) return 1;
+  if ((uintptr_t)A % 16 || (uintptr_t)B % 16 || sA % 4 || sB % 4) return 1;
+  if ((long)M * K >= (1L << 30) || (long)N * K >= (1L << 30)) return 1;
+  PgemmTnP p{};
+  p.A = A; p.B = B; p.C = C;
+  p.M = M; p.N = N; p.K = K;
+  p.sA = sA; p.sB = sB;
+  p.kchunk = kchunk; p.slices = slices;
+  p.tiles_n = N / (32 * nt);
+  const long tiles_mn = icg_cdiv(M, 128) * p.tiles_n, total = tiles_mn * planes * slices;
+  if (total <= 0 || total >= 0x7fffffffL) return 1;
+  p.tiles_mn = (int)tiles_mn;
+  p.total = (unsigned)total;
+  static const bool no_swz = [] { const char* e = getenv("ICG_NO_XCD_SWIZZLE"); return e && e[0] == '1'; }();
+  p.swz = (total >= 16 && !no_swz) ? 1 : 0;
+  dim3 grid((unsigned)total), block(512);
+  if (nt == 4) {
+    if (levels == 2) hipLaunchKernelGGL((icg_pgemm_tn_kernel<4, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((icg_pgemm_tn_kernel<4, 1>), grid, block, 0, st, p);
+  } else {
+    if (levels == 2) hipLaunchKernelGGL((icg_pgemm_tn_kernel<3, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((icg_pgemm_tn_kernel<3, 1>), grid, block, 0, st, p);
   }
   if (tn_out) *tn_out = nt;
   return icg_check_launch();

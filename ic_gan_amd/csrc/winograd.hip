@@ -301,6 +301,18 @@ extern "C" int icg_gemm_tn_batched(const float* A, const float* B, float* C, int
                                    int64_t strideB, int64_t strideC, int batch, void* workspace, size_t workspace_bytes,
                                    void* stream);
 
+extern "C" size_t icg_plane_gemm_tn_workspace_bytes(int M, int N, int K, int planes) {
+  return icg_gemm_tn_batched_workspace_bytes(M, N, K, planes);
+}
+
+extern "C" int icg_plane_gemm_tn(const float* A, const float* B, float* C, int M, int N, int K, int planes, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && planes > 0);
+  PlanesScope ps(stream, planes, M, N, K);
+  return icg_gemm_tn_batched(A, B, C, M, N, K, (int64_t)K * M, (int64_t)K * N, (int64_t)M * N, planes, workspace, workspace_bytes,
+                             stream);
+}
+
 static size_t wino_al(size_t b) { return (b + 255) & ~(size_t)255; }
 
 extern "C" size_t icg_conv2d_wino_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {

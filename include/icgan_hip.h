@@ -282,6 +282,16 @@ int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int
 int icg_plane_gemm(const float* A, const float* B, float* C, int M, int N, int K, int planes, float alpha, void* stream);
 
 /*
+ * ... and its weight-gradient counterpart: C[z] = A[z]^T B[z], A [planes][K][M] (V planes: tiles x Cin), B [planes][K][N]
+ * (transformed dy: tiles x Cout), C [planes][M][N]; K = tiles is long and is cut into slices whose partial slabs (workspace) are
+ * summed in fixed order.  Launched as icg_conv2d_wino4_wgrad* launch it (second-generation kernel where M % 4 == 0, K % 32 == 0
+ * and N is a multiple of 128 or 96).
+ */
+size_t icg_plane_gemm_tn_workspace_bytes(int M, int N, int K, int planes);
+int icg_plane_gemm_tn(const float* A, const float* B, float* C, int M, int N, int K, int planes, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/*
  * Measurement support (no reference counterpart): template arguments {AMODE, BMODE, TN, PATH} of the last
  * icg_gemm_kernel<AMODE, BMODE, TN, PATH> launched by the calling host thread through any of the conv / GEMM
  * entry points above ({-1,...} before the first launch; {-2, 0 fprop / 1 wgrad, Cout, Cin} when the direct

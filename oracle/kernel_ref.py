@@ -390,6 +390,14 @@ def icg_plane_gemm(A, Bm, C, M, N, K, planes, alpha):
     icg_gemm_batched(A, Bm, C, M, N, K, 0, 1, M * K, N * K, M * N, planes, alpha)
 
 
+def icg_plane_gemm_tn_workspace_bytes(M, N, K, planes):
+    return 16
+
+
+def icg_plane_gemm_tn(A, Bm, C, M, N, K, planes, workspace, workspace_bytes):
+    icg_gemm_batched(A, Bm, C, M, N, K, 1, 0, K * M, K * N, M * N, planes, 1.0)
+
+
 # ---------------------------------------------------------------- BN
 def icg_bn_workspace_bytes(rows, C):
     return 2 * C * 4

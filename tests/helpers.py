@@ -50,6 +50,7 @@ def noise_grad_names(gold, prefix, rel=1e-3):
 
 
 SOFT_REPORT = None      # tools/parity_report.py sets this to a list: failures are recorded as (label, err/tol) instead of raised
+STATS = None            # ... and this to a list: (group label, tensor name, golden rms, tolerance, samples) of every compared tensor
 
 
 def _fail(cond, msg, ratio):
@@ -81,6 +82,8 @@ def check_group(gold, prefix, tensors, rtol, atol, what="", noise_floor=2e-3, ex
         scale = max(scales[i], floor)
         tol = atol + rtol * scale + (extra_atol or {}).get(n, 0.0)
         err = float(np.max(np.abs(samp - gsamp)))
+        if STATS is not None:
+            STATS.append((what, n, scales[i], tol, samp))
         if err / tol > worst[0]:
             worst = (err / tol, n)
         _fail(err <= tol, f"{what}{n}: samples differ, max abs {err:.3e} > tol {tol:.3e} (rms {scales[i]:.3e})", err / tol)

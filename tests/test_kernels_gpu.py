@@ -504,6 +504,45 @@ def test_plane_gemm(case):
     assert rel < 3e-6, rel
 
 
+PLANE_GEMM_TN_CASES = [
+    # M (Cin), N (Cout), K (tiles), planes
+    (96, 96, 64, 2),              # one slice, 96-column tile (lanes 48..63 masked in the B DMA), M < 128: clamped columns
+    (128, 128, 32, 3),            # shortest K: prologue + over-fetch only
+    (192, 384, 4096, 4),          # several slices, ragged last m-tile (192 = 128 + 64), three n-tiles
+    (384, 192, 2048, 25),         # 25 planes, 96-column tiles
+    (768, 768, 1024, 2),          # many output tiles per plane
+    (96, 192, 131072, 2),         # the product's longest K (D block 1 conv1 at B = 128): many slices
+    (100, 96, 4096, 2),           # M % 4 == 0 but not a multiple of 16
+    (96, 160, 4096, 2),           # N takes neither tile -> first generation
+    (96, 96, 4112, 2),            # K % 32 != 0 -> first generation
+]
+
+
+@pytest.mark.parametrize("case", PLANE_GEMM_TN_CASES)
+def test_plane_gemm_tn(case):
+    M, N, K, planes = case
+    L = _L()
+    A = rnd(planes, K * M, seed=13)
+    Bm = rnd(planes, K * N, seed=14, scale=1 / np.sqrt(K))
+    nb = L.query("icg_plane_gemm_tn_workspace_bytes", M, N, K, planes)
+    C = torch.full((planes, M * N), float("nan"))
+    Ad, Bd, Cd = A.cuda(), Bm.cuda(), C.cuda()
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        Cd.fill_(float("nan"))
+        L.call("icg_plane_gemm_tn", Ad, Bd, Cd, M, N, K, planes, ws, nb)
+        torch.cuda.synchronize()
+        outs.append(Cd.clone())
+    assert torch.equal(outs[0], outs[1])
+    ref64 = torch.bmm(A.view(planes, K, M).double().transpose(1, 2), Bm.view(planes, K, N).double())
+    got = outs[0].cpu().double().view(planes, M, N)
+    assert torch.isfinite(got).all()
+    rel = float((got - ref64).norm() / ref64.norm())
+    assert rel < 3e-6, rel
+    close(outs[0].cpu(), ref64.float().reshape(planes, M * N), rtol=1e-4, atol_rel=2e-5, what=f"plane gemm tn {case}")
+
+
 def test_plane_gemm_is_deterministic_and_leaves_neighbours_alone():
     """same launch twice -> bit-identical (no race between the DMA ring and the fragment reads shows up as run-to-run
     differences); rows / planes beyond the problem are not written (ragged M, guard regions around C)."""

@@ -27,16 +27,51 @@ ROUTES = {   # --routes: which layers take a Winograd form (production threshold
 }
 
 
+def error_stats(case):
+    """--stats: per gradient tensor of a real-width case, the distance of the HIP result and of the fp32 reference from the
+    fp64 reference over the stored samples (4096 per tensor): rms and max, in units of the tensor's rms.  Says whether the HIP
+    path is as close to the exact gradient as the reference's own fp32 arithmetic is."""
+    import json
+    f64 = os.path.join(H.GOLDEN_DIR, "biggan_%s_f64.npz" % case)
+    if not os.path.exists(f64):
+        return
+    g32, g64 = H.load_golden(case), np.load(f64, allow_pickle=False)
+    rows = []
+    for what, name, rms, tol, samp in H.STATS:
+        prefix = {"G grad ": "step1/G_grad/", "D grad ": "step1/D_grad/"}.get(what)
+        if prefix is None:
+            continue
+        names = json.loads(str(g32[prefix + "names"]))
+        i = names.index(name)
+        r32, r64 = g32[prefix + "samp"][i], g64[prefix + "samp"][i]
+        k = int(np.count_nonzero(r64)) or 1
+        s = max(rms, 1e-30)
+        e_hip64, e_ref, e_hip32 = samp - r64, r32 - r64, samp - r32
+        rows.append((what + name, k, rms, np.sqrt((e_hip64 ** 2).sum() / k) / s, np.abs(e_hip64).max() / s,
+                     np.sqrt((e_ref ** 2).sum() / k) / s, np.abs(e_ref).max() / s, np.abs(e_hip32).max() / tol))
+    rows.sort(key=lambda r: -r[4])
+    print("  STATS %s: distance from the fp64 reference in units of the tensor rms -- HIP rms / max | fp32 reference rms / max | HIP vs fp32 golden max / tol" % case)
+    for r in rows[:12]:
+        print("    %-40s n=%5d rms %.2e   HIP %.2e / %.2e | ref32 %.2e / %.2e | x%.2f" % r)
+    hip = np.array([r[3] for r in rows]); ref = np.array([r[5] for r in rows])
+    print("    all %d tensors: median HIP rms error %.2e, median fp32-reference rms error %.2e, worst ratio HIP/ref of the rms errors %.1f (%s)" % (
+        len(rows), np.median(hip), np.median(ref), float(np.max(hip / np.maximum(ref, 1e-12))), rows[int(np.argmax(hip / np.maximum(ref, 1e-12)))][0]))
+
+
 def main():
     args = sys.argv[1:]
     routes = None
+    stats = "--stats" in args
+    if stats:
+        args.remove("--stats")
     if "--routes" in args:
         args.remove("--routes")
         routes = list(ROUTES)
-    cases = args or (H.REAL_CASES + H.CASES)
+    cases = args or (H.REAL_CASES + H.BENCH_CASES + H.CASES)
     for case in cases:
-        for wino in (routes or ([-1, 0] if case in H.REAL_CASES else T.WINO_VARIANTS)):
+        for wino in (routes or ([-1, 0] if case in H.REAL_CASES + H.BENCH_CASES else T.WINO_VARIANTS)):
             H.SOFT_REPORT = []
+            H.STATS = [] if stats else None
             mp = pytest.MonkeyPatch()
             t0 = time.time()
             err = ""
@@ -59,7 +94,10 @@ def main():
             line = "; ".join("%s x%.2f" % (m[:70], r) for m, r in worst.values())
             tag = ("route=%-10s" % label) if routes else ("wino=%2d" % wino)
             print("PARITY %-18s %s  %5.1fs  %s%s" % (case, tag, time.time() - t0, line or "ok (all ratios <= 1)", err), flush=True)
+            if stats:
+                error_stats(case)
     H.SOFT_REPORT = None
+    H.STATS = None
 
 
 if __name__ == "__main__":

@@ -50,3 +50,36 @@ for name, M, N, K, planes in SHAPES:
     tot += t
     print(f"{name:38s} M={M:7d} N={N:5d} K={K:5d} z={planes:2d}  {t * 1e3:8.3f} ms  {tf:6.1f} TF  {tf / PEAK:5.3f}  err {err:.2e}", flush=True)
 print(f"sum {tot * 1e3:.3f} ms")
+
+# weight-gradient plane GEMMs: C[z] = A[z]^T B[z], A [K][M] = V planes (tiles x Cin), B [K][N] = transformed dy (tiles x Cout)
+TN_SHAPES = [
+    ("G.b0.conv2 1536->1536 @8   F4  B64", 1536, 1536, 64 * 2 * 2, 36),
+    ("G.b2.conv2 768->768 @32    F4  B64", 768, 768, 64 * 8 * 8, 36),
+    ("G.b3.conv1 768->384 up@64  RS  B64", 768, 384, 64 * 16 * 16, 25),
+    ("G.b3.conv2 384->384 @64    F4  B64", 384, 384, 64 * 16 * 16, 36),
+    ("D.b3.conv1 384->768 @32    F4 B128", 384, 768, 128 * 8 * 8, 36),
+    ("D.b2.conv1 192->384 @64    F4 B128", 192, 384, 128 * 16 * 16, 36),
+    ("G.b4.conv2 192->192 @128   F4  B64", 192, 192, 64 * 32 * 32, 36),
+    ("D.b1.conv1 96->192 @128    F4 B128", 96, 192, 128 * 32 * 32, 36),
+    ("G.b5.conv1 192->96 up@256  RS  B64", 192, 96, 64 * 64 * 64, 25),
+    ("G.b5.conv2 96->96 @256     F4  B64", 96, 96, 64 * 64 * 64, 36),
+]
+if len(sys.argv) > 1:
+    TN_SHAPES = [s for s in TN_SHAPES if sys.argv[1] in s[0]]
+print("---- weight-gradient plane GEMMs (A^T B, split-K + reduction included)")
+tot = 0.0
+for name, M, N, K, planes in TN_SHAPES:
+    g = torch.Generator(device="cuda").manual_seed(2)
+    A = torch.randn(planes, K, M, device="cuda", generator=g)
+    Bm = torch.randn(planes, K, N, device="cuda", generator=g) / K ** 0.5
+    C = torch.empty(planes, M, N, device="cuda")
+    nb = L.query("icg_plane_gemm_tn_workspace_bytes", M, N, K, planes)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda")
+    t = ev_time(lambda: L.call("icg_plane_gemm_tn", A, Bm, C, M, N, K, planes, ws, nb))
+    tf = 2.0 * planes * M * N * K / t / 1e12
+    zs = [0, planes - 1]
+    ref = torch.bmm(A[zs].double().transpose(1, 2), Bm[zs].double())
+    err = float((C[zs].double() - ref).norm() / ref.norm())
+    tot += t
+    print(f"{name:38s} M={M:5d} N={N:5d} K={K:7d} z={planes:2d}  {t * 1e3:8.3f} ms  {tf:6.1f} TF  {tf / PEAK:5.3f}  err {err:.2e}", flush=True)
+print(f"sum {tot * 1e3:.3f} ms")
