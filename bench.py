@@ -258,6 +258,20 @@ class KernelTimer:
         return agg
 
 
+def csrc_sha256():
+    """content hash of the kernel sources (ic_gan_amd/csrc/*.hip, *.h): tools/pmc_hbm.py stores it in the traffic file, the bench
+    line compares it with the tree it runs from (`traffic_stale`) -- the GPU box has no .git to ask"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ic_gan_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(kname):
     """HBM bytes per launch of `kname` from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE
     / --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 correction; tools/pmc_hbm.py writes the
@@ -270,6 +284,7 @@ def measured_traffic(kname):
             table = json.load(f)
     except (OSError, ValueError, IndexError):
         return None, None, None, None
+    measured_traffic.stale = table.get("csrc_sha256") != csrc_sha256()      # kernels changed since the PMC passes were taken
     per_launch = table.get("kernels", {}).get(kname, {}).get("hbm_bytes_per_launch")
     steps = table.get("steps_profiled", 3)          # r01 file: `--steps 2 --warmup 1` = 3 steps in the profiled process
     total = sum(k["launches"] * k["hbm_bytes_per_launch"] for k in table.get("kernels", {}).values())
@@ -297,7 +312,8 @@ def assemble_roofline(timer, steps, elapsed, with_step_traffic=True):
     t_hbm = (step_hbm_gb / PEAK_HBM_GBPS * 1e3) if step_hbm_gb else None
     return {"bound": "mfma", "kernel": variant, "achieved": round(exe_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(exe_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(byt / n),
+            "traffic_source": traffic_src, "traffic_stale": (getattr(measured_traffic, "stale", None) if traffic_src else None),
+            "algorithmic_bytes_per_launch": round(byt / n),
             "algorithmic_tflops": round(alg_tf, 2), "algorithmic_speedup": round(alg_tf / exe_tf, 3),
             "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
             "executed_gflop_per_launch_avg": round(exe / n / 1e9, 3),
@@ -669,6 +685,13 @@ def main():
                     help="ablation: ReLU backward of D's layers as a separate pass instead of the data-gradient epilogue")
     ap.add_argument("--sync-bn", action="store_true", help="cross-replica BN statistics over RCCL (cfg3 variant)")
     ap.add_argument("--fp16", action="store_true", help="cfg4: the reference's cfg=auto precision (num_fp16_res=4, conv_clamp=256)")
+    ap.add_argument("--accumulate", type=int, default=1,
+                    help="gradient accumulation rounds per phase (num_D_accumulations = num_G_accumulations); `--accumulate 4 --batch 16` is "
+                         "the shipped cfg3 schedule (cc_icgan_res256.json:22-24,40): 64 images per GPU and step as 4 x 16")
+    ap.add_argument("--no-kernel-timer", action="store_true",
+                    help="no HIP-event instrumentation at all (no roofline object): the un-instrumented step time as the value")
+    ap.add_argument("--no-uninstrumented-leg", action="store_true",
+                    help="skip the second, un-instrumented timed region the N = 1 run reports beside the instrumented one")
     args = ap.parse_args()
 
     if args.cpu_baseline_only:          # child process of the N=1 run: bounded CPU sample, prints one JSON object
@@ -722,6 +745,8 @@ def main():
     cfg.update(over)
     if args.sync_bn:
         cfg["sync_bn"] = True
+    acc = max(args.accumulate, 1)
+    cfg["num_D_accumulations"] = cfg["num_G_accumulations"] = acc
     from ic_gan_amd import train_fns, utils
     utils.seed_rng(0 + rank)
     M, G, D, G_ema, ema, opt_g, opt_d, init = build_models(cfg, device, args.init)
@@ -736,11 +761,30 @@ def main():
     sampler = conditioning_sampler(cfg, dim_z, batch, device, seed=1000 + rank)
     train = train_fns.GAN_training_function(G, D, GD, ema, state, cfg, sampler, embedded_optimizers=False,
                                             device=device, batch_size=batch)
-    x, y, f = synthetic_batch(cfg, batch, seed=7 + rank)
+    x, y, f = synthetic_batch(cfg, batch * acc, seed=7 + rank)      # train() consumes batch x num_D_accumulations real images
     x, y, f = x.to(device), (y.to(device) if y is not None else None), (f.to(device) if f is not None else None)
 
     timer = KernelTimer()
-    timer.install()
+    if not args.no_kernel_timer:
+        timer.install()
+    comm = None
+    if use_ddp:
+        # what the step all-reduces: a counting communication hook on both wrappers (bytes, buckets); the hook otherwise does
+        # what the default one does (average).  `exposed_ms_per_step` below = step time with - without the collectives.
+        class _Comm:
+            def __init__(self):
+                self.bytes = self.buckets = 0
+
+        def _hook(state, bucket):
+            buf = bucket.buffer()
+            state.bytes += buf.numel() * buf.element_size()
+            state.buckets += 1
+            buf.div_(dist.get_world_size())
+            return dist.all_reduce(buf, async_op=True).get_future().then(lambda fut: fut.value()[0])
+
+        comm = {"G": _Comm(), "D": _Comm()}
+        G.register_comm_hook(comm["G"], _hook)
+        D.register_comm_hook(comm["D"], _hook)
 
     def one_step():
         state["itr"] += 1
@@ -752,8 +796,10 @@ def main():
     if use_ddp:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
-    timer.planes(True)
+    if comm:
+        comm["G"].bytes = comm["G"].buckets = comm["D"].bytes = comm["D"].buckets = 0
+    timer.enabled = not args.no_kernel_timer
+    timer.planes(not args.no_kernel_timer)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         metrics = one_step()
@@ -768,19 +814,66 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    def timed_region(n):
+        """a further timed region of n steps, bracketed like the one above (barrier + synchronize, maximum over the ranks)"""
+        if use_ddp:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            one_step()
+        torch.cuda.synchronize()
+        if use_ddp:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        if use_ddp:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    uninstr = None
+    if not args.no_kernel_timer and not args.no_uninstrumented_leg:
+        # the figure above is measured with the HIP-event brackets of KernelTimer / icg_planes_timing active; the same K steps again
+        # without any instrumentation, reported beside it
+        timer.planes(False)
+        uninstr = timed_region(args.steps)
+    comm_report = None
+    if comm:
+        per_step = {k: {"allreduce_bytes_per_step": v.bytes // args.steps, "buckets_per_step": v.buckets // args.steps}
+                    for k, v in comm.items()}
+        # exposed (non-overlapped) communication: the same steps with every collective of the two wrappers suppressed (no_sync:
+        # each rank then trains on its own gradients -- a timing leg only, run after the measurement)
+        import contextlib
+        with G.no_sync(), D.no_sync():
+            t_nosync = timed_region(args.steps)
+        base = uninstr if uninstr is not None else elapsed
+        comm_report = {**per_step, "ms_per_step_without_collectives": round(t_nosync / args.steps * 1e3, 3),
+                       "exposed_ms_per_step": round((base - t_nosync) / args.steps * 1e3, 3),
+                       "hook": "counting comm hook (default averaging all-reduce); train_fns.COMM_SAVINGS=%s" % train_fns.COMM_SAVINGS}
+
     if rank == 0:
-        roof = assemble_roofline(timer, args.steps, elapsed, with_step_traffic=(args.workload == "cfg3"))
+        roof = None if args.no_kernel_timer else assemble_roofline(timer, args.steps, elapsed,
+                                                                    with_step_traffic=(args.workload == "cfg3" and acc == 1))
         out = {
             "metric": "images/sec G+D train step, IC-GAN BigGAN 256^2 bs=64/GPU" if args.workload == "cfg3"
             else ("images/sec G+D train step, IC-GAN BigGAN-deep 256^2 ch=128 bs=128/GPU (cfg5, secondary workload)"
                   if args.workload == "cfg5" else f"images/sec G+D train step, IC-GAN BigGAN ({args.workload})"),
-            "value": round(batch * world * args.steps / elapsed, 3), "unit": "images/sec", "n_gpus": world,
+            "value": round(batch * acc * world * args.steps / elapsed, 3), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: IC-GAN {cfg.get('model', 'BigGAN')} {cfg['resolution']}x{cfg['resolution']} ch={cfg['G_ch']}"
                                    f" class_cond={cfg['class_cond']} instance_cond={cfg['instance_cond']} hier attn@{cfg['G_attn']},"
-                                   f" 1 D step + 1 G step + Adam x2 + EMA, fp32 exact MFMA",
-                       "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
+                                   f" 1 D step + 1 G step + Adam x2 + EMA, fp32 exact MFMA"
+                                   + (f", {acc} accumulation rounds of {batch} images per phase" if acc > 1 else "")
+                                   + ("; parity: UNPINNED (the reference has no instance-conditioned BigGAN-deep, SURVEY F5)" if args.workload == "cfg5" else ""),
+                       "batch_per_gpu": batch * acc, "micro_batch": batch, "accumulations": acc, "global_batch": batch * acc * world,
+                       "parallelism": f"dp{world}",
+                       "instrumented": not args.no_kernel_timer,
+                       "uninstrumented_ms_per_step": (round(uninstr / args.steps * 1e3, 3) if uninstr is not None else None),
+                       "uninstrumented_images_per_sec": (round(batch * acc * world * args.steps / uninstr, 3) if uninstr is not None else None),
+                       "comm": comm_report,
                        "rccl_world_size": (dist.get_world_size() if use_ddp else 1), "init": init, "sync_bn": bool(args.sync_bn), "winograd": not args.no_winograd,
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "losses_last_step": metrics},
             "roofline": roof,

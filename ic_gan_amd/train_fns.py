@@ -8,12 +8,38 @@
 
 Every forward/backward op, both Adam steps and the EMA run in the HIP kernels; this file is host control
 flow only.  Returns the same three floats (three device->host reads per step, as in the reference).
+
+Data-parallel traffic (G and D wrapped in DistributedDataParallel as trainer.py:196-210 does), COMM_SAVINGS (False restores
+the reference's pattern):
+  (1) accumulation rounds before the last run under DistributedDataParallel.no_sync() and accumulate locally; the last
+      round's all-reduce carries the sum (mean of sums == sum of means up to the fp32 rounding of the all-reduce itself).  The
+      reference all-reduces every round: num_*_accumulations x the bytes (4x for the shipped 16 x 4 schedule at 256x256);
+  (2) D runs under no_sync() in the G phase while toggle_grads has it frozen.  With find_unused_parameters=True a reducer
+      could ship the 100 M unused parameters (400 MB per step at cfg3); torch 2.10's does not (no autograd hook of the wrapper
+      fires, so nothing is marked ready) -- measured by tests/test_ddp_gloo_cpu.py with a counting communication hook -- and the
+      explicit no_sync() keeps it that way independently of the reducer's internals.
+Neither changes a result: same losses, replicas bit-identical, bucket traffic counted in the tests.
 """
 from __future__ import annotations
+
+import contextlib
 
 import torch
 
 from . import losses, utils
+
+COMM_SAVINGS = True
+
+
+def _no_sync(module, on):
+    """module.no_sync() when `module` is a DistributedDataParallel wrapper and `on`, else a null context."""
+    if on and COMM_SAVINGS and hasattr(module, "no_sync") and hasattr(module, "module"):
+        return module.no_sync()
+    return contextlib.nullcontext()
+
+
+def _frozen(module):
+    return not any(p.requires_grad for p in module.parameters())
 
 
 def dummy_training_function():
@@ -67,14 +93,15 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
             utils.toggle_grad(G, False)
         for _ in range(config["num_D_steps"]):
             opt_D.zero_grad()
-            for _ in range(config["num_D_accumulations"]):
+            for acc in range(config["num_D_accumulations"]):
                 z_, labels_g, f_g = draw(features, y, truncate=True)
-                D_fake, D_real = GD(z_, labels_g, f_g, x[counter], y[counter] if y is not None else None,
-                                    f_[counter] if f_ is not None else None, train_G=False,
-                                    split_D=config["split_D"], policy=config["DiffAugment"], DA=config["DA"])
-                D_loss_real, D_loss_fake = losses.discriminator_loss(D_fake, D_real)
-                D_loss = (D_loss_real + D_loss_fake) / float(config["num_D_accumulations"])
-                D_loss.backward()
+                with _no_sync(D, acc + 1 < config["num_D_accumulations"]):     # earlier rounds accumulate locally
+                    D_fake, D_real = GD(z_, labels_g, f_g, x[counter], y[counter] if y is not None else None,
+                                        f_[counter] if f_ is not None else None, train_G=False,
+                                        split_D=config["split_D"], policy=config["DiffAugment"], DA=config["DA"])
+                    D_loss_real, D_loss_fake = losses.discriminator_loss(D_fake, D_real)
+                    D_loss = (D_loss_real + D_loss_fake) / float(config["num_D_accumulations"])
+                    D_loss.backward()
                 counter += 1
             if config["D_ortho"] > 0.0:
                 print("using modified ortho reg in D")
@@ -84,12 +111,14 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
             utils.toggle_grad(D, False)
             utils.toggle_grad(G, True)
         opt_G.zero_grad()
-        for _ in range(config["num_G_accumulations"]):
+        d_frozen = _frozen(D)             # toggle_grads: D takes no gradient in this phase -> nothing of D's to all-reduce
+        for acc in range(config["num_G_accumulations"]):
             z_, labels_g, f_g = draw(features, y, truncate=False)
-            D_fake = GD(z_, labels_g, f_g, train_G=True, split_D=config["split_D"], policy=config["DiffAugment"],
-                        DA=config["DA"])
-            G_loss = losses.generator_loss(D_fake) / float(config["num_G_accumulations"])
-            G_loss.backward()
+            with _no_sync(D, d_frozen), _no_sync(G, acc + 1 < config["num_G_accumulations"]):
+                D_fake = GD(z_, labels_g, f_g, train_G=True, split_D=config["split_D"], policy=config["DiffAugment"],
+                            DA=config["DA"])
+                G_loss = losses.generator_loss(D_fake) / float(config["num_G_accumulations"])
+                G_loss.backward()
         if config["G_ortho"] > 0.0:
             print("using modified ortho reg in G")
             module = G.module if hasattr(G, "module") else G

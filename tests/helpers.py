@@ -51,6 +51,7 @@ def noise_grad_names(gold, prefix, rel=1e-3):
 
 SOFT_REPORT = None      # tools/parity_report.py sets this to a list: failures are recorded as (label, err/tol) instead of raised
 STATS = None            # ... and this to a list: (group label, tensor name, golden rms, tolerance, samples) of every compared tensor
+DENSE_REPORT = None     # ... and this: (tensor, sub-grid max / tol, max / tol, rms difference / tol, share of samples above tol)
 
 
 def _fail(cond, msg, ratio):
@@ -62,12 +63,31 @@ def _fail(cond, msg, ratio):
         raise AssertionError(msg)
 
 
+DENSE_EXCEED_SHARE = 1.0 / 64     # dense groups: share of a tensor's samples that may exceed the per-element tolerance ...
+DENSE_MAX_MULT = 4.0              # ... by at most this factor,
+DENSE_RMS_FRAC = 0.5              # ... while the rms of the differences stays below this fraction of the tolerance
+
+
 def check_group(gold, prefix, tensors, rtol, atol, what="", noise_floor=2e-3, extra_atol=None):
     """Compare a dict name->tensor with the packed fingerprints stored under `prefix`.
 
     Per tensor the tolerance is  atol + rtol * max(rms(golden), noise_floor * max rms in the group):
     tensors that are pure rounding noise relative to their siblings (e.g. the gradient of a conv bias
-    that feeds a BatchNorm, mathematically zero) are compared on the group's scale, not their own."""
+    that feeds a BatchNorm, mathematically zero) are compared on the group's scale, not their own.
+
+    64-sample groups (every state group; the gradients of the small goldens): max |difference| <= tolerance.
+    DENSE groups (4096 samples per tensor: the gradients of the real-width and bench-configuration cases):
+      (1) the 64-sample sub-grid (every 64th sample = the positions the 64-sample fingerprints hold) is held to the same
+          max criterion as before, and over ALL samples
+      (2) the rms of the differences <= DENSE_RMS_FRAC x tolerance,
+      (3) at most DENSE_EXCEED_SHARE of the samples exceed the tolerance (the exceedance rate a 64-sample max test admits), and
+      (4) none by more than DENSE_MAX_MULT x.
+    Why not a plain max over 4096 samples: two fp32 evaluations of a ReLU / max-pool network differ in ISOLATED elements by
+    far more than their rms difference -- units whose pre-activation lies within rounding of zero take the other branch, which
+    moves single weight-gradient elements by a few per cent of the tensor rms when the gradient sums over few pixels.  The
+    unmodified reference does this to itself: with its weights perturbed by 1e-6 (relative) its own cfg2 gradients move by
+    2e-3 rms with maxima of 7e-2 of the tensor rms, max / rms = 34 (tools/ref_sensitivity.py ->
+    profiles/r03_reference_sensitivity.txt); the HIP path against the goldens shows the same figures (2.4e-3 / 8.5e-2 / 35)."""
     names = json.loads(str(gold[prefix + "names"]))
     assert set(names) == set(tensors.keys()), (what, sorted(set(names) ^ set(tensors.keys()))[:8])
     scales = []
@@ -77,16 +97,35 @@ def check_group(gold, prefix, tensors, rtol, atol, what="", noise_floor=2e-3, ex
     worst = (0.0, None)
     for i, n in enumerate(names):
         gs, gq, gsamp = gold[prefix + "sum"][i], gold[prefix + "sq"][i], gold[prefix + "samp"][i]
-        s, q, samp = fingerprint(tensors[n], gsamp.shape[0])
+        ns = gsamp.shape[0]
+        s, q, samp = fingerprint(tensors[n], ns)
         n_el = max(tensors[n].numel(), 1)
         scale = max(scales[i], floor)
         tol = atol + rtol * scale + (extra_atol or {}).get(n, 0.0)
-        err = float(np.max(np.abs(samp - gsamp)))
+        diff = np.abs(samp - gsamp)
         if STATS is not None:
             STATS.append((what, n, scales[i], tol, samp))
-        if err / tol > worst[0]:
-            worst = (err / tol, n)
-        _fail(err <= tol, f"{what}{n}: samples differ, max abs {err:.3e} > tol {tol:.3e} (rms {scales[i]:.3e})", err / tol)
+        if ns <= NS:
+            err = float(diff.max())
+            ratio = err / tol
+            _fail(err <= tol, f"{what}{n}: samples differ, max abs {err:.3e} > tol {tol:.3e} (rms {scales[i]:.3e})", ratio)
+        else:
+            k = min(n_el, ns)                                   # samples that exist (short tensors are stored in full, zero-padded)
+            sub = float(diff[:: ns // NS].max())                # (1) the positions of the 64-sample fingerprint
+            rms_err = float(np.sqrt((diff[:k] ** 2).sum() / k))
+            share = float((diff[:k] > tol).mean())
+            err = float(diff.max())
+            ratio = max(sub / tol, rms_err / (DENSE_RMS_FRAC * tol), share / DENSE_EXCEED_SHARE, err / (DENSE_MAX_MULT * tol))
+            _fail(sub <= tol, f"{what}{n}: 64-sample sub-grid differs, max abs {sub:.3e} > tol {tol:.3e} (rms {scales[i]:.3e})", sub / tol)
+            _fail(rms_err <= DENSE_RMS_FRAC * tol, f"{what}{n}: rms difference {rms_err:.3e} > {DENSE_RMS_FRAC} x tol {tol:.3e}",
+                  rms_err / (DENSE_RMS_FRAC * tol))
+            _fail(share <= DENSE_EXCEED_SHARE, f"{what}{n}: {share:.4f} of {k} samples exceed tol {tol:.3e}", share / DENSE_EXCEED_SHARE)
+            _fail(err <= DENSE_MAX_MULT * tol, f"{what}{n}: max abs {err:.3e} > {DENSE_MAX_MULT} x tol {tol:.3e} (rms {scales[i]:.3e})",
+                  err / (DENSE_MAX_MULT * tol))
+            if DENSE_REPORT is not None:
+                DENSE_REPORT.append((what + n, sub / tol, err / tol, rms_err / tol, share))
+        if ratio > worst[0]:
+            worst = (ratio, n)
         _fail(abs(np.sqrt(q / n_el) - np.sqrt(gq / n_el)) <= 4 * tol, f"{what}{n}: rms {q} vs {gq}",
               abs(np.sqrt(q / n_el) - np.sqrt(gq / n_el)) / (4 * tol))
         _fail(abs(s - gs) <= 32 * tol * n_el ** 0.5 + atol * n_el, f"{what}{n}: sum {s} vs {gs}",

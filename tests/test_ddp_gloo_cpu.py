@@ -52,11 +52,29 @@ def _models(cfg):
     return M, G, D
 
 
-def _worker_step(rank, world, port, out):
+class _Traffic:
+    """state of a DDP communication hook that counts what a wrapper all-reduces (elements and buckets)"""
+
+    def __init__(self):
+        self.elements, self.buckets = 0, 0
+
+
+def _traffic_hook(state, bucket):
+    """... and otherwise does what the default hook does (average over the ranks)"""
+    buf = bucket.buffer()
+    state.elements += buf.numel()
+    state.buckets += 1
+    buf.div_(dist.get_world_size())
+    return dist.all_reduce(buf, async_op=True).get_future().then(lambda f: f.value()[0])
+
+
+def _worker_step(rank, world, port, out, savings=True, accumulations=1):
     from torch.nn.parallel import DistributedDataParallel as DDP
     from ic_gan_amd import train_fns, utils
     from ic_gan_amd.optim import FusedAdam
     _init(rank, world, port)
+    train_fns.COMM_SAVINGS = savings
+    CFG = dict(globals()["CFG"], num_D_accumulations=accumulations, num_G_accumulations=accumulations)
     M, G, D = _models(CFG)
     if rank == 1:                       # perturb rank 1's buffers: the per-forward broadcast must overwrite them (F3)
         with torch.no_grad():
@@ -66,20 +84,26 @@ def _worker_step(rank, world, port, out):
     opt_d = FusedAdam(D.parameters(), lr=2e-3, betas=(0.0, 0.999), eps=1e-6)
     opt_g = FusedAdam(G.parameters(), lr=1e-3, betas=(0.0, 0.999), eps=1e-6)
     Gd, Dd = DDP(G, find_unused_parameters=True), DDP(D, find_unused_parameters=True)
+    tg, td = _Traffic(), _Traffic()
+    Gd.register_comm_hook(tg, _traffic_hook)
+    Dd.register_comm_hook(td, _traffic_hook)
     GD = M.G_D(Gd, Dd, optimizer_G=opt_g, optimizer_D=opt_d)
     gb = 2
     train = train_fns.GAN_training_function(Gd, Dd, GD, ema, {"itr": 1}, CFG, synth.CondSampler(CFG, G.dim_z, gb, 50 + rank),
                                             embedded_optimizers=False, device="cpu", batch_size=gb)
-    x, y, f = synth.synth_batch(CFG, gb, seed=70 + rank)
+    x, y, f = synth.synth_batch(CFG, gb * accumulations, seed=70 + rank)
     Gd.train(); Dd.train()
     m = train(x, y, f)
     flat = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     if rank == 0:
-        out["identical"] = bool(torch.equal(gathered[0], gathered[1]))
+        out["identical"] = all(bool(torch.equal(gathered[0], g)) for g in gathered[1:])
         out["finite"] = bool(torch.isfinite(flat).all())
         out["loss"] = m
+        out["flat"] = flat.clone()
+        out["traffic"] = {"G": tg.elements, "D": td.elements, "G_params": sum(p.numel() for p in G.parameters()),
+                          "D_params": sum(p.numel() for p in D.parameters())}
     dist.destroy_process_group()
 
 
@@ -96,7 +120,7 @@ def _worker_syncbn(rank, world, port, out, split=(2, 2), skew=False):
                 if hasattr(m, "stored_mean"):
                     m.stored_mean.add_(0.37)
     Gd = DDP(G, broadcast_buffers=not skew)
-    B = 4
+    B = sum(split)
     c = synth.CondSampler(cfg, G.dim_z, B, 9)()
     z, lab, fg = c
     wts = torch.from_numpy(__import__("numpy").random.RandomState(3).standard_normal((B, 3, 32, 32))).float()
@@ -117,10 +141,10 @@ def _worker_syncbn(rank, world, port, out, split=(2, 2), skew=False):
     dist.destroy_process_group()
 
 
-def _spawn(fn, *extra):
+def _spawn(fn, *extra, world=2):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(fn, args=(2, _free_port(), out) + extra, nprocs=2, join=True)
+    mp.spawn(fn, args=(world, _free_port(), out) + extra, nprocs=world, join=True)
     return dict(out)
 
 
@@ -130,20 +154,60 @@ def test_ddp_step_keeps_replicas_identical():
     assert out["finite"] and out["identical"], out
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("split,skew", [((2, 2), False), ((3, 1), False), ((2, 2), True)])
+@pytest.mark.timeout(900)
+def test_ddp_g_phase_does_not_allreduce_the_frozen_discriminator():
+    """D's buckets must not be all-reduced in the G phase (toggle_grads froze D; 400 MB per step at cfg3 if they were): per step
+    D's traffic is exactly ONE pass over its parameters and G's one pass over G's.  Measured here with a counting
+    communication hook: torch 2.10's reducer already skips a wrapper none of whose parameters produced a gradient (no autograd
+    hook fires, so the lazily marked 'unused' parameters are never shipped), i.e. the reference's wiring (COMM_SAVINGS = False)
+    has the same traffic; train_fns additionally runs the frozen D under no_sync() so that this does not hinge on the reducer's
+    internals.  Either way the step's result is bit-identical and the replicas stay identical."""
+    lean, ref = _spawn(_worker_step, True), _spawn(_worker_step, False)
+    assert lean["finite"] and lean["identical"] and ref["identical"]
+    t, r = lean["traffic"], ref["traffic"]
+    assert t["D"] == t["D_params"] and t["G"] == t["G_params"], t
+    assert r["D"] == r["D_params"] and r["G"] == r["G_params"], r
+    assert lean["loss"] == ref["loss"]
+    assert torch.equal(lean["flat"], ref["flat"])
+
+
+@pytest.mark.timeout(900)
+def test_ddp_accumulation_allreduces_once_per_phase():
+    """the shipped cfg3 schedule accumulates 4 x 16 images per step (cc_icgan_res256.json:22-24): with COMM_SAVINGS the first
+    rounds accumulate locally (no_sync) and ONE all-reduce per phase carries the sum; the reference pattern all-reduces every
+    round.  Same result up to the rounding of the averaged sum."""
+    lean, ref = _spawn(_worker_step, True, 2), _spawn(_worker_step, False, 2)
+    assert lean["finite"] and lean["identical"] and ref["identical"]
+    t, r = lean["traffic"], ref["traffic"]
+    assert t["D"] == t["D_params"] and t["G"] == t["G_params"], t
+    assert r["D"] == 2 * r["D_params"] and r["G"] == 2 * r["G_params"], r   # reference pattern: one all-reduce per round
+    for k in lean["loss"]:
+        assert abs(lean["loss"][k] - ref["loss"][k]) <= 1e-5 * (1 + abs(ref["loss"][k])), (k, lean["loss"], ref["loss"])
+    rel = float((lean["flat"] - ref["flat"]).norm() / ref["flat"].norm())
+    assert rel < 1e-5, rel
+
+
+@pytest.mark.timeout(900)
+def test_ddp_step_world_size_4():
+    out = _spawn(_worker_step, True, 1, world=4)
+    assert out["finite"] and out["identical"], out
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("split,skew", [((2, 2), False), ((3, 1), False), ((2, 2), True), ((1, 3, 2, 2), False)])
 def test_syncbn_two_ranks_equal_one_process_on_full_batch(monkeypatch, split, skew):
-    out = _spawn(_worker_syncbn, split, skew)
+    """(also world_size 4 with an uneven 1 + 3 + 2 + 2 split of an 8-image batch)"""
+    out = _spawn(_worker_syncbn, split, skew, world=len(split))
     kernel_ref.install(monkeypatch)
     cfg = dict(CFG, sync_bn=False)
     _, G, _ = _models(cfg)
-    B = 4
+    B = sum(split)
     z, lab, fg = synth.CondSampler(cfg, G.dim_z, B, 9)()
     import numpy as np
     wts = torch.from_numpy(np.random.RandomState(3).standard_normal((B, 3, 32, 32))).float()
     G.train()
     img = G(z, lab, fg)
-    ((img * wts).sum() / 2).backward()          # DDP averages the two ranks' gradients
+    ((img * wts).sum() / len(split)).backward()          # DDP averages the ranks' gradients
     grads = torch.cat([p.grad.reshape(-1) for p in G.parameters()])
     assert torch.allclose(out["img"], img.detach(), rtol=1e-4, atol=1e-5)
     assert torch.allclose(out["rm"], G.blocks[0][0].bn1.stored_mean, rtol=1e-5, atol=1e-6)      # rank 0's buffers

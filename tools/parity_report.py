@@ -72,6 +72,7 @@ def main():
         for wino in (routes or ([-1, 0] if case in H.REAL_CASES + H.BENCH_CASES else T.WINO_VARIANTS)):
             H.SOFT_REPORT = []
             H.STATS = [] if stats else None
+            H.DENSE_REPORT = []
             mp = pytest.MonkeyPatch()
             t0 = time.time()
             err = ""
@@ -94,10 +95,17 @@ def main():
             line = "; ".join("%s x%.2f" % (m[:70], r) for m, r in worst.values())
             tag = ("route=%-10s" % label) if routes else ("wino=%2d" % wino)
             print("PARITY %-18s %s  %5.1fs  %s%s" % (case, tag, time.time() - t0, line or "ok (all ratios <= 1)", err), flush=True)
+            if H.DENSE_REPORT:      # dense (4096-sample) gradient groups: the four criteria of helpers.check_group, worst tensor of each
+                d = H.DENSE_REPORT
+                a, b, c, e = (max(d, key=lambda r: r[j]) for j in (1, 2, 3, 4))
+                print("  DENSE %d tensors: sub-grid max/tol x%.2f (%s); max/tol x%.2f of %.1f allowed (%s); rms/tol x%.3f of %.2f allowed (%s); "
+                      "share above tol %.4f of %.4f allowed (%s)" % (len(d), a[1], a[0], b[2], H.DENSE_MAX_MULT, b[0], c[3], H.DENSE_RMS_FRAC,
+                                                                      c[0], e[4], H.DENSE_EXCEED_SHARE, e[0]), flush=True)
             if stats:
                 error_stats(case)
     H.SOFT_REPORT = None
     H.STATS = None
+    H.DENSE_REPORT = None
 
 
 if __name__ == "__main__":

@@ -7,6 +7,9 @@ on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md §HBM, checked her
 """
 import csv
 import glob
+import sys as _sys
+import os as _os
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import json
 import os
 import sys
@@ -36,6 +39,7 @@ def main():
                      "MI355X_MICROARCH.md HBM section; tools/pmc_hbm.py",
            "steps_profiled": int(os.environ.get("ICG_PMC_STEPS", "3")),       # --steps 2 --warmup 1
            "commit": os.environ.get("ICG_PMC_COMMIT", "unknown"),
+           "csrc_sha256": __import__("bench").csrc_sha256(),      # bench.py prints traffic_stale when the kernel sources differ
            "kernels": {}}
     for k in sorted(ft, key=lambda k: -ft[k]):
         if fc[k] == 0:
