@@ -149,9 +149,9 @@ __global__ __launch_bounds__(512, 4) void icg_pgemm_nn_kernel(PgemmP p) {
           const float bv = s == 0 ? b[j].x : (s == 1 ? b[j].y : (s == 2 ? b[j].z : b[j].w));
           if (LEVELS == 2 && FLUSH && s == 0) {
             acc2[i][j] += acc[i][j];
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
           }
         }
       }
@@ -166,22 +166,201 @@ __global__ __launch_bounds__(512, 4) void icg_pgemm_nn_kernel(PgemmP p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the over-fetched tiles: nothing may land after the exit
 
-  // ---- epilogue.  C/D layout of 16x16x4: column = lane & 15, row = 4 (lane >> 4) + reg
+  // ---- epilogue.  The MFMA operands are swapped (D = B-fragment x A-fragment), so lane (r, kk) holds C[16 i + r][16 j + 4 kk .. + 3]
+  // of its wave tile: one 16-byte store per 16 x 16 tile when C allows it
   float* __restrict__ Cg = p.C + (long)z * p.sC;
+  const bool c_vec = (((uintptr_t)p.C | (uintptr_t)(p.ldc * 4) | (uintptr_t)(p.sC * 4)) & 15) == 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int mrow = m0 + 32 * wm + 16 * i + 4 * kk;
+    const int m = m0 + 32 * wm + 16 * i + r;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int n = n0 + 16 * NT * wn + 16 * j + r;
-      const f32x4 v = (LEVELS == 2) ? acc[i][j] + acc2[i][j] : acc[i][j];
-      if (n < p.N) {
+      const int n = n0 + 16 * NT * wn + 16 * j + 4 * kk;
+      f32x4 v = (LEVELS == 2) ? acc[i][j] + acc2[i][j] : acc[i][j];
+      v *= p.alpha;
+      if (m < p.M && n < p.N) {
+        float* dst = Cg + (long)m * p.ldc + n;
+        if (c_vec) {
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (mrow + e < p.M) Cg[(long)(mrow + e) * p.ldc + n] = p.alpha * v[e];
+          for (int e = 0; e < 4; ++e) dst[e] = v[e];
+        }
       }
     }
   }
+}
+
+// ---- streaming form of the kernel above: a workgroup owns a RUN of output tiles (first, first + vstep, ... inside its XCD's
+// contiguous range of the tile order, like icg_planes_body) and treats their K-tiles as one stream -- the DMA for the next
+// output tile's first two K-tiles is in flight while the last MFMAs and the epilogue of the current one run, so the pipeline
+// fill (two K-tiles of HBM latency) is paid once per workgroup instead of once per output tile.  That is what the short-K
+// layers need (K = 96 / 192: 6 / 12 K-tiles per output tile).  The MFMA operands are swapped (D = B-fragment x A-fragment), which
+// leaves lane (r, kk) with C[m = r][n = 4 kk .. 4 kk + 3]: the epilogue is one 16-byte store per 16 x 16 tile instead of four
+// 4-byte stores.  Epilogue stores count on vmcnt like the DMA loads but complete out of order with them, so the first K-tile after
+// an epilogue waits for vmcnt(0) (its two prefetched K-tiles were issued before the epilogue: no bubble).
+struct PgemmSP {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  long ldc;
+  long sA, sB, sC;
+  float alpha;
+  int tiles_n, tiles_mn;
+  unsigned total;         // output tiles over all planes
+  int swz;
+};
+
+template <int NT, int LEVELS>
+__global__ __launch_bounds__(512, 4) void icg_pgemm_nn_stream_kernel(PgemmSP p) {
+  constexpr int BM = 128, BN = 32 * NT, BK = 16;
+  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, SLOT = A_BYTES + B_BYTES, NBUF = 3;
+  constexpr int BROWS = BN / 8;
+  __shared__ __attribute__((aligned(1024))) char lds[NBUF * SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv & 3, wn = wv >> 2;
+  const int r = lane & 15, kk = lane >> 4;
+
+  // this workgroup's run of output tiles
+  const unsigned tot = p.total, lin = blockIdx.x;
+  unsigned first, last, vstep;
+  if (p.swz) {
+    const unsigned q = tot >> 3, rr = tot & 7u, xcd = lin & 7u;
+    const unsigned base = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+    vstep = gridDim.x >> 3;
+    first = base + (lin >> 3);
+    last = base + q + (xcd < rr ? 1u : 0u);
+  } else {
+    vstep = gridDim.x;
+    first = lin;
+    last = tot;
+  }
+  if (first >= last) return;
+
+  const int nk = p.K / BK;                                          // even
+  const bool dma_b_lane = (BROWS == 16) || ((lane >> 2) < BROWS);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned ldsA = lds_base + (unsigned)wv * 1024u, ldsB = lds_base + (unsigned)A_BYTES + (unsigned)wv * (BROWS * 64u);
+
+  // ---- load cursor: (output tile lv, K-tile lk) of the next DMA
+  unsigned lv = first;
+  int lk = 0;
+  const float* lAg;
+  const float* lBg;
+  unsigned lvoffA, lvoffB;
+  auto set_load_tile = [&](unsigned v) {
+    // (runs once per output tile: the lane constants of the DMA role are recomputed here, from a lane id that costs no live
+    // register, instead of being kept in registers the 128-register budget does not have)
+    int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // lane id, from the exec mask
+    asm volatile("" : "+v"(ln));                                                            // (what follows stays in this branch)
+    const int drowA = 16 * wv + (ln >> 2), drowB = BROWS * wv + (ln >> 2);
+    const unsigned swzA = 4u * (unsigned)((ln & 3) ^ pg_swz(drowA)), swzB = 4u * (unsigned)((ln & 3) ^ pg_swz(drowB));
+    const int z = (int)(v / (unsigned)p.tiles_mn);
+    const int tile = (int)(v - (unsigned)z * (unsigned)p.tiles_mn);
+    const int nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+    lAg = p.A + (long)z * p.sA;
+    lBg = p.B + (long)z * p.sB;
+    lvoffA = ((unsigned)min(mt * BM + drowA, p.M - 1) * (unsigned)p.K + swzA) * 4u;
+    lvoffB = ((unsigned)min(nt * BN + min(drowB, BN - 1), p.N - 1) * (unsigned)p.K + swzB) * 4u;
+  };
+  auto issue_next = [&](unsigned slot_off) {
+    pg_dma16(lAg + lk * BK, lvoffA, ldsA + slot_off);
+    if (dma_b_lane) pg_dma16(lBg + lk * BK, lvoffB, ldsB + slot_off);
+    if (++lk == nk) {
+      if (lv + vstep < last) { lv += vstep; lk = 0; set_load_tile(lv); }
+      else lk = nk - 1;                                             // past the end of the run: the last K-tile again (never read)
+    }
+  };
+  auto next_slot = [](unsigned off) -> unsigned { return off == (unsigned)((NBUF - 1) * SLOT) ? 0u : off + (unsigned)SLOT; };
+
+  const int fo = r * 64 + ((kk ^ pg_swz(r)) * 16);
+  const char* fa = lds + fo + (32 * wm) * 64;
+  const char* fb = lds + fo + A_BYTES + (16 * NT * wn) * 64;
+
+  f32x4 acc[2][NT], acc2[2][NT];
+  set_load_tile(lv);
+  issue_next(0u);
+  issue_next((unsigned)SLOT);
+
+  // one K-tile.  Every MFMA accumulates in place (same registers in and out, in every step): with separate "fresh chain" forms
+  // of the step the register allocator rotates the accumulators through new registers at the joins (+20 registers, spills).
+  // FLUSH (every even K-tile): the finished 32-deep chains are folded into the second level and cleared by VALU moves; at the
+  // first K-tile of an output tile both levels are zero already (cleared after the epilogue), so the same code serves.
+  auto tile_step = [&](unsigned cur, auto flush_c, bool first_of_tile) {
+    constexpr bool FLUSH = decltype(flush_c)::value;
+    if (FLUSH && first_of_tile) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_next(next_slot(next_slot(cur)));
+    if (FLUSH && LEVELS == 2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc2[i][j] += acc[i][j];
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    float4 a[2], b[NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const float4*>(fa + cur + i * 1024);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float4*>(fb + cur + j * 1024);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float av = s == 0 ? a[i].x : (s == 1 ? a[i].y : (s == 2 ? a[i].z : a[i].w));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float bv = s == 0 ? b[j].x : (s == 1 ? b[j].y : (s == 2 ? b[j].z : b[j].w));
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+  unsigned cur = 0u;
+  for (unsigned v = first; v < last; v += vstep) {
+    for (int kt = 0; kt < nk; kt += 2) {
+      tile_step(cur, std::true_type{}, kt == 0);
+      cur = next_slot(cur);
+      tile_step(cur, std::false_type{}, false);
+      cur = next_slot(cur);
+    }
+    // epilogue of output tile v: swapped operands -> lane (r, kk) holds C[16 i + r][16 j + 4 kk .. + 3] of its wave tile
+    const int z = (int)(v / (unsigned)p.tiles_mn);
+    const int tile = (int)(v - (unsigned)z * (unsigned)p.tiles_mn);
+    const int n0 = (tile % p.tiles_n) * BN, m0 = (tile / p.tiles_n) * BM;
+    // address = wave-uniform base (scalar registers) + one 32-bit lane offset that is the same for every tile of the run
+    float* __restrict__ Cw = p.C + (long)z * p.sC + (long)(m0 + 32 * wm) * p.ldc + (n0 + 16 * NT * wn);
+    const unsigned loff = (unsigned)r * (unsigned)p.ldc + 4u * (unsigned)kk;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool row_ok = m0 + 32 * wm + 16 * i + r < p.M;          // (N is a multiple of the tile width)
+      float* __restrict__ Ci = Cw + (long)(16 * i) * p.ldc;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x4 v4 = (LEVELS == 2) ? acc[i][j] + acc2[i][j] : acc[i][j];
+        v4 *= p.alpha;
+        if (row_ok) *reinterpret_cast<f32x4*>(Ci + 16 * j + loff) = v4;
+        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};                      // both levels clear for the next output tile
+        if (LEVELS == 2) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---- weight-gradient plane GEMM: C[z][s] = A[z]^T B[z] over the K-slice s, A [K][M] (V planes: tiles x Cin), B [K][N] (transformed
@@ -329,6 +508,11 @@ static bool pgemm_enabled() {      // measurement switch (ICG_PGEMM=0: first-gen
   return on;
 }
 
+static int pgemm_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
+}
+
 // -> ICG_OK when launched, 1 when the shape is not one this kernel takes (caller falls back to icg_planes_body)
 int icg_pgemm_nn_launch(const float* A, const float* B, float* C, int M, int N, int K, long ldc, long sA, long sB, long sC,
                         int planes, float alpha, int levels, hipStream_t st, int* tn_out) {
@@ -337,19 +521,50 @@ int icg_pgemm_nn_launch(const float* A, const float* B, float* C, int M, int N, 
   if (nt == 0 || K % 32 != 0 || M < 1 || planes < 1) return 1;
   if ((uintptr_t)A % 16 || (uintptr_t)B % 16 || sA % 4 || sB % 4) return 1;
   if ((long)M * K >= (1L << 30) || (long)N * K >= (1L << 30)) return 1;        // 32-bit byte offsets inside a plane
+  const int tiles_n = N / (32 * nt);
+  const long tiles_mn = icg_cdiv(M, 128) * tiles_n, total = tiles_mn * planes;
+  if (total <= 0 || total >= 0x7fffffffL) return 1;
+  static const bool no_swz = [] { const char* e = getenv("ICG_NO_XCD_SWIZZLE"); return e && e[0] == '1'; }();
+  const int swz = (total >= 16 && !no_swz) ? 1 : 0;
+  static const int stream = pgemm_env_int("ICG_PGEMM_STREAM", 1);              // measurement switches, read once
+  static const int run_ktiles = pgemm_env_int("ICG_PGEMM_RUN_KTILES", 48);
+  const bool c_vec = ((uintptr_t)C % 16 == 0) && (ldc % 4 == 0) && (sC % 4 == 0);
+  if (tn_out) *tn_out = nt;
+  dim3 block(512);
+  static const int l1_maxk = pgemm_env_int("ICG_PGEMM_L1_MAXK", 0);           // K up to which chains stay single-level (experiments)
+  if (K <= l1_maxk) levels = 1;
+  // the 128-column two-level kernel holds 64 + 64 accumulator registers: its streaming form does not fit the 128-register budget
+  // of 4 waves per SIMD without spills (scratch traffic would sit on the hand-counted vmcnt), so it keeps one tile per workgroup
+  if (stream && c_vec && !(nt == 4 && levels == 2)) {
+    // streaming form: every workgroup owns a run of output tiles worth ~run_ktiles K-tiles, as long as the launch still queues
+    // several workgroups per CU (2 resident per CU)
+    PgemmSP p{};
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.ldc = ldc; p.sA = sA; p.sB = sB; p.sC = sC; p.alpha = alpha;
+    p.tiles_n = tiles_n; p.tiles_mn = (int)tiles_mn; p.total = (unsigned)total; p.swz = swz;
+    const int nk = K / 16;
+    int run = (run_ktiles + nk - 1) / nk;
+    if (run > 32) run = 32;
+    while (run > 1 && total / run < 2048) --run;
+    const long per_xcd = icg_cdiv(icg_cdiv(total, 8), run);
+    dim3 grid(swz ? (unsigned)(8 * per_xcd) : (unsigned)icg_cdiv(total, run));
+    if (nt == 4) {
+      hipLaunchKernelGGL((icg_pgemm_nn_stream_kernel<4, 1>), grid, block, 0, st, p);       // (levels == 1: see above)
+    } else {
+      if (levels == 2) hipLaunchKernelGGL((icg_pgemm_nn_stream_kernel<3, 2>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((icg_pgemm_nn_stream_kernel<3, 1>), grid, block, 0, st, p);
+    }
+    return icg_check_launch();
+  }
   PgemmP p{};
   p.A = A; p.B = B; p.C = C;
   p.M = M; p.N = N; p.K = K;
   p.ldc = ldc; p.sA = sA; p.sB = sB; p.sC = sC;
   p.alpha = alpha;
-  p.tiles_n = N / (32 * nt);
-  const long tiles_mn = icg_cdiv(M, 128) * p.tiles_n, total = tiles_mn * planes;
-  if (total <= 0 || total >= 0x7fffffffL) return 1;
+  p.tiles_n = tiles_n;
   p.tiles_mn = (int)tiles_mn;
   p.total = (unsigned)total;
-  static const bool no_swz = [] { const char* e = getenv("ICG_NO_XCD_SWIZZLE"); return e && e[0] == '1'; }();
-  p.swz = (total >= 16 && !no_swz) ? 1 : 0;
-  dim3 grid((unsigned)total), block(512);
+  p.swz = swz;
+  dim3 grid((unsigned)total);
   if (nt == 4) {
     if (levels == 2) hipLaunchKernelGGL((icg_pgemm_nn_kernel<4, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((icg_pgemm_nn_kernel<4, 1>), grid, block, 0, st, p);
@@ -357,7 +572,6 @@ int icg_pgemm_nn_launch(const float* A, const float* B, float* C, int M, int N, 
     if (levels == 2) hipLaunchKernelGGL((icg_pgemm_nn_kernel<3, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((icg_pgemm_nn_kernel<3, 1>), grid, block, 0, st, p);
   }
-  if (tn_out) *tn_out = nt;
   return icg_check_launch();
 }
 

@@ -32,6 +32,9 @@ SHAPES = [
     ("G.b5.conv1 192->96 up@256  RS  B64", 64 * 64 * 64, 96, 192, 25),
     ("G.b5.conv2 96->96 @256     F4  B64", 64 * 64 * 64, 96, 96, 36),
 ]
+NN_ONLY = len(sys.argv) > 1 and sys.argv[1] == "nn_only"
+if NN_ONLY:
+    sys.argv.pop(1)
 if len(sys.argv) > 1:
     SHAPES = [s for s in SHAPES if sys.argv[1] in s[0]]
 gen = "first-generation (ICG_PGEMM=0)" if os.environ.get("ICG_PGEMM", "1")[:1] == "0" else "second-generation where it has a tile"
@@ -50,6 +53,8 @@ for name, M, N, K, planes in SHAPES:
     tot += t
     print(f"{name:38s} M={M:7d} N={N:5d} K={K:5d} z={planes:2d}  {t * 1e3:8.3f} ms  {tf:6.1f} TF  {tf / PEAK:5.3f}  err {err:.2e}", flush=True)
 print(f"sum {tot * 1e3:.3f} ms")
+if NN_ONLY:
+    sys.exit(0)
 
 # weight-gradient plane GEMMs: C[z] = A[z]^T B[z], A [K][M] = V planes (tiles x Cin), B [K][N] = transformed dy (tiles x Cout)
 TN_SHAPES = [
