@@ -246,6 +246,11 @@ class KernelTimer:
                 "all_hbm_ops": {k: {"GB/s": round(v[0] / v[1] / 1e9, 1), "frac": round(v[0] / v[1] / 1e9 / PEAK_HBM_GBPS, 4),
                                     "launches": v[2], "total_ms": round(v[1] * 1e3, 3)} for k, v in agg.items()}}
 
+    def freeze_planes(self):
+        """drain the library's plane-GEMM records now (icg_planes_timing(0) discards them): called at the end of the instrumented
+        timed region, before the un-instrumented one switches the brackets off"""
+        self._planes = self.planes_summary()
+
     def summary(self):
         agg = {}
         for kname, alg, exe, byt, s, e in self.records:
@@ -295,7 +300,8 @@ def measured_traffic(kname):
 def assemble_roofline(timer, steps, elapsed, with_step_traffic=True):
     """roofline object (see the module docstring) from the HIP-event records of the timed region; None without records."""
     agg = timer.summary()
-    agg.update(timer.planes_summary())       # inner GEMMs of the composites (their time is part of the composite rows too)
+    # inner GEMMs of the composites (their time is part of the composite rows too)
+    agg.update(timer._planes if getattr(timer, "_planes", None) is not None else timer.planes_summary())
     cands = [(k, v) for k, v in agg.items() if not k.startswith("composite:")]
     if not cands:
         return None
@@ -683,6 +689,8 @@ def main():
                     help="implicit-GEMM / phase / 4x4-stride-2 kernels only (ops.disable_winograd): the strict-parity route")
     ap.add_argument("--no-fuse-relu-backward", action="store_true",
                     help="ablation: ReLU backward of D's layers as a separate pass instead of the data-gradient epilogue")
+    ap.add_argument("--no-wgrad-stream", action="store_true",
+                    help="ablation: weight gradients on the main stream, after the data gradient (ops.WGRAD_SIDE_STREAM = False)")
     ap.add_argument("--sync-bn", action="store_true", help="cross-replica BN statistics over RCCL (cfg3 variant)")
     ap.add_argument("--fp16", action="store_true", help="cfg4: the reference's cfg=auto precision (num_fp16_res=4, conv_clamp=256)")
     ap.add_argument("--accumulate", type=int, default=1,
@@ -734,6 +742,9 @@ def main():
     if args.no_fuse_relu_backward:
         import ic_gan_amd.ops as _ops
         _ops.FUSE_RELU_BACKWARD = False
+    if args.no_wgrad_stream:
+        import ic_gan_amd.ops as _ops
+        _ops.WGRAD_SIDE_STREAM = False
 
     if args.workload == "sample":
         return bench_sampling(args, device, rank, world)
@@ -837,6 +848,7 @@ def main():
     if not args.no_kernel_timer and not args.no_uninstrumented_leg:
         # the figure above is measured with the HIP-event brackets of KernelTimer / icg_planes_timing active; the same K steps again
         # without any instrumentation, reported beside it
+        timer.freeze_planes()
         timer.planes(False)
         uninstr = timed_region(args.steps)
     comm_report = None
@@ -874,7 +886,7 @@ def main():
                        "uninstrumented_ms_per_step": (round(uninstr / args.steps * 1e3, 3) if uninstr is not None else None),
                        "uninstrumented_images_per_sec": (round(batch * acc * world * args.steps / uninstr, 3) if uninstr is not None else None),
                        "comm": comm_report,
-                       "rccl_world_size": (dist.get_world_size() if use_ddp else 1), "init": init, "sync_bn": bool(args.sync_bn), "winograd": not args.no_winograd,
+                       "rccl_world_size": (dist.get_world_size() if use_ddp else 1), "init": init, "sync_bn": bool(args.sync_bn), "winograd": not args.no_winograd, "wgrad_side_stream": not args.no_wgrad_stream,
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "losses_last_step": metrics},
             "roofline": roof,
         }

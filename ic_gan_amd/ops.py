@@ -198,6 +198,25 @@ def _conv_fprop(x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, 
 
 
 FUSE_RELU_BACKWARD = True       # ReLU backward of a ReLU-only prologue in the data-gradient epilogue (ICG_RES_RELU_MASK)
+# A layer's weight gradient (transform of dy: HBM-bound; plane / split-K GEMMs: MFMA-bound; spectral-norm backward) depends on
+# the forward's saved tensors and dout only, its data gradient (transform, GEMM, transform) on dout and the weights only: the
+# two are launched on two HIP streams and overlap inside every layer's backward -- the MFMA-bound phases of one run beside the
+# HBM-bound phases of the other instead of after them.  The main stream waits for the layer's weight gradient before the
+# backward node returns, so everything downstream (autograd accumulation, DDP's bucket hooks, Adam) sees finished gradients.
+WGRAD_SIDE_STREAM = True
+_WGRAD_STREAMS = {}
+
+
+def _wgrad_stream(dev):
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        return None
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _WGRAD_STREAMS.get(key)
+    if st is None:
+        st = _WGRAD_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
 KEEP_WINOGRAD_V = True          # keep the forward pass's transformed input for the weight gradient (memory for one HBM pass)
 
 
@@ -437,6 +456,10 @@ class FusedConvFn(Function):
         need = ctx.needs_input_grad
         dx = dweight = dbias = dres = dgain = dbeta = None
         bn_state = None
+        entry = None
+        if WGRAD_SIDE_STREAM and dout.is_cuda and need[0] and need[1]:
+            entry = torch.cuda.Event()
+            entry.record()               # dout (and everything the forward saved) is ready on the main stream here
         if need[0] or (bn is not None and (need[4] or need[5])):
             # ReLU-only prologue (every D layer): its backward, dx = (x > 0) ? da : 0, runs in the epilogue of the data-gradient
             # convolution (ICG_RES_RELU_MASK) -- da is never written and no separate pass reads x and da
@@ -489,58 +512,86 @@ class FusedConvFn(Function):
                 L.call("icg_bn_bwd_apply", x, da, None, None, 0, None, None, None, B, Hs, Ws, Cin, flags, dx)
             else:
                 dx = da
-        if need[1] and (ctx.down or ctx.phase) and sn.rs[2]:
-            # weight gradient of the resample-fused layer in the 25-plane domain: plain HWIO 3x3 result
-            dw_hwio = _f32(9 * Cin * Cout, dev)
-            Hf, Wf = (Hs, Ws) if ctx.down else (H, W)                # full resolution of the layer
-            if ctx.saved_v is not None and ctx.saved_v[1] == 25:
-                dbias = _wgrad_from_v(ctx.saved_v[0], dout, dw_hwio, B, Hf, Wf, Cin, Cout, 25, 1 if ctx.down else 0,
-                                      0.25 if ctx.down else 1.0, has_bias and need[2])
-                ctx.saved_v = None
-            elif ctx.down:
-                nb = L.query("icg_conv2d_rs_wino_wgrad_workspace_bytes", B, Hs, Ws, Cin, Cout)
-                L.call("icg_conv2d_down_wino_wgrad", x, dout, dw_hwio, B, H, W, Cin, Cout, ctx.flags, _bytes(nb, dev), nb)
-            else:
-                nb = L.query("icg_conv2d_rs_wino_wgrad_workspace_bytes", B, H, W, Cin, Cout)
-                L.call("icg_conv2d_up_wino_wgrad", x, dout, dw_hwio, scale, shift, ssb, B, Hs, Ws, Cin, Cout,
-                       ctx.flags & ~L.ICG_UPSAMPLE2X, _bytes(nb, dev), nb)
-            dweight = _sn_backward(dw_hwio, None, sn, ctx.weight_like)
-        elif need[1] and ctx.down:
-            nb = L.query("icg_conv2d_down_wgrad_workspace_bytes", B, H, W, Cin, Cout)
-            ws = _bytes(nb, dev)
-            dw_down = _f32(16 * Cin * Cout, dev)
-            L.call("icg_conv2d_down_wgrad", x, dout, dw_down, B, H, W, Cin, Cout, ctx.flags, ws, nb)
-            dweight = _sn_backward(None, None, sn, ctx.weight_like, dw_down=dw_down)
-        elif need[1] and ctx.phase:
-            nb = L.query("icg_conv2d_up_wgrad_workspace_bytes", B, Hs, Ws, Cin, Cout)
-            ws = _bytes(nb, dev)
-            dw_up = _f32(16 * Cin * Cout, dev)
-            L.call("icg_conv2d_up_wgrad", x, dout, dw_up, scale, shift, ssb, B, Hs, Ws, Cin, Cout,
-                   ctx.flags & ~L.ICG_UPSAMPLE2X, ws, nb)
-            dweight = _sn_backward(None, None, sn, ctx.weight_like, dw_up=dw_up)
-        elif need[1]:
-            dw_hwio = _f32(R * R * Cin * Cout, dev)
-            wt = winograd_wgrad_tile(Cin, Cout, H, W, B) if sn.w_wino is not None else 0
-            if wt == 4 and ctx.saved_v is not None and ctx.saved_v[1] == 36:
-                dbias = _wgrad_from_v(ctx.saved_v[0], dout, dw_hwio, B, H, W, Cin, Cout, 36, 0, 1.0, has_bias and need[2])
-                ctx.saved_v = None
-            elif wt:
-                # wide 3x3 stride-1 layer: weight gradient through the Winograd domain (16/36 or 9/36 of the MACs)
-                v = "wino4" if wt == 4 else "wino"
-                nb = L.query("icg_conv2d_%s_wgrad_workspace_bytes" % v, B, H, W, Cin, Cout)
-                L.call("icg_conv2d_%s_wgrad" % v, x, dout, dw_hwio, scale, shift, ssb, B, H, W, Cin, Cout, ctx.flags,
-                       _bytes(nb, dev), nb)
-            else:
-                nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, Cin, Cout, R)
+        def weight_and_bias_gradients():
+            """dweight (through the spectral-norm backward) and dbias of this layer: everything that depends only on the saved
+            forward tensors and dout, not on the data gradient."""
+            dweight = dbias = None
+            if need[1] and (ctx.down or ctx.phase) and sn.rs[2]:
+                # weight gradient of the resample-fused layer in the 25-plane domain: plain HWIO 3x3 result
+                dw_hwio = _f32(9 * Cin * Cout, dev)
+                Hf, Wf = (Hs, Ws) if ctx.down else (H, W)                # full resolution of the layer
+                if ctx.saved_v is not None and ctx.saved_v[1] == 25:
+                    dbias = _wgrad_from_v(ctx.saved_v[0], dout, dw_hwio, B, Hf, Wf, Cin, Cout, 25, 1 if ctx.down else 0,
+                                          0.25 if ctx.down else 1.0, has_bias and need[2])
+                    ctx.saved_v = None
+                elif ctx.down:
+                    nb = L.query("icg_conv2d_rs_wino_wgrad_workspace_bytes", B, Hs, Ws, Cin, Cout)
+                    L.call("icg_conv2d_down_wino_wgrad", x, dout, dw_hwio, B, H, W, Cin, Cout, ctx.flags, _bytes(nb, dev), nb)
+                else:
+                    nb = L.query("icg_conv2d_rs_wino_wgrad_workspace_bytes", B, H, W, Cin, Cout)
+                    L.call("icg_conv2d_up_wino_wgrad", x, dout, dw_hwio, scale, shift, ssb, B, Hs, Ws, Cin, Cout,
+                           ctx.flags & ~L.ICG_UPSAMPLE2X, _bytes(nb, dev), nb)
+                dweight = _sn_backward(dw_hwio, None, sn, ctx.weight_like)
+            elif need[1] and ctx.down:
+                nb = L.query("icg_conv2d_down_wgrad_workspace_bytes", B, H, W, Cin, Cout)
                 ws = _bytes(nb, dev)
-                L.call("icg_conv2d_wgrad", x, dout, dw_hwio, scale, shift, ssb, B, H, W, Cin, Cout, R, ctx.flags, ws, nb)
-            dweight = _sn_backward(dw_hwio, None, sn, ctx.weight_like)
-        if has_bias and need[2] and dbias is None:
-            rows = B * H * W
-            nb = L.query("icg_colsum_workspace_bytes", rows, Cout)
-            ws = _bytes(nb, dev)
-            dbias = _f32(Cout, dev)
-            L.call("icg_colsum", dout, rows, Cout, dbias, ws, nb)
+                dw_down = _f32(16 * Cin * Cout, dev)
+                L.call("icg_conv2d_down_wgrad", x, dout, dw_down, B, H, W, Cin, Cout, ctx.flags, ws, nb)
+                dweight = _sn_backward(None, None, sn, ctx.weight_like, dw_down=dw_down)
+            elif need[1] and ctx.phase:
+                nb = L.query("icg_conv2d_up_wgrad_workspace_bytes", B, Hs, Ws, Cin, Cout)
+                ws = _bytes(nb, dev)
+                dw_up = _f32(16 * Cin * Cout, dev)
+                L.call("icg_conv2d_up_wgrad", x, dout, dw_up, scale, shift, ssb, B, Hs, Ws, Cin, Cout,
+                       ctx.flags & ~L.ICG_UPSAMPLE2X, ws, nb)
+                dweight = _sn_backward(None, None, sn, ctx.weight_like, dw_up=dw_up)
+            elif need[1]:
+                dw_hwio = _f32(R * R * Cin * Cout, dev)
+                wt = winograd_wgrad_tile(Cin, Cout, H, W, B) if sn.w_wino is not None else 0
+                if wt == 4 and ctx.saved_v is not None and ctx.saved_v[1] == 36:
+                    dbias = _wgrad_from_v(ctx.saved_v[0], dout, dw_hwio, B, H, W, Cin, Cout, 36, 0, 1.0, has_bias and need[2])
+                    ctx.saved_v = None
+                elif wt:
+                    # wide 3x3 stride-1 layer: weight gradient through the Winograd domain (16/36 or 9/36 of the MACs)
+                    v = "wino4" if wt == 4 else "wino"
+                    nb = L.query("icg_conv2d_%s_wgrad_workspace_bytes" % v, B, H, W, Cin, Cout)
+                    L.call("icg_conv2d_%s_wgrad" % v, x, dout, dw_hwio, scale, shift, ssb, B, H, W, Cin, Cout, ctx.flags,
+                           _bytes(nb, dev), nb)
+                else:
+                    nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, Cin, Cout, R)
+                    ws = _bytes(nb, dev)
+                    L.call("icg_conv2d_wgrad", x, dout, dw_hwio, scale, shift, ssb, B, H, W, Cin, Cout, R, ctx.flags, ws, nb)
+                dweight = _sn_backward(dw_hwio, None, sn, ctx.weight_like)
+            if has_bias and need[2] and dbias is None:
+                rows = B * H * W
+                nb = L.query("icg_colsum_workspace_bytes", rows, Cout)
+                ws = _bytes(nb, dev)
+                dbias = _f32(Cout, dev)
+                L.call("icg_colsum", dout, rows, Cout, dbias, ws, nb)
+            return dweight, dbias
+
+        if need[1] or (has_bias and need[2]):
+            side = _wgrad_stream(dev) if (need[1] and need[0] and entry is not None) else None
+            if side is None:
+                dweight, dbias = weight_and_bias_gradients()
+            else:
+                # weight gradient on the side stream, concurrently with the data-gradient kernels queued on the main stream above
+                # (see WGRAD_SIDE_STREAM).  Cross-stream tensor lifetimes are declared to the caching allocator.
+                main = torch.cuda.current_stream(dev)
+                held = [x, dout, scale, shift, ctx.saved_v[0] if ctx.saved_v is not None else None,
+                        sn.w_ohwi, sn.u, sn.v, sn.sigma]
+                side.wait_event(entry)
+                with torch.cuda.stream(side):
+                    dweight, dbias = weight_and_bias_gradients()
+                    done = torch.cuda.Event()
+                    done.record(side)
+                for t in held:
+                    if t is not None:
+                        t.record_stream(side)
+                main.wait_event(done)
+                for t in (dweight, dbias):
+                    if t is not None:
+                        t.record_stream(main)
         if has_res and need[3]:
             if opt.res_up:
                 dres = _empty_cl(B, Cout, H // 2, W // 2, dev)
