@@ -192,6 +192,8 @@ class KernelTimer:
                     while lp < last[3] // 4:
                         lp *= 2
                     kname = "void narrow_%s_kernel<%d, %d>" % ("wgrad" if last[1] else "fprop", last[2], lp)
+            elif last[0] == 4:       # second-generation implicit-GEMM convolution (pgemm.hip): {4, ReLU prologue, NT, levels}
+                kname = "void icg_pconv_kernel<%d, %d, %d>(PconvP)" % (last[2], last[1], last[3])
             elif last[3] == 4:       # prologue-free 1x1 convolution on the persistent plain-GEMM body (single-level chains)
                 kname = "void icg_gemm_planes1_kernel<%d, %d, %d>(GemmP)" % (last[0], last[1], last[2])
             else:
@@ -689,8 +691,8 @@ def main():
                     help="implicit-GEMM / phase / 4x4-stride-2 kernels only (ops.disable_winograd): the strict-parity route")
     ap.add_argument("--no-fuse-relu-backward", action="store_true",
                     help="ablation: ReLU backward of D's layers as a separate pass instead of the data-gradient epilogue")
-    ap.add_argument("--no-wgrad-stream", action="store_true",
-                    help="ablation: weight gradients on the main stream, after the data gradient (ops.WGRAD_SIDE_STREAM = False)")
+    ap.add_argument("--wgrad-stream", action="store_true",
+                    help="opt-in: weight gradients on a side HIP stream, concurrently with the data gradient (ops.WGRAD_SIDE_STREAM)")
     ap.add_argument("--sync-bn", action="store_true", help="cross-replica BN statistics over RCCL (cfg3 variant)")
     ap.add_argument("--fp16", action="store_true", help="cfg4: the reference's cfg=auto precision (num_fp16_res=4, conv_clamp=256)")
     ap.add_argument("--accumulate", type=int, default=1,
@@ -742,9 +744,9 @@ def main():
     if args.no_fuse_relu_backward:
         import ic_gan_amd.ops as _ops
         _ops.FUSE_RELU_BACKWARD = False
-    if args.no_wgrad_stream:
+    if args.wgrad_stream:
         import ic_gan_amd.ops as _ops
-        _ops.WGRAD_SIDE_STREAM = False
+        _ops.WGRAD_SIDE_STREAM = True
 
     if args.workload == "sample":
         return bench_sampling(args, device, rank, world)
@@ -886,7 +888,7 @@ def main():
                        "uninstrumented_ms_per_step": (round(uninstr / args.steps * 1e3, 3) if uninstr is not None else None),
                        "uninstrumented_images_per_sec": (round(batch * acc * world * args.steps / uninstr, 3) if uninstr is not None else None),
                        "comm": comm_report,
-                       "rccl_world_size": (dist.get_world_size() if use_ddp else 1), "init": init, "sync_bn": bool(args.sync_bn), "winograd": not args.no_winograd, "wgrad_side_stream": not args.no_wgrad_stream,
+                       "rccl_world_size": (dist.get_world_size() if use_ddp else 1), "init": init, "sync_bn": bool(args.sync_bn), "winograd": not args.no_winograd, "wgrad_side_stream": bool(args.wgrad_stream),
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "losses_last_step": metrics},
             "roofline": roof,
         }

@@ -185,8 +185,11 @@ class Generator(nn.Module):
                                           mybn=self.mybn,
                                           input_size=(self.cond_dim + self.dim_z if self.G_shared else self.n_classes),
                                           norm_style=self.norm_style, eps=self.BN_eps, sync_bn=sync_bn)
-        if class_cond:
-            self.shared = self.which_embedding(n_classes, self.shared_dim) if G_shared else layers.identity()
+        # `shared` always exists, as in BigGAN.py (identity when there is no class embedding): reference-style callers do
+        # `G.shared(y)` unconditionally (train_fns.py:174, utils.py:1471-1474, G_D's class-conditional branch); an identity has no
+        # parameters, so the state_dict of the instance-only model is unchanged
+        self.shared = (self.which_embedding(n_classes, self.shared_dim) if G_shared else layers.identity()) if class_cond \
+            else layers.identity()
         if instance_cond:
             self.shared_feat = self.which_linear(2048, self.shared_dim_feat) if G_shared_feat else layers.identity()
         self.linear = self.which_linear(self.dim_z + self.cond_dim,

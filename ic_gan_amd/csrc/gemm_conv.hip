@@ -1070,6 +1070,10 @@ int icg_pgemm_nn_launch(const float* A, const float* B, float* C, int M, int N, 
                         int planes, float alpha, int levels, hipStream_t st, int* tn_out);
 int icg_pgemm_tn_launch(const float* A, const float* B, float* C, int M, int N, int K, long sA, long sB, int planes, int kchunk,
                         int slices, int levels, hipStream_t st, int* tn_out);
+int icg_pconv_launch(const float* A, const float* B, float* C, int M, int N, int K, int H, int W, int Cin, int R, int up, int Hs,
+                     int Ws, int pad_h, int pad_w, int gs, int Hb, int Wb, long ldb, long ldc, const float* bias, const float* res,
+                     int res_mode, float alpha, long strideB, int phase_mode, int oH, int oW, int pre_relu, int zdim,
+                     hipStream_t st, int* tn_out);
 
 // deterministic second stage of split-K: out[i] = sum_z slab[z][i]
 __global__ void icg_splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, long n,
@@ -1156,6 +1160,21 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
   g_last_variant[0] = AMODE; g_last_variant[1] = BMODE; g_last_variant[2] = tn; g_last_variant[3] = path;
   const bool plain = p.plain != 0 && plain_body && !g_gemm_planes;
   if constexpr (AMODE == A_K && BMODE == B_K) {
+    // second-generation implicit-GEMM convolution (pgemm.hip, icg_pconv_kernel) for the forward / data-gradient shaped launches
+    // of the fast path that have no affine prologue, no split-K and enough output tiles to fill the chip: D's 3x3 / 4x4-stride-2 /
+    // 2x2-phase layers, the data gradients without a BN in front, the prologue-free 1x1 convolutions
+    if (path == 2 && !g_gemm_planes && p.plain != 1 && p.kchunk == 0 && p.bsplit == 0 && p.zmask == 0 && !p.pre_affine &&
+        p.Cin % 16 == 0 && p.K == p.R * p.R * p.Cin && (p.phase_mode == 0 || (p.phase_mode == 1 && zdim == 4)) &&
+        (p.phase_mode != 0 || zdim == 1) && p.res_up != 1 && (p.strideA == 0 || zdim == 1) && (p.strideC == 0 || zdim == 1)) {
+      int nt2 = 0;
+      const int rc = icg_pconv_launch(p.A, p.B, p.C, p.M, p.N, p.K, p.H, p.W, p.Cin, p.R, p.up, p.Hs, p.Ws, p.pad_h, p.pad_w, p.gs,
+                                      p.Hb, p.Wb, p.ldb, p.ldc, p.bias, p.res, p.res != nullptr ? p.res_up : 0, p.alpha, p.strideB,
+                                      p.phase_mode, p.oH, p.oW, p.pre_relu, zdim, st, &nt2);
+      if (rc != 1) {
+        g_last_variant[0] = 4; g_last_variant[1] = p.pre_relu; g_last_variant[2] = nt2; g_last_variant[3] = (nt2 == 3) ? 2 : 1;
+        return rc;
+      }
+    }
     // second-generation plane GEMM (pgemm.hip: LDS-DMA staging, 16-byte operand fragments, 8 waves per workgroup) for the
     // Winograd-plane GEMMs it has a tile for (N a multiple of 128 or 96, K a multiple of 32); everything else stays below
     if (path == 2 && g_gemm_planes && plain_body && p.bias == nullptr && p.res == nullptr && p.ldb == p.K) {

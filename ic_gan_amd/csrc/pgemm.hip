@@ -503,6 +503,203 @@ __global__ __launch_bounds__(512, 4) void icg_pgemm_tn_kernel(PgemmTnP p) {
   }
 }
 
+// ---- second-generation implicit-GEMM convolution (forward / data-gradient shaped: A gathered from an NHWC activation, B = weights
+// [N][taps][Cin], K = taps x Cin in tap-minor order -- all taps of a 16-channel slice, then the next slice, like icg_gemm_body's
+// fast path).  Same pipeline as the plane GEMM; the A tile's DMA source address is recomputed per K-tile (one tap of one slice:
+// pixel * stride + tap - pad, bounds check; out-of-image taps fetch from a 64-byte zero page, so zero padding costs no extra
+// instruction in the MFMA loop), the B tile advances by a scalar.  Prologue: none or ReLU (applied to the A fragments after
+// the LDS read: max(0, 0) keeps the padding zero); a BN / ccbn affine prologue stays on the first-generation kernel.  Epilogue:
+// alpha, bias, residual add or ReLU mask, optional phase scatter (the 4-phase 2x2 forms), 16-byte stores.  Chains are two-level
+// (32 k-values), which a direct convolution's K of up to 13 824 needs even more than the plane GEMMs do.
+struct PconvP {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  int H, W, Cin, R, up, Hs, Ws;
+  int pad_h, pad_w, gs, Hb, Wb;
+  long ldb, ldc;
+  const float* bias;
+  const float* res;
+  int res_mode;            // 0: added, 2: ReLU mask (output kept where res > 0)
+  float alpha;
+  long strideB;            // per phase
+  int phase_mode, oH, oW;  // 1: blockIdx selects the phase (al, be): pad = (1 - al, 1 - be), output row (2h + al, 2w + be)
+  int pre_relu;
+  int tiles_n, tiles_mn;
+  unsigned total;
+  int swz;
+};
+
+__device__ float g_pg_zero_page[16];      // zero-initialised: DMA source of the padding taps
+
+__device__ __forceinline__ void pg_dma16_ptr(const float* lane_src, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_src), "s"(lds_dst)
+      : "memory");
+}
+
+// LEVELS: 2 on the 96-column tile; the 128-column tile keeps single-level chains (64 + 64 accumulator registers plus the gather
+// state do not fit the 128-register budget of 4 waves per SIMD), which is what the first-generation direct kernel does everywhere
+template <int NT, int RELU, int LEVELS>
+__global__ __launch_bounds__(512, 4) void icg_pconv_kernel(PconvP p) {
+  constexpr int BM = 128, BN = 32 * NT, BK = 16;
+  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, SLOT = A_BYTES + B_BYTES, NBUF = 3;
+  constexpr int BROWS = BN / 8;
+  __shared__ __attribute__((aligned(1024))) char lds[NBUF * SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv & 3, wn = wv >> 2;
+  const int r = lane & 15, kk = lane >> 4;
+
+  unsigned t = blockIdx.x;
+  if (p.swz) {
+    const unsigned tot = p.total, q = tot >> 3, rr = tot & 7u, xcd = t & 7u;
+    t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
+  }
+  const int z = (int)(t / (unsigned)p.tiles_mn);                    // phase (phase_mode 1), else 0
+  const int tile = (int)(t - (unsigned)z * (unsigned)p.tiles_mn);
+  const int nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int ph_a = p.phase_mode ? (z >> 1) : 0, ph_b = p.phase_mode ? (z & 1) : 0;
+  const int pad_h = p.phase_mode ? 1 - ph_a : p.pad_h, pad_w = p.phase_mode ? 1 - ph_b : p.pad_w;
+  const float* __restrict__ Bg = p.B + (long)z * p.strideB;
+
+  // ---- DMA role, A: pixel row 16 wv + (lane >> 2) of the tile, chunk position lane & 3
+  const int drowA = 16 * wv + (lane >> 2), drowB = BROWS * wv + (lane >> 2);
+  const int am = m0 + drowA;
+  const bool a_row_ok = am < p.M;
+  const int amm = a_row_ok ? am : 0;
+  const int aw = amm % p.W, at = amm / p.W, ah = at % p.H, ab = at / p.H;
+  const int hs0 = ah * p.gs - pad_h, ws0 = aw * p.gs - pad_w;       // source coordinate of tap (0, 0)
+  const unsigned img = (unsigned)ab * (unsigned)(p.Hs * p.Ws);
+  const unsigned achunk = 4u * (unsigned)((lane & 3) ^ pg_swz(drowA));
+  const unsigned voffB =
+      ((unsigned)min(n0 + min(drowB, BN - 1), p.N - 1) * (unsigned)p.ldb + 4u * (unsigned)((lane & 3) ^ pg_swz(drowB))) * 4u;
+  const bool dma_b_lane = (BROWS == 16) || ((lane >> 2) < BROWS);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned ldsA = lds_base + (unsigned)wv * 1024u, ldsB = lds_base + (unsigned)A_BYTES + (unsigned)wv * (BROWS * 64u);
+  const int nk = p.K / BK;                                          // even (Cin % 16 == 0 and R*R*Cin/16 even: checked by the launcher)
+
+  // load cursor (wave-uniform): K-tile -> (channel slice lc0, tap (ltr, lts)); tap-minor order
+  int lc0 = 0, ltr = 0, lts = 0, ltap = 0, lkt = 0;
+  auto issue_next = [&](unsigned slot_off) {
+    const int hi = hs0 + ltr, wi = ws0 + lts;
+    const bool ok = a_row_ok & ((unsigned)hi < (unsigned)p.Hb) & ((unsigned)wi < (unsigned)p.Wb);
+    const unsigned pix = img + (unsigned)(hi >> p.up) * (unsigned)p.Ws + (unsigned)(wi >> p.up);
+    const float* src = ok ? p.A + ((size_t)pix * (unsigned)p.Cin + (unsigned)lc0 + achunk) : g_pg_zero_page;
+    pg_dma16_ptr(src, ldsA + slot_off);
+    if (dma_b_lane) pg_dma16(Bg + (ltap * p.Cin + lc0), voffB, ldsB + slot_off);
+    if (++lkt < nk) {                                               // past the end: the last K-tile again (never read)
+      ++ltap;
+      if (++lts == p.R) { lts = 0; ++ltr; }
+      if (ltap == p.R * p.R) { ltap = 0; ltr = 0; lts = 0; lc0 += BK; }
+    } else {
+      lkt = nk;
+    }
+  };
+  auto next_slot = [](unsigned off) -> unsigned { return off == (unsigned)((NBUF - 1) * SLOT) ? 0u : off + (unsigned)SLOT; };
+
+  const int fo = r * 64 + ((kk ^ pg_swz(r)) * 16);
+  const char* fa = lds + fo + (32 * wm) * 64;
+  const char* fb = lds + fo + A_BYTES + (16 * NT * wn) * 64;
+
+  f32x4 acc[2][NT], acc2[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+  issue_next(0u);
+  issue_next((unsigned)SLOT);
+
+  auto tile_step = [&](unsigned cur, auto flush_c) {
+    constexpr bool FLUSH = decltype(flush_c)::value;
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_next(next_slot(next_slot(cur)));
+    float4 a[2], b[NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[i] = *reinterpret_cast<const float4*>(fa + cur + i * 1024);
+      if (RELU) { a[i].x = fmaxf(a[i].x, 0.f); a[i].y = fmaxf(a[i].y, 0.f); a[i].z = fmaxf(a[i].z, 0.f); a[i].w = fmaxf(a[i].w, 0.f); }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float4*>(fb + cur + j * 1024);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float av = s == 0 ? a[i].x : (s == 1 ? a[i].y : (s == 2 ? a[i].z : a[i].w));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float bv = s == 0 ? b[j].x : (s == 1 ? b[j].y : (s == 2 ? b[j].z : b[j].w));
+          if (LEVELS == 2 && FLUSH && s == 0) {
+            acc2[i][j] += acc[i][j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  unsigned cur = 0u;
+  for (int kt = 0; kt < nk; kt += 2) {
+    tile_step(cur, std::true_type{});
+    cur = next_slot(cur);
+    tile_step(cur, std::false_type{});
+    cur = next_slot(cur);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: lane (r, kk) holds C[16 i + r][16 j + 4 kk .. + 3] of its wave tile
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + 32 * wm + 16 * i + r;
+    long out_row = m;
+    if (p.phase_mode) {
+      const int mm = m < p.M ? m : 0;
+      const int w = mm % p.W, tq = mm / p.W, h = tq % p.H, b = tq / p.H;
+      const int oh = p.oH ? p.oH : 2 * p.H, ow = p.oW ? p.oW : 2 * p.W;
+      const int y = 2 * h + ph_a, x = 2 * w + ph_b;
+      out_row = (y < oh && x < ow) ? ((long)b * oh + y) * ow + x : -1;
+    }
+    const bool row_ok = m < p.M && out_row >= 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + 16 * NT * wn + 16 * j + 4 * kk;
+      f32x4 v = (LEVELS == 2) ? acc[i][j] + acc2[i][j] : acc[i][j];
+      v *= p.alpha;
+      if (row_ok && n < p.N) {
+        if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (p.res != nullptr) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + out_row * p.ldc + n);
+          if (p.res_mode == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rv[e] > 0.f ? v[e] : 0.f;
+          } else {
+            v += rv;
+          }
+        }
+        *reinterpret_cast<f32x4*>(p.C + out_row * p.ldc + n) = v;
+      }
+    }
+  }
+}
+
 static bool pgemm_enabled() {      // measurement switch (ICG_PGEMM=0: first-generation plane GEMMs), read once per process
   static const bool on = [] { const char* e = getenv("ICG_PGEMM"); return !(e && e[0] == '0'); }();
   return on;
@@ -603,6 +800,45 @@ int icg_pgemm_tn_launch(const float* A, const float* B, float* C, int M, int N, 
   } else {
     if (levels == 2) hipLaunchKernelGGL((icg_pgemm_tn_kernel<3, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((icg_pgemm_tn_kernel<3, 1>), grid, block, 0, st, p);
+  }
+  if (tn_out) *tn_out = nt;
+  return icg_check_launch();
+}
+
+// -> ICG_OK when launched, 1 when this kernel does not take the problem (caller continues on icg_gemm_body)
+int icg_pconv_launch(const float* A, const float* B, float* C, int M, int N, int K, int H, int W, int Cin, int R, int up, int Hs,
+                     int Ws, int pad_h, int pad_w, int gs, int Hb, int Wb, long ldb, long ldc, const float* bias, const float* res,
+                     int res_mode, float alpha, long strideB, int phase_mode, int oH, int oW, int pre_relu, int zdim,
+                     hipStream_t st, int* tn_out) {
+  if (!pgemm_enabled()) return 1;
+  static const int on = pgemm_env_int("ICG_PCONV", 1);
+  static const long min_tiles = pgemm_env_int("ICG_PCONV_MIN_TILES", 512);
+  if (!on) return 1;
+  const int nt = (N % 128 == 0) ? 4 : ((N % 96 == 0) ? 3 : 0);
+  if (nt == 0 || Cin % 16 != 0 || K != R * R * Cin || (K / 16) % 2 != 0 || R < 1 || R > 4) return 1;
+  if (res_mode == 1 || (phase_mode != 0 && (phase_mode != 1 || zdim != 4)) || (phase_mode == 0 && zdim != 1)) return 1;
+  if ((uintptr_t)A % 16 || (uintptr_t)B % 16 || (uintptr_t)C % 16 || ldb % 4 || ldc % 4 || strideB % 4) return 1;
+  if ((bias && (uintptr_t)bias % 16) || (res && (uintptr_t)res % 16)) return 1;
+  if ((long)N * ldb >= (1L << 30)) return 1;
+  const int tiles_n = N / (32 * nt);
+  const long tiles_mn = icg_cdiv(M, 128) * tiles_n, total = tiles_mn * zdim;
+  if (total < min_tiles || total >= 0x7fffffffL) return 1;         // small launches: split-K / the first-generation kernel
+  PconvP p{};
+  p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K;
+  p.H = H; p.W = W; p.Cin = Cin; p.R = R; p.up = up; p.Hs = Hs; p.Ws = Ws;
+  p.pad_h = pad_h; p.pad_w = pad_w; p.gs = gs; p.Hb = Hb; p.Wb = Wb;
+  p.ldb = ldb; p.ldc = ldc; p.bias = bias; p.res = res; p.res_mode = res_mode; p.alpha = alpha;
+  p.strideB = strideB; p.phase_mode = phase_mode; p.oH = oH; p.oW = oW; p.pre_relu = pre_relu;
+  p.tiles_n = tiles_n; p.tiles_mn = (int)tiles_mn; p.total = (unsigned)total;
+  static const bool no_swz = [] { const char* e = getenv("ICG_NO_XCD_SWIZZLE"); return e && e[0] == '1'; }();
+  p.swz = (total >= 16 && !no_swz) ? 1 : 0;
+  dim3 grid((unsigned)total), block(512);
+  if (nt == 4) {
+    if (pre_relu) hipLaunchKernelGGL((icg_pconv_kernel<4, 1, 1>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((icg_pconv_kernel<4, 0, 1>), grid, block, 0, st, p);
+  } else {
+    if (pre_relu) hipLaunchKernelGGL((icg_pconv_kernel<3, 1, 2>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((icg_pconv_kernel<3, 0, 2>), grid, block, 0, st, p);
   }
   if (tn_out) *tn_out = nt;
   return icg_check_launch();

@@ -203,7 +203,9 @@ FUSE_RELU_BACKWARD = True       # ReLU backward of a ReLU-only prologue in the d
 # two are launched on two HIP streams and overlap inside every layer's backward -- the MFMA-bound phases of one run beside the
 # HBM-bound phases of the other instead of after them.  The main stream waits for the layer's weight gradient before the
 # backward node returns, so everything downstream (autograd accumulation, DDP's bucket hooks, Adam) sees finished gradients.
-WGRAD_SIDE_STREAM = True
+WGRAD_SIDE_STREAM = False     # measured (profiles/r03_wgrad_side_stream.txt): 264.4 -> 263.0 ms per step only -- both kernels fill the chip, the
+#                               second one's workgroups are dispatched as the first one's drain -- and the per-kernel timings stop being
+#                               comparable with a profile; kept as an opt-in (bench.py --wgrad-stream), validated by the whole GPU suite
 _WGRAD_STREAMS = {}
 
 
