@@ -381,16 +381,20 @@ struct PgemmTnP {
   int swz;
 };
 
-template <int NT, int LEVELS>
-__global__ __launch_bounds__(512, 4) void icg_pgemm_tn_kernel(PgemmTnP p) {
-  constexpr int BM = 128, BN = 32 * NT, BK = 16;
+// WM: 32-row wave tiles along M (4: 128-row workgroup tile, 8 waves; 3: 96-row tile, 6 waves -- for M = Cin = 96 / 192, where a
+// 128-row tile would spend a quarter of its MFMAs on rows that do not exist)
+template <int NT, int LEVELS, int WM = 4>
+__global__ __launch_bounds__(128 * WM, (WM == 4 ? 4 : 3)) void icg_pgemm_tn_kernel(PgemmTnP p) {
+  constexpr int BM = 32 * WM, BN = 32 * NT, BK = 16, NW = 2 * WM;
   constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, SLOT = A_BYTES + B_BYTES, NBUF = 3;
-  constexpr int BCH = BN / 4;                                       // 16-byte chunks per B row: 32 or 24
+  constexpr int ACH = BM / 4, BCH = BN / 4;                         // 16-byte chunks per A / B row: 32 or 24
+  constexpr int A_LANES = A_BYTES / 16 / NW, B_LANES = B_BYTES / 16 / NW;   // chunks (lanes) per wave and K-tile: 64, or 48 for 6 KB over 8 waves
+  static_assert(A_LANES * NW * 16 == A_BYTES && B_LANES * NW * 16 == B_BYTES && A_LANES <= 64 && B_LANES <= 64, "tile / wave split");
   __shared__ __attribute__((aligned(1024))) char lds[NBUF * SLOT];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv & 3, wn = wv >> 2;
+  const int wm = wv % WM, wn = wv / WM;
   const int r = lane & 15, kk = lane >> 4;
 
   unsigned t = blockIdx.x;
@@ -408,19 +412,20 @@ __global__ __launch_bounds__(512, 4) void icg_pgemm_tn_kernel(PgemmTnP p) {
   const float* __restrict__ Ag = p.A + (long)z * p.sA + (long)kbeg * p.M;
   const float* __restrict__ Bg = p.B + (long)z * p.sB + (long)kbeg * p.N;
 
-  // DMA role: k-rows 2 wv, 2 wv + 1 of both tiles; columns beyond the matrix are clamped (they only feed masked outputs)
-  const int arow = 2 * wv + (lane >> 5), achunk = (lane & 31) ^ (4 * (arow & 1));
+  // DMA role: the wave's contiguous piece of each tile image (chunk index L = wave * lanes-per-wave + lane -> row L / chunks-per-
+  // row, chunk L % chunks-per-row); columns beyond the matrix are clamped (they only feed masked outputs)
+  const int la = min(wv * A_LANES + lane, BK * ACH - 1), lb = min(wv * B_LANES + lane, BK * BCH - 1);
+  const int arow = la / ACH, achunk = (la % ACH) ^ (4 * (arow & 1));
   const unsigned voffA = ((unsigned)arow * (unsigned)p.M + (unsigned)min(m0 + 4 * achunk, p.M - 4)) * 4u;
-  const int bl = lane % BCH;
-  const int brow = 2 * wv + min(lane / BCH, 1), bchunk = bl ^ (4 * (brow & 1));
+  const int brow = lb / BCH, bchunk = (lb % BCH) ^ (4 * (brow & 1));
   const unsigned voffB = ((unsigned)brow * (unsigned)p.N + (unsigned)min(n0 + 4 * bchunk, p.N - 4)) * 4u;
-  const bool dma_b_lane = (BCH == 32) || (lane < 2 * BCH);
+  const bool dma_a_lane = (A_LANES == 64) || (lane < A_LANES), dma_b_lane = (B_LANES == 64) || (lane < B_LANES);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
-  const unsigned ldsA = lds_base + (unsigned)wv * 1024u, ldsB = lds_base + (unsigned)A_BYTES + (unsigned)wv * (2u * BN * 4u);
+  const unsigned ldsA = lds_base + (unsigned)wv * (A_LANES * 16u), ldsB = lds_base + (unsigned)A_BYTES + (unsigned)wv * (B_LANES * 16u);
   const long a_step = (long)BK * p.M, b_step = (long)BK * p.N;      // elements per K-tile
   auto issue = [&](int kt, unsigned slot_off) {
     const int kc = min(kt, nk - 1);
-    pg_dma16(Ag + kc * a_step, voffA, ldsA + slot_off);
+    if (dma_a_lane) pg_dma16(Ag + kc * a_step, voffA, ldsA + slot_off);
     if (dma_b_lane) pg_dma16(Bg + kc * b_step, voffB, ldsB + slot_off);
   };
   auto next_slot = [](unsigned off) -> unsigned { return off == (unsigned)((NBUF - 1) * SLOT) ? 0u : off + (unsigned)SLOT; };
@@ -781,20 +786,26 @@ int icg_pgemm_tn_launch(const float* A, const float* B, float* C, int M, int N, 
   if ((long)(slices - 1) * kchunk >= K) return 1;
   if ((uintptr_t)A % 16 || (uintptr_t)B % 16 || sA % 4 || sB % 4) return 1;
   if ((long)M * K >= (1L << 30) || (long)N * K >= (1L << 30)) return 1;
+  static const int wm3 = pgemm_env_int("ICG_PGEMM_TN_WM3", 1);
+  const bool m96 = wm3 && nt == 3 && (M % 96 == 0) && (M % 128 != 0);          // 96-row tiles: no padded rows at M = 96 / 192
   PgemmTnP p{};
   p.A = A; p.B = B; p.C = C;
   p.M = M; p.N = N; p.K = K;
   p.sA = sA; p.sB = sB;
   p.kchunk = kchunk; p.slices = slices;
   p.tiles_n = N / (32 * nt);
-  const long tiles_mn = icg_cdiv(M, 128) * p.tiles_n, total = tiles_mn * planes * slices;
+  const long tiles_mn = icg_cdiv(M, m96 ? 96 : 128) * p.tiles_n, total = tiles_mn * planes * slices;
   if (total <= 0 || total >= 0x7fffffffL) return 1;
   p.tiles_mn = (int)tiles_mn;
   p.total = (unsigned)total;
   static const bool no_swz = [] { const char* e = getenv("ICG_NO_XCD_SWIZZLE"); return e && e[0] == '1'; }();
   p.swz = (total >= 16 && !no_swz) ? 1 : 0;
   dim3 grid((unsigned)total), block(512);
-  if (nt == 4) {
+  if (m96) {
+    block = dim3(384);
+    if (levels == 2) hipLaunchKernelGGL((icg_pgemm_tn_kernel<3, 2, 3>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((icg_pgemm_tn_kernel<3, 1, 3>), grid, block, 0, st, p);
+  } else if (nt == 4) {
     if (levels == 2) hipLaunchKernelGGL((icg_pgemm_tn_kernel<4, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((icg_pgemm_tn_kernel<4, 1>), grid, block, 0, st, p);
   } else {

@@ -512,6 +512,9 @@ PLANE_GEMM_TN_CASES = [
     (384, 192, 2048, 25),         # 25 planes, 96-column tiles
     (768, 768, 1024, 2),          # many output tiles per plane
     (96, 192, 131072, 2),         # the product's longest K (D block 1 conv1 at B = 128): many slices
+    (192, 192, 2048, 3),          # 96-row tiles (M a multiple of 96, not of 128): two m-tiles, two n-tiles, 6 waves per workgroup
+    (192, 96, 4096, 25),          # ... 25 planes
+    (288, 96, 1024, 2),           # ... three m-tiles
     (100, 96, 4096, 2),           # M % 4 == 0 but not a multiple of 16
     (96, 160, 4096, 2),           # N takes neither tile -> first generation
     (96, 96, 4112, 2),            # K % 32 != 0 -> first generation
