@@ -212,10 +212,11 @@ struct PgemmSP {
   int swz;
 };
 
-template <int NT, int LEVELS>
+// NBUF: LDS ring slots; the DMA runs NBUF - 1 K-tiles ahead of the MFMAs
+template <int NT, int LEVELS, int NBUF = 3>
 __global__ __launch_bounds__(512, 4) void icg_pgemm_nn_stream_kernel(PgemmSP p) {
   constexpr int BM = 128, BN = 32 * NT, BK = 16;
-  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, SLOT = A_BYTES + B_BYTES, NBUF = 3;
+  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, SLOT = A_BYTES + B_BYTES;
   constexpr int BROWS = BN / 8;
   __shared__ __attribute__((aligned(1024))) char lds[NBUF * SLOT];
 
@@ -282,8 +283,8 @@ __global__ __launch_bounds__(512, 4) void icg_pgemm_nn_stream_kernel(PgemmSP p) 
 
   f32x4 acc[2][NT], acc2[2][NT];
   set_load_tile(lv);
-  issue_next(0u);
-  issue_next((unsigned)SLOT);
+#pragma unroll
+  for (int d = 0; d < NBUF - 1; ++d) issue_next((unsigned)(d * SLOT));
 
   // one K-tile.  Every MFMA accumulates in place (same registers in and out, in every step): with separate "fresh chain" forms
   // of the step the register allocator rotates the accumulators through new registers at the joins (+20 registers, spills).
@@ -292,10 +293,10 @@ __global__ __launch_bounds__(512, 4) void icg_pgemm_nn_stream_kernel(PgemmSP p) 
   auto tile_step = [&](unsigned cur, auto flush_c, bool first_of_tile) {
     constexpr bool FLUSH = decltype(flush_c)::value;
     if (FLUSH && first_of_tile) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (NBUF - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue_next(next_slot(next_slot(cur)));
+    issue_next(cur == 0u ? (unsigned)((NBUF - 1) * SLOT) : cur - (unsigned)SLOT);      // the slot K-tile kt-1 occupied
     if (FLUSH && LEVELS == 2) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -383,10 +384,10 @@ struct PgemmTnP {
 
 // WM: 32-row wave tiles along M (4: 128-row workgroup tile, 8 waves; 3: 96-row tile, 6 waves -- for M = Cin = 96 / 192, where a
 // 128-row tile would spend a quarter of its MFMAs on rows that do not exist)
-template <int NT, int LEVELS, int WM = 4>
+template <int NT, int LEVELS, int WM = 4, int NBUF = 3>
 __global__ __launch_bounds__(128 * WM, (WM == 4 ? 4 : 3)) void icg_pgemm_tn_kernel(PgemmTnP p) {
   constexpr int BM = 32 * WM, BN = 32 * NT, BK = 16, NW = 2 * WM;
-  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, SLOT = A_BYTES + B_BYTES, NBUF = 3;
+  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, SLOT = A_BYTES + B_BYTES;
   constexpr int ACH = BM / 4, BCH = BN / 4;                         // 16-byte chunks per A / B row: 32 or 24
   constexpr int A_LANES = A_BYTES / 16 / NW, B_LANES = B_BYTES / 16 / NW;   // chunks (lanes) per wave and K-tile: 64, or 48 for 6 KB over 8 waves
   static_assert(A_LANES * NW * 16 == A_BYTES && B_LANES * NW * 16 == B_BYTES && A_LANES <= 64 && B_LANES <= 64, "tile / wave split");
@@ -449,15 +450,15 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 4 : 3)) void icg_pgemm_tn_kern
       acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-  issue(0, 0u);
-  issue(1, (unsigned)SLOT);
+#pragma unroll
+  for (int d = 0; d < NBUF - 1; ++d) issue(d, (unsigned)(d * SLOT));
 
   auto tile_step = [&](int kt, unsigned cur, auto flush_c) {
     constexpr bool FLUSH = decltype(flush_c)::value;
-    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (NBUF - 2)) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    issue(kt + 2, next_slot(next_slot(cur)));
+    issue(kt + NBUF - 1, cur == 0u ? (unsigned)((NBUF - 1) * SLOT) : cur - (unsigned)SLOT);
     float a[4][2], b[4][NT];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -749,8 +750,12 @@ int icg_pgemm_nn_launch(const float* A, const float* B, float* C, int M, int N, 
     while (run > 1 && total / run < 2048) --run;
     const long per_xcd = icg_cdiv(icg_cdiv(total, 8), run);
     dim3 grid(swz ? (unsigned)(8 * per_xcd) : (unsigned)icg_cdiv(total, run));
+    static const int nbuf = pgemm_env_int("ICG_PGEMM_NBUF", 3);
     if (nt == 4) {
       hipLaunchKernelGGL((icg_pgemm_nn_stream_kernel<4, 1>), grid, block, 0, st, p);       // (levels == 1: see above)
+    } else if (nbuf == 4) {
+      if (levels == 2) hipLaunchKernelGGL((icg_pgemm_nn_stream_kernel<3, 2, 4>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((icg_pgemm_nn_stream_kernel<3, 1, 4>), grid, block, 0, st, p);
     } else {
       if (levels == 2) hipLaunchKernelGGL((icg_pgemm_nn_stream_kernel<3, 2>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((icg_pgemm_nn_stream_kernel<3, 1>), grid, block, 0, st, p);
@@ -801,10 +806,14 @@ int icg_pgemm_tn_launch(const float* A, const float* B, float* C, int M, int N, 
   static const bool no_swz = [] { const char* e = getenv("ICG_NO_XCD_SWIZZLE"); return e && e[0] == '1'; }();
   p.swz = (total >= 16 && !no_swz) ? 1 : 0;
   dim3 grid((unsigned)total), block(512);
+  static const int nbuf = pgemm_env_int("ICG_PGEMM_NBUF", 3);
   if (m96) {
     block = dim3(384);
-    if (levels == 2) hipLaunchKernelGGL((icg_pgemm_tn_kernel<3, 2, 3>), grid, block, 0, st, p);
+    if (levels == 2 && nbuf == 4) hipLaunchKernelGGL((icg_pgemm_tn_kernel<3, 2, 3, 4>), grid, block, 0, st, p);
+    else if (levels == 2) hipLaunchKernelGGL((icg_pgemm_tn_kernel<3, 2, 3>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((icg_pgemm_tn_kernel<3, 1, 3>), grid, block, 0, st, p);
+  } else if (nt == 3 && levels == 2 && nbuf == 4) {
+    hipLaunchKernelGGL((icg_pgemm_tn_kernel<3, 2, 4, 4>), grid, block, 0, st, p);
   } else if (nt == 4) {
     if (levels == 2) hipLaunchKernelGGL((icg_pgemm_tn_kernel<4, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((icg_pgemm_tn_kernel<4, 1>), grid, block, 0, st, p);
