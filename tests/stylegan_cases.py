@@ -80,6 +80,24 @@ SG2_NETS["ic_r32_fp16"] = dict(
     # loss gain of the per-phase gradient comparison: at gain 1 the gradients inside the fp16 blocks of this synthetic net are
     # ~1e-6, i.e. at fp16's subnormal step (6e-8), and both implementations return quantisation noise there
     batch=4, phase_gain=1024.0)
+# BASELINE.json configs[3] at its REAL network: IC-GAN StyleGAN2 256x256, `cfg=auto` on one GPU (stylegan2_ada_pytorch/train.py:291-372:
+# fmaps 0.5 -> channel_base 16384, channel_max 512, 2 mapping layers, mbstd group 4, h_dim 2048), batch cut to 2 for the CPU run of
+# the reference; fp32 throughout (`cfg4_r256`) and with the reference's block precision (`cfg4_r256_fp16`: num_fp16_res=4, conv_clamp=256)
+_CFG4_COMMON = dict(channel_base=16384, channel_max=512)
+SG2_REAL_NETS = {
+    "cfg4_r256": dict(
+        G=dict(z_dim=512, c_dim=0, h_dim=2048, w_dim=512, img_resolution=256, img_channels=3, mapping_kwargs=dict(num_layers=2),
+               synthesis_kwargs=dict(**_CFG4_COMMON)),
+        D=dict(c_dim=0, h_dim=2048, img_resolution=256, img_channels=3, mapping_kwargs=dict(num_layers=2),
+               epilogue_kwargs=dict(mbstd_group_size=4), **_CFG4_COMMON),
+        batch=2),
+    "cfg4_r256_fp16": dict(
+        G=dict(z_dim=512, c_dim=0, h_dim=2048, w_dim=512, img_resolution=256, img_channels=3, mapping_kwargs=dict(num_layers=2),
+               synthesis_kwargs=dict(num_fp16_res=4, conv_clamp=256, **_CFG4_COMMON)),
+        D=dict(c_dim=0, h_dim=2048, img_resolution=256, img_channels=3, mapping_kwargs=dict(num_layers=2), num_fp16_res=4,
+               conv_clamp=256, epilogue_kwargs=dict(mbstd_group_size=4), **_CFG4_COMMON),
+        batch=2, phase_gain=1024.0),
+}
 SG2_LOSS = dict(style_mixing_prob=0, r1_gamma=1.0, pl_batch_shrink=2, pl_decay=0.01, pl_weight=2)
 SG2_OPT = dict(lr=0.0025, betas=[0, 0.99], eps=1e-8)
 

@@ -15,9 +15,12 @@ import torch
 
 from oracle import kernel_ref
 from tests.helpers import GOLDEN_DIR, check_group
-from tests.stylegan_cases import SG2_LOSS, SG2_NETS, SG2_OPT, sg2_inputs, sg2_state
+from tests.stylegan_cases import SG2_LOSS, SG2_NETS, SG2_OPT, SG2_REAL_NETS, sg2_inputs, sg2_state
 
 CASES = sorted(SG2_NETS)
+# BASELINE.json configs[3] at its real network (256x256, cfg=auto: 512 ... 64 channels, h_dim 2048), batch 2: GPU only
+REAL_CASES = sorted(SG2_REAL_NETS)
+ALL_NETS = {**SG2_NETS, **SG2_REAL_NETS}
 
 
 @pytest.fixture
@@ -44,7 +47,7 @@ def _build(name, dev, monkeypatch):
     from ic_gan_amd.stylegan2 import loss as L, networks as N
     monkeypatch.setattr(N, "_randn", lambda shape, device: torch.randn(shape).to(device))
     monkeypatch.setattr(L, "_randn_like", lambda t: torch.randn(t.shape).to(t.device))
-    cfg = SG2_NETS[name]
+    cfg = ALL_NETS[name]
     G = N.Generator(**cfg["G"]).train().requires_grad_(False).to(dev)
     D = N.Discriminator(**cfg["D"]).train().requires_grad_(False).to(dev)
     _load(G, 1, dev)
@@ -66,11 +69,11 @@ def _close(got, ref, rtol, what):
     assert got.shape == ref.shape and err <= rtol * scale + 1e-6, "%s: err %.3e rms %.3e" % (what, err, scale)
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + REAL_CASES)
 def test_state_dict_contract(name):
     from ic_gan_amd.stylegan2 import networks as N
     g = _gold(name)
-    cfg = SG2_NETS[name]
+    cfg = ALL_NETS[name]
     G, D = N.Generator(**cfg["G"]), N.Discriminator(**cfg["D"])
     assert _spec(G) == json.loads(str(g["gspec"]))
     assert _spec(D) == json.loads(str(g["dspec"]))
@@ -176,18 +179,18 @@ def test_training_iterations_host_logic(name, emu, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + REAL_CASES)
 def test_forward_hip(name, monkeypatch):
     _forward(name, "cuda:0", monkeypatch)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + REAL_CASES)
 def test_phase_gradients_hip(name, monkeypatch):
     _phase_grads(name, "cuda:0", monkeypatch)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + REAL_CASES)
 def test_training_iterations_hip(name, monkeypatch):
     _iterations(name, "cuda:0", monkeypatch)
