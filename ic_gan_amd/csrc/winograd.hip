@@ -534,8 +534,7 @@ __device__ __forceinline__ void w4_out_pool(const float4 m[6], float4 y[2]) {
 
 // one thread per (tile, channel quad).  POOL = 0: y[b, 4ty+a, 4tx+c] = alpha (A^T m A)[a][c] + bias + residual on [B][H][W][C];
 // POOL = 1: the 2x2 sums of each tile, y [B][H/2][W/2][C] (alpha = 1/4 makes it the average pool), bias / residual at that size
-// NTL: the M planes are read exactly once -> non-temporal loads (measurement switch ICG_WINO_NT, see launch_wino4_output)
-template <int POOL, int NP, int NTL = 0>
+template <int POOL, int NP>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mb, const float* __restrict__ bias,
                                                            const float* __restrict__ res, int res_up, float alpha,
                                                            float* __restrict__ y, int B, int H, int W, int C4) {
@@ -563,17 +562,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
       }
       float4 col[6], yy[4];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        if (!w4_has<NP>(r)) { col[r] = f4zero(); continue; }
-        const float4* src = mp + (long)(w4_slot<NP>(r) * NP + w4_slot<NP>(j)) * plane;
-        if (NTL) {
-          typedef float nt_f4 __attribute__((ext_vector_type(4)));
-          const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(src));
-          col[r] = make_float4(v.x, v.y, v.z, v.w);
-        } else {
-          col[r] = *src;
-        }
-      }
+      for (int r = 0; r < 6; ++r) col[r] = w4_has<NP>(r) ? mp[(long)(w4_slot<NP>(r) * NP + w4_slot<NP>(j)) * plane] : f4zero();
       if constexpr (POOL) w4_out_pool(col, yy); else w4_out4(col, yy);
 #pragma unroll
       for (int a = 0; a < NO; ++a) s[a][j] = yy[a];
@@ -683,13 +672,6 @@ static void launch_wino4_output(hipStream_t st, int pool, int np, const float* M
   long nb = icg_cdiv(T * (Cout / 4), 256);
   if (nb > 256 * 64) nb = 256 * 64;
   const dim3 g((unsigned)nb), blk(256);
-  static const bool nt = [] { const char* e = getenv("ICG_WINO_NT"); return e && e[0] == '1'; }();
-  if (nt) {
-    if (pool) hipLaunchKernelGGL((wino4_output_kernel<1, 5, 1>), g, blk, 0, st, Mb, bias, res, res_up, alpha, y, B, H, W, Cout / 4);
-    else if (np == 5) hipLaunchKernelGGL((wino4_output_kernel<0, 5, 1>), g, blk, 0, st, Mb, bias, res, res_up, alpha, y, B, H, W, Cout / 4);
-    else hipLaunchKernelGGL((wino4_output_kernel<0, 6, 1>), g, blk, 0, st, Mb, bias, res, res_up, alpha, y, B, H, W, Cout / 4);
-    return;
-  }
   if (pool) hipLaunchKernelGGL((wino4_output_kernel<1, 5>), g, blk, 0, st, Mb, bias, res, res_up, alpha, y, B, H, W, Cout / 4);
   else if (np == 5) hipLaunchKernelGGL((wino4_output_kernel<0, 5>), g, blk, 0, st, Mb, bias, res, res_up, alpha, y, B, H, W, Cout / 4);
   else hipLaunchKernelGGL((wino4_output_kernel<0, 6>), g, blk, 0, st, Mb, bias, res, res_up, alpha, y, B, H, W, Cout / 4);
