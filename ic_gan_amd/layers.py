@@ -314,9 +314,14 @@ class Attention(nn.Module):
         self.gamma = P(torch.tensor(0.0), requires_grad=True)
 
     def forward(self, x, y=None):
-        theta = self.theta(x)
-        phi = ops.MaxPool2Fn.apply(self.phi(x))
-        g = ops.MaxPool2Fn.apply(self.g(x))
+        # x has four consumers (theta, phi, g and the residual path).  Each projection hands x on to the next consumer
+        # (`chain=True`: second output = x itself), so that in the backward pass the gradients of x arrive one after the
+        # other and every projection adds the running sum in the epilogue of its own data-gradient GEMM: no elementwise
+        # gradient-accumulation passes over [B, C, 64, 64] (three per block and backward pass, 1.2 GB of traffic each at cfg3)
+        theta, x = self.theta(x, chain=True)
+        phi, x = self.phi(x, chain=True)
+        g, x = self.g(x, chain=True)
+        phi, g = ops.MaxPool2Fn.apply(phi), ops.MaxPool2Fn.apply(g)
         o = self.o(ops.AttnCoreFn.apply(theta, phi, g))
         return ops.ScaleAddFn.apply(self.gamma, o, x)
 
@@ -352,8 +357,13 @@ class GBlock(nn.Module):
             return self._forward_sync(x, y, up, o1, o2)
         g1, b1 = self.bn1.affine(y) if isinstance(self.bn1, ccbn) else (self.bn1.gain, self.bn1.bias)
         g2, b2 = self.bn2.affine(y) if isinstance(self.bn2, ccbn) else (self.bn2.gain, self.bn2.bias)
-        # 1x1 shortcut commutes with nearest upsampling: run it at the input resolution
-        sc = self.conv_sc(x) if self.learnable_sc else x
+        # 1x1 shortcut commutes with nearest upsampling: run it at the input resolution.  x feeds the shortcut and the main path:
+        # the shortcut hands x on (`chain=True`, see Attention.forward), so the main path's gradient of x is added in the
+        # epilogue of the shortcut's data-gradient GEMM instead of by an elementwise pass
+        if self.learnable_sc:
+            sc, x = self.conv_sc(x, chain=True)
+        else:
+            sc = x
         h = self.conv1(x, relu=True, upsample=up, bn=o1, gain=g1, beta=b1)
         return self.conv2(h, relu=True, bn=o2, gain=g2, beta=b2, residual=sc, res_up=up)
 
@@ -366,7 +376,7 @@ class GBlock(nn.Module):
         g2, b2 = self.bn2.affine(y) if isinstance(self.bn2, ccbn) else (self.bn2.gain, self.bn2.bias)
         h = self.conv1(x, relu=True, upsample=up, bn=o1, gain=g1, beta=b1, bn_stats=st1)
         st2 = ops.bn_stats_begin(h, o2)
-        sc = self.conv_sc(x) if self.learnable_sc else x
+        sc = self.conv_sc(x) if self.learnable_sc else x          # (launch order matters here: no gradient chain)
         return self.conv2(h, relu=True, bn=o2, gain=g2, beta=b2, residual=sc, res_up=up, bn_stats=st2)
 
 

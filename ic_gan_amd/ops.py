@@ -334,6 +334,7 @@ class ConvOpt:
     bn: Optional[BNOpt] = None
     downsample: bool = False    # conv3x3 -> 2x2 average pool, run as one 4x4/stride-2 conv (needs sn.w_down)
     bn_stats: object = None     # BNStats started ahead by bn_stats_begin (cross-replica BN: all-reduce in flight)
+    chain: bool = False         # also return the input as a second output whose gradient is folded into this layer's data gradient
 
 
 @dataclass
@@ -364,7 +365,10 @@ class FusedConvFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, gain, beta, opt: ConvOpt):
         _require_gpu(x)
+        x_in = x
         x = _cl(x)
+        if opt.chain and (x.data_ptr() != x_in.data_ptr() or x.dtype != x_in.dtype):
+            x_in = x                          # a layout copy was made: chain on the copy
         sn = opt.sn
         B, Cin, Hs, Ws = x.shape
         assert Cin == sn.cin, (Cin, sn.cin)
@@ -444,12 +448,20 @@ class FusedConvFn(Function):
         ctx.has = (bias is not None, residual is not None, gain is not None, beta is not None)
         ctx.weight_like = weight
         ctx.save_for_backward(x, scale, shift, mean, invstd, gain, count_dev)
+        if opt.chain:
+            # gradient chain: the caller feeds `x_next` (the same values as x) to the next consumer of x instead of x itself, so
+            # that the consumers' data gradients arrive here one after the other and are ADDED IN THE EPILOGUE of this layer's
+            # data-gradient convolution (residual operand) -- instead of autograd summing separate tensors with elementwise adds
+            # (three per attention block and backward pass: theta / phi / g / the residual path all read x)
+            return out, x_in
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dcarry=None):
         x, scale, shift, mean, invstd, gain, count_dev = ctx.saved_tensors
         opt, flags = ctx.opt, ctx.flags
+        if dcarry is not None:
+            dcarry = _cl(dcarry)
         sn, bn = opt.sn, opt.bn
         B, Cin, Hs, Ws, H, W, Cout, R, gb_rows, ssb, count = ctx.dims
         has_bias, has_res, has_gain, has_beta = ctx.has
@@ -497,6 +509,8 @@ class FusedConvFn(Function):
                     raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
                 da = _empty_cl(B, Cin, H, W, dev)
                 mres, mflag = (x, L.ICG_RES_RELU_MASK) if mask else (None, 0)
+                if dcarry is not None and not mask and bn is None and not opt.relu and not opt.upsample:
+                    mres, mflag, dcarry = dcarry, 0, None      # the later consumers' gradient of x: residual add in the epilogue
                 if sn.w_wino_dgrad is not None:
                     _wino_fprop(dout, sn.w_wino_dgrad, None, mres, da, None, None, 0, B, H, W, Cout, Cin, mflag, sn.wino_m)
                 else:
@@ -603,6 +617,10 @@ class FusedConvFn(Function):
         if bn_state is not None:
             dx, dgain, dbeta = _bn_backward_end(bn_state, x, da, bn, scale, shift, ssb, mean, invstd, gb_rows, count,
                                                 bn_flags, has_gain, has_beta, (B, Cin, Hs, Ws))
+        if dcarry is not None and dx is not None:
+            dx = dx + dcarry                   # (layer forms whose epilogue is taken: fall back to the elementwise add)
+        elif dcarry is not None and need[0]:
+            dx = dcarry
         if not need[0]:
             dx = None
         return dx, dweight, dbias, dres, dgain, dbeta, None
@@ -743,10 +761,12 @@ def norm_act(x, bn: BNOpt, gain, beta, relu=False):
 
 
 def fused_conv(x, weight, bias, sn: SNState, *, relu=False, upsample=False, residual=None, res_up=False,
-               bn: Optional[BNOpt] = None, gain=None, beta=None, downsample=False, bn_stats: Optional[BNStats] = None):
+               bn: Optional[BNOpt] = None, gain=None, beta=None, downsample=False, bn_stats: Optional[BNStats] = None,
+               chain=False):
     """conv(act(x)) with act = [BN affine] -> [ReLU] -> [nearest x2]; `gain`/`beta` are [B,C] (ccbn) or [C] (bn);
     downsample=True appends the 2x2 average pool (residual is then at the pooled resolution)."""
-    opt = ConvOpt(sn=sn, relu=relu, upsample=upsample, res_up=res_up, bn=bn, downsample=downsample, bn_stats=bn_stats)
+    opt = ConvOpt(sn=sn, relu=relu, upsample=upsample, res_up=res_up, bn=bn, downsample=downsample, bn_stats=bn_stats,
+                  chain=bool(chain))
     if bn is not None:
         g2 = gain if gain is None or gain.dim() == 2 else gain.view(1, -1)
         b2 = beta if beta is None or beta.dim() == 2 else beta.view(1, -1)
