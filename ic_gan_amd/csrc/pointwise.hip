@@ -135,7 +135,12 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ x, 
       out[i] = v;
     } else if (MODE == 1) {
       const float g = scale * dy[i];
-      out[base] = g; out[base + o01] = g; out[base + o10] = g; out[base + o11] = g;
+      if (aux) {      // + running gradient at the full resolution (icg_avgpool2_bwd_add)
+        out[base] = g + aux[base]; out[base + o01] = g + aux[base + o01];
+        out[base + o10] = g + aux[base + o10]; out[base + o11] = g + aux[base + o11];
+      } else {
+        out[base] = g; out[base + o01] = g; out[base + o10] = g; out[base + o11] = g;
+      }
     } else if (MODE == 2) {
       float m = x[base];
       m = fmaxf(m, x[base + o01]);
@@ -179,6 +184,10 @@ extern "C" int icg_avgpool2_fwd(const float* x, const float* add, float* y, int 
 extern "C" int icg_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
   ICG_REQUIRE(dy);
   return launch_pool<1>(nullptr, nullptr, dy, dx, B, H, W, C, stream);
+}
+extern "C" int icg_avgpool2_bwd_add(const float* dy, const float* carry, float* dx, int B, int H, int W, int C, void* stream) {
+  ICG_REQUIRE(dy && carry);
+  return launch_pool<1>(nullptr, carry, dy, dx, B, H, W, C, stream);
 }
 extern "C" int icg_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
   ICG_REQUIRE(x);

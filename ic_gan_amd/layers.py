@@ -397,10 +397,12 @@ class DBlock(nn.Module):
             self.conv_sc = which_conv(in_channels, out_channels, kernel_size=1, padding=0)
 
     def forward(self, x):
-        h = self.conv1(x, relu=bool(self.preactivation))
         if self.downsample:
-            # avg-pool and the 1x1 shortcut are both linear: pool first (4x fewer MACs) for either block kind
-            s = ops.AvgPool2Fn.apply(x, None)
+            # avg-pool and the 1x1 shortcut are both linear: pool first (4x fewer MACs) for either block kind.  The pooling hands
+            # x on to the main path (gradient chain, see Attention.forward): conv1's gradient of x is added inside the pooling
+            # backward kernel instead of by an elementwise pass
+            s, x = ops.AvgPool2Fn.apply(x, None, True)
+            h = self.conv1(x, relu=bool(self.preactivation))
             if self.learnable_sc:
                 s = self.conv_sc(s)
             if self.conv2.in_channels % 4 == 0 and self.conv2.out_channels % 4 == 0:
@@ -408,5 +410,6 @@ class DBlock(nn.Module):
                 return self.conv2(h, relu=True, downsample=True, residual=s)
             h = self.conv2(h, relu=True)
             return ops.AvgPool2Fn.apply(h, s)
+        h = self.conv1(x, relu=bool(self.preactivation))
         s = self.conv_sc(x) if self.learnable_sc else x
         return self.conv2(h, relu=True, residual=s)

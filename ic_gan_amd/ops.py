@@ -806,10 +806,13 @@ class SNEmbeddingFn(Function):
 # pooling / pointwise
 # ----------------------------------------------------------------------------------------------
 class AvgPool2Fn(Function):
-    """y = avgpool2x2(x) (+ add)   (nn.AvgPool2d(2), BigGAN.py:528; residual add of layers.py:613)."""
+    """y = avgpool2x2(x) (+ add)   (nn.AvgPool2d(2), BigGAN.py:528; residual add of layers.py:613).
+    chain=True: also returns x as a second output (see FusedConvFn: gradient chain) -- the next consumer's gradient of x is added
+    inside the pooling backward kernel (icg_avgpool2_bwd_add)."""
 
     @staticmethod
-    def forward(ctx, x, add):
+    def forward(ctx, x, add, chain=False):
+        x_in = x
         x = _cl(x)
         B, C, H, W = x.shape
         y = _empty_cl(B, C, H // 2, W // 2, x.device)
@@ -817,17 +820,22 @@ class AvgPool2Fn(Function):
         L.call("icg_avgpool2_fwd", x, a, y, B, H, W, C)
         ctx.dims = (B, C, H, W)
         ctx.has_add = add is not None
+        if chain:
+            return y, (x_in if x.data_ptr() == x_in.data_ptr() and x.dtype == x_in.dtype else x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dcarry=None):
         B, C, H, W = ctx.dims
         dy = _cl(dy)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _empty_cl(B, C, H, W, dy.device)
-            L.call("icg_avgpool2_bwd", dy, dx, B, H, W, C)
-        return dx, (dy if ctx.has_add and ctx.needs_input_grad[1] else None)
+            if dcarry is not None:
+                L.call("icg_avgpool2_bwd_add", dy, _cl(dcarry), dx, B, H, W, C)
+            else:
+                L.call("icg_avgpool2_bwd", dy, dx, B, H, W, C)
+        return dx, (dy if ctx.has_add and ctx.needs_input_grad[1] else None), None
 
 
 class MaxPool2Fn(Function):

@@ -426,6 +426,9 @@ int icg_avgpool2_fwd(const float* x, const float* add, float* y, int B, int H, i
 int icg_sumpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
 /* dx = 0.25 * dy broadcast over the 2x2 window */
 int icg_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+/* ... plus a running gradient of the pooled tensor's source: dx = 0.25 * dy broadcast + carry (carry [B][H][W][C]; gradient chain
+ * of the DBlock shortcut, ic_gan_amd/layers.py: the main path's gradient of x is added here instead of by an elementwise pass) */
+int icg_avgpool2_bwd_add(const float* dy, const float* carry, float* dx, int B, int H, int W, int C, void* stream);
 /* 2x2 max pool (F.max_pool2d, layers.py:230-231); backward routes to the first maximum */
 int icg_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
 int icg_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream);

@@ -681,6 +681,12 @@ def icg_avgpool2_bwd(dy, dx, B, H, W, C):
     mem(dx)[: B * H * W * C].copy_(g.view(B, H // 2, 1, W // 2, 1, C).expand(B, H // 2, 2, W // 2, 2, C).reshape(-1))
 
 
+def icg_avgpool2_bwd_add(dy, carry, dx, B, H, W, C):
+    g = _nhwc(dy, B, H // 2, W // 2, C) * 0.25
+    full = g.view(B, H // 2, 1, W // 2, 1, C).expand(B, H // 2, 2, W // 2, 2, C).reshape(-1)
+    mem(dx)[: B * H * W * C].copy_(full + mem(carry)[: B * H * W * C])
+
+
 def icg_maxpool2_fwd(x, y, B, H, W, C):
     xn = _nhwc(x, B, H, W, C).permute(0, 3, 1, 2)
     mem(y)[: B * H * W * C // 4].copy_(F.max_pool2d(xn, 2).permute(0, 2, 3, 1).reshape(-1))

@@ -743,6 +743,7 @@ def test_layout_pool_pointwise(B, C, H, W):
     (p,) = run_pair("icg_avgpool2_fwd", [x, None, yp.clone(), B, H, W, C], [2]); close(*p, what="avgpool")
     (p,) = run_pair("icg_sumpool2_fwd", [x, yp.clone(), B, H, W, C], [1]); close(*p, what="sumpool")
     (p,) = run_pair("icg_avgpool2_bwd", [add, torch.empty_like(x), B, H, W, C], [1]); close(*p, what="avgpool bwd")
+    (p,) = run_pair("icg_avgpool2_bwd_add", [add, cl(B, C, H, W, seed=13), torch.empty_like(x), B, H, W, C], [2]); close(*p, what="avgpool bwd + carry")
     (p,) = run_pair("icg_maxpool2_fwd", [x, yp.clone(), B, H, W, C], [1]); close(*p, what="maxpool")
     (p,) = run_pair("icg_maxpool2_bwd", [x, add, torch.empty_like(x), B, H, W, C], [2]); close(*p, what="maxpool bwd")
     # pointwise
