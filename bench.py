@@ -74,10 +74,35 @@ class KernelTimer:
             "icg_conv2d_g_wgrad": (3, "gconv"), "icg_bias_act": (6, "bias_act"), "icg_bias_act_typed": (6, "bias_act"),
             "icg_upfirdn2d": (3, "upfirdn2d"), "icg_upfirdn2d_nhwc": (3, "upfirdn2d"), "icg_upfirdn2d_typed": (3, "upfirdn2d")}
 
-    def __init__(self):
-        self.records = []      # (kernel name, algorithmic flops, executed flops, algorithmic bytes, start, end)
-        self.hbm_records = []  # (op name, algorithmic bytes, start, end) of the HBM-bound StyleGAN2 plugins
+    def __init__(self, period=4):
+        # Stratified sampling: every launch is COUNTED per (entry point, shape); every `period`-th launch of such a key is bracketed
+        # by HIP events.  A key's launches do identical work, so its time is (mean bracketed launch) x (launch count); period 1
+        # brackets every launch.  An event pair drains the stream's launch pipeline for a few microseconds -- bracketing all of the
+        # ~1300 launches of a cfg3 step costs ~2.7 ms/step of the very time being measured (`--timer-period 1` to see it).
+        self.period = max(int(period), 1)
+        self.keys = {}         # (entry point, shape ints) -> [kernel name, alg flops, exe flops, alg bytes, launches, [(start, end), ...]]
+        self.hbm_keys = {}     # the same for the HBM-bound StyleGAN2 plugins: -> [op name, bytes, launches, [(start, end), ...]]
         self.enabled = False
+
+    @property
+    def records(self):
+        """[(kernel name, alg flops, exe flops, alg bytes, seconds)] per counted launch (seconds: the key's mean bracketed launch)"""
+        out = []
+        for kname, alg, exe, byt, n, ev in self.keys.values():
+            if not ev:
+                continue
+            mean = sum(s.elapsed_time(e) for s, e in ev) * 1e-3 / len(ev)
+            out.extend([(kname, alg, exe, byt, mean)] * n)
+        return out
+
+    @property
+    def hbm_records(self):
+        out = []
+        for name, byt, n, ev in self.hbm_keys.values():
+            if ev:
+                mean = sum(s.elapsed_time(e) for s, e in ev) * 1e-3 / len(ev)
+                out.extend([(name, byt, mean)] * n)
+        return out
 
     def install(self):
         import ctypes
@@ -101,11 +126,16 @@ class KernelTimer:
                     oh, ow = args[sl + 16:sl + 18]
                     esz = {1: 2, 2: 8}.get(args[-2], 4) if name.endswith("typed") else 4
                     byt = float(N) * C * (H * W + oh * ow) * esz
+                key = (name,) + tuple(a for a in args[sl:] if isinstance(a, int))
+                rec = timer.hbm_keys.setdefault(key, [mode + " (" + name + ")", byt, 0, []])
+                rec[2] += 1
+                if (rec[2] - 1) % timer.period:
+                    return raw(name, *args)
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 raw(name, *args)
                 e.record()
-                timer.hbm_records.append((mode + " (" + name + ")", byt, s, e))
+                rec[3].append((s, e))
                 return
             if mode == "gconv":      # out[b,oy,ox,co] = sum src(...)*w: one multiply-add per (output, Cin, tap)
                 B, Hin, Win, Cin, Hout, Wout, Cout, R = args[sl:sl + 8]
@@ -143,10 +173,19 @@ class KernelTimer:
                 exe = 2.0 * B * Hs * Ws * Cout * Cin * 16
                 lo, hi = (Cin, Cout) if "_up_" in name else (Cout, Cin)
                 byt = 4.0 * (B * Hs * Ws * (lo + 4 * hi) + 16 * Cout * Cin)
+            key = (name,) + tuple(a for a in args[sl:] if isinstance(a, int))
+            rec = timer.keys.get(key)
+            if rec is not None:
+                rec[4] += 1
+                if (rec[4] - 1) % timer.period:
+                    return raw(name, *args)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             raw(name, *args)
             e.record()
+            if rec is not None:
+                rec[5].append((s, e))
+                return
             query(last)
             pk = "icg_gemm_planes1_kernel" if last[3] == 4 else "icg_gemm_planes_kernel"     # single- / two-level chains
 
@@ -198,7 +237,7 @@ class KernelTimer:
                 kname = "void icg_gemm_planes1_kernel<%d, %d, %d>(GemmP)" % (last[0], last[1], last[2])
             else:
                 kname = "void icg_gemm_kernel<%d, %d, %d, %d>(GemmP)" % tuple(last)
-            timer.records.append((kname, alg, exe, byt, s, e))
+            timer.keys[key] = [kname, alg, exe, byt, 1, [(s, e)]]
 
         L.call = timed_call
 
@@ -207,7 +246,7 @@ class KernelTimer:
         """the Winograd-plane GEMMs run inside the composite entry points: the library brackets them with HIP events on the
         launch stream itself (icg_planes_timing)"""
         import ic_gan_amd._lib as L
-        L.lib().icg_planes_timing(1 if enable else 0)
+        L.lib().icg_planes_timing(int(enable))      # 0: off; P: count every launch per shape, bracket every P-th
 
     @staticmethod
     def planes_summary():
@@ -235,9 +274,9 @@ class KernelTimer:
     def hbm_roofline(self):
         """roofline object of the HBM-bound op with the largest total time (None when the workload launched none)."""
         agg = {}
-        for name, byt, s, e in self.hbm_records:
+        for name, byt, secs in self.hbm_records:
             a = agg.setdefault(name, [0.0, 0.0, 0])
-            a[0] += byt; a[1] += s.elapsed_time(e) * 1e-3; a[2] += 1
+            a[0] += byt; a[1] += secs; a[2] += 1
         if not agg:
             return None
         name, (byt, secs, n) = max(agg.items(), key=lambda kv: kv[1][1])
@@ -255,10 +294,10 @@ class KernelTimer:
 
     def summary(self):
         agg = {}
-        for kname, alg, exe, byt, s, e in self.records:
+        for kname, alg, exe, byt, secs in self.records:
             a = agg.setdefault(kname, [0.0, 0.0, 0, 0.0, 0.0])
             a[0] += alg
-            a[1] += s.elapsed_time(e) * 1e-3
+            a[1] += secs
             a[2] += 1
             a[3] += exe
             a[4] += byt
@@ -441,7 +480,7 @@ def bench_stylegan2(args, device, rank, world, local_rank, use_ddp):
     def one_step():
         return step(img, real_c, real_h, torch.randn([n_ph * b, 512], device=device), gen_c, gen_h)
 
-    timer = KernelTimer()
+    timer = KernelTimer(args.timer_period)
     timer.install()
     for _ in range(args.warmup):
         one_step()
@@ -453,7 +492,7 @@ def bench_stylegan2(args, device, rank, world, local_rank, use_ddp):
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
-    timer.planes(True)
+    timer.planes(timer.period)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -504,7 +543,7 @@ def bench_sampling(args, device, rank, world):
     sampler = conditioning_sampler(cfg, G.dim_z, b, device, seed=1000 + rank)
     if args.graph:
         G = inference.GraphedGenerator(G, b, class_cond=True, instance_cond=True, device=device, static_weights=True)
-    timer = KernelTimer()
+    timer = KernelTimer(args.timer_period)
     if not args.graph:                 # (a HIP-graph replay has no per-launch events: roofline null there)
         timer.install()
     for _ in range(args.warmup):
@@ -512,7 +551,7 @@ def bench_sampling(args, device, rank, world):
     torch.cuda.synchronize()
     timer.enabled = not args.graph
     if not args.graph:
-        timer.planes(True)
+        timer.planes(timer.period)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img, _, _ = inference.sample(G, sampler, cfg, class_cond=True, instance_cond=True, device=device)
@@ -700,6 +739,8 @@ def main():
                          "the shipped cfg3 schedule (cc_icgan_res256.json:22-24,40): 64 images per GPU and step as 4 x 16")
     ap.add_argument("--no-kernel-timer", action="store_true",
                     help="no HIP-event instrumentation at all (no roofline object): the un-instrumented step time as the value")
+    ap.add_argument("--timer-period", type=int, default=4,
+                    help="HIP-event brackets on every P-th launch of each (entry point, shape); all launches are counted (1: bracket all)")
     ap.add_argument("--no-uninstrumented-leg", action="store_true",
                     help="skip the second, un-instrumented timed region the N = 1 run reports beside the instrumented one")
     args = ap.parse_args()
@@ -777,7 +818,7 @@ def main():
     x, y, f = synthetic_batch(cfg, batch * acc, seed=7 + rank)      # train() consumes batch x num_D_accumulations real images
     x, y, f = x.to(device), (y.to(device) if y is not None else None), (f.to(device) if f is not None else None)
 
-    timer = KernelTimer()
+    timer = KernelTimer(args.timer_period)
     if not args.no_kernel_timer:
         timer.install()
     comm = None
@@ -812,7 +853,7 @@ def main():
     if comm:
         comm["G"].bytes = comm["G"].buckets = comm["D"].bytes = comm["D"].buckets = 0
     timer.enabled = not args.no_kernel_timer
-    timer.planes(not args.no_kernel_timer)
+    timer.planes(0 if args.no_kernel_timer else timer.period)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         metrics = one_step()
@@ -885,6 +926,7 @@ def main():
                        "batch_per_gpu": batch * acc, "micro_batch": batch, "accumulations": acc, "global_batch": batch * acc * world,
                        "parallelism": f"dp{world}",
                        "instrumented": not args.no_kernel_timer,
+                       "timer_period": (None if args.no_kernel_timer else timer.period),   # HIP-event brackets on every P-th launch per (entry point, shape)
                        "uninstrumented_ms_per_step": (round(uninstr / args.steps * 1e3, 3) if uninstr is not None else None),
                        "uninstrumented_images_per_sec": (round(batch * acc * world * args.steps / uninstr, 3) if uninstr is not None else None),
                        "comm": comm_report,

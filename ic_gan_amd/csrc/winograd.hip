@@ -219,38 +219,61 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
 void icg_gemm_mark_planes(int on);       // gemm_conv.hip: launch the following GEMMs as icg_gemm_planes_kernel (profile name)
 extern "C" int icg_gemm_last_variant(int* out4);
 
-// measurement hook for bench.py: HIP events on the launch stream around every plane-GEMM launch.  Off by default -- the
-// product path then pays one relaxed atomic load per plane-GEMM call and touches no shared state; when enabled, the record
-// list is appended under a mutex, so launches from several threads are safe (their rows simply interleave).
-struct PlanesRecord { hipEvent_t e0, e1; int amode, tn, planes, levels; double flops, bytes; };
+// measurement hook for bench.py: HIP events on the launch stream around plane-GEMM launches.  Off by default -- the product path
+// then pays one relaxed atomic load per plane-GEMM call and touches no shared state; when enabled, the tables below are updated
+// under a mutex, so launches from several threads are safe.  icg_planes_timing(P): every launch is COUNTED per distinct shape
+// (M, N, K, planes, NN / TN), every P-th launch of a shape is TIMED (P = 1: all of them); a shape's launches do the same work, so
+// its total time is estimated as (mean of its timed launches) x (its launch count) -- stratified sampling that keeps the event
+// pairs (each one drains the stream's launch pipeline for a few microseconds) out of three launches in four.
+struct PlanesShape { double M, N, K; int planes, tn_form; int amode, tn, levels; long launches, timed; double flops, bytes; };
+struct PlanesRecord { hipEvent_t e0, e1; int shape; };
+static std::vector<PlanesShape> g_planes_shapes;
 static std::vector<PlanesRecord> g_planes_records;
 static std::mutex g_planes_mutex;
-static std::atomic<bool> g_planes_timing{false};
+static std::atomic<int> g_planes_timing{0};
 
 struct PlanesScope {
   hipStream_t st;
-  int planes;
-  double flops, bytes;
+  int shape = -1;
   hipEvent_t e0 = nullptr;
-  // M x N x K per plane
-  PlanesScope(void* stream, int planes_, double M, double N, double K)
-      : st((hipStream_t)stream), planes(planes_), flops(2.0 * planes_ * M * N * K), bytes(4.0 * planes_ * (M * K + K * N + M * N)) {
+  // M x N x K per plane; tn_form: weight-gradient (TN) launch
+  PlanesScope(void* stream, int planes, double M, double N, double K, int tn_form = 0) : st((hipStream_t)stream) {
     icg_gemm_mark_planes(1);
-    if (g_planes_timing.load(std::memory_order_relaxed) && hipEventCreate(&e0) == hipSuccess) hipEventRecord(e0, st);
+    const int period = g_planes_timing.load(std::memory_order_relaxed);
+    if (period <= 0) return;
+    bool timed = false;
+    {
+      std::lock_guard<std::mutex> lock(g_planes_mutex);
+      for (size_t i = 0; i < g_planes_shapes.size(); ++i) {
+        const PlanesShape& h = g_planes_shapes[i];
+        if (h.M == M && h.N == N && h.K == K && h.planes == planes && h.tn_form == tn_form) { shape = (int)i; break; }
+      }
+      if (shape < 0) {
+        g_planes_shapes.push_back(PlanesShape{M, N, K, planes, tn_form, 0, 0, 2, 0, 0, 2.0 * planes * M * N * K,
+                                              4.0 * planes * (M * K + K * N + M * N)});
+        shape = (int)g_planes_shapes.size() - 1;
+      }
+      timed = (g_planes_shapes[shape].launches++ % period) == 0;
+    }
+    if (timed && hipEventCreate(&e0) == hipSuccess) hipEventRecord(e0, st);
   }
   ~PlanesScope() {
     icg_gemm_mark_planes(0);
-    if (e0) {
-      PlanesRecord r{e0, nullptr, 0, 0, planes, 2, flops, bytes};
-      int v[4] = {0, 0, 0, 0};
-      icg_gemm_last_variant(v);
-      r.amode = v[0]; r.tn = v[2]; r.levels = (v[3] == 4) ? 1 : 2;
-      if (hipEventCreate(&r.e1) == hipSuccess) {
-        hipEventRecord(r.e1, st);
-        std::lock_guard<std::mutex> lock(g_planes_mutex);
-        g_planes_records.push_back(r);
-      }
+    if (shape < 0) return;
+    int v[4] = {0, 0, 0, 0};
+    icg_gemm_last_variant(v);
+    hipEvent_t e1 = nullptr;
+    if (e0 && hipEventCreate(&e1) == hipSuccess) hipEventRecord(e1, st);
+    std::lock_guard<std::mutex> lock(g_planes_mutex);
+    if ((size_t)shape >= g_planes_shapes.size()) {        // tables were reset while this launch was in flight
+      if (e0) hipEventDestroy(e0);
+      if (e1) hipEventDestroy(e1);
+      return;
     }
+    PlanesShape& h = g_planes_shapes[shape];
+    h.amode = v[0]; h.tn = v[2]; h.levels = (v[3] == 4) ? 1 : 2;
+    if (e0 && e1) g_planes_records.push_back(PlanesRecord{e0, e1, shape});
+    else if (e0) hipEventDestroy(e0);
   }
 };
 
@@ -258,31 +281,45 @@ extern "C" int icg_planes_timing(int enable) {
   std::lock_guard<std::mutex> lock(g_planes_mutex);
   for (auto& r : g_planes_records) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   g_planes_records.clear();
-  g_planes_timing.store(enable != 0);
+  g_planes_shapes.clear();
+  g_planes_timing.store(enable > 0 ? enable : 0);
   return ICG_OK;
 }
 
 // out[i] = {amode, tn + 10 * (levels == 1), planes, launches, total ms, total executed flops, total operand bytes} per distinct
 // (amode, tn, levels, planes) -- levels: accumulation levels of the kernel that ran (icg_gemm_planes1_kernel / icg_gemm_planes_kernel);
+// total ms = sum over shapes of (mean timed launch) x launches (exact when the sampling period is 1);
 // returns the number of rows written (synchronises on the recorded events)
 extern "C" int icg_planes_timing_drain(double* out, int max_rows) {
   ICG_REQUIRE(out && max_rows > 0);
   std::lock_guard<std::mutex> lock(g_planes_mutex);
-  int rows = 0;
+  std::vector<double> ms_sum(g_planes_shapes.size(), 0.0);
+  for (auto& h : g_planes_shapes) h.timed = 0;
   for (auto& r : g_planes_records) {
-    if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+    if ((size_t)r.shape >= g_planes_shapes.size() || hipEventSynchronize(r.e1) != hipSuccess) continue;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    ms_sum[r.shape] += ms;
+    g_planes_shapes[r.shape].timed += 1;
+  }
+  int rows = 0;
+  for (size_t i = 0; i < g_planes_shapes.size(); ++i) {
+    const PlanesShape& h = g_planes_shapes[i];
+    if (h.timed == 0 || h.launches == 0) continue;
+    const double code = h.tn + (h.levels == 1 ? 10 : 0);
     int k = 0;
     for (; k < rows; ++k)
-      if ((int)out[7 * k] == r.amode && (int)out[7 * k + 1] == r.tn + (r.levels == 1 ? 10 : 0) && (int)out[7 * k + 2] == r.planes) break;
+      if ((int)out[7 * k] == h.amode && out[7 * k + 1] == code && (int)out[7 * k + 2] == h.planes) break;
     if (k == rows) {
       if (rows == max_rows) continue;
-      out[7 * k] = r.amode; out[7 * k + 1] = r.tn + (r.levels == 1 ? 10 : 0); out[7 * k + 2] = r.planes;
+      out[7 * k] = h.amode; out[7 * k + 1] = code; out[7 * k + 2] = h.planes;
       out[7 * k + 3] = out[7 * k + 4] = out[7 * k + 5] = out[7 * k + 6] = 0.0;
       ++rows;
     }
-    out[7 * k + 3] += 1.0; out[7 * k + 4] += ms; out[7 * k + 5] += r.flops; out[7 * k + 6] += r.bytes;
+    out[7 * k + 3] += (double)h.launches;
+    out[7 * k + 4] += ms_sum[i] / (double)h.timed * (double)h.launches;
+    out[7 * k + 5] += h.flops * (double)h.launches;
+    out[7 * k + 6] += h.bytes * (double)h.launches;
   }
   return rows;
 }
@@ -308,7 +345,7 @@ extern "C" size_t icg_plane_gemm_tn_workspace_bytes(int M, int N, int K, int pla
 extern "C" int icg_plane_gemm_tn(const float* A, const float* B, float* C, int M, int N, int K, int planes, void* workspace,
                                  size_t workspace_bytes, void* stream) {
   ICG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && planes > 0);
-  PlanesScope ps(stream, planes, M, N, K);
+  PlanesScope ps(stream, planes, M, N, K, 1);
   return icg_gemm_tn_batched(A, B, C, M, N, K, (int64_t)K * M, (int64_t)K * N, (int64_t)M * N, planes, workspace, workspace_bytes,
                              stream);
 }
@@ -347,7 +384,7 @@ extern "C" int icg_conv2d_wino_wgrad(const float* x, const float* dy, float* dw,
   if (nb > 256 * 64) nb = 256 * 64;
   hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, DY, B, H, W, Cout / 4);
   int rc;
-  { PlanesScope ps(stream, 16, Cin, Cout, (double)T); rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, 16, gws, gws_bytes, stream); }
+  { PlanesScope ps(stream, 16, Cin, Cout, (double)T, 1); rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, 16, gws, gws_bytes, stream); }
   if (rc != ICG_OK) return rc;
   const long n = (long)Cin * Cout;
   nb = icg_cdiv(n, 256);
@@ -1001,7 +1038,7 @@ static int wino4_wgrad_run(const float* x, int x_up, const float* dy, int dy_up,
   if (db_part)
     hipLaunchKernelGGL(wino_db_final_kernel, dim3((unsigned)Cout), dim3(256), 0, st, (const float*)db_part, (int)nb, Cout, dbias);
   int rc;
-  { PlanesScope ps(stream, (int)P, Cin, Cout, (double)T); rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, (int)P, gws, gws_bytes, stream); }
+  { PlanesScope ps(stream, (int)P, Cin, Cout, (double)T, 1); rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, (int)P, gws, gws_bytes, stream); }
   if (rc != ICG_OK) return rc;
   const long n = (long)Cin * Cout;
   nb = icg_cdiv(n, 256);

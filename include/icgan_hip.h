@@ -253,6 +253,8 @@ int icg_conv2d_wino4_wgrad_from_v_db(const float* V, const float* dy, float* dw,
  * icg_gemm_planes_kernel<AMODE, BMODE, TN>) is bracketed by HIP events on its launch stream.  drain() writes rows of
  * {amode, tn (+ 10 when the single-level kernel icg_gemm_planes1_kernel ran), planes, launches, total ms, total executed
  * flops, total operand bytes} and returns the row count.
+ * enable = P > 0: every launch is counted per distinct shape (M, N, K, planes, NN / TN); every P-th launch of a shape is bracketed
+ * (P = 1: all); "total ms" = sum over shapes of (mean bracketed launch) x launches -- a shape's launches do identical work.
  * Disabled (the default) the product path pays one relaxed atomic load per call; enabled, records are appended under a mutex. */
 int icg_planes_timing(int enable);
 int icg_planes_timing_drain(double* out, int max_rows);

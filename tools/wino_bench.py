@@ -23,7 +23,7 @@ for name, B, H, W, Cin, Cout in LAYERS:
     out = torch.empty(B, Cout, H, W, device=dev).contiguous(memory_format=torch.channels_last)
     out2 = torch.empty_like(out)
     sc, sh = torch.rand(B, Cin, device=dev) + 0.5, torch.randn(B, Cin, device=dev) * 0.1
-    fl = 3
+    fl = int(os.environ.get("WINO_BENCH_FLAGS", "3"))      # 3: BN affine + ReLU prologue (G);  1: ReLU only (D: second-generation implicit GEMM)
     nf = L.query("icg_conv2d_fprop_workspace_bytes", B, H, W, Cin, Cout, 3, fl)
     wf = torch.empty(max(nf, 16), dtype=torch.uint8, device=dev)
     t_d = ev_time(lambda: L.call("icg_conv2d_fprop_ws", x, w, None, None, out, sc, sh, Cin, B, H, W, Cin, Cout, 3, fl, 1.0, wf, nf))
