@@ -36,6 +36,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: fp16 / bf16 MFMA, dense (StyleGAN2's fp16 blocks: v_mfma_f32_16x16x32_f16)
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable by a float4 copy)
 
 WORKLOADS = {
@@ -71,7 +72,7 @@ class KernelTimer:
             "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_dgrad_relu": (4, "up"), "icg_conv2d_down_wgrad": (3, "up"),
             # StyleGAN2 (cfg4): general-geometry convolutions and the two HBM-bound plugins
             "icg_conv2d_g_fprop": (4, "gconv"), "icg_conv2d_g_fprop_ws": (4, "gconv"), "icg_conv2d_tr2_fprop": (4, "tr2"),
-            "icg_conv2d_g_wgrad": (3, "gconv"), "icg_bias_act": (6, "bias_act"), "icg_bias_act_typed": (6, "bias_act"),
+            "icg_conv2d_g_wgrad": (3, "gconv"), "icg_conv2d_g_fprop_f16": (3, "hconv"), "icg_bias_act": (6, "bias_act"), "icg_bias_act_typed": (6, "bias_act"),
             "icg_upfirdn2d": (3, "upfirdn2d"), "icg_upfirdn2d_nhwc": (3, "upfirdn2d"), "icg_upfirdn2d_typed": (3, "upfirdn2d")}
 
     def __init__(self, period=4):
@@ -137,7 +138,12 @@ class KernelTimer:
                 e.record()
                 rec[3].append((s, e))
                 return
-            if mode == "gconv":      # out[b,oy,ox,co] = sum src(...)*w: one multiply-add per (output, Cin, tap)
+            if mode == "hconv":      # the same gather on fp16 operands (csrc/hconv.hip); zero-inserted sources: 1 tap slot in 4 is non-zero
+                B, Hin, Win, Cin, Hout, Wout, Cout, R = args[sl:sl + 8]
+                exe = 2.0 * B * Hout * Wout * Cout * Cin * R * R
+                alg = exe / (4.0 if args[sl + 10] == 2 else 1.0)
+                byt = 2.0 * (B * (Hin * Win * Cin + Hout * Wout * Cout) + Cout * Cin * R * R)
+            elif mode == "gconv":    # out[b,oy,ox,co] = sum src(...)*w: one multiply-add per (output, Cin, tap)
                 B, Hin, Win, Cin, Hout, Wout, Cout, R = args[sl:sl + 8]
                 alg = exe = 2.0 * B * Hout * Wout * Cout * Cin * R * R
                 byt = 4.0 * (B * (Hin * Win * Cin + Hout * Wout * Cout) + Cout * Cin * R * R)
@@ -198,7 +204,10 @@ class KernelTimer:
                 if last[0] == 3:
                     return "icg_pgemm_tn_kernel<%d, %d>" % (last[2], 1 if last[3] == 4 else 2)
                 return "%s<1, 1, %d>" % (pk, last[2])
-            if mode == "from_v":
+            if mode == "hconv":
+                cout = args[sl + 6]
+                kname = "void icg_hconv_kernel<%d>(HconvP)" % (4 if cout % 128 == 0 else (3 if cout % 96 == 0 else 2))
+            elif mode == "from_v":
                 kname = "composite: weight gradient from the saved V planes (wino4_dy_kernel + %d batched split-K %s GEMMs + reduce + wino4_dw_kernel)" % (args[sl + 5], wg_gemm())
             elif mode in ("rs_up", "rs_down"):
                 kind = (name[:-5] if name.endswith("_relu") else name).rsplit("_", 1)[1]
@@ -355,10 +364,12 @@ def assemble_roofline(timer, steps, elapsed, with_step_traffic=True):
     # resample-fused 25-plane form: 144/25, 2x2-phase / 4x4-stride-2 forms: 36/16).
     step_exe = sum(r[2] for r in timer.records) / steps              # entry-point level: no double counting
     step_ms = elapsed / steps * 1e3
-    t_mfma = step_exe / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e3
+    t_mfma = sum(r[2] / ((PEAK_F16_MFMA_TFLOPS if "icg_hconv_kernel" in r[0] else PEAK_F32_MFMA_TFLOPS) * 1e12)
+                 for r in timer.records) / steps * 1e3                # every launch against the MFMA roof of its own operand type
     t_hbm = (step_hbm_gb / PEAK_HBM_GBPS * 1e3) if step_hbm_gb else None
-    return {"bound": "mfma", "kernel": variant, "achieved": round(exe_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(exe_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+    peak = PEAK_F16_MFMA_TFLOPS if "icg_hconv_kernel" in variant else PEAK_F32_MFMA_TFLOPS       # the dominant kernel's own MFMA roof
+    return {"bound": "mfma", "kernel": variant, "achieved": round(exe_tf, 2), "peak": peak,
+            "unit": "TFLOP/s", "frac": round(exe_tf / peak, 4), "traffic": traffic,
             "traffic_source": traffic_src, "traffic_stale": (getattr(measured_traffic, "stale", None) if traffic_src else None),
             "algorithmic_bytes_per_launch": round(byt / n),
             "algorithmic_tflops": round(alg_tf, 2), "algorithmic_speedup": round(alg_tf / exe_tf, 3),
@@ -513,7 +524,7 @@ def bench_stylegan2(args, device, rank, world, local_rank, use_ddp):
             "metric": "images/sec training iteration, IC-GAN StyleGAN2 256^2 (cfg4, secondary workload)",
             "value": round(b * world * args.steps / elapsed, 3), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("f16 storage / f32 arithmetic" if args.fp16 else "f32"), "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("f16 (fp16 blocks: fp16 operands, fp32 accumulation, as the reference) / f32" if args.fp16 else "f32"), "data": "synthetic",
             "config": {"workload": "cfg4: IC-GAN StyleGAN2 256x256 cfg=auto, h_dim 2048, " + ("fp16 blocks (num_fp16_res=4, conv_clamp=256), fp32 MFMA arithmetic" if args.fp16 else "fp32 (num_fp16_res=0)") + "; Gmain+Dmain every iteration, "
                                    "Greg every 4, Dreg every 16 (steps should be a multiple of 16)",
                        "batch_per_gpu": b, "global_batch": b * world, "parallelism": f"dp{world}"},

@@ -1,0 +1,206 @@
+// fp16-input gather convolution for StyleGAN2's fp16 blocks (stylegan2_ada_pytorch/training/networks.py:77-91, 581-601: with
+// `num_fp16_res` the reference casts activations AND weights of the highest resolutions to fp16 and lets cuDNN convolve in fp16
+// with fp32 accumulation).  One kernel serves every forward / data-gradient contraction of conv2d_gradfix there:
+//
+//     out[b, oy, ox, n] = sum_{r, s, c}  src[b, (oy * stride + r - pad) / zins, (ox * stride + s - pad) / zins, c] * w[n][r][s][c]
+//
+// (terms whose coordinate is negative, past the source, or -- zins = 2, the stride-2 transposed convolution as a gather over the
+// zero-inserted source -- odd, are zero).  fp16 products are exact in fp32, accumulation is fp32 (v_mfma_f32_16x16x32_f16), the
+// result is rounded to fp16 once: the arithmetic of the reference's fp16 path.
+//
+// Structure = icg_pconv_kernel (pgemm.hip) with 2-byte elements: a K-tile is one tap of one 32-channel slice, i.e. the same 64-byte
+// rows, the same lane-linear LDS-DMA image with the source-side chunk permutation, the same 3-slot ring with one raw s_barrier per
+// K-tile and hand-counted vmcnt; out-of-image / odd taps fetch from the zero page.  A lane's 16-byte fragment (8 halfs, k = 8 kk ..
+// 8 kk + 7 of row r) is exactly one operand of v_mfma_f32_16x16x32_f16, so a K-tile is 2 x NT MFMAs of 16 cycles per wave instead of
+// 8 x NT of 32: 16x the fp32 rate per K-tile, which moves the bound of these batch-16 layers from the MFMA pipe to the L2 -> LDS
+// stream.  The stride-2 transposed form spends 3 of 4 taps on zeros; at this rate that is cheaper than a phase decomposition's
+// four launches.
+#include "icg_common.h"
+#include <stdlib.h>
+
+typedef float hc_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 hc_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hc_h4 __attribute__((ext_vector_type(4)));
+
+struct HconvP {
+  const _Float16* A;      // [B][Hs][Ws][Cin]
+  const _Float16* Bw;     // [N][R][R][Cin]
+  _Float16* C;            // [B][Ho][Wo][N]
+  int M, N, K;            // M = B Ho Wo, K = R R Cin
+  int Ho, Wo, Hs, Ws, Cin, R, stride, pad, zs;      // zs = log2(zero-insertion factor)
+  int tiles_n;
+  unsigned total;
+  int swz;
+};
+
+__device__ __attribute__((aligned(64))) _Float16 g_hc_zero_page[32];      // zero-initialised: DMA source of the padding taps
+
+__device__ __forceinline__ int hc_swz(int row) { return (row & 8) ? 3 : 0; }      // = pg_swz (pgemm.hip)
+
+// LDS-DMA, 16 bytes per lane: wave-uniform base + per-lane byte offset / per-lane pointer (see pg_dma16, pgemm.hip)
+__device__ __forceinline__ void hc_dma16(const void* gbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(gbase), "s"(lds_dst)
+      : "memory");
+}
+__device__ __forceinline__ void hc_dma16_ptr(const void* lane_src, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_src), "s"(lds_dst)
+      : "memory");
+}
+
+// NT: 16-column MFMA tiles per wave (workgroup tile 128 x 32 NT; 8 waves as 4 x 2, wave tile 32 x 16 NT)
+template <int NT>
+__global__ __launch_bounds__(512, 4) void icg_hconv_kernel(HconvP p) {
+  constexpr int BM = 128, BN = 32 * NT, BKC = 32;                   // BKC: channels (halfs) per K-tile = 64 bytes per row
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, SLOT = A_BYTES + B_BYTES, NBUF = 3;
+  constexpr int BROWS = BN / 8;                                     // B rows per wave and K-tile: 16 / 12 / 8
+  __shared__ __attribute__((aligned(1024))) char lds[NBUF * SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv & 3, wn = wv >> 2;
+  const int r = lane & 15, kk = lane >> 4;
+
+  unsigned t = blockIdx.x;
+  if (p.swz) {
+    const unsigned tot = p.total, q = tot >> 3, rr = tot & 7u, xcd = t & 7u;
+    t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
+  }
+  const int nt = (int)(t % (unsigned)p.tiles_n), mt = (int)(t / (unsigned)p.tiles_n);
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- DMA role, A: output pixel 16 wv + (lane >> 2) of the tile, chunk position lane & 3; B: weight row BROWS wv + (lane >> 2)
+  const int drowA = 16 * wv + (lane >> 2), drowB = BROWS * wv + (lane >> 2);
+  const int am = m0 + drowA;
+  const bool a_row_ok = am < p.M;
+  const int amm = a_row_ok ? am : 0;
+  const int aw = amm % p.Wo, at = amm / p.Wo, ah = at % p.Ho, ab = at / p.Ho;
+  const int hs0 = ah * p.stride - p.pad, ws0 = aw * p.stride - p.pad;        // (zero-inserted) source coordinate of tap (0, 0)
+  const unsigned img = (unsigned)ab * (unsigned)(p.Hs * p.Ws);
+  const unsigned achunk = 8u * (unsigned)((lane & 3) ^ hc_swz(drowA));       // halfs
+  const unsigned voffB =
+      ((unsigned)min(n0 + min(drowB, BN - 1), p.N - 1) * (unsigned)p.K + 8u * (unsigned)((lane & 3) ^ hc_swz(drowB))) * 2u;
+  const bool dma_b_lane = (BROWS == 16) || ((lane >> 2) < BROWS);
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned ldsA = lds_base + (unsigned)wv * 1024u, ldsB = lds_base + (unsigned)A_BYTES + (unsigned)wv * (BROWS * 64u);
+  const int nk = p.K / BKC;
+  const unsigned hb = (unsigned)(p.Hs << p.zs), wb = (unsigned)(p.Ws << p.zs), zmask = (1u << p.zs) - 1u;
+
+  // load cursor (wave-uniform): K-tile -> (channel slice lc0, tap (ltr, lts)); tap-minor order
+  int lc0 = 0, ltr = 0, lts = 0, ltap = 0, lkt = 0;
+  auto issue_next = [&](unsigned slot_off) {
+    const int hi = hs0 + ltr, wi = ws0 + lts;
+    const bool ok = a_row_ok & ((unsigned)hi < hb) & ((unsigned)wi < wb) & ((((unsigned)hi | (unsigned)wi) & zmask) == 0u);
+    const unsigned pix = img + (unsigned)(hi >> p.zs) * (unsigned)p.Ws + (unsigned)(wi >> p.zs);
+    const _Float16* src = ok ? p.A + ((size_t)pix * (unsigned)p.Cin + (unsigned)lc0 + achunk) : g_hc_zero_page;
+    hc_dma16_ptr(src, ldsA + slot_off);
+    if (dma_b_lane) hc_dma16(p.Bw + (ltap * p.Cin + lc0), voffB, ldsB + slot_off);
+    if (++lkt < nk) {                                               // past the end: the last K-tile again (never read)
+      ++ltap;
+      if (++lts == p.R) { lts = 0; ++ltr; }
+      if (ltap == p.R * p.R) { ltap = 0; ltr = 0; lts = 0; lc0 += BKC; }
+    } else {
+      lkt = nk;
+    }
+  };
+  auto next_slot = [](unsigned off) -> unsigned { return off == (unsigned)((NBUF - 1) * SLOT) ? 0u : off + (unsigned)SLOT; };
+
+  const int fo = r * 64 + ((kk ^ hc_swz(r)) * 16);
+  const char* fa = lds + fo + (32 * wm) * 64;
+  const char* fb = lds + fo + A_BYTES + (16 * NT * wn) * 64;
+
+  hc_f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = hc_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue_next(0u);
+  issue_next((unsigned)SLOT);
+
+  unsigned cur = 0u;
+  for (int kt = 0; kt < nk; ++kt) {
+    // K-tile kt has landed once at most the two DMAs of K-tile kt + 1 are outstanding; after the barrier the slot of K-tile kt - 1
+    // (all of whose LDS reads have returned: lgkmcnt(0)) may be overwritten
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_next(next_slot(next_slot(cur)));
+    hc_h8 a[2], b[NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const hc_h8*>(fa + cur + i * 1024);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const hc_h8*>(fb + cur + j * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+    cur = next_slot(cur);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: operands swapped (D = B-fragment x A-fragment), so lane (r, kk) holds C[16 i + r][16 j + 4 kk .. + 3]: one
+  // 8-byte store of four halfs per 16 x 16 tile
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + 32 * wm + 16 * i + r;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + 16 * NT * wn + 16 * j + 4 * kk;
+      if (m < p.M && n < p.N) {
+        const hc_f32x4 v = acc[i][j];
+        hc_h4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        *reinterpret_cast<hc_h4*>(p.C + (size_t)m * (unsigned)p.N + n) = o;
+      }
+    }
+  }
+}
+
+// 1 when the shape is one the kernel takes (the Python side keeps the fp32 kernel + two casts for everything else: 3-channel
+// toRGB / fromRGB layers, channel counts that are not multiples of 32 / 64)
+extern "C" int icg_conv2d_g_fprop_f16_applies(int Cin, int Cout, int R, int stride, int zins) {
+  if (Cin < 32 || Cin % 32 != 0 || Cout < 64 || Cout % 32 != 0 || (Cout % 128 != 0 && Cout % 96 != 0 && Cout % 64 != 0)) return 0;
+  if (R < 1 || R > 7 || stride < 1 || (zins != 0 && zins != 1 && zins != 2) || (zins == 2 && stride != 1)) return 0;
+  return 1;
+}
+
+extern "C" int icg_conv2d_g_fprop_f16(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Hout, int Wout,
+                                      int Cout, int R, int stride, int pad, int zins, void* stream) {
+  ICG_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && Hout > 0 && Wout > 0 && pad >= 0);
+  ICG_REQUIRE(icg_conv2d_g_fprop_f16_applies(Cin, Cout, R, stride, zins));
+  ICG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 8) == 0);
+  const long M = (long)B * Hout * Wout;
+  ICG_REQUIRE(M < 0x7fffffffL && (long)B * H * W < 0x7fffffffL && (long)Cout * R * R * Cin < 0x3fffffffL);
+  const int nt = (Cout % 128 == 0) ? 4 : ((Cout % 96 == 0) ? 3 : 2);
+  HconvP p{};
+  p.A = (const _Float16*)x; p.Bw = (const _Float16*)w; p.C = (_Float16*)y;
+  p.M = (int)M; p.N = Cout; p.K = R * R * Cin;
+  p.Ho = Hout; p.Wo = Wout; p.Hs = H; p.Ws = W; p.Cin = Cin; p.R = R; p.stride = stride; p.pad = pad; p.zs = (zins == 2) ? 1 : 0;
+  p.tiles_n = Cout / (32 * nt);
+  const long total = icg_cdiv(M, 128) * p.tiles_n;
+  ICG_REQUIRE(total > 0 && total < 0x7fffffffL);
+  p.total = (unsigned)total;
+  static const bool no_swz = [] { const char* e = getenv("ICG_NO_XCD_SWIZZLE"); return e && e[0] == '1'; }();
+  p.swz = (total >= 16 && !no_swz) ? 1 : 0;
+  const dim3 grid((unsigned)total), block(512);
+  hipStream_t st = (hipStream_t)stream;
+  if (nt == 4) hipLaunchKernelGGL((icg_hconv_kernel<4>), grid, block, 0, st, p);
+  else if (nt == 3) hipLaunchKernelGGL((icg_hconv_kernel<3>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((icg_hconv_kernel<2>), grid, block, 0, st, p);
+  return icg_check_launch();
+}

@@ -18,6 +18,12 @@ so both autograd Functions below express their backward with each other and grad
 Tensors are logical NCHW fp32 stored channels-last (NHWC in memory), weights are handed to the kernel as
 [Cout][R][R][Cin].  groups > 1, dilation > 1 and non-square stride/padding are not supported (StyleGAN2 training uses
 none of them: `fused_modconv` — the only groups>1 user — is off in training mode, networks.py:440-444).
+
+fp16 (the reference's `num_fp16_res` blocks, training/networks.py:77-91, 581-601: activations and weights cast to fp16, cuDNN
+convolves in fp16 with fp32 accumulation): G runs on icg_conv2d_g_fprop_f16 -- fp16 operands straight into
+v_mfma_f32_16x16x32_f16, fp32 accumulation, one rounding to fp16 -- whenever the kernel serves the shape (Cin % 32 == 0,
+Cout % 64 == 0 or % 96 == 0; every 3x3 / 1x1 / stride-2 / transposed layer of those blocks and all their data gradients); the
+3-channel toRGB / fromRGB layers and W (weight gradients) keep the exact-fp32 kernels between two casts.
 """
 import contextlib
 from dataclasses import dataclass
@@ -28,6 +34,7 @@ from .. import _lib as L
 from .. import ops as _ops
 
 enabled = True                       # kept for API parity; the HIP path is the only path
+FP16_MFMA = True                     # fp16 blocks on the fp16-input MFMA kernel (False: exact-fp32 kernel between two casts; measurement switch)
 weight_gradients_disabled = False    # conv2d_gradfix.py:26-37
 
 
@@ -83,8 +90,26 @@ class _GatherConv(torch.autograd.Function):
         # the autograd inputs themselves are saved (not their re-laid-out copies): the backward differentiates through them
         ctx.geo = geo
         ctx.save_for_backward(x, w)
-        x = _ops._cl(x)
-        w = w.contiguous()
+        half = x.dtype == torch.float16
+        if half and w.dtype == torch.float16 and FP16_MFMA and \
+                L.query("icg_conv2d_g_fprop_f16_applies", int(x.shape[1]), int(w.shape[0]), geo.R, geo.stride, geo.zins):
+            # the reference's fp16 arithmetic: fp16 operands, fp32 accumulation, one rounding (csrc/hconv.hip)
+            x = x.contiguous(memory_format=torch.channels_last)
+            w = w.contiguous()
+            B, Cin, H, W = x.shape
+            Cout = w.shape[0]
+            assert (H, W) == geo.src and w.shape == (Cout, geo.R, geo.R, Cin), (x.shape, w.shape, geo)
+            y = torch.empty((B, Cout, geo.out[0], geo.out[1]), device=x.device, dtype=torch.float16,
+                            memory_format=torch.channels_last)
+            L.call("icg_conv2d_g_fprop_f16", x, w, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout, geo.R, geo.stride, geo.pad,
+                   geo.zins)
+            return y
+        if half:      # shapes the fp16 kernel does not serve: exact-fp32 kernel between two casts (layout glue)
+            return _GatherConv._forward_f32(_ops._cl(x), w.float().contiguous(), geo).to(torch.float16)
+        return _GatherConv._forward_f32(_ops._cl(x), w.contiguous(), geo)
+
+    @staticmethod
+    def _forward_f32(x, w, geo):
         B, Cin, H, W = x.shape
         Cout = w.shape[0]
         assert (H, W) == geo.src and w.shape == (Cout, geo.R, geo.R, Cin), (x.shape, w.shape, geo)
@@ -134,6 +159,7 @@ class _GatherWgrad(torch.autograd.Function):
         _ops._require_gpu(x)
         ctx.geo = geo
         ctx.save_for_backward(x, dy)
+        out_dtype = x.dtype                       # fp16 blocks: the gradient of an fp16 weight is fp16 (rounded once, from fp32)
         x, dy = _ops._cl(x), _ops._cl(dy)
         B, Cin, H, W = x.shape
         Cout = dy.shape[1]
@@ -158,7 +184,7 @@ class _GatherWgrad(torch.autograd.Function):
             L.call("icg_conv2d_g_wgrad", x, dy, t, B, H, W, Cin, geo.out[0], geo.out[1], Cout, R, geo.stride, geo.pad,
                    _ops._bytes(ws_bytes, x.device), ws_bytes)
             dw = t.permute(3, 0, 1, 2).contiguous()
-        return dw
+        return dw if out_dtype == torch.float32 else dw.to(out_dtype)
 
     @staticmethod
     def backward(ctx, ddw):

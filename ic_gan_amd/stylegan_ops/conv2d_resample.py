@@ -21,11 +21,8 @@ def _conv(x, w, stride=1, padding=0, groups=1, transpose=False, flip_weight=True
     if not flip_weight:          # F.conv2d correlates; flip_weight=False asks for a true convolution
         w = w.flip([2, 3])
     op = conv2d_gradfix.conv_transpose2d if transpose else conv2d_gradfix.conv2d
-    if x.dtype == torch.float16:
-        # fp16 blocks (`num_fp16_res`, training/networks.py:505-515,593-600): activations and (rounded) weights are STORED in
-        # fp16 like the reference's; the contraction itself runs on the exact-fp32 MFMA kernel (cuDNN accumulates fp16
-        # products in fp32 too), and the result is rounded to fp16 once.  The two casts are layout glue around the kernel.
-        return op(x.float(), w.float(), stride=stride, padding=padding, groups=groups).to(torch.float16)
+    # fp16 blocks (`num_fp16_res`, training/networks.py:505-515,593-600): fp16 activations and fp16 weights go to conv2d_gradfix as
+    # they are -- it contracts them on the fp16-input MFMA kernel with fp32 accumulation, the reference's arithmetic there
     return op(x, w, stride=stride, padding=padding, groups=groups)
 
 

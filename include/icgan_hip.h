@@ -155,6 +155,16 @@ int icg_conv2d_g_fprop_ws(const float* x, const float* w, const float* bias, flo
  */
 int icg_conv2d_tr2_fprop(const float* x, const float* wp, const float* bias, float* out, int B, int Hin, int Win,
                          int Cin, int Hout, int Wout, int Cout, void* stream);
+/*
+ * The same gather with fp16 storage and fp16-input MFMA (v_mfma_f32_16x16x32_f16: exact fp16 products, fp32 accumulation, one
+ * rounding to fp16) -- the arithmetic of the reference's fp16 blocks, which cast activations AND weights to fp16 and convolve in
+ * fp16 (training/networks.py:77-91, 581-601; `num_fp16_res`).  x [B][Hin][Win][Cin], w [Cout][R][R][Cin], out [B][Hout][Wout][Cout],
+ * all fp16; no bias (bias_act applies it).  zero_insert in {0, 2}.  `_applies` -> 1 when the shape is served (Cin a multiple of
+ * 32, Cout of 64 or 96); the caller keeps icg_conv2d_g_fprop + two casts for the rest (3-channel toRGB / fromRGB layers).
+ */
+int icg_conv2d_g_fprop_f16_applies(int Cin, int Cout, int R, int stride, int zero_insert);
+int icg_conv2d_g_fprop_f16(const void* x, const void* w, void* out, int B, int Hin, int Win, int Cin, int Hout, int Wout,
+                           int Cout, int R, int stride, int pad, int zero_insert, void* stream);
 /*   dw[r][s][ci][co] = sum_{b,oy,ox} x[b, oy*stride + r - pad, ox*stride + s - pad, ci] * dy[b,oy,ox,co]
  * (weight gradient of either direction: for the transposed convolution swap the roles of x and dy). */
 size_t icg_conv2d_g_wgrad_workspace_bytes(int B, int Hout, int Wout, int Cin, int Cout, int R);

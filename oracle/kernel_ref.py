@@ -897,6 +897,19 @@ def icg_conv2d_g_fprop(x, w, bias, out, B, Hin, Win, Cin, Hout, Wout, Cout, R, s
     mem(out)[: B * Hout * Wout * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))
 
 
+def icg_conv2d_g_fprop_f16_applies(Cin, Cout, R, stride, zero_insert):
+    return int(Cin >= 32 and Cin % 32 == 0 and Cout >= 64 and (Cout % 64 == 0 or Cout % 96 == 0) and 1 <= R <= 7 and stride >= 1
+               and zero_insert in (0, 1, 2) and not (zero_insert == 2 and stride != 1))
+
+
+def icg_conv2d_g_fprop_f16(x, w, out, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, zero_insert):
+    """fp16 storage, exact products, wide accumulation, one rounding (the kernel accumulates in fp32; fp64 here)."""
+    assert x.dtype == torch.float16 and w.dtype == torch.float16 and out.dtype == torch.float16
+    y = torch.empty(B * Hout * Wout * Cout, dtype=torch.float64)
+    icg_conv2d_g_fprop(x.double(), w.double(), None, y, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, zero_insert)
+    mem(out)[: y.numel()].copy_(y.to(torch.float16))
+
+
 def icg_conv2d_g_fprop_workspace_bytes(B, Hout, Wout, Cin, Cout, R, zero_insert):
     return 0
 

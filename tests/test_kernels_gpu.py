@@ -1097,3 +1097,41 @@ def test_knn_l2_ties_and_duplicates():
         assert len(set(got)) == k - 1 and all(3 <= j < 11 and j != q for j in got), (q, idx[q].tolist())
         assert float(d2[q, 1:].abs().max()) < 1e-5
     assert bool((d2[:, 1:] >= d2[:, :-1]).all())
+
+
+# ------------------------------------------------------------------------------------------------ fp16 gather convolution
+HCONV_CASES = [
+    # B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, zero_insert
+    (2, 16, 16, 64, 16, 16, 64, 3, 1, 1, 0),             # 3x3 'same', 64-column tile
+    (3, 9, 7, 32, 9, 7, 128, 3, 1, 1, 0),                # odd sizes, ragged last pixel tile, a single channel slice, 128-column tile
+    (2, 8, 8, 96, 8, 8, 192, 1, 1, 0, 0),                # 1x1, 96-column tile
+    (1, 4, 4, 32, 4, 4, 64, 3, 1, 1, 0),                 # 16 pixels: one partial tile
+    (2, 17, 17, 64, 8, 8, 128, 3, 2, 0, 0),              # stride 2 (the discriminator's down-sampling conv after its blur)
+    (2, 16, 16, 64, 8, 8, 64, 1, 2, 0, 0),               # 1x1 stride 2
+    (2, 8, 8, 128, 17, 17, 64, 3, 1, 2, 2),              # stride-2 transposed 3x3 (zero-inserted source, extent 15, output 17)
+    (2, 8, 8, 128, 17, 17, 64, 3, 1, 0, 2),              # data gradient geometry of a padded stride-2 convolution (adjoint pad)
+    (2, 8, 8, 64, 16, 16, 96, 3, 1, 1, 2),               # output grid past the zero-inserted source (those positions read zeros)
+    (2, 12, 12, 64, 10, 10, 64, 5, 1, 1, 0),             # 5x5, partial padding
+    (4, 32, 32, 512, 32, 32, 512, 3, 1, 1, 0),           # cfg4, resolution 32: 144 K-tiles
+    (3, 64, 64, 256, 129, 129, 128, 3, 1, 2, 2),         # cfg4 synthesis b128.conv0 (up): 50k output pixels
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", HCONV_CASES)
+def test_conv2d_g_fprop_f16(case):
+    """icg_conv2d_g_fprop_f16 (csrc/hconv.hip): fp16 operands, fp32 accumulation, one rounding -- against the same contraction in
+    fp64 rounded to fp16 once (oracle/kernel_ref.py).  Tolerance: 2 fp16 ulps of the value + 1e-3 of the tensor maximum (an fp32
+    sum that lands next to a rounding boundary rounds the other way than the fp64 sum)."""
+    B, H, W, Cin, Ho, Wo, Cout, R, stride, pad, zins = case
+    assert _hconv_applies(Cin, Cout, R, stride, zins)
+    x = cl(B, Cin, H, W, seed=1).half()
+    w = (rnd(Cout, R, R, Cin, seed=2) * (Cin * R * R) ** -0.5).half()
+    out = torch.zeros(B, Cout, Ho, Wo, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    (p,) = run_pair("icg_conv2d_g_fprop_f16", [x, w, out, B, H, W, Cin, Ho, Wo, Cout, R, stride, pad, zins], [2])
+    close(*p, rtol=2e-3, atol_rel=1e-3, what="fp16 gather conv %r" % (case,))
+
+
+def _hconv_applies(Cin, Cout, R, stride, zins):
+    return _L().query("icg_conv2d_g_fprop_f16_applies", Cin, Cout, R, stride, zins) == 1 and \
+        R.icg_conv2d_g_fprop_f16_applies(Cin, Cout, R, stride, zins) == 1

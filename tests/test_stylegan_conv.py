@@ -147,3 +147,42 @@ def test_conv2d_gradfix_winograd_path(dev, m, monkeypatch):
     _resample_case(4, dev)    # plain 3x3 through conv2d_resample
     _modconv_case(0, dev)     # modulated conv, 8 -> 6 channels... (Cout % 4 != 0 -> direct)
     _modconv_case(3, dev)     # 8 -> 8 channels at 4x4 -> Winograd
+
+
+@pytest.mark.parametrize("kind", ["same", "down", "tr"])
+@pytest.mark.parametrize("dev", ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)])
+def test_conv2d_gradfix_fp16_mfma_route(dev, kind, monkeypatch):
+    """conv2d_gradfix on fp16 tensors (the reference's `num_fp16_res` blocks): the fp16-input MFMA route (icg_conv2d_g_fprop_f16) against
+    the exact-fp32 kernels between two casts (FP16_MFMA = False) -- outputs, first- and second-order gradients of a 3x3 'same', a
+    stride-2 and a transposed stride-2 layer.  Both routes round every tensor to fp16 at the same places; they differ by the
+    accumulation order inside fp32, i.e. by an occasional fp16 rounding flip: 4 fp16 ulps of the value + 2e-3 of the tensor maximum."""
+    from ic_gan_amd.stylegan_ops import conv2d_gradfix as cg
+    if dev == "cpu":
+        kernel_ref.install(monkeypatch)
+
+    def run(route):
+        monkeypatch.setattr(cg, "FP16_MFMA", route)
+        x = rnd((4, 64, 16, 16), 3).to(dev).half().requires_grad_(True)
+        shape = (64, 128, 3, 3) if kind == "tr" else (128, 64, 3, 3)
+        wt = (rnd(shape, 4) * (64 * 9) ** -0.5).to(dev).half().requires_grad_(True)
+        if kind == "same":
+            y = cg.conv2d(x, wt, padding=1)
+        elif kind == "down":
+            y = cg.conv2d(x, wt, stride=2, padding=1)
+        else:
+            y = cg.conv_transpose2d(x, wt, stride=2, padding=0)
+        assert y.dtype == torch.float16
+        dy = rnd(tuple(y.shape), 5).to(dev).half().requires_grad_(True)
+        gx, gw = torch.autograd.grad(y, (x, wt), dy, create_graph=True)
+        assert gx.dtype == torch.float16 and gw.dtype == torch.float16
+        s = (gx.float() * rnd(tuple(gx.shape), 6).to(dev)).sum() + (gw.float() * rnd(tuple(gw.shape), 7).to(dev)).sum()
+        g2 = torch.autograd.grad(s, (x, wt, dy))
+        return [t.detach().float().cpu() for t in (y, gx, gw) + tuple(g2)]
+
+    a, b = run(True), run(False)
+    for name, u, v in zip(("y", "dx", "dw", "ddx", "ddw", "ddy"), a, b):
+        assert u.shape == v.shape and torch.isfinite(u).all()
+        tol = 2e-3 * float(v.abs().max()) + 4e-3 * v.abs()
+        bad = (u - v).abs() > tol
+        assert not bad.any(), "%s %s: %d / %d beyond tolerance, worst %.3e" % (kind, name, int(bad.sum()), bad.numel(),
+                                                                               float(((u - v).abs() - tol).max()))
