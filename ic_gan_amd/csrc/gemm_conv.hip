@@ -1812,6 +1812,26 @@ extern "C" int icg_conv2d_g_fprop(const float* x, const float* w, const float* b
                              stream);
 }
 
+// out[m][n] = bias[n] + sum_{k < K} x[m][k] w[n][k] for K <= 3: the data gradient of StyleGAN2's toRGB layers (dy [M][3] against
+// w^T [Cin][3]) and its fromRGB layers -- three multiply-adds per output, bound by the write of out; one float4 of n per thread
+__global__ __launch_bounds__(256) void conv1x1_k3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out, long M, int N,
+                                                         int K) {
+  const int N4 = N >> 2;
+  const long total = M * N4, gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const int n4 = (int)(i % N4);
+    const long m = i / N4;
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + 4 * n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < K; ++k) {
+      const float xv = x[m * K + k];
+      const float* wr = w + (long)(4 * n4) * K + k;
+      acc.x = fmaf(xv, wr[0], acc.x); acc.y = fmaf(xv, wr[K], acc.y); acc.z = fmaf(xv, wr[2 * K], acc.z); acc.w = fmaf(xv, wr[3 * K], acc.w);
+    }
+    *reinterpret_cast<float4*>(out + m * N + 4 * n4) = acc;
+  }
+}
+
 static int conv2d_g_fprop_impl(const float* x, const float* w, const float* bias, float* out, int B, int Hin, int Win,
                                int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, int zero_insert,
                                void* workspace, size_t workspace_bytes, void* stream) {
@@ -1820,6 +1840,14 @@ static int conv2d_g_fprop_impl(const float* x, const float* w, const float* bias
   ICG_REQUIRE(zero_insert == 0 || ((zero_insert == 2 || zero_insert == 4) && stride == 1));
   const long M = (long)B * Hout * Wout;
   ICG_REQUIRE(M < 0x7fffffffL);
+  if (R == 1 && stride == 1 && pad == 0 && zero_insert == 0 && Hout == Hin && Wout == Win && Cin <= 3 && Cout % 4 == 0 && Cout >= 16 &&
+      aligned16(out) && (!bias || aligned16(bias))) {
+    g_last_variant[0] = -5; g_last_variant[1] = 0; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
+    long nb = icg_cdiv(M * (Cout / 4), 256);
+    if (nb > 256 * 32) nb = 256 * 32;
+    hipLaunchKernelGGL(conv1x1_k3_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, M, Cout, Cin);
+    return icg_check_launch();
+  }
   GemmP p{};
   p.A = x; p.B = w; p.C = out;
   p.M = (int)M; p.N = Cout; p.K = R * R * Cin;

@@ -1132,6 +1132,6 @@ def test_conv2d_g_fprop_f16(case):
     close(*p, rtol=2e-3, atol_rel=1e-3, what="fp16 gather conv %r" % (case,))
 
 
-def _hconv_applies(Cin, Cout, R, stride, zins):
-    return _L().query("icg_conv2d_g_fprop_f16_applies", Cin, Cout, R, stride, zins) == 1 and \
-        R.icg_conv2d_g_fprop_f16_applies(Cin, Cout, R, stride, zins) == 1
+def _hconv_applies(Cin, Cout, taps, stride, zins):
+    return _L().query("icg_conv2d_g_fprop_f16_applies", Cin, Cout, taps, stride, zins) == 1 and \
+        R.icg_conv2d_g_fprop_f16_applies(Cin, Cout, taps, stride, zins) == 1
