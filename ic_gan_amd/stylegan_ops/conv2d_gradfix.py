@@ -160,11 +160,28 @@ class _GatherWgrad(torch.autograd.Function):
         ctx.geo = geo
         ctx.save_for_backward(x, dy)
         out_dtype = x.dtype                       # fp16 blocks: the gradient of an fp16 weight is fp16 (rounded once, from fp32)
-        x, dy = _ops._cl(x), _ops._cl(dy)
         B, Cin, H, W = x.shape
         Cout = dy.shape[1]
         assert (H, W) == geo.src and tuple(dy.shape[2:]) == geo.out, (x.shape, dy.shape, geo)
         R = geo.R
+        if x.dtype == torch.float16 and dy.dtype == torch.float16 and FP16_MFMA and \
+                L.query("icg_conv2d_g_wgrad_f16_applies", int(Cin), int(Cout), R, geo.zins if geo.zins else geo.stride):
+            # fp16 operands straight into the MFMA (csrc/hwgrad.hip); fp32 accumulation, fp32 HWIO result, rounded to fp16 once
+            x = x.contiguous(memory_format=torch.channels_last)
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            if geo.zins:      # zero-inserted direction: dy is the gathered tensor, x lives on the pixel grid
+                adj = geo.adjoint()
+                nb = L.query("icg_conv2d_g_wgrad_f16_workspace_bytes", B, H, W, Cout, Cin, R)
+                t = torch.empty(R, R, Cout, Cin, device=x.device, dtype=torch.float32)
+                L.call("icg_conv2d_g_wgrad_f16", dy, x, t, B, geo.out[0], geo.out[1], Cout, H, W, Cin, R, adj.stride, adj.pad,
+                       _ops._bytes(nb, x.device), nb)
+                return t.flip(0, 1).permute(2, 0, 1, 3).contiguous().to(out_dtype)
+            nb = L.query("icg_conv2d_g_wgrad_f16_workspace_bytes", B, geo.out[0], geo.out[1], Cin, Cout, R)
+            t = torch.empty(R, R, Cin, Cout, device=x.device, dtype=torch.float32)
+            L.call("icg_conv2d_g_wgrad_f16", x, dy, t, B, H, W, Cin, geo.out[0], geo.out[1], Cout, R, geo.stride, geo.pad,
+                   _ops._bytes(nb, x.device), nb)
+            return t.permute(3, 0, 1, 2).contiguous().to(out_dtype)
+        x, dy = _ops._cl(x), _ops._cl(dy)
         if geo.zins:      # zero-inserted direction: dy is the gathered tensor, x lives on the pixel grid
             adj = geo.adjoint()
             ws_bytes = L.query("icg_conv2d_g_wgrad_workspace_bytes", B, H, W, Cout, Cin, R)
@@ -280,6 +297,14 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     if min(out) < 1 or p < 0:
         raise ValueError("conv2d: empty output / negative padding")
     geo = _Geo(R, s, p, 0, (H, W), out)
+    cin = int(input.shape[1])
+    if cin % 4 and cin >= 8:
+        # channel counts like 513 (the discriminator epilogue's conv after MinibatchStd, training/networks.py:706-712): zero channels
+        # up to a multiple of 4 keep the layer on the 16-byte-vector / split-K path (at 4x4 x batch 16 the scalar path is 8
+        # workgroups running a 4 617-deep chain: 1 ms per launch); autograd slices the padding off again
+        extra = 4 - cin % 4
+        input = torch.nn.functional.pad(input, (0, 0, 0, 0, 0, extra))
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, extra))
     return _with_bias(_GatherConv.apply(input, weight.permute(0, 2, 3, 1), geo), bias)
 
 

@@ -155,6 +155,13 @@ int icg_conv2d_g_fprop_ws(const float* x, const float* w, const float* bias, flo
  */
 int icg_conv2d_tr2_fprop(const float* x, const float* wp, const float* bias, float* out, int B, int Hin, int Win,
                          int Cin, int Hout, int Wout, int Cout, void* stream);
+/* icg_conv2d_g_wgrad (below) on fp16 operands (x, dy fp16; dw fp32 HWIO): v_mfma_f32_16x16x32_f16 with fp32 accumulation, split-K over
+ * pixel slices into fp32 slabs in the caller's workspace + a fixed-order reduction -- cudnn_convolution_backward_weight on the fp16
+ * blocks' tensors (conv2d_gradfix.py:139-272).  `_applies` -> 1 when Cin and Cout are multiples of 32. */
+int icg_conv2d_g_wgrad_f16_applies(int Cin, int Cout, int R, int stride);
+size_t icg_conv2d_g_wgrad_f16_workspace_bytes(int B, int Hout, int Wout, int Cin, int Cout, int R);
+int icg_conv2d_g_wgrad_f16(const void* x, const void* dy, float* dw, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                           int R, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
 /*
  * The same gather with fp16 storage and fp16-input MFMA (v_mfma_f32_16x16x32_f16: exact fp16 products, fp32 accumulation, one
  * rounding to fp16) -- the arithmetic of the reference's fp16 blocks, which cast activations AND weights to fp16 and convolve in

@@ -933,6 +933,19 @@ def icg_conv2d_tr2_fprop(x, wp, bias, out, B, Hin, Win, Cin, Hout, Wout, Cout):
     mem(out)[: B * Hout * Wout * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))
 
 
+def icg_conv2d_g_wgrad_f16_applies(Cin, Cout, R, stride):
+    return int(Cin >= 32 and Cin % 32 == 0 and Cout >= 32 and Cout % 32 == 0 and 1 <= R <= 7 and 1 <= stride <= 4)
+
+
+def icg_conv2d_g_wgrad_f16_workspace_bytes(B, Hout, Wout, Cin, Cout, R):
+    return 16
+
+
+def icg_conv2d_g_wgrad_f16(x, dy, dw, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, workspace, workspace_bytes):
+    assert x.dtype == torch.float16 and dy.dtype == torch.float16 and dw.dtype == torch.float32
+    icg_conv2d_g_wgrad(x.float(), dy.float(), dw, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, workspace, workspace_bytes)
+
+
 def icg_conv2d_g_wgrad_workspace_bytes(B, Hout, Wout, Cin, Cout, R):
     return 16
 

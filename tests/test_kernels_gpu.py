@@ -1135,3 +1135,34 @@ def test_conv2d_g_fprop_f16(case):
 def _hconv_applies(Cin, Cout, taps, stride, zins):
     return _L().query("icg_conv2d_g_fprop_f16_applies", Cin, Cout, taps, stride, zins) == 1 and \
         R.icg_conv2d_g_fprop_f16_applies(Cin, Cout, taps, stride, zins) == 1
+
+
+HWGRAD_CASES = [
+    # B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad
+    (2, 16, 16, 64, 16, 16, 64, 3, 1, 1),                # 3x3 'same': 576 (tap, ci) rows = 4.5 row tiles, 64 of 128 columns
+    (3, 9, 7, 32, 9, 7, 128, 3, 1, 1),                   # odd sizes: every 32-pixel block has a zero-filled tail
+    (2, 40, 40, 32, 40, 40, 32, 1, 1, 0),                # 1x1; 40-pixel rows: a full and a partial block per row
+    (2, 17, 17, 64, 8, 8, 128, 3, 2, 0),                 # stride 2
+    (2, 17, 17, 128, 8, 8, 64, 3, 2, 2),                 # the zero-inserted direction's geometry (roles of x and dy swapped by the caller)
+    (2, 12, 12, 64, 10, 10, 96, 5, 1, 1),                # 5x5, partial padding, 96 output channels
+    (4, 32, 32, 512, 32, 32, 512, 3, 1, 1),              # cfg4, resolution 32: 36 x 4 tiles, 8 pixel slices
+    (2, 128, 128, 128, 128, 128, 128, 3, 1, 1),          # cfg4, resolution 128: 9 row tiles, 100+ slices
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", HWGRAD_CASES)
+def test_conv2d_g_wgrad_f16(case):
+    """icg_conv2d_g_wgrad_f16 (csrc/hwgrad.hip): fp16 operands through the transposing LDS read into v_mfma_f32_16x16x32_f16, fp32
+    accumulation over pixel slices, fp32 result -- against the fp32 reference of the same contraction on the same fp16 values.
+    Tolerance: 5e-5 of the tensor maximum + 1e-4 relative (fp32 sums of up to 32k exact products in a different order)."""
+    B, H, W, Cin, Ho, Wo, Cout, taps, stride, pad = case
+    L = _L()
+    assert L.query("icg_conv2d_g_wgrad_f16_applies", Cin, Cout, taps, stride) == 1 and R.icg_conv2d_g_wgrad_f16_applies(Cin, Cout, taps, stride) == 1
+    x = cl(B, Cin, H, W, seed=1).half()
+    dy = cl(B, Cout, Ho, Wo, seed=2).half()
+    dw = torch.zeros(taps, taps, Cin, Cout)
+    nb = L.query("icg_conv2d_g_wgrad_f16_workspace_bytes", B, Ho, Wo, Cin, Cout, taps)
+    ws = torch.zeros(nb, dtype=torch.uint8)
+    (p,) = run_pair("icg_conv2d_g_wgrad_f16", [x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, taps, stride, pad, ws, nb], [2])
+    close(*p, rtol=1e-4, atol_rel=5e-5, what="fp16 weight gradient %r" % (case,))
