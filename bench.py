@@ -72,7 +72,7 @@ class KernelTimer:
             "icg_conv2d_down_dgrad": (3, "up"), "icg_conv2d_down_dgrad_relu": (4, "up"), "icg_conv2d_down_wgrad": (3, "up"),
             # StyleGAN2 (cfg4): general-geometry convolutions and the two HBM-bound plugins
             "icg_conv2d_g_fprop": (4, "gconv"), "icg_conv2d_g_fprop_ws": (4, "gconv"), "icg_conv2d_tr2_fprop": (4, "tr2"),
-            "icg_conv2d_g_wgrad": (3, "gconv"), "icg_conv2d_g_fprop_f16": (3, "hconv"), "icg_bias_act": (6, "bias_act"), "icg_bias_act_typed": (6, "bias_act"),
+            "icg_conv2d_g_wgrad": (3, "gconv"), "icg_conv2d_g_fprop_f16": (3, "hconv"), "icg_conv2d_g_wgrad_f16": (3, "hwgrad"), "icg_bias_act": (6, "bias_act"), "icg_bias_act_typed": (6, "bias_act"),
             "icg_upfirdn2d": (3, "upfirdn2d"), "icg_upfirdn2d_nhwc": (3, "upfirdn2d"), "icg_upfirdn2d_typed": (3, "upfirdn2d")}
 
     def __init__(self, period=4):
@@ -143,6 +143,11 @@ class KernelTimer:
                 exe = 2.0 * B * Hout * Wout * Cout * Cin * R * R
                 alg = exe / (4.0 if args[sl + 10] == 2 else 1.0)
                 byt = 2.0 * (B * (Hin * Win * Cin + Hout * Wout * Cout) + Cout * Cin * R * R)
+            elif mode == "hwgrad":   # fp16 weight gradient (csrc/hwgrad.hip): executed on 128 x 128 tiles of the [R R Cin][Cout] result
+                B, Hin, Win, Cin, Hout, Wout, Cout, R = args[sl:sl + 8]
+                alg = 2.0 * B * Hout * Wout * Cout * Cin * R * R
+                exe = 2.0 * B * Hout * (32 * ((Wout + 31) // 32)) * (128 * ((Cout + 127) // 128)) * (128 * ((R * R * Cin + 127) // 128))
+                byt = 2.0 * B * (Hin * Win * Cin + Hout * Wout * Cout) + 4.0 * Cout * Cin * R * R
             elif mode == "gconv":    # out[b,oy,ox,co] = sum src(...)*w: one multiply-add per (output, Cin, tap)
                 B, Hin, Win, Cin, Hout, Wout, Cout, R = args[sl:sl + 8]
                 alg = exe = 2.0 * B * Hout * Wout * Cout * Cin * R * R
@@ -204,7 +209,9 @@ class KernelTimer:
                 if last[0] == 3:
                     return "icg_pgemm_tn_kernel<%d, %d>" % (last[2], 1 if last[3] == 4 else 2)
                 return "%s<1, 1, %d>" % (pk, last[2])
-            if mode == "hconv":
+            if mode == "hwgrad":
+                kname = "icg_hwgrad_kernel(HwgradP)"
+            elif mode == "hconv":
                 cout = args[sl + 6]
                 kname = "void icg_hconv_kernel<%d>(HconvP)" % (4 if cout % 128 == 0 else (3 if cout % 96 == 0 else 2))
             elif mode == "from_v":
@@ -366,10 +373,10 @@ def assemble_roofline(timer, steps, elapsed, with_step_traffic=True):
     # resample-fused 25-plane form: 144/25, 2x2-phase / 4x4-stride-2 forms: 36/16).
     step_exe = sum(r[2] for r in timer.records) / steps              # entry-point level: no double counting
     step_ms = elapsed / steps * 1e3
-    t_mfma = sum(r[2] / ((PEAK_F16_MFMA_TFLOPS if "icg_hconv_kernel" in r[0] else PEAK_F32_MFMA_TFLOPS) * 1e12)
+    t_mfma = sum(r[2] / ((PEAK_F16_MFMA_TFLOPS if ("icg_hconv_kernel" in r[0] or "icg_hwgrad_kernel" in r[0]) else PEAK_F32_MFMA_TFLOPS) * 1e12)
                  for r in timer.records) / steps * 1e3                # every launch against the MFMA roof of its own operand type
     t_hbm = (step_hbm_gb / PEAK_HBM_GBPS * 1e3) if step_hbm_gb else None
-    peak = PEAK_F16_MFMA_TFLOPS if "icg_hconv_kernel" in variant else PEAK_F32_MFMA_TFLOPS       # the dominant kernel's own MFMA roof
+    peak = PEAK_F16_MFMA_TFLOPS if ("icg_hconv_kernel" in variant or "icg_hwgrad_kernel" in variant) else PEAK_F32_MFMA_TFLOPS       # the dominant kernel's own MFMA roof
     return {"bound": "mfma", "kernel": variant, "achieved": round(exe_tf, 2), "peak": peak,
             "unit": "TFLOP/s", "frac": round(exe_tf / peak, 4), "traffic": traffic,
             "traffic_source": traffic_src, "traffic_stale": (getattr(measured_traffic, "stale", None) if traffic_src else None),

@@ -2026,10 +2026,62 @@ extern "C" int icg_gemm_tn_batched(const float* A, const float* B, float* C, int
   return icg_check_launch();
 }
 
+// C[m][n] = alpha sum_k A[m][k] B[n][k] for a handful of rows (StyleGAN2's mapping / affine / epilogue dense layers at batch 16:
+// M = 16, N = 512, K = 512 .. 8192).  On the tiled MFMA kernel such a GEMM is N / 128 = 4 workgroups walking the whole K chain
+// (35 us at K = 512, 550 us at K = 8192); here one WAVE owns 4 output columns, its lanes stride over K with 16-byte loads (a B row
+// is read as contiguous 1 KiB pieces) and the MR x 4 partial sums are combined by a butterfly over the 64 lanes (fixed order).
+template <int MR>
+__global__ __launch_bounds__(256) void smallm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                        int M, int N, int K, float alpha) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n0 = ((int)blockIdx.x * 4 + wv) * 4;
+  const int mbase = (int)blockIdx.y * MR;
+  if (n0 >= N) return;                                   // wave-uniform
+  float acc[MR][4];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+  const int K4 = K >> 2;
+  const float4* Bp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) Bp[j] = reinterpret_cast<const float4*>(B + (long)min(n0 + j, N - 1) * K);
+  for (int k4 = lane; k4 < K4; k4 += 64) {
+    float4 b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = Bp[j][k4];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const float4 a = reinterpret_cast<const float4*>(A + (long)min(mbase + m, M - 1) * K)[k4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[m][j] = fmaf(a.w, b[j].w, fmaf(a.z, b[j].z, fmaf(a.y, b[j].y, fmaf(a.x, b[j].x, acc[m][j]))));
+    }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[m][j];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == m * 4 + j) mine = v;                   // lane l keeps element (l / 4, l % 4)
+    }
+  const int m = mbase + (lane >> 2), n = n0 + (lane & 3);
+  if ((lane >> 2) < MR && m < M && n < N) C[(long)m * N + n] = alpha * mine;
+}
+
 extern "C" int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int transA,
                                 int transB, int64_t strideA, int64_t strideB, int64_t strideC, int batch,
                                 float alpha, void* stream) {
   ICG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0);
+  if (transA == 0 && transB == 1 && batch == 1 && M <= 32 && K % 4 == 0 && K >= 128 && N >= 16 && aligned16(A) && aligned16(B)) {
+    g_last_variant[0] = -6; g_last_variant[1] = 0; g_last_variant[2] = N; g_last_variant[3] = K;
+    const dim3 grid((unsigned)icg_cdiv(N, 16), (unsigned)icg_cdiv(M, 16));
+    hipLaunchKernelGGL((smallm_nt_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, alpha);
+    return icg_check_launch();
+  }
   GemmP p{};
   p.A = A; p.B = B; p.C = C;
   p.M = M; p.N = N; p.K = K;

@@ -227,6 +227,10 @@ class _Matmul(torch.autograd.Function):
         ctx.mode = mode
         ctx.save_for_backward(a, b)
         a, b = a.contiguous().float(), b.contiguous().float()
+        if mode == 1 and a.shape[0] <= 32 and a.shape[1] >= 128:
+            # a handful of rows (batch 16): the row-streaming kernel behind mode 0 (gemm_conv.hip: smallm_nt_kernel) wants K contiguous
+            # in both operands -- transpose the (<= 16 MB) weight once instead of walking it with 4 workgroups
+            b, mode = b.t().contiguous(), 0
         if mode == 0:
             (m, k), n = a.shape, b.shape[0]
             assert b.shape == (n, k)

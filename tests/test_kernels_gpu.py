@@ -458,6 +458,8 @@ GEMM_CASES = [
     (256, 64, 4, 0, 1, 3), (256, 16, 64, 0, 0, 3), (64, 16, 256, 1, 0, 3), (64, 4, 256, 1, 0, 2),
     (1024, 256, 48, 0, 1, 2), (1024, 192, 256, 0, 0, 2), (256, 192, 1024, 1, 0, 2), (256, 24, 1024, 1, 0, 2),
     (130, 70, 24, 0, 1, 1), (100, 36, 52, 0, 0, 1), (36, 20, 100, 1, 0, 2),
+    # a handful of rows, one GEMM (StyleGAN2's dense layers at batch 16): the row-streaming kernel (gemm_conv.hip: smallm_nt_kernel)
+    (16, 512, 512, 0, 1, 1), (16, 512, 8192, 0, 1, 1), (5, 36, 132, 0, 1, 1), (32, 70, 1024, 0, 1, 1), (17, 16, 128, 0, 1, 1),
 ]
 
 
