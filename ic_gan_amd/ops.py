@@ -273,7 +273,9 @@ def winograd_applies(cin, cout, h, w, batch):
 # resample-fused layers in the 25-plane domain (tools/rs_wino_bench.py, speed-up over the phase / 4x4-stride-2 forms at
 # min(Cin, Cout) = 96 / 192 / 384 / 768 / 1536):  upsample-fused fprop 1.1 / 1.6 / 2.0 / 2.1 / 2.6x, dgrad 0.9 / 1.3 / 1.8 / 2.0 / 4.8x,
 # wgrad 1.2 / 1.9 / 2.1 / 2.2 / 2.0x;  pool-fused fprop 0.7 / 1.1 / 1.6 / 1.9 / 2.2x, dgrad 0.9 / 1.3 / 1.7 / 2.1 / 2.3x, wgrad 0.7 / 1.05 / 1.6 / 1.8 / 2.1x
-RS_WINOGRAD_MIN_CHANNELS = {True: (96, 192, 96), False: (192, 192, 192)}       # upsample?: (fprop, dgrad, wgrad)
+# round 3, against the second-generation kernels (profiles/r03_rs_winograd_thresholds.txt): upsample-fused 192 -> 96 @256: fprop 1.39x, dgrad 1.13x,
+# wgrad 1.42x; pool-fused 96 -> 96 @256: 0.97 / 1.05 / 0.98x (stays on the 4x4-stride-2 form), 192 -> 192 @128: 1.49 / 1.51 / 1.37x
+RS_WINOGRAD_MIN_CHANNELS = {True: (96, 96, 96), False: (192, 192, 192)}       # upsample?: (fprop, dgrad, wgrad)
 
 
 def resample_winograd_applies(cin, cout, h, w, batch):

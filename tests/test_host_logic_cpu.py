@@ -261,7 +261,8 @@ def test_winograd_routing_rules(monkeypatch):
     for batch in (1, 64, 128):
         assert ops.resample_winograd_applies(192, 96, 256, 256, batch) == 5
     assert ops.resample_winograd_applies(192, 96, 6, 6, 64) == 0
-    assert ops.resample_winograd_directions(192, 96, True) == (True, False, True)      # upsample-fused: fprop / dgrad / wgrad
+    assert ops.resample_winograd_directions(192, 96, True) == (True, True, True)       # upsample-fused: fprop / dgrad / wgrad (round 3: dgrad too)
+    assert ops.resample_winograd_directions(192, 64, True) == (False, False, False)
     assert ops.resample_winograd_directions(96, 96, False) == (False, False, False)    # pool-fused pays from 192 channels
     assert ops.resample_winograd_directions(384, 192, False) == (True, True, True)
     # the strict route
