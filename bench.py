@@ -138,10 +138,9 @@ class KernelTimer:
                 e.record()
                 rec[3].append((s, e))
                 return
-            if mode == "hconv":      # the same gather on fp16 operands (csrc/hconv.hip); zero-inserted sources: 1 tap slot in 4 is non-zero
+            if mode == "hconv":      # the same gather on fp16 operands (csrc/hconv.hip); zero-inserted sources run as four tap phases
                 B, Hin, Win, Cin, Hout, Wout, Cout, R = args[sl:sl + 8]
-                exe = 2.0 * B * Hout * Wout * Cout * Cin * R * R
-                alg = exe / (4.0 if args[sl + 10] == 2 else 1.0)
+                alg = exe = 2.0 * B * Hout * Wout * Cout * Cin * R * R / (4.0 if args[sl + 10] == 2 else 1.0)   # phased: R R / 4 taps per output
                 byt = 2.0 * (B * (Hin * Win * Cin + Hout * Wout * Cout) + Cout * Cin * R * R)
             elif mode == "hwgrad":   # fp16 weight gradient (csrc/hwgrad.hip): executed on 128 x 128 tiles of the [R R Cin][Cout] result
                 B, Hin, Win, Cin, Hout, Wout, Cout, R = args[sl:sl + 8]

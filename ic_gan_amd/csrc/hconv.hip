@@ -13,8 +13,9 @@
 // K-tile and hand-counted vmcnt; out-of-image / odd taps fetch from the zero page.  A lane's 16-byte fragment (8 halfs, k = 8 kk ..
 // 8 kk + 7 of row r) is exactly one operand of v_mfma_f32_16x16x32_f16, so a K-tile is 2 x NT MFMAs of 16 cycles per wave instead of
 // 8 x NT of 32: 16x the fp32 rate per K-tile, which moves the bound of these batch-16 layers from the MFMA pipe to the L2 -> LDS
-// stream.  The stride-2 transposed form spends 3 of 4 taps on zeros; at this rate that is cheaper than a phase decomposition's
-// four launches.
+// stream.  The stride-2 transposed form (zins = 2) runs as four PHASES in one launch: output pixels of parity (al, be) meet only the
+// taps r = (pad + al) mod 2, + 2, ... (x likewise), so a workgroup of phase (al, be) walks that tap sub-grid of the same weight
+// tensor -- 9 tap visits per 4 outputs instead of 36, no zero operand ever reaches the MFMA.
 #include "icg_common.h"
 #include <stdlib.h>
 
@@ -31,6 +32,9 @@ struct HconvP {
   int tiles_n;
   unsigned total;
   int swz;
+  // zs = 1: four phases; phase ph = 2 al + be owns the output pixels (2 my + al, 2 mx + be), my < (Ho - al + 1) / 2, and the
+  // workgroup tiles [ph_tile0[ph], ph_tile0[ph + 1]) of the launch (pixel-tile major, column-tile minor inside a phase)
+  unsigned ph_tile0[5];
 };
 
 __device__ __attribute__((aligned(64))) _Float16 g_hc_zero_page[32];      // zero-initialised: DMA source of the padding taps
@@ -81,16 +85,29 @@ __global__ __launch_bounds__(512, 4) void icg_hconv_kernel(HconvP p) {
     const unsigned tot = p.total, q = tot >> 3, rr = tot & 7u, xcd = t & 7u;
     t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
   }
+  // phase of this workgroup (wave-uniform): al / be = parity of its output rows / columns; one phase (0, 0) when zs = 0
+  int al = 0, be = 0;
+  if (p.zs) {
+    const int ph = (t >= p.ph_tile0[2] ? 2 : 0) + ((t >= p.ph_tile0[2] ? t >= p.ph_tile0[3] : t >= p.ph_tile0[1]) ? 1 : 0);
+    al = ph >> 1; be = ph & 1;
+    t -= p.ph_tile0[ph];
+  }
+  const int Hph = p.zs ? (p.Ho - al + 1) >> 1 : p.Ho, Wph = p.zs ? (p.Wo - be + 1) >> 1 : p.Wo;      // pixel grid of the phase
+  const int Mph = p.zs ? (p.M / (p.Ho * p.Wo)) * Hph * Wph : p.M;
   const int nt = (int)(t % (unsigned)p.tiles_n), mt = (int)(t / (unsigned)p.tiles_n);
   const int m0 = mt * BM, n0 = nt * BN;
+  // taps this phase meets: r = r0, r0 + rstep, ... < R (all of them when zs = 0)
+  const int rstep = 1 << p.zs, r0 = p.zs ? ((p.pad + al) & 1) : 0, s0 = p.zs ? ((p.pad + be) & 1) : 0;
+  const int ntr = (p.R - r0 + rstep - 1) >> p.zs, nts = (p.R - s0 + rstep - 1) >> p.zs;
 
   // ---- DMA role, A: output pixel 16 wv + (lane >> 2) of the tile, chunk position lane & 3; B: weight row BROWS wv + (lane >> 2)
   const int drowA = 16 * wv + (lane >> 2), drowB = BROWS * wv + (lane >> 2);
   const int am = m0 + drowA;
-  const bool a_row_ok = am < p.M;
+  const bool a_row_ok = am < Mph;
   const int amm = a_row_ok ? am : 0;
-  const int aw = amm % p.Wo, at = amm / p.Wo, ah = at % p.Ho, ab = at / p.Ho;
-  const int hs0 = ah * p.stride - p.pad, ws0 = aw * p.stride - p.pad;        // (zero-inserted) source coordinate of tap (0, 0)
+  const int aw = amm % Wph, at = amm / Wph, ah = at % Hph, ab = at / Hph;
+  // (zero-inserted) source coordinate of tap (0, 0) of this lane's output pixel (2 ah + al, 2 aw + be when phased)
+  const int hs0 = (p.zs ? 2 * ah + al : ah * p.stride) - p.pad, ws0 = (p.zs ? 2 * aw + be : aw * p.stride) - p.pad;
   const unsigned img = (unsigned)ab * (unsigned)(p.Hs * p.Ws);
   const unsigned achunk = 8u * (unsigned)((lane & 3) ^ hc_swz(drowA));       // halfs
   const unsigned voffB =
@@ -98,22 +115,22 @@ __global__ __launch_bounds__(512, 4) void icg_hconv_kernel(HconvP p) {
   const bool dma_b_lane = (BROWS == 16) || ((lane >> 2) < BROWS);
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
   const unsigned ldsA = lds_base + (unsigned)wv * 1024u, ldsB = lds_base + (unsigned)A_BYTES + (unsigned)wv * (BROWS * 64u);
-  const int nk = p.K / BKC;
-  const unsigned hb = (unsigned)(p.Hs << p.zs), wb = (unsigned)(p.Ws << p.zs), zmask = (1u << p.zs) - 1u;
+  const int nk = ntr * nts * (p.Cin / BKC);                          // K-tiles: the phase's taps x 32-channel slices
+  const unsigned hb = (unsigned)(p.Hs << p.zs), wb = (unsigned)(p.Ws << p.zs);
 
-  // load cursor (wave-uniform): K-tile -> (channel slice lc0, tap (ltr, lts)); tap-minor order
-  int lc0 = 0, ltr = 0, lts = 0, ltap = 0, lkt = 0;
+  // load cursor (wave-uniform): K-tile -> (channel slice lc0, tap (ltr, lts) of the phase's tap sub-grid); tap-minor order
+  int lc0 = 0, ltr = r0, lts = s0, lkt = 0;
   auto issue_next = [&](unsigned slot_off) {
-    const int hi = hs0 + ltr, wi = ws0 + lts;
-    const bool ok = a_row_ok & ((unsigned)hi < hb) & ((unsigned)wi < wb) & ((((unsigned)hi | (unsigned)wi) & zmask) == 0u);
+    const int hi = hs0 + ltr, wi = ws0 + lts;                       // even by construction when zs = 1
+    const bool ok = a_row_ok & ((unsigned)hi < hb) & ((unsigned)wi < wb);
     const unsigned pix = img + (unsigned)(hi >> p.zs) * (unsigned)p.Ws + (unsigned)(wi >> p.zs);
     const _Float16* src = ok ? p.A + ((size_t)pix * (unsigned)p.Cin + (unsigned)lc0 + achunk) : g_hc_zero_page;
     hc_dma16_ptr(src, ldsA + slot_off);
-    if (dma_b_lane) hc_dma16(p.Bw + (ltap * p.Cin + lc0), voffB, ldsB + slot_off);
+    if (dma_b_lane) hc_dma16(p.Bw + ((ltr * p.R + lts) * p.Cin + lc0), voffB, ldsB + slot_off);
     if (++lkt < nk) {                                               // past the end: the last K-tile again (never read)
-      ++ltap;
-      if (++lts == p.R) { lts = 0; ++ltr; }
-      if (ltap == p.R * p.R) { ltap = 0; ltr = 0; lts = 0; lc0 += BKC; }
+      lts += rstep;
+      if (lts >= p.R) { lts = s0; ltr += rstep; }
+      if (ltr >= p.R) { ltr = r0; lc0 += BKC; }
     } else {
       lkt = nk;
     }
@@ -130,8 +147,10 @@ __global__ __launch_bounds__(512, 4) void icg_hconv_kernel(HconvP p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = hc_f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue_next(0u);
-  issue_next((unsigned)SLOT);
+  if (nk > 0) {                                                     // (a phase without taps -- 1x1, odd parity -- stores zeros)
+    issue_next(0u);
+    issue_next((unsigned)SLOT);
+  }
 
   unsigned cur = 0u;
   for (int kt = 0; kt < nk; ++kt) {
@@ -159,13 +178,19 @@ __global__ __launch_bounds__(512, 4) void icg_hconv_kernel(HconvP p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + 32 * wm + 16 * i + r;
+    size_t orow = (size_t)m;
+    if (p.zs) {                                                     // phase pixel -> output pixel (2 my + al, 2 mx + be)
+      const int mm = m < Mph ? m : 0;
+      const int mx = mm % Wph, tq = mm / Wph, my = tq % Hph, b = tq / Hph;
+      orow = ((size_t)b * (unsigned)p.Ho + (unsigned)(2 * my + al)) * (unsigned)p.Wo + (unsigned)(2 * mx + be);
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + 16 * NT * wn + 16 * j + 4 * kk;
-      if (m < p.M && n < p.N) {
+      if (m < Mph && n < p.N) {
         const hc_f32x4 v = acc[i][j];
         hc_h4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        *reinterpret_cast<hc_h4*>(p.C + (size_t)m * (unsigned)p.N + n) = o;
+        *reinterpret_cast<hc_h4*>(p.C + orow * (unsigned)p.N + n) = o;
       }
     }
   }
@@ -192,7 +217,16 @@ extern "C" int icg_conv2d_g_fprop_f16(const void* x, const void* w, void* y, int
   p.M = (int)M; p.N = Cout; p.K = R * R * Cin;
   p.Ho = Hout; p.Wo = Wout; p.Hs = H; p.Ws = W; p.Cin = Cin; p.R = R; p.stride = stride; p.pad = pad; p.zs = (zins == 2) ? 1 : 0;
   p.tiles_n = Cout / (32 * nt);
-  const long total = icg_cdiv(M, 128) * p.tiles_n;
+  long total = icg_cdiv(M, 128) * p.tiles_n;
+  if (p.zs) {                                                       // four phases, each with its own pixel grid
+    total = 0;
+    for (int ph = 0; ph < 4; ++ph) {
+      const long hp = (Hout - (ph >> 1) + 1) / 2, wp = (Wout - (ph & 1) + 1) / 2;
+      p.ph_tile0[ph] = (unsigned)total;
+      total += icg_cdiv((long)B * hp * wp, 128) * p.tiles_n;
+    }
+    p.ph_tile0[4] = (unsigned)total;
+  }
   ICG_REQUIRE(total > 0 && total < 0x7fffffffL);
   p.total = (unsigned)total;
   static const bool no_swz = [] { const char* e = getenv("ICG_NO_XCD_SWIZZLE"); return e && e[0] == '1'; }();

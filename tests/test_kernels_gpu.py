@@ -1114,6 +1114,9 @@ HCONV_CASES = [
     (2, 8, 8, 128, 17, 17, 64, 3, 1, 0, 2),              # data gradient geometry of a padded stride-2 convolution (adjoint pad)
     (2, 8, 8, 64, 16, 16, 96, 3, 1, 1, 2),               # output grid past the zero-inserted source (those positions read zeros)
     (2, 12, 12, 64, 10, 10, 64, 5, 1, 1, 0),             # 5x5, partial padding
+    (2, 8, 8, 64, 15, 15, 64, 1, 1, 0, 2),               # 1x1 over a zero-inserted source: three of the four phases have no tap at all
+    (1, 6, 5, 32, 13, 11, 64, 3, 1, 1, 2),               # odd phase grids (13 x 11 outputs: 7/6 rows, 6/5 columns per phase), pad 1
+    (2, 7, 7, 64, 16, 16, 128, 4, 1, 2, 2),              # 4x4 taps: two per phase and axis
     (4, 32, 32, 512, 32, 32, 512, 3, 1, 1, 0),           # cfg4, resolution 32: 144 K-tiles
     (3, 64, 64, 256, 129, 129, 128, 3, 1, 2, 2),         # cfg4 synthesis b128.conv0 (up): 50k output pixels
 ]
