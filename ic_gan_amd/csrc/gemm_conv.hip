@@ -1209,7 +1209,7 @@ static int launch_gemm(const GemmP& p0, bool vec, int zdim, hipStream_t st, bool
       const int rc = icg_pgemm_nn_launch(p.A, p.B, p.C, p.M, p.N, p.K, p.ldc, p.strideA, p.strideB, p.strideC, zdim, p.alpha,
                                          levels, st, &nt2);
       if (rc != 1) {
-        g_last_variant[0] = 2; g_last_variant[1] = 0; g_last_variant[2] = nt2; g_last_variant[3] = (levels == 1) ? 4 : 2;
+        g_last_variant[0] = 2; g_last_variant[1] = 0; g_last_variant[2] = nt2 % 100; g_last_variant[3] = (nt2 >= 100) ? 4 : 2;
         return rc;
       }
     }

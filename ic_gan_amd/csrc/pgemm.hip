@@ -711,6 +711,9 @@ static bool pgemm_enabled() {      // measurement switch (ICG_PGEMM=0: first-gen
   return on;
 }
 
+#ifndef ICG_PGEMM_L1_MINK_DEFAULT
+#define ICG_PGEMM_L1_MINK_DEFAULT 0      // 0: two-level chains at every K ("accumulation levels")
+#endif
 static int pgemm_env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return (e && e[0]) ? atoi(e) : dflt;
@@ -732,10 +735,12 @@ int icg_pgemm_nn_launch(const float* A, const float* B, float* C, int M, int N, 
   static const int stream = pgemm_env_int("ICG_PGEMM_STREAM", 1);              // measurement switches, read once
   static const int run_ktiles = pgemm_env_int("ICG_PGEMM_RUN_KTILES", 48);
   const bool c_vec = ((uintptr_t)C % 16 == 0) && (ldc % 4 == 0) && (sC % 4 == 0);
-  if (tn_out) *tn_out = nt;
   dim3 block(512);
   static const int l1_maxk = pgemm_env_int("ICG_PGEMM_L1_MAXK", 0);           // K up to which chains stay single-level (experiments)
   if (K <= l1_maxk) levels = 1;
+  static const int l1_mink = pgemm_env_int("ICG_PGEMM_L1_MINK", ICG_PGEMM_L1_MINK_DEFAULT);      // K from which chains are single-level
+  if (l1_mink > 0 && K >= l1_mink) levels = 1;
+  if (tn_out) *tn_out = nt + (levels == 1 ? 100 : 0);                          // (+100: single-level chains ran)
   // the 128-column two-level kernel holds 64 + 64 accumulator registers: its streaming form does not fit the 128-register budget
   // of 4 waves per SIMD without spills (scratch traffic would sit on the hand-counted vmcnt), so it keeps one tile per workgroup
   if (stream && c_vec && !(nt == 4 && levels == 2)) {
