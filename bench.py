@@ -754,6 +754,8 @@ def main():
                     help="implicit-GEMM / phase / 4x4-stride-2 kernels only (ops.disable_winograd): the strict-parity route")
     ap.add_argument("--no-fuse-relu-backward", action="store_true",
                     help="ablation: ReLU backward of D's layers as a separate pass instead of the data-gradient epilogue")
+    ap.add_argument("--no-fused-attention", action="store_true",
+                    help="ablation: attention scores as GEMM + stand-alone softmax instead of the fused kernel (ops.FUSED_ATTENTION_SCORES)")
     ap.add_argument("--wgrad-stream", action="store_true",
                     help="opt-in: weight gradients on a side HIP stream, concurrently with the data gradient (ops.WGRAD_SIDE_STREAM)")
     ap.add_argument("--sync-bn", action="store_true", help="cross-replica BN statistics over RCCL (cfg3 variant)")
@@ -812,6 +814,9 @@ def main():
     if args.wgrad_stream:
         import ic_gan_amd.ops as _ops
         _ops.WGRAD_SIDE_STREAM = True
+    if args.no_fused_attention:
+        import ic_gan_amd.ops as _ops
+        _ops.FUSED_ATTENTION_SCORES = False
 
     if args.workload == "sample":
         return bench_sampling(args, device, rank, world)

@@ -1,0 +1,133 @@
+// Attention scores with the softmax in the epilogue: beta[b][i][:] = softmax_j( sum_k theta[b][i][k] phi[b][j][k] )
+// (layers.py:233-238: beta = F.softmax(torch.bmm(theta^T, phi), -1); theta [B][n][d] and phi [B][m][d] are the NHWC outputs of the
+// two 1x1 projections, m = n / 4 after the 2x2 max-pool).
+//
+// The three-kernel form writes the scores s [B][n][m] (1 GiB at B = 64, n = 4096, m = 1024), reads them back for the softmax and
+// writes beta: 3 passes over that tensor for 26 GFLOP of arithmetic.  Here a workgroup owns 32 query rows and ALL m keys: wave w
+// holds the 32 x 128 scores of keys [128 w, 128 w + 128) in 64 accumulator registers (exact-fp32 v_mfma_f32_16x16x4_f32, operand
+// fragments loaded straight from L2 -- d is 24 or 48, there is nothing to stage), the row maxima / sums are combined by two
+// wave shuffles and one LDS exchange between the waves, and beta is written once.  The kernel is bound by that write.
+// A lane's V consecutive k-values are the operands of V successive MFMAs (the K order is permuted identically in both operands,
+// as in pgemm.hip), so a fragment is one 8- or 16-byte load; operands are swapped (D = phi-fragment x theta-fragment), which leaves
+// lane (r, kk) with beta[row r][key 4 kk .. 4 kk + 3]: 16-byte stores.
+#include "icg_common.h"
+#include <math.h>
+
+typedef float at_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int V> struct at_vec;
+template <> struct at_vec<4> { typedef float4 type; };
+template <> struct at_vec<2> { typedef float2 type; };
+__device__ __forceinline__ float at_get(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
+__device__ __forceinline__ float at_get(const float2& v, int s) { return s == 0 ? v.x : v.y; }
+
+// V: k-values per lane and K-tile (a K-tile is 4 V wide); NKT: K-tiles (d = 4 V NKT); waves = m / 128 (blockDim = 64 waves)
+template <int V, int NKT>
+__global__ __launch_bounds__(512) void icg_attn_scores_softmax_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
+                                                                      float* __restrict__ beta, int n, int m) {
+  typedef typename at_vec<V>::type vec;
+  constexpr int D = 4 * V * NKT;
+  __shared__ float red[2][8][32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  const int rows_per_img = n >> 5;
+  const int b = blockIdx.x / rows_per_img, row0 = (blockIdx.x - b * rows_per_img) << 5;
+  const float* __restrict__ Q = theta + ((long)b * n + row0) * D;
+  const float* __restrict__ Kp = phi + ((long)b * m + 128 * wv) * D;
+
+  vec qa[2][NKT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) qa[i][t] = *reinterpret_cast<const vec*>(Q + (16 * i + r) * D + 4 * V * t + V * kk);
+
+  at_f32x4 acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    vec kb[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) kb[t] = *reinterpret_cast<const vec*>(Kp + (16 * j + r) * D + 4 * V * t + V * kk);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      at_f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int s = 0; s < V; ++s) a = __builtin_amdgcn_mfma_f32_16x16x4f32(at_get(kb[t], s), at_get(qa[i][t], s), a, 0, 0, 0);
+      acc[i][j] = a;
+    }
+  }
+
+  // ---- row maxima: lane -> the 4 lanes of a row (xor 16, 32) -> the waves (LDS)
+  float mx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float v = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v = fmaxf(fmaxf(v, fmaxf(acc[i][j][0], acc[i][j][1])), fmaxf(acc[i][j][2], acc[i][j][3]));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    if (kk == 0) red[0][wv][16 * i + r] = v;
+    mx[i] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float v = red[0][0][16 * i + r];
+    for (int w = 1; w < nw; ++w) v = fmaxf(v, red[0][w][16 * i + r]);
+    mx[i] = v;
+  }
+  // ---- exponentials and row sums (same path; fixed order over the waves)
+  float inv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = expf(acc[i][j][e] - mx[i]);
+      s += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (kk == 0) red[1][wv][16 * i + r] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float s = red[1][0][16 * i + r];
+    for (int w = 1; w < nw; ++w) s += red[1][w][16 * i + r];
+    inv[i] = 1.0f / s;
+  }
+  float* __restrict__ out = beta + ((long)b * n + row0) * m + 128 * wv + 4 * kk;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      *reinterpret_cast<at_f32x4*>(out + (long)(16 * i + r) * m + 16 * j) = acc[i][j] * inv[i];
+}
+
+// 1 when the fused kernel serves the shape: n a multiple of 32, m a multiple of 128 up to 1024, d in {8, 16, 24, 32, 48, 64}
+extern "C" int icg_attn_scores_softmax_applies(int n, int m, int d) {
+  if (n < 32 || n % 32 != 0 || m < 128 || m % 128 != 0 || m > 1024) return 0;
+  return (d == 8 || d == 16 || d == 24 || d == 32 || d == 48 || d == 64) ? 1 : 0;
+}
+
+extern "C" int icg_attn_scores_softmax(const float* theta, const float* phi, float* beta, int B, int n, int m, int d, void* stream) {
+  ICG_REQUIRE(theta && phi && beta && B > 0);
+  ICG_REQUIRE(icg_attn_scores_softmax_applies(n, m, d));
+  ICG_REQUIRE(((uintptr_t)theta % 16) == 0 && ((uintptr_t)phi % 16) == 0 && ((uintptr_t)beta % 16) == 0);
+  const long blocks = (long)B * (n / 32);
+  ICG_REQUIRE(blocks < 0x7fffffffL);
+  const dim3 grid((unsigned)blocks), block((unsigned)(64 * (m / 128)));
+  hipStream_t st = (hipStream_t)stream;
+  switch (d) {
+    case 8: hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<2, 1>), grid, block, 0, st, theta, phi, beta, n, m); break;
+    case 16: hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<4, 1>), grid, block, 0, st, theta, phi, beta, n, m); break;
+    case 24: hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<2, 3>), grid, block, 0, st, theta, phi, beta, n, m); break;
+    case 32: hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<4, 2>), grid, block, 0, st, theta, phi, beta, n, m); break;
+    case 48: hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<4, 3>), grid, block, 0, st, theta, phi, beta, n, m); break;
+    default: hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<4, 4>), grid, block, 0, st, theta, phi, beta, n, m); break;
+  }
+  return icg_check_launch();
+}

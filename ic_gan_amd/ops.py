@@ -929,6 +929,9 @@ class ScaleAddFn(Function):
 # ----------------------------------------------------------------------------------------------
 # attention core: beta = softmax(theta^T phi); o = g beta^T   (layers.py:233-243)
 # ----------------------------------------------------------------------------------------------
+FUSED_ATTENTION_SCORES = True       # False: scores GEMM + stand-alone softmax (measurement switch, bench.py --no-fused-attention)
+
+
 class AttnCoreFn(Function):
     @staticmethod
     def forward(ctx, theta, phi, g):
@@ -938,11 +941,15 @@ class AttnCoreFn(Function):
         n, m = H * W, phi.shape[2] * phi.shape[3]
         dev = theta.device
         # NHWC memory: theta = Q [B][n][d], phi = K [B][m][d], g = V [B][m][dv]
-        s = torch.empty(B, n, m, device=dev, dtype=torch.float32)
-        L.call("icg_gemm_batched", theta, phi, s, n, m, d, 0, 1, n * d, m * d, n * m, B, 1.0)
-        beta = torch.empty_like(s)
-        L.call("icg_softmax_fwd", s, beta, B * n, m)
-        del s
+        beta = torch.empty(B, n, m, device=dev, dtype=torch.float32)
+        if FUSED_ATTENTION_SCORES and L.query("icg_attn_scores_softmax_applies", n, m, d):
+            # scores + softmax in one kernel (csrc/attn.hip): the [B][n][m] score tensor is never written
+            L.call("icg_attn_scores_softmax", theta, phi, beta, B, n, m, d)
+        else:
+            s = torch.empty_like(beta)
+            L.call("icg_gemm_batched", theta, phi, s, n, m, d, 0, 1, n * d, m * d, n * m, B, 1.0)
+            L.call("icg_softmax_fwd", s, beta, B * n, m)
+            del s
         o = _empty_cl(B, dv, H, W, dev)
         L.call("icg_gemm_batched", beta, g, o, n, dv, m, 0, 0, n * m, m * dv, n * dv, B, 1.0)
         ctx.save_for_backward(theta, phi, g, beta)

@@ -453,6 +453,12 @@ int icg_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void*
 int icg_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream);
 /* row softmax over the last dim (layers.py:237) */
 int icg_softmax_fwd(const float* x, float* y, int64_t rows, int cols, void* stream);
+/* Attention scores with the softmax in the epilogue (layers.py:233-238: beta = softmax(bmm(theta^T, phi), -1)):
+ *   beta[b][i][:] = softmax_j( sum_k theta[b][i][k] * phi[b][j][k] ),  theta [B][n][d], phi [B][m][d], beta [B][n][m]
+ * -- the scores are never written: one pass over beta instead of three (icg_gemm_batched + icg_softmax_fwd).  `_applies` -> 1 for
+ * n % 32 == 0, m % 128 == 0, m <= 1024, d in {8, 16, 24, 32, 48, 64}; the caller keeps the two-kernel form otherwise. */
+int icg_attn_scores_softmax_applies(int n, int m, int d);
+int icg_attn_scores_softmax(const float* theta, const float* phi, float* beta, int B, int n, int m, int d, void* stream);
 int icg_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int cols, void* stream);
 /* h[b][c] = sum_hw relu(x[b,h,w,c])   (BigGAN.py:625) and its backward */
 int icg_relu_sumpool_fwd(const float* x, float* y, int B, int HW, int C, void* stream);

@@ -705,6 +705,16 @@ def icg_softmax_fwd(x, y, rows, cols):
     mem(y)[: rows * cols].copy_(F.softmax(mem(x)[: rows * cols].view(rows, cols), -1).reshape(-1))
 
 
+def icg_attn_scores_softmax_applies(n, m, d):
+    return int(n >= 32 and n % 32 == 0 and m >= 128 and m % 128 == 0 and m <= 1024 and d in (8, 16, 24, 32, 48, 64))
+
+
+def icg_attn_scores_softmax(theta, phi, beta, B, n, m, d):
+    q = mem(theta)[: B * n * d].view(B, n, d)
+    k = mem(phi)[: B * m * d].view(B, m, d)
+    mem(beta)[: B * n * m].copy_(F.softmax(torch.bmm(q, k.transpose(1, 2)), -1).reshape(-1))
+
+
 def icg_softmax_bwd(y, dy, dx, rows, cols):
     yy = mem(y)[: rows * cols].view(rows, cols)
     g = mem(dy)[: rows * cols].view(rows, cols)

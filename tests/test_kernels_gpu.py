@@ -1171,3 +1171,26 @@ def test_conv2d_g_wgrad_f16(case):
     ws = torch.zeros(nb, dtype=torch.uint8)
     (p,) = run_pair("icg_conv2d_g_wgrad_f16", [x, dy, dw, B, H, W, Cin, Ho, Wo, Cout, taps, stride, pad, ws, nb], [2])
     close(*p, rtol=1e-4, atol_rel=5e-5, what="fp16 weight gradient %r" % (case,))
+
+
+# ------------------------------------------------------------------------------------------------ attention scores + softmax
+ATTN_CASES = [
+    # B, n, m, d
+    (2, 64, 128, 48), (3, 32, 256, 24), (1, 96, 1024, 48), (2, 128, 1024, 24), (2, 64, 512, 16), (1, 32, 128, 8), (2, 64, 384, 64),
+    (1, 4096, 1024, 48),          # the generator's attention block at 64 x 64 (one image)
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attn_scores_softmax(case):
+    """icg_attn_scores_softmax (csrc/attn.hip) against softmax(bmm(theta, phi^T)) in fp32 on the CPU; scores of a few units, so the
+    probabilities span many decades: 2e-5 of the row maximum + 1e-4 relative."""
+    B, n, m, d = case
+    assert _L().query("icg_attn_scores_softmax_applies", n, m, d) == 1 and R.icg_attn_scores_softmax_applies(n, m, d) == 1
+    theta = rnd(B, n, d, seed=1)
+    phi = rnd(B, m, d, seed=2, scale=0.7)
+    beta = torch.zeros(B, n, m)
+    (p,) = run_pair("icg_attn_scores_softmax", [theta, phi, beta, B, n, m, d], [2])
+    close(*p, rtol=1e-4, atol_rel=2e-5, what="attention scores + softmax %r" % (case,))
+    assert float((p[0].cpu().sum(-1) - 1).abs().max()) < 1e-5
