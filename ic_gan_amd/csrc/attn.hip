@@ -6,7 +6,7 @@
 // writes beta: 3 passes over that tensor for 26 GFLOP of arithmetic.  Here a workgroup owns 32 query rows and ALL m keys: wave w
 // holds the 32 x 128 scores of keys [128 w, 128 w + 128) in 64 accumulator registers (exact-fp32 v_mfma_f32_16x16x4_f32, operand
 // fragments loaded straight from L2 -- d is 24 or 48, there is nothing to stage), the row maxima / sums are combined by two
-// wave shuffles and one LDS exchange between the waves, and beta is written once.  The kernel is bound by that write.
+// wave shuffles and one LDS exchange between the waves, and beta is written once.
 // A lane's V consecutive k-values are the operands of V successive MFMAs (the K order is permuted identically in both operands,
 // as in pgemm.hip), so a fragment is one 8- or 16-byte load; operands are swapped (D = phi-fragment x theta-fragment), which leaves
 // lane (r, kk) with beta[row r][key 4 kk .. 4 kk + 3]: 16-byte stores.
@@ -20,6 +20,11 @@ template <> struct at_vec<4> { typedef float4 type; };
 template <> struct at_vec<2> { typedef float2 type; };
 __device__ __forceinline__ float at_get(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
 __device__ __forceinline__ float at_get(const float2& v, int s) { return s == 0 ? v.x : v.y; }
+
+// exp(x) for x <= 0 as 2^(x log2 e) on the hardware exponential (v_exp_f32, 1 ulp): the argument's rounding adds |x| 2^-24 relative
+// error -- < 2e-6 down to the e^-30 terms that still register in a float sum -- against ~25 VALU instructions for expf(); with 64
+// exponentials per lane the accurate form was half of this kernel's issue time
+__device__ __forceinline__ float at_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 // V: k-values per lane and K-tile (a K-tile is 4 V wide); NKT: K-tiles (d = 4 V NKT); waves = m / 128 (blockDim = 64 waves)
 template <int V, int NKT>
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(512) void icg_attn_scores_softmax_kernel(const floa
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[i][j][e] = expf(acc[i][j][e] - mx[i]);
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = at_exp(acc[i][j][e] - mx[i]);
       s += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
     }
     s += __shfl_xor(s, 16, 64);
