@@ -28,7 +28,7 @@ __device__ __forceinline__ float at_exp(float x) { return __builtin_amdgcn_exp2f
 
 // V: k-values per lane and K-tile (a K-tile is 4 V wide); NKT: K-tiles (d = 4 V NKT); waves = m / 128 (blockDim = 64 waves)
 template <int V, int NKT>
-__global__ __launch_bounds__(512) void icg_attn_scores_softmax_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
+__global__ __launch_bounds__(512, 4) void icg_attn_scores_softmax_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
                                                                       float* __restrict__ beta, int n, int m) {
   typedef typename at_vec<V>::type vec;
   constexpr int D = 4 * V * NKT;
@@ -61,6 +61,7 @@ __global__ __launch_bounds__(512) void icg_attn_scores_softmax_kernel(const floa
         for (int s = 0; s < V; ++s) a = __builtin_amdgcn_mfma_f32_16x16x4f32(at_get(kb[t], s), at_get(qa[i][t], s), a, 0, 0, 0);
       acc[i][j] = a;
     }
+    if (j & 1) asm volatile("" ::: "memory");       // keeps the fragment loads at most two column tiles ahead (128-register budget: 2 workgroups per CU)
   }
 
   // ---- row maxima: lane -> the 4 lanes of a row (xor 16, 32) -> the waves (LDS)

@@ -14,7 +14,7 @@ for tag in ("off", "on"):
             d = json.loads(l); r = d["roofline"]
             print("BENCH fused attention", tag, d["ms_per_step"], d["value"], "uninstr", d["config"]["uninstrumented_ms_per_step"], r["kernel"], r["achieved"], r["frac"])
 PY
-timeout 1200 python -m pytest tests/test_parity_gpu.py tests/test_checkpoint.py tests/test_biggan_deep.py -m gpu -q -p no:cacheprovider > gpurun_out/r3t_parity.log 2>&1; echo "parity rc=$?"
+timeout 600 python -m pytest tests/test_parity_gpu.py -m gpu -q -p no:cacheprovider -k "bench_config or real_widths" > gpurun_out/r3t_parity.log 2>&1; echo "parity rc=$?"
 grep -E "^(FAILED|ERROR)|passed|failed" gpurun_out/r3t_parity.log | tail -12 | cut -c1-300
 cat > /tmp/attn_time.py <<'PY'
 import torch, sys, os
