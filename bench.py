@@ -916,6 +916,8 @@ def main():
             dt = float(tt.item())
         return dt
 
+    # what the K timed steps all-reduced (the legs below run the hooks again)
+    comm_counts = {k: (v.bytes, v.buckets) for k, v in comm.items()} if comm else None
     uninstr = None
     if not args.no_kernel_timer and not args.no_uninstrumented_leg:
         # the figure above is measured with the HIP-event brackets of KernelTimer / icg_planes_timing active; the same K steps again
@@ -925,8 +927,8 @@ def main():
         uninstr = timed_region(args.steps)
     comm_report = None
     if comm:
-        per_step = {k: {"allreduce_bytes_per_step": v.bytes // args.steps, "buckets_per_step": v.buckets // args.steps}
-                    for k, v in comm.items()}
+        per_step = {k: {"allreduce_bytes_per_step": v[0] // args.steps, "buckets_per_step": v[1] // args.steps}
+                    for k, v in comm_counts.items()}
         # exposed (non-overlapped) communication: the same steps with every collective of the two wrappers suppressed (no_sync:
         # each rank then trains on its own gradients -- a timing leg only, run after the measurement)
         import contextlib
