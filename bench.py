@@ -237,7 +237,7 @@ class KernelTimer:
                         lp *= 2
                     kname = "void thin_%s_kernel<%d, %d>" % ("wgrad" if last[1] else "fprop", last[3], lp)
             elif last[0] == -3:      # skinny linear kernels (narrow_conv.hip): {-3, fprop/wgrad, Cout, Cin}
-                kname = "skinny_wgrad_kernel" if last[1] else "void skinny_fprop_kernel<8>"
+                kname = "skinny_wgrad_kernel" if last[1] else "void smallm_nt_kernel<16, %d>" % (4 if last[3] % 4 == 0 else 1)
             elif last[0] == -2:      # direct narrow-output kernels (narrow_conv.hip): {-2, fprop/wgrad, Cout, Cin}
                 if last[2] <= 3 and last[3] % 32 == 0 and last[3] <= 128:      # MFMA forms (narrow_conv.hip: narrow_*_mfma_ok)
                     kname = ("void thin_wgrad_mfma_kernel<%d, %d, 1>" if last[1] else "void narrow_fprop_mfma_kernel<%d, %d>") % (last[2], last[3] // 32)

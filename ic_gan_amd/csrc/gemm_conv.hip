@@ -1356,6 +1356,82 @@ static int launch_fprop_splitk(const GemmP& p0, bool vec, hipStream_t st, bool s
   return icg_check_launch();
 }
 
+// C[m][n] = alpha sum_k A[m][k] B[n][k] (+ bias[n]) for a handful of rows: StyleGAN2's mapping / affine / epilogue dense layers at batch
+// 16 (M = 16, N = 512, K = 512 .. 8192) and BigGAN's conditional-BN projections (M = 64, K = 657, N = the block's channels, layers.py:
+// 367-374).  On the tiled MFMA kernel such a GEMM is N / 128 workgroups walking the whole K chain (35 us at K = 512, 550 us at
+// K = 8192); the first row-per-lane kernel for the K = 657 layers (skinny_fprop_kernel) ran N / 8 blocks of 165 dependent steps: 37 us.
+// Here one WAVE owns 4 output columns and 16 rows, its lanes stride over K (16-byte loads when K % 4 == 0, dwords otherwise: a B row is
+// read as contiguous pieces) and the 16 x 4 partial sums are combined by a butterfly over the 64 lanes (fixed order).
+template <int MR, int VEC>
+__global__ __launch_bounds__(256) void smallm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                        const float* __restrict__ bias, float* __restrict__ C, int M, int N, int K,
+                                                        float alpha) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n0 = ((int)blockIdx.x * 4 + wv) * 4;
+  const int mbase = (int)blockIdx.y * MR;
+  if (n0 >= N) return;                                   // wave-uniform
+  float acc[MR][4];
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+  if constexpr (VEC == 4) {
+    const int K4 = K >> 2;
+    const float4* Bp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Bp[j] = reinterpret_cast<const float4*>(B + (long)min(n0 + j, N - 1) * K);
+    for (int k4 = lane; k4 < K4; k4 += 64) {
+      float4 b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bp[j][k4];
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const float4 a = reinterpret_cast<const float4*>(A + (long)min(mbase + m, M - 1) * K)[k4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[m][j] = fmaf(a.w, b[j].w, fmaf(a.z, b[j].z, fmaf(a.y, b[j].y, fmaf(a.x, b[j].x, acc[m][j]))));
+      }
+    }
+  } else {
+    const float* Bp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Bp[j] = B + (long)min(n0 + j, N - 1) * K;
+    for (int k = lane; k < K; k += 64) {
+      float b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bp[j][k];
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const float a = A[(long)min(mbase + m, M - 1) * K + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = fmaf(a, b[j], acc[m][j]);
+      }
+    }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[m][j];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == m * 4 + j) mine = v;                   // lane l keeps element (l / 4, l % 4)
+    }
+  const int m = mbase + (lane >> 2), n = n0 + (lane & 3);
+  if ((lane >> 2) < MR && m < M && n < N) C[(long)m * N + n] = alpha * mine + (bias ? bias[n] : 0.f);
+}
+
+static int smallm_nt_launch(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, float alpha,
+                            hipStream_t st) {
+  const dim3 grid((unsigned)icg_cdiv(N, 16), (unsigned)icg_cdiv(M, 16));
+  if (K % 4 == 0 && aligned16(A) && aligned16(B))
+    hipLaunchKernelGGL((smallm_nt_kernel<16, 4>), grid, dim3(256), 0, st, A, B, bias, C, M, N, K, alpha);
+  else
+    hipLaunchKernelGGL((smallm_nt_kernel<16, 1>), grid, dim3(256), 0, st, A, B, bias, C, M, N, K, alpha);
+  return icg_check_launch();
+}
+
 static int conv2d_fprop_impl(const float* x, const float* w, const float* bias, const float* residual, float* out,
                              const float* scale, const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin,
                              int Cout, int R, unsigned flags, float alpha, void* workspace, size_t workspace_bytes,
@@ -1411,7 +1487,9 @@ static int conv2d_fprop_impl(const float* x, const float* w, const float* bias, 
   }
   if (!up && !residual && !(flags & (ICG_PRE_AFFINE | ICG_PRE_RELU)) && icg_skinny_ok(M, Cin, R)) {
     g_last_variant[0] = -3; g_last_variant[1] = 0; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
-    return icg_skinny_fprop(x, w, bias, out, (int)M, Cout, Cin, alpha, (hipStream_t)stream);
+    static const bool first_gen = [] { const char* e = getenv("ICG_SKINNY_FIRST_GEN"); return e && e[0] == '1'; }();     // measurement switch
+    if (first_gen) return icg_skinny_fprop(x, w, bias, out, (int)M, Cout, Cin, alpha, (hipStream_t)stream);
+    return smallm_nt_launch(x, w, bias, out, (int)M, Cout, Cin, alpha, (hipStream_t)stream);
   }
   GemmP p{};
   p.A = x; p.B = w; p.C = out;
@@ -2026,61 +2104,13 @@ extern "C" int icg_gemm_tn_batched(const float* A, const float* B, float* C, int
   return icg_check_launch();
 }
 
-// C[m][n] = alpha sum_k A[m][k] B[n][k] for a handful of rows (StyleGAN2's mapping / affine / epilogue dense layers at batch 16:
-// M = 16, N = 512, K = 512 .. 8192).  On the tiled MFMA kernel such a GEMM is N / 128 = 4 workgroups walking the whole K chain
-// (35 us at K = 512, 550 us at K = 8192); here one WAVE owns 4 output columns, its lanes stride over K with 16-byte loads (a B row
-// is read as contiguous 1 KiB pieces) and the MR x 4 partial sums are combined by a butterfly over the 64 lanes (fixed order).
-template <int MR>
-__global__ __launch_bounds__(256) void smallm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
-                                                        int M, int N, int K, float alpha) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int n0 = ((int)blockIdx.x * 4 + wv) * 4;
-  const int mbase = (int)blockIdx.y * MR;
-  if (n0 >= N) return;                                   // wave-uniform
-  float acc[MR][4];
-#pragma unroll
-  for (int m = 0; m < MR; ++m)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
-  const int K4 = K >> 2;
-  const float4* Bp[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) Bp[j] = reinterpret_cast<const float4*>(B + (long)min(n0 + j, N - 1) * K);
-  for (int k4 = lane; k4 < K4; k4 += 64) {
-    float4 b[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b[j] = Bp[j][k4];
-#pragma unroll
-    for (int m = 0; m < MR; ++m) {
-      const float4 a = reinterpret_cast<const float4*>(A + (long)min(mbase + m, M - 1) * K)[k4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[m][j] = fmaf(a.w, b[j].w, fmaf(a.z, b[j].z, fmaf(a.y, b[j].y, fmaf(a.x, b[j].x, acc[m][j]))));
-    }
-  }
-  float mine = 0.f;
-#pragma unroll
-  for (int m = 0; m < MR; ++m)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v = acc[m][j];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == m * 4 + j) mine = v;                   // lane l keeps element (l / 4, l % 4)
-    }
-  const int m = mbase + (lane >> 2), n = n0 + (lane & 3);
-  if ((lane >> 2) < MR && m < M && n < N) C[(long)m * N + n] = alpha * mine;
-}
-
 extern "C" int icg_gemm_batched(const float* A, const float* B, float* C, int M, int N, int K, int transA,
                                 int transB, int64_t strideA, int64_t strideB, int64_t strideC, int batch,
                                 float alpha, void* stream) {
   ICG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0);
   if (transA == 0 && transB == 1 && batch == 1 && M <= 32 && K % 4 == 0 && K >= 128 && N >= 16 && aligned16(A) && aligned16(B)) {
     g_last_variant[0] = -6; g_last_variant[1] = 0; g_last_variant[2] = N; g_last_variant[3] = K;
-    const dim3 grid((unsigned)icg_cdiv(N, 16), (unsigned)icg_cdiv(M, 16));
-    hipLaunchKernelGGL((smallm_nt_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, A, B, C, M, N, K, alpha);
-    return icg_check_launch();
+    return smallm_nt_launch(A, B, nullptr, C, M, N, K, alpha, (hipStream_t)stream);
   }
   GemmP p{};
   p.A = A; p.B = B; p.C = C;
