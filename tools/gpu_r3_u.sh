@@ -4,11 +4,11 @@ mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
 timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "conv2d or gemm_batched or linear" > gpurun_out/r3u_kern.log 2>&1; echo "kernel tests rc=$?"
 grep -E "^(FAILED|ERROR)|passed|failed|mismatch" gpurun_out/r3u_kern.log | tail -8 | cut -c1-300
-ICG_SKINNY_FIRST_GEN=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r3u_bench_old.log 2>&1
+true
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r3u_bench_new.log 2>&1
 python - <<'PY'
 import json
-for tag in ("old", "new"):
+for tag in ("new",):
     for l in open("gpurun_out/r3u_bench_%s.log" % tag):
         if l.startswith("{"):
             d = json.loads(l); r = d["roofline"]
