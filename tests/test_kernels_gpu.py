@@ -89,6 +89,10 @@ CONV_CASES = [
     (64, 1, 1, 17, 256, 1, 0, 0, True),                  # z-chunk linear
     (4, 1, 1, 2048, 512, 1, 0, 0, True),                 # shared_feat
     (8, 1, 1, 128, 1, 1, 0, 0, True),                    # D output linear (N = 1)
+    (64, 1, 1, 1536, 1, 1, 0, 0, True),                  # ... at a training batch: >= 16 rows -> row-streaming GEMM (smallm_nt_kernel), N = 1
+    (128, 1, 1, 2048, 1536, 1, 0, 0, True),              # linear_feat at the D step's batch: 8 row groups, 16-byte loads
+    (64, 1, 1, 96, 657, 1, 0, 0, False),                 # data gradient of a conditional-BN projection (N = 657)
+    (17, 1, 1, 40, 22, 1, 0, 0, True),                   # ragged everything, two row groups
     (1, 32, 32, 32, 160, 3, 0, 0, True),                 # N = 160 -> TN = 4 with ragged last tile
     (5, 2, 2, 20, 20, 3, PRE_AFFINE, 0, True),           # tiny spatial, affine without relu
     (3, 7, 5, 16, 1, 3, 0, 0, False),                    # direct narrow-output kernels (narrow_conv.hip): LP = 4
