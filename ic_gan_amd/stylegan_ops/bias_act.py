@@ -8,6 +8,8 @@ training/loss.py:126-131,182-187) is grad=2.  fp16 / fp32 / fp64 storage with th
 fp64 for double: bias_act.cu:18-21); contiguous or channels-last tensors; no fallback implementation."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -82,6 +84,36 @@ def bias_act(x, b=None, dim=1, act="linear", alpha=None, gain=None, clamp=None, 
     return _BiasAct.apply(x, b, dim, act_id, alpha, gain, clamp, ref, has2)
 
 
+class _BiasGrad(torch.autograd.Function):
+    """db = dx.sum(all dims but `dim`) of bias_act.py:127 / 149 for fp16 channels-last tensors on icg_colsum_f16 (fp32 sums in a fixed
+    order, rounded to the bias dtype once; torch's strided fp16 reduction took 30 - 80 us per layer and pass).  Linear in dx, so its
+    backward is the broadcast -- differentiable again."""
+
+    @staticmethod
+    def forward(ctx, dx):
+        ctx.shape = tuple(dx.shape)
+        n, c, h, w = dx.shape
+        rows = n * h * w
+        nb = L.query("icg_colsum_f16_workspace_bytes", rows, c)
+        out = torch.empty(c, device=dx.device, dtype=torch.float32)
+        L.call("icg_colsum_f16", dx, rows, c, out, _ops._bytes(nb, dx.device), nb)
+        return out.to(dx.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.reshape(1, -1, 1, 1).expand(ctx.shape)
+
+
+def _bias_grad(dx, dim):
+    if (FUSED_BIAS_GRAD and dx.dtype == torch.float16 and dx.is_cuda and _is_cl(dx, dim)
+            and L.query("icg_colsum_f16_applies", int(dx.shape[1]))):
+        return _BiasGrad.apply(dx)
+    return dx.sum([i for i in range(dx.ndim) if i != dim])
+
+
+FUSED_BIAS_GRAD = os.environ.get("ICG_FUSED_BIAS_GRAD", "1") != "0"        # measurement switch
+
+
 class _BiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, b, dim, act_id, alpha, gain, clamp, ref, has2):
@@ -107,7 +139,7 @@ class _BiasAct(torch.autograd.Function):
             if act_id != 1 or gain != 1 or clamp >= 0:
                 dx = _BiasActGrad.apply(dy, x, b, y, ctx.cfg)
         if ctx.has_b and ctx.needs_input_grad[1]:
-            db = dx.sum([i for i in range(dx.ndim) if i != dim])
+            db = _bias_grad(dx, dim)
         return dx, db, None, None, None, None, None, None, None
 
 
@@ -130,5 +162,5 @@ class _BiasActGrad(torch.autograd.Function):
         if has2 and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
             d_x = _kernel(d_dx, b, x, y, dy, 2, dim, act_id, alpha, gain, clamp)
         if has2 and ctx.needs_input_grad[2] and d_x is not None:
-            d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
+            d_b = _bias_grad(d_x, dim)
         return d_dy, d_x, d_b, None, None

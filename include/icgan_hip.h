@@ -537,6 +537,11 @@ int icg_bias_act_typed(const void* x, const void* b, const void* xref, const voi
 int icg_upfirdn2d_typed(const void* x, const float* f, void* y, int N, int C, int H, int W, int fh, int fw, int upx,
                         int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
                         int outH, int outW, int dtype, int channels_last, void* stream);
+/* out[c] = sum_rows x[row][c] in fp32 for an fp16 channels-last tensor [rows][C] (the bias gradient of bias_act in the fp16 blocks,
+ * bias_act.py:127); `_applies` -> 1 for C = 8 * 2^k <= 2048; fixed summation order (per-block partials in the workspace). */
+int icg_colsum_f16_applies(int C);
+size_t icg_colsum_f16_workspace_bytes(int64_t rows, int C);
+int icg_colsum_f16(const void* x, int64_t rows, int C, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* the same operation on channels-last data: x [N][H][W][C], y [N][outH][outW][C], C % 4 == 0 (what the NHWC
  * convolutions produce and consume: no layout change between conv, FIR resampling and bias_act) */

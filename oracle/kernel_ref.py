@@ -825,6 +825,20 @@ def _up(t, dtype):
     return t.double() if dtype == 2 else t.float()
 
 
+def icg_colsum_f16_applies(C):
+    v = C // 8
+    return int(C >= 8 and C % 8 == 0 and v <= 256 and (v & (v - 1)) == 0)
+
+
+def icg_colsum_f16_workspace_bytes(rows, C):
+    return 16
+
+
+def icg_colsum_f16(x, rows, C, out, workspace, workspace_bytes):
+    assert x.dtype == torch.float16 and out.dtype == torch.float32
+    mem(out)[:C].copy_(mem(x)[: rows * C].view(rows, C).double().sum(0).float())
+
+
 def icg_bias_act_typed(x, b, xref, yref, dy, y, n, step_b, size_b, grad, act, alpha, gain, clamp, dtype):
     """fp16 / fp64 storage: compute in the internal type, round once into y (bias_act.cu:26-150)."""
     if dtype == 0:

@@ -1198,3 +1198,16 @@ def test_attn_scores_softmax(case):
     (p,) = run_pair("icg_attn_scores_softmax", [theta, phi, beta, B, n, m, d], [2])
     close(*p, rtol=1e-4, atol_rel=2e-5, what="attention scores + softmax %r" % (case,))
     assert float((p[0].cpu().sum(-1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C", [(1000, 64), (37, 8), (5000, 512), (70000, 128), (300, 2048), (4 * 129 * 129, 256)])
+def test_colsum_f16(rows, C):
+    """icg_colsum_f16 (bias gradient of bias_act in StyleGAN2's fp16 blocks): fp32 column sums of an fp16 [rows][C] tensor against fp64."""
+    L = _L()
+    assert L.query("icg_colsum_f16_applies", C) == 1 and R.icg_colsum_f16_applies(C) == 1
+    assert L.query("icg_colsum_f16_applies", 24) == 0 and L.query("icg_colsum_f16_applies", 4) == 0
+    x = rnd(rows, C, seed=1).half()
+    nb = L.query("icg_colsum_f16_workspace_bytes", rows, C)
+    (p,) = run_pair("icg_colsum_f16", [x, rows, C, torch.zeros(C), torch.zeros(nb, dtype=torch.uint8), nb], [3])
+    close(*p, rtol=1e-5, atol_rel=1e-5, what="fp16 column sums %d x %d" % (rows, C))
