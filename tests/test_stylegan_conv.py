@@ -186,3 +186,39 @@ def test_conv2d_gradfix_fp16_mfma_route(dev, kind, monkeypatch):
         bad = (u - v).abs() > tol
         assert not bad.any(), "%s %s: %d / %d beyond tolerance, worst %.3e" % (kind, name, int(bad.sum()), bad.numel(),
                                                                                float(((u - v).abs() - tol).max()))
+
+
+def test_odd_channel_count_is_padded_onto_the_vector_path(emu):
+    """conv2d with Cin % 4 != 0 (the 513-channel layer behind MinibatchStd, training/networks.py:706-712) pads x and w with zero
+    channels; outputs and both gradients equal F.conv2d's, the padding never shows in the gradient shapes."""
+    from ic_gan_amd.stylegan_ops import conv2d_gradfix as cg
+    x = rnd((2, 9, 6, 6), 1).requires_grad_(True)
+    w = (rnd((8, 9, 3, 3), 2) * 0.1).requires_grad_(True)
+    y = cg.conv2d(x, w, padding=1)
+    ref = torch.nn.functional.conv2d(x, w, padding=1)
+    assert float((y - ref).detach().abs().max()) < 1e-5
+    gx, gw = torch.autograd.grad((y * rnd(tuple(y.shape), 3)).sum(), (x, w))
+    rx, rw = torch.autograd.grad((ref * rnd(tuple(y.shape), 3)).sum(), (x, w))
+    assert gx.shape == x.shape and gw.shape == w.shape
+    assert float((gx - rx).abs().max()) < 1e-5 and float((gw - rw).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("m", [4, 16, 40])
+def test_linear_nt_all_orders(m, emu):
+    """linear_nt (conv2d_gradfix._Matmul): x w^T with first- and second-order gradients against torch; m <= 32 rows takes the transposed-
+    weight route in its data gradient (mode 1 -> mode 0 of the row-streaming GEMM)."""
+    from ic_gan_amd.stylegan_ops import conv2d_gradfix as cg
+    x = rnd((m, 160), 4).requires_grad_(True)
+    w = (rnd((24, 160), 5) * 0.1).requires_grad_(True)
+    x2, w2 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    y, ref = cg.linear_nt(x, w), x2 @ w2.t()
+    assert float((y - ref).detach().abs().max()) < 1e-5
+    dy = rnd((m, 24), 6)
+    g = torch.autograd.grad(y, (x, w), dy, create_graph=True)
+    r = torch.autograd.grad(ref, (x2, w2), dy, create_graph=True)
+    for a, b in zip(g, r):
+        assert float((a - b).detach().abs().max()) < 1e-5
+    s = (g[0] * rnd((m, 160), 7)).sum() + (g[1] * rnd((24, 160), 8)).sum()
+    s2 = (r[0] * rnd((m, 160), 7)).sum() + (r[1] * rnd((24, 160), 8)).sum()
+    for a, b in zip(torch.autograd.grad(s, (x, w)), torch.autograd.grad(s2, (x2, w2))):
+        assert float((a - b).abs().max()) < 1e-4
