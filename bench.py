@@ -738,6 +738,29 @@ def run_cpu_baseline_child(workload):
                 "sample": f"not completed within 240 s ({type(exc).__name__})"}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch_command(n, argv=None, port=None):
+    """the command line `python bench.py --gpus N ...` re-executes itself as (one rank per GPU of this node, rendezvous on 127.0.0.1)"""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port or free_port()), os.path.abspath(__file__)] + argv
+
+
+def self_launch(n):
+    import subprocess
+    env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    rc = subprocess.call(self_launch_command(n), env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -786,6 +809,13 @@ def main():
                 res["cfg1_full_batch"] = cpu_baseline(c1, "cfg1", budget_s=8.0)
         print("CPU_BASELINE " + json.dumps(res), flush=True)
         return
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here, as the reference's trainer does with
+        # mp.spawn(train, nprocs=world_size) (BigGAN_PyTorch/trainer.py:70-75).  Re-executing this script under
+        # torch.distributed.run gives the ranks exactly the environment of the driver's torchrun form (which keeps working:
+        # WORLD_SIZE is set there and this branch is not taken).  Rank 0's JSON line goes to this process' stdout.
+        return self_launch(args.gpus)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -69,3 +69,21 @@ def test_traffic_hash_ignores_sources_the_cfg3_step_does_not_launch(bench, tmp_p
     with open(dst / "ic_gan_amd" / "csrc" / "pgemm.hip", "a") as f:
         f.write("// touched\n")
     assert bench.csrc_sha256() != h0
+
+
+def test_self_launch_command_is_the_drivers_torchrun_form(bench, monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE re-executes itself under torch.distributed.run (reference: mp.spawn in
+    BigGAN_PyTorch/trainer.py:70-75): one node, N ranks, rendezvous on 127.0.0.1, the original arguments passed through."""
+    cmd = bench.self_launch_command(4, ["--gpus", "4", "--steps", "3", "--workload", "cfg1"], port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--workload", "cfg1"]
+    assert 1024 < bench.free_port() < 65536
+    # the branch is taken only without a launcher: with WORLD_SIZE set main() must not re-launch
+    called = []
+    monkeypatch.setattr(bench, "self_launch", lambda n: called.append(n))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--workload", "cfg1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    bench.main()
+    assert called == [2]

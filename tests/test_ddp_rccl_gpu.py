@@ -109,6 +109,25 @@ def test_bench_script_two_ranks_sharing_one_gpu(extra):
     assert "cpu_baseline" not in d
 
 
+def test_bench_script_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the script starts its ranks itself, as the
+    reference's trainer does with mp.spawn (BigGAN_PyTorch/trainer.py:70-75); one JSON line from rank 0, world size 2."""
+    import json
+    env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0", "PYTHONDONTWRITEBYTECODE": "1", "ICG_BENCH_SHARED_GPU": "1"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg1",
+           "--init", "N02"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_world_size"] == 2 and d["config"]["global_batch"] == 16
+    assert d["config"]["comm"] is not None and d["config"]["comm"]["G"]["allreduce_bytes_per_step"] > 0
+    assert "cpu_baseline" not in d
+
+
 def test_syncbn_path_single_rank_rccl_matches_local_statistics(monkeypatch):
     """world_size 1 over RCCL with the cross-replica path forced on: pack kernel, async all-reduce (a no-op sum), device-side
     count in finalize / backward coefficients -- against the plain path on the same inputs (fp64 payload algebra: equal to
