@@ -208,7 +208,11 @@ class KernelTimer:
                 if last[0] == 3:
                     return "icg_pgemm_tn_kernel<%d, %d>" % (last[2], 1 if last[3] == 4 else 2)
                 return "%s<1, 1, %d>" % (pk, last[2])
-            if mode == "hwgrad":
+            if last[0] == 5 and mode in ("wino4", "rs_up", "rs_down"):
+                # narrow layer on the fused F(4x4,3x3) kernel (csrc/fwino.hip): ONE kernel (+ a 1.3 MB weight re-layout), comparable
+                # with its rocprofv3 row; executed FLOPs = the 36 / 25 plane GEMMs
+                kname = "void icg_fwino_kernel<%d, %d, %d>(FwinoP)" % (last[1], last[2], last[3])
+            elif mode == "hwgrad":
                 kname = "icg_hwgrad_kernel(HwgradP)"
             elif mode == "hconv":
                 cout = args[sl + 6]

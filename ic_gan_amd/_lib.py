@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "icgan_hip.h")
 LIB_PATH = os.path.join(_HERE, "lib", "libicgan_hip.so")
 
-ICG_PRE_RELU, ICG_PRE_AFFINE, ICG_UPSAMPLE2X, ICG_RES_UPSAMPLE2X, ICG_RES_RELU_MASK = 1, 2, 4, 8, 16
+ICG_PRE_RELU, ICG_PRE_AFFINE, ICG_UPSAMPLE2X, ICG_RES_UPSAMPLE2X, ICG_RES_RELU_MASK, ICG_WINO_KEEP_V = 1, 2, 4, 8, 16, 32
 
 _SCALARS = {
     "int": ctypes.c_int, "unsigned": ctypes.c_uint, "float": ctypes.c_float, "double": ctypes.c_double,

@@ -1,0 +1,469 @@
+// Fused Winograd F(4x4, 3x3) convolution for the NARROW 3x3 layers (Cin <= 192 per pass, Cout a multiple of 96): input
+// transform, the 36 (25) plane GEMMs, output transform and epilogue in ONE kernel -- the V and M planes of the three-kernel
+// composite of winograd.hip never touch HBM.  Reference: the 96- / 192-channel 3x3 convolutions of GBlock / DBlock
+// (BigGAN_PyTorch/layers.py:144-153 SNConv2d.forward, 542-552 GBlock.forward, 587-613 DBlock.forward) and their data gradients.
+//
+// Why: at K = Cin = 96 a plane GEMM has 24 FLOP per byte of V + M traffic -- the HBM ridge -- so the composite moves
+// 2.25 x (in + out) x 2 bytes through HBM around an MFMA phase that cannot hide them (0.34 - 0.51 of the fp32
+// MFMA peak, 101 GB per step in icg_pgemm_nn_stream_kernel<3,2,3> alone).  Here a workgroup owns a 4 x 4 block of output
+// tiles (16 x 16 pixels) x 96 output channels and keeps ALL planes' accumulators in registers:
+//     36 planes x 16 tiles x 96 columns = 55 296 fp32 = 108 registers per lane over 8 MFMA waves
+// (the register file, not the LDS, is what bounds the tile count: 37 tiles would fill the CU's 512 KB).
+//
+// Warp specialisation (12 waves = 768 threads, 3 per SIMD):
+//   * waves 8..11, PRODUCERS: lane = (tile, channel) of a 32-channel chunk; 6 x 6 (4 x 4 source pixels, upsample-fused form)
+//     window loads straight from x (128-byte segments), BN / ccbn affine + ReLU + zero padding, B^T d B in registers, the 36
+//     values go to LDS in the MFMA operand order (one ds_write_b32 each, conflict-free through an XOR of the tile index with the
+//     channel quad); optionally also to HBM as the V planes the weight gradient wants (icg_conv2d_wino4_wgrad_from_v).
+//     Their global loads are HBM-latency loads; keeping them in waves of their own keeps the in-order vmcnt queue of the MFMA
+//     waves free of them.
+//   * waves 0..7, CONSUMERS: wave (pg, ng) owns planes pg, pg+4, ... and 48 of the 96 columns: per plane and 16-channel
+//     group ONE ds_read_b128 (the tile operand of four k-steps) and three 16-byte global loads of the fragment-major weights
+//     (icg_fwino_pack_kernel: every wave-load is 1 KiB contiguous = 8 full cache lines from L2) feed 12
+//     v_mfma_f32_16x16x4_f32.  Weight fragments are prefetched one half-step (12 MFMAs) ahead.
+//   * double-buffered V chunk in LDS (2 x 72 KiB), ONE raw s_barrier per 32-channel chunk.
+//   * output: accumulators -> LDS (the V buffers are dead by then) in two 48-column rounds, every thread then owns one
+//     (tile, column): A^T m A from 36 LDS reads, alpha / bias / residual (plain, upsample-on-read, ReLU mask) and the stores.
+// Chains are single-level over K <= 192 (48 MFMA steps); the routes through this kernel are gated on that (fwino_applies).
+#include "icg_common.h"
+#include <stdlib.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct FwinoP {
+  const float* x;
+  const float* Uf;       // fragment-major Winograd weights (icg_fwino_pack_kernel)
+  const float* bias;
+  const float* res;
+  float* out;
+  const float* scale;
+  const float* shift;
+  float* V;              // optional: the V planes [NP*NP][T][K] as a by-product (nullptr: not written)
+  long ssb;              // per-sample stride of scale / shift (elements)
+  long planeV;           // T * K
+  int B, H, W;           // resolution of the Winograd domain (the conv's full resolution)
+  int K, N;              // Cin, Cout
+  int affine, relu, res_mode;
+  float alpha;
+  int tbw, tbh;          // 4x4-tile blocks per image row / column (W / 16, H / 16)
+  int nblk;              // N / 96
+  unsigned total;        // workgroups
+  int swz;
+};
+
+template <int NP> __device__ __forceinline__ constexpr int fw_slot(int k) { return NP == 6 ? k : (k < 2 ? k : k - 1); }
+template <int NP> __device__ __forceinline__ constexpr bool fw_has(int k) { return NP == 6 || k != 2; }
+
+// scalar forms of the 1-D transforms of winograd.hip (w4_in6 / w4_in_up / w4_out4 / w4_out_pool), same operation order
+__device__ __forceinline__ void fw_in6(const float d[6], float t[6]) {
+  t[0] = fmaf(d[2], -5.f, d[0] * 4.f) + d[4];
+  const float a = fmaf(d[2], -4.f, d[4]), b = fmaf(d[1], -4.f, d[3]);
+  t[1] = a + b;
+  t[2] = a - b;
+  const float c = d[4] - d[2], e = (d[3] - d[1]) * 2.f;
+  t[3] = c + e;
+  t[4] = c - e;
+  t[5] = fmaf(d[3], -5.f, d[1] * 4.f) + d[5];
+}
+__device__ __forceinline__ void fw_in_up(const float l[4], float t[6]) {
+  t[0] = fmaf(l[1], -5.f, l[0] * 4.f) + l[2];
+  t[1] = fmaf(l[1], -8.f, l[2] * 2.f);
+  t[2] = 0.f;
+  const float c = l[2] - l[1];
+  t[3] = c * 3.f;
+  t[4] = c * -1.f;
+  t[5] = fmaf(l[2], -5.f, l[1] * 4.f) + l[3];
+}
+__device__ __forceinline__ void fw_out4(const float m[6], float y[4]) {
+  const float p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
+  y[0] = (m[0] + p) + r;
+  y[1] = fmaf(s, 2.f, q);
+  y[2] = fmaf(r, 4.f, p);
+  y[3] = fmaf(s, 8.f, q) + m[5];
+}
+__device__ __forceinline__ void fw_out_pool(const float m[6], float y[2]) {
+  const float a = m[1] * 2.f;
+  y[0] = fmaf(m[3], 3.f, m[0] + a) - m[4];
+  y[1] = fmaf(m[4], -4.f, fmaf(m[3], 12.f, a)) + m[5];
+}
+
+__device__ __forceinline__ void fw_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// Uf[((p * NT + jt) * KG + kg) * 64 + l][e] = U[p][16 jt + (l & 15)][16 kg + 4 (l >> 4) + e]      (U: [planes][N][K])
+__global__ __launch_bounds__(256) void icg_fwino_pack_kernel(const float* __restrict__ U, float* __restrict__ Uf, int planes, int N,
+                                                             int K) {
+  const int NT = N >> 4, KG = K >> 4;
+  const long total = (long)planes * NT * KG * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    long r = i >> 6;
+    const int kg = (int)(r % KG);
+    r /= KG;
+    const int jt = (int)(r % NT);
+    const int pl = (int)(r / NT);
+    const float4 v = *reinterpret_cast<const float4*>(U + ((long)pl * N + 16 * jt + (l & 15)) * K + 16 * kg + 4 * (l >> 4));
+    reinterpret_cast<float4*>(Uf)[i] = v;
+  }
+}
+
+template <int UP, int POOL, int NP>
+__global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
+  static_assert(!(UP && POOL), "no layer is resampled on both sides");
+  static_assert((!UP && !POOL) || NP == 5, "resample-fused forms live in the 25-plane domain");
+  constexpr int NPL = NP * NP;                // planes
+  constexpr int NPW = (NPL + 3) / 4;          // plane slots per consumer wave
+  constexpr int NL = UP ? 4 : 6;              // window size in stored pixels
+  constexpr int NO = POOL ? 2 : 4;            // outputs per tile and dimension
+  constexpr int VBUF = NPL * 2048;            // one V chunk: planes x 2 channel groups x 64 lanes x 16 B
+  constexpr int MROW = 52;                    // padded row of the accumulator exchange (48 columns)
+  constexpr int MBYTES = NPL * 16 * MROW * 4;
+  constexpr int LDS_BYTES = (2 * VBUF > MBYTES) ? 2 * VBUF : MBYTES;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..11
+
+  // ---- this workgroup: (image b, tile block (by, bx), column block nb); XCD-aware order as in pgemm.hip
+  unsigned t = blockIdx.x;
+  if (p.swz) {
+    const unsigned tot = p.total, q = tot >> 3, rr = tot & 7u, xcd = t & 7u;
+    t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
+  }
+  const int nb = (int)(t % (unsigned)p.nblk);
+  unsigned tb = t / (unsigned)p.nblk;
+  const int bx = (int)(tb % (unsigned)p.tbw);
+  tb /= (unsigned)p.tbw;
+  const int by = (int)(tb % (unsigned)p.tbh);
+  const int b = (int)(tb / (unsigned)p.tbh);
+
+  const int K = p.K, N = p.N, H = p.H, W = p.W;
+  const int nc = K >> 5;                                            // 32-channel chunks
+  const int th = H >> 2, tw = W >> 2;
+
+  // ---- output side, shared by both roles: item -> (tile, column) of a 48-column round (768 items per round)
+  const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+  auto output_item = [&](int round, int item) {
+    const int otile = item / 48, ocol = item - 48 * otile;
+    const int oty = 4 * by + (otile >> 2), otx = 4 * bx + (otile & 3);
+    const int n = nb * 96 + round * 48 + ocol;
+    const float* mp = reinterpret_cast<const float*>(lds) + otile * MROW + ocol;
+    // y = A^T M A accumulated column by column: for column j of M the 1-D transform yy = A^T M[:, j], then
+    // y[a][c] += yy[a] * A[j][c] with the constants of A folded (rows of A^T: [1 1 1 1 1 0], [0 1 -1 2 -2 0], [0 1 1 4 4 0],
+    // [0 1 -1 8 -8 1]; pooled: [1 2 0 3 -1 0], [0 2 0 12 -4 1]) -- 16 + 6 + 4 live values instead of 36 + 24
+    constexpr float AT4[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+    constexpr float ATP[2][6] = {{1, 2, 0, 3, -1, 0}, {0, 2, 0, 12, -4, 1}};
+    float y[NO][NO];
+#pragma unroll
+    for (int a = 0; a < NO; ++a)
+#pragma unroll
+      for (int c = 0; c < NO; ++c) y[a][c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if (!fw_has<NP>(j)) continue;
+      float col[6], yy[4];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) col[r] = fw_has<NP>(r) ? mp[(fw_slot<NP>(r) * NP + fw_slot<NP>(j)) * 16 * MROW] : 0.f;
+      if constexpr (POOL) fw_out_pool(col, yy); else fw_out4(col, yy);
+#pragma unroll
+      for (int a = 0; a < NO; ++a)
+#pragma unroll
+        for (int c = 0; c < NO; ++c) {
+          const float w = POOL ? ATP[c][j] : AT4[c][j];
+          if (w == 1.f) y[a][c] += yy[a];
+          else if (w == -1.f) y[a][c] -= yy[a];
+          else if (w != 0.f) y[a][c] = fmaf(yy[a], w, y[a][c]);
+        }
+    }
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int a = 0; a < NO; ++a) {
+      const int oy = NO * oty + a;
+      const long p0 = (((long)b * Ho + oy) * Wo + NO * otx) * N + n;
+#pragma unroll
+      for (int c = 0; c < NO; ++c) {
+        float v = p.alpha * y[a][c] + bv;
+        if (p.res) {
+          const long rp = (!POOL && p.res_mode == 1)
+                              ? (((long)b * (H >> 1) + (oy >> 1)) * (W >> 1) + ((4 * otx + c) >> 1)) * N + n
+                              : p0 + (long)c * N;
+          const float r = p.res[rp];
+          v = (p.res_mode == 2) ? (r > 0.f ? v : 0.f) : v + r;
+        }
+        p.out[p0 + (long)c * N] = v;
+      }
+    }
+  };
+  if (wv >= 8) {
+    // =========================================================== producers ===========================================================
+    // Addressing: wave-uniform base pointer + ONE 32-bit lane offset per access (saddr + voffset loads / stores); the offsets are
+    // rebuilt from 6 + 6 row / column terms at every use (fw_opaque keeps the compiler from hoisting 36 + 36 + 36 precomputed
+    // 64-bit addresses out of the chunk loop, which is what spilled this branch).
+    const int pl = tid - 512;
+    const int tc = pl & 31, tq = pl >> 5;                           // channel of the chunk; items: tiles tq and tq + 8
+    const int Hx = UP ? (H >> 1) : H, Wx = UP ? (W >> 1) : W;       // stored tensor
+    const int txg = 4 * bx + (tq & 3), tyg = 4 * by + (tq >> 2);    // second item: tyg + 2
+    const int w0 = UP ? 2 * txg - 1 : 4 * txg - 1;
+    const float* __restrict__ xb = p.x + (long)b * Hx * Wx * K;     // this image (uniform)
+    const unsigned WxK = (unsigned)(Wx * K);
+    unsigned coloff[NL];
+    unsigned colok = 0;
+#pragma unroll
+    for (int s = 0; s < NL; ++s) {
+      const int w = w0 + s;
+      coloff[s] = (unsigned)(min(max(w, 0), Wx - 1) * K + tc);
+      colok |= ((unsigned)w < (unsigned)Wx ? 1u : 0u) << s;
+    }
+    // LDS position of this lane's values inside a plane's 2 KiB: [sg][kq*16 + (tile ^ (kq + 4 sg))][s4]
+    const int sg = tc >> 4, kq = (tc >> 2) & 3, s4 = tc & 3;
+    const bool wantV = (p.V != nullptr) && nb == 0;
+
+    float d[2][NL][NL];
+    auto load_chunk = [&](int ck) {
+      const float* xc = xb + 32 * ck;                               // uniform
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int h0 = UP ? 2 * (tyg + 2 * it) - 1 : 4 * (tyg + 2 * it) - 1;
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {
+          unsigned ro = (unsigned)min(max(h0 + r, 0), Hx - 1) * WxK;
+          asm volatile("" : "+v"(ro));
+#pragma unroll
+          for (int s = 0; s < NL; ++s) d[it][r][s] = xc[ro + coloff[s]];
+        }
+      }
+    };
+    auto transform_chunk = [&](int ck, unsigned vb) {
+      float sc = 1.f, sh = 0.f;
+      if (p.affine) {
+        sc = p.scale[(long)b * p.ssb + 32 * ck + tc];
+        sh = p.shift[(long)b * p.ssb + 32 * ck + tc];
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int ty = tyg + 2 * it;
+        const int h0 = UP ? 2 * ty - 1 : 4 * ty - 1;
+        float E[NL][6];
+#pragma unroll
+        for (int r = 0; r < NL; ++r) {
+          const bool rok = (unsigned)(h0 + r) < (unsigned)Hx;
+          float row[NL];
+#pragma unroll
+          for (int s = 0; s < NL; ++s) {
+            float v = d[it][r][s];
+            if (p.affine) v = fmaf(v, sc, sh);
+            if (p.relu) v = fmaxf(v, 0.f);
+            row[s] = (rok && ((colok >> s) & 1u)) ? v : 0.f;
+          }
+          if constexpr (UP) fw_in_up(row, E[r]); else fw_in6(row, E[r]);
+        }
+        const int ti = tq + 8 * it;
+        unsigned wpos = vb + (unsigned)((sg * 64 + kq * 16 + (ti ^ (kq + 4 * sg))) * 16 + s4 * 4);
+        unsigned vpos = (unsigned)((((b * th + ty) * tw + txg) * K + tc)) * 4u;     // byte offset inside a V plane
+        unsigned pv4 = (unsigned)p.planeV * 4u;                     // bytes per plane; planes x pv4 < 2^32 (icg_fwino_applies)
+        asm volatile("" : "+v"(wpos), "+v"(vpos), "+s"(pv4));
+        char* vplane = reinterpret_cast<char*>(p.V + 32 * ck);      // uniform
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          if (!fw_has<NP>(j)) continue;
+          float col[NL], o[6];
+#pragma unroll
+          for (int r = 0; r < NL; ++r) col[r] = E[r][j];
+          if constexpr (UP) fw_in_up(col, o); else fw_in6(col, o);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            if (!fw_has<NP>(r)) continue;
+            const int plane = fw_slot<NP>(r) * NP + fw_slot<NP>(j);
+            *reinterpret_cast<float*>(lds + wpos + plane * 2048) = o[r];
+            if (wantV) *reinterpret_cast<float*>(vplane + (size_t)((unsigned)plane * pv4 + vpos)) = o[r];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    load_chunk(0);
+    transform_chunk(0, 0u);
+    if (nc > 1) load_chunk(1);
+    fw_barrier();
+    for (int ck = 0; ck < nc; ++ck) {
+      if (ck + 1 < nc) {
+        transform_chunk(ck + 1, ((ck + 1) & 1) ? (unsigned)VBUF : 0u);
+        if (ck + 2 < nc) load_chunk(ck + 2);
+      }
+      fw_barrier();
+    }
+    // output: the consumers hand their accumulators over in two 48-column rounds (the V buffers are dead: every wave has passed
+    // the barrier that closes the last chunk)
+    // Round 0 is worked by the 512 threads that hold no accumulators any more (first-round consumers + producers), the
+    // second-round consumers wait with theirs: no point of the program has 108 accumulators AND an output transform live.
+    fw_barrier();
+    output_item(0, tid - 256);                                      // items 256..511 (the first-round consumers: 0..255, 512..767)
+    fw_barrier();
+    fw_barrier();
+    output_item(1, tid);
+  } else {
+    // =========================================================== consumers ===========================================================
+    const int pg = wv & 3, ng = wv >> 2;
+    const int it = lane & 15, kq = lane >> 4;
+    f32x4 acc[NPW][3];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned apos[2] = {(unsigned)((kq * 16 + (it ^ kq)) * 16), (unsigned)((64 + kq * 16 + (it ^ (kq + 4))) * 16)};
+    // weight fragments: wave-uniform base (column block, column group, plane group, chunk -- all scalar arithmetic) + 16 B x lane
+    const int NT = N >> 4, KG = K >> 4;
+    const unsigned pstride = (unsigned)NT * (unsigned)KG * 1024u;    // bytes per plane of Uf
+    const unsigned jstride = (unsigned)KG * 1024u;
+    const char* __restrict__ ub = reinterpret_cast<const char*>(p.Uf) + (size_t)(nb * 6 + ng * 3) * jstride + (size_t)pg * pstride;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto load_b = [&](f32x4 (&bf)[3], unsigned ckoff, int i, int sgg) {      // ckoff = 2048 x chunk (bytes)
+      const char* src = ub + (size_t)(4u * (unsigned)i * pstride + ckoff + (unsigned)sgg * 1024u);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const f32x4*>(src + (size_t)((unsigned)j * jstride) + lane16);
+    };
+    auto valid = [&](int i) -> bool { return NPL % 4 == 0 || i < NPW - 1 || pg + 4 * i < NPL; };
+
+    f32x4 bcur[3], acur;
+    load_b(bcur, 0u, 0, 0);
+    fw_barrier();
+    for (int ck = 0; ck < nc; ++ck) {
+      unsigned ckoff = (unsigned)ck * 2048u, ckoff_next = (unsigned)min(ck + 1, nc - 1) * 2048u;
+      asm volatile("" : "+s"(ckoff), "+s"(ckoff_next));            // (addresses are rebuilt per chunk, not hoisted as 54 pointers)
+      const char* vbase = lds + ((ck & 1) ? VBUF : 0) + pg * 2048;
+      acur = *reinterpret_cast<const f32x4*>(vbase + apos[0]);
+#pragma unroll
+      for (int q = 0; q < 2 * NPW; ++q) {
+        const int i = q >> 1, sgg = q & 1;
+        f32x4 bnext[3], anext;
+        const bool last = (q + 1 == 2 * NPW);
+        const int ni = last ? 0 : (q + 1) >> 1, nsg = last ? 0 : (q + 1) & 1;
+        if (valid(ni)) {
+          load_b(bnext, last ? ckoff_next : ckoff, ni, nsg);
+          if (!last) anext = *reinterpret_cast<const f32x4*>(vbase + ni * 4 * 2048 + apos[nsg]);
+        }
+        if (valid(i)) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[j][s], acur[s], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bcur[j] = bnext[j];
+        acur = anext;
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch distance at one half-step (register budget: 168)
+      }
+      fw_barrier();
+    }
+    auto hand_over = [&]() {
+#pragma unroll
+      for (int i = 0; i < NPW; ++i) {
+        const int plane = pg + 4 * i;
+        if (NPL % 4 != 0 && i == NPW - 1 && plane >= NPL) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          *reinterpret_cast<f32x4*>(lds + ((plane * 16 + it) * MROW + 16 * j + 4 * kq) * 4) = acc[i][j];
+      }
+    };
+    if (ng == 0) {
+      hand_over();
+      fw_barrier();
+      output_item(0, tid);                                          // items 0..255 (+ 512..767 below)
+      output_item(0, tid + 512);
+      fw_barrier();
+      fw_barrier();
+    } else {
+      fw_barrier();
+      fw_barrier();
+      hand_over();
+      fw_barrier();
+    }
+    output_item(1, tid);
+  }
+
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+static int fwino_env(const char* name, int dflt) {      // read per call: a measurement / test switch that can be flipped at run time
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// Does the fused kernel take this layer on its own?  (H, W: resolution of the Winograd domain.)  K <= 192: single-level chains.
+extern "C" int icg_fwino_applies(int B, int H, int W, int Cin, int Cout) {
+  if (!fwino_env("ICG_FWINO", 1)) return 0;
+  if (Cin % 32 || Cin > fwino_env("ICG_FWINO_MAXK", 192) || Cout % 96 || Cout > fwino_env("ICG_FWINO_MAXN", 192) || H % 16 || W % 16)
+    return 0;
+  const long wgs = (long)B * (H / 16) * (W / 16) * (Cout / 96);
+  return (wgs >= fwino_env("ICG_FWINO_MIN_WGS", 512) && wgs < 0x7fffffffL) ? 1 : 0;
+}
+
+extern "C" size_t icg_fwino_weight_bytes(int planes, int Cin, int Cout) { return (size_t)planes * Cin * Cout * sizeof(float); }
+
+// U [planes][Cout][Cin] (icg_wino4_weight_transform / icg_wino4r_weight_transform) -> fragment-major Uf, same size
+extern "C" int icg_fwino_pack_weights(const float* U, float* Uf, int planes, int Cin, int Cout, void* stream) {
+  ICG_REQUIRE(U && Uf && (planes == 25 || planes == 36) && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0);
+  const long total = (long)planes * (Cout / 16) * (Cin / 16) * 64;
+  long nb = icg_cdiv(total, 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(icg_fwino_pack_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, U, Uf, planes, Cout, Cin);
+  return icg_check_launch();
+}
+
+void icg_gemm_set_last_variant(int a, int b, int c, int d);     // gemm_conv.hip: the label bench.py reads back
+
+// The fused forward: out = epilogue(conv3x3(prologue(x))) with x / out resampled as (in_up, out_pool) say; Uf from
+// icg_fwino_pack_weights; V (optional) receives the transformed input planes [np*np][T][Cin] as a by-product.
+int icg_fwino_run(const float* x, int in_up, const float* Uf, const float* bias, const float* residual, int res_mode, float* out,
+                  int out_pool, const float* scale, const float* shift, int64_t ssb, int B, int H, int W, int Cin, int Cout,
+                  unsigned flags, float alpha, int np, float* V, void* stream) {
+  static const bool no_swz = [] { const char* e = getenv("ICG_NO_XCD_SWIZZLE"); return e && e[0] == '1'; }();
+  FwinoP p;
+  p.x = x; p.Uf = Uf; p.bias = bias; p.res = residual; p.out = out; p.scale = scale; p.shift = shift; p.V = V;
+  p.ssb = (long)ssb;
+  p.planeV = (long)B * (H / 4) * (W / 4) * Cin;
+  p.B = B; p.H = H; p.W = W; p.K = Cin; p.N = Cout;
+  p.affine = (flags & ICG_PRE_AFFINE) ? 1 : 0;
+  p.relu = (flags & ICG_PRE_RELU) ? 1 : 0;
+  p.res_mode = res_mode;
+  p.alpha = alpha;
+  p.tbw = W / 16; p.tbh = H / 16; p.nblk = Cout / 96;
+  p.total = (unsigned)((long)B * p.tbw * p.tbh * p.nblk);
+  p.swz = (p.total >= 16 && !no_swz) ? 1 : 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(p.total), blk(768);
+  icg_gemm_set_last_variant(5, in_up ? 1 : 0, out_pool ? 1 : 0, np);
+  if (in_up) {
+    if (np != 5 || out_pool) return ICG_ERR_ARG;
+    hipLaunchKernelGGL((icg_fwino_kernel<1, 0, 5>), g, blk, 0, st, p);
+  } else if (out_pool) {
+    if (np != 5) return ICG_ERR_ARG;
+    hipLaunchKernelGGL((icg_fwino_kernel<0, 1, 5>), g, blk, 0, st, p);
+  } else {
+    if (np != 6) return ICG_ERR_ARG;
+    hipLaunchKernelGGL((icg_fwino_kernel<0, 0, 6>), g, blk, 0, st, p);
+  }
+  return icg_check_launch();
+}
+
+// The kernel as an entry point of its own (tests, microbenchmarks; the layer entry points of winograd.hip route to it by
+// icg_fwino_applies): H, W = resolution of the Winograd domain (multiples of 16), Cin % 32 == 0, Cout % 96 == 0;
+// (in_up, out_pool) in {(0,0): 36 planes, (1,0) / (0,1): 25 planes}; V: nullptr or [planes][B H/4 W/4][Cin].
+extern "C" int icg_fwino_conv(const float* x, const float* Uf, const float* bias, const float* residual, float* out,
+                              const float* scale, const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin, int Cout,
+                              unsigned flags, float alpha, int in_up, int out_pool, float* V, void* stream) {
+  ICG_REQUIRE(x && Uf && out && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  ICG_REQUIRE(H % 16 == 0 && W % 16 == 0 && Cin % 32 == 0 && Cout % 96 == 0 && !(in_up && out_pool));
+  if (flags & ICG_PRE_AFFINE) ICG_REQUIRE(scale && shift);
+  if (flags & ICG_RES_RELU_MASK) ICG_REQUIRE(residual && !(flags & ICG_RES_UPSAMPLE2X));
+  const int np = (in_up || out_pool) ? 5 : 6;
+  const double T = (double)B * (H / 4) * (W / 4);
+  ICG_REQUIRE(T * (Cout / 96) / 16 < 2147483647.0);
+  if (V) ICG_REQUIRE((double)np * np * T * Cin * 4.0 < 4294967296.0);
+  return icg_fwino_run(x, in_up, Uf, bias, residual, icg_res_mode(flags), out, out_pool, scale, shift, ss_bstride, B, H, W, Cin,
+                       Cout, flags, alpha, np, V, stream);
+}

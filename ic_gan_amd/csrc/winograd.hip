@@ -756,6 +756,11 @@ extern "C" size_t icg_conv2d_wino4_workspace_bytes(int B, int H, int W, int Cin,
   return 36 * T * ((size_t)Cin + (size_t)Cout) * sizeof(float);
 }
 
+// fwino.hip: the fused kernel for the narrow layers
+int icg_fwino_run(const float* x, int in_up, const float* Uf, const float* bias, const float* residual, int res_mode, float* out,
+                  int out_pool, const float* scale, const float* shift, int64_t ssb, int B, int H, int W, int Cin, int Cout,
+                  unsigned flags, float alpha, int np, float* V, void* stream);
+
 // shared driver: V = input transform, M[xi] = V[xi] U[xi]^T (np*np batched GEMMs), output transform
 static int wino4_run(const float* x, int in_up, const float* U, const float* bias, const float* residual, int res_up, float* out,
                      int out_pool, const float* scale, const float* shift, int64_t ssb, int B, int H, int W, int Cin, int Cout,
@@ -767,6 +772,16 @@ static int wino4_run(const float* x, int in_up, const float* U, const float* bia
   hipStream_t st = (hipStream_t)stream;
   float* V = (float*)workspace;
   float* Mb = V + (long)np * np * T * Cin;
+  const bool keep_v = (flags & ICG_WINO_KEEP_V) != 0;
+  if (icg_fwino_applies(B, H, W, Cin, Cout) && (!keep_v || (double)np * np * T * Cin * 4.0 < 4294967296.0)) {
+    // narrow layer: one fused kernel (fwino.hip).  The M region of the workspace (np^2 T Cout floats, T >= 8192 there) holds the
+    // fragment-major copy of U; V is written only when the caller keeps it for the weight gradient.
+    float* Uf = Mb;
+    int rc = icg_fwino_pack_weights(U, Uf, np * np, Cin, Cout, stream);
+    if (rc != ICG_OK) return rc;
+    return icg_fwino_run(x, in_up, Uf, bias, residual, res_up, out, out_pool, scale, shift, ssb, B, H, W, Cin, Cout, flags, alpha,
+                         np, keep_v ? V : nullptr, stream);
+  }
   launch_wino4_input(st, in_up, np, x, scale, shift, (long)ssb, V, B, H, W, Cin, flags);
   int rc;
   { PlanesScope ps(stream, np * np, (double)T, Cout, Cin); rc = icg_gemm_batched(V, U, Mb, (int)T, Cout, Cin, 0, 1, T * Cin, (long)Cout * Cin, T * Cout, np * np, 1.0f, stream); }
@@ -824,7 +839,7 @@ extern "C" int icg_conv2d_up_wino_dgrad(const float* dy, const float* U, float* 
 extern "C" int icg_conv2d_down_wino_fprop(const float* x, const float* U, const float* bias, const float* residual, float* out,
                                           int B, int Hp, int Wp, int Cin, int Cout, unsigned flags, void* workspace,
                                           size_t workspace_bytes, void* stream) {
-  ICG_REQUIRE(x && U && out && workspace && !(flags & ~ICG_PRE_RELU));
+  ICG_REQUIRE(x && U && out && workspace && !(flags & ~(ICG_PRE_RELU | ICG_WINO_KEEP_V)));
   ICG_RS_REQUIRE(B, Hp, Wp, Cin, Cout);
   if (workspace_bytes < icg_conv2d_rs_wino_workspace_bytes(B, 2 * Hp, 2 * Wp, Cin, Cout)) return ICG_ERR_WORKSPACE;
   return wino4_run(x, 0, U, bias, residual, 0, out, 1, nullptr, nullptr, 0, B, 2 * Hp, 2 * Wp, Cin, Cout, flags, 0.25f, 5,

@@ -247,8 +247,11 @@ def _wino_fprop(x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, fla
     v = "wino4" if m == 4 else "wino"
     nb = L.query("icg_conv2d_%s_workspace_bytes" % v, B, H, W, Cin, Cout)
     ws = _bytes(nb, out.device)
-    L.call("icg_conv2d_%s_fprop" % v, x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, flags, 1.0, ws, nb)
-    return _saved_v(ws, 36, B, H, W, Cin) if (keep_v and m == 4 and KEEP_WINOGRAD_V) else None
+    keep = bool(keep_v and m == 4 and KEEP_WINOGRAD_V)
+    # ICG_WINO_KEEP_V: V is read back below (the fused narrow-layer kernel writes it only on request, csrc/fwino.hip)
+    L.call("icg_conv2d_%s_fprop" % v, x, U, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout,
+           flags | (L.ICG_WINO_KEEP_V if keep else 0), 1.0, ws, nb)
+    return _saved_v(ws, 36, B, H, W, Cin) if keep else None
 
 
 WINOGRAD_WGRAD = True            # weight gradient of those layers through the Winograd domain as well
@@ -418,7 +421,8 @@ class FusedConvFn(Function):
             # conv3x3 + avgpool2 in the 25-plane F(4x4,3x3) domain (25/64 of the 4x4-stride-2 form's MACs)
             nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, Hs, Ws, Cin, Cout)
             ws = _bytes(nb, dev)
-            L.call("icg_conv2d_down_wino_fprop", x, sn.w_wino, bias, res, out, B, H, W, Cin, Cout, flags, ws, nb)
+            L.call("icg_conv2d_down_wino_fprop", x, sn.w_wino, bias, res, out, B, H, W, Cin, Cout,
+                   flags | (L.ICG_WINO_KEEP_V if (keep_v and sn.rs[2]) else 0), ws, nb)
             if keep_v and sn.rs[2]:
                 saved_v = (_saved_v(ws, 25, B, Hs, Ws, Cin), 25)
         elif down:
@@ -429,7 +433,7 @@ class FusedConvFn(Function):
             nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cin, Cout)
             ws = _bytes(nb, dev)
             L.call("icg_conv2d_up_wino_fprop", x, sn.w_wino, bias, out, scale, shift, ssb, B, Hs, Ws, Cin, Cout,
-                   flags & ~L.ICG_UPSAMPLE2X, ws, nb)
+                   (flags & ~L.ICG_UPSAMPLE2X) | (L.ICG_WINO_KEEP_V if (keep_v and sn.rs[2]) else 0), ws, nb)
             if keep_v and sn.rs[2]:
                 saved_v = (_saved_v(ws, 25, B, H, W, Cin), 25)
         elif phase:

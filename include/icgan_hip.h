@@ -44,6 +44,10 @@ int icg_version(void);
                                * DBlock.forward (`self.activation(x)`, layers.py:587-600) folded into the epilogue of the
                                * data-gradient convolution.  Accepted by icg_conv2d_fprop[_ws], icg_conv2d_wino_fprop and
                                * icg_conv2d_wino4_fprop; excludes ICG_RES_UPSAMPLE2X. */
+#define ICG_WINO_KEEP_V 32u   /* F(4x4,3x3) forward entries (icg_conv2d_wino4_fprop, icg_conv2d_{up,down}_wino_fprop): the caller will read
+                               * the transformed-input planes V back from the start of `workspace` (icg_conv2d_wino4_wgrad_from_v).  The
+                               * three-kernel composite leaves them there anyway; the fused kernel (icg_fwino_applies) writes them only
+                               * when this flag is set -- V is its by-product, not an intermediate. */
 
 /*
  * Fused implicit-GEMM convolution, stride 1, pad R/2, R in {1,3}; also every Linear
@@ -252,6 +256,25 @@ int icg_conv2d_down_wino_dgrad_relu(const float* dy, const float* U, const float
                                     int Cin, int Cout, void* workspace, size_t workspace_bytes, void* stream);
 int icg_conv2d_down_wino_wgrad(const float* x, const float* dy, float* dw, int B, int Hp, int Wp, int Cin, int Cout,
                                unsigned flags, void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * Fused form of the F(4x4,3x3) forward entries above for the NARROW layers (csrc/fwino.hip): input transform, the 36 / 25 plane
+ * GEMMs, output transform and epilogue in one kernel -- neither V nor M goes through HBM (at Cin = 96 the plane GEMM sits on
+ * the HBM ridge: 24 FLOP per byte of V + M).  icg_conv2d_wino4_fprop, icg_conv2d_{up,down}_wino_{fprop,dgrad[_relu]} take it on their own
+ * when icg_fwino_applies says 1 (Cin % 32 == 0, Cin <= 192, Cout % 96 == 0, Cout <= 192, H and W of the Winograd domain multiples of
+ * 16, >= 512 workgroups; ICG_FWINO=0 in the environment switches it off): same arguments, same workspace, same result up
+ * to fp32 summation order (single-level chains over K <= 192).  V is written only under ICG_WINO_KEEP_V.
+ *   icg_fwino_pack_weights: U [planes][Cout][Cin] (icg_wino4_weight_transform / icg_wino4r_weight_transform) -> the
+ *   fragment-major copy the kernel streams (every wave-load 1 KiB contiguous); the entries above do it into their workspace.
+ */
+int icg_fwino_applies(int B, int H, int W, int Cin, int Cout);
+size_t icg_fwino_weight_bytes(int planes, int Cin, int Cout);
+int icg_fwino_pack_weights(const float* U, float* Uf, int planes, int Cin, int Cout, void* stream);
+/* the kernel as an entry point of its own (tests, microbenchmarks): H, W = resolution of the Winograd domain (multiples of 16);
+ * (in_up, out_pool) = (0,0): plain 3x3, 36 planes; (1,0): x is [B][H/2][W/2][Cin], nearest x2 on read, 25 planes; (0,1): out is
+ * [B][H/2][W/2][Cout] = 2x2 sums x alpha, 25 planes.  flags: ICG_PRE_*, ICG_RES_*.  V: NULL or [planes][B H/4 W/4][Cin]. */
+int icg_fwino_conv(const float* x, const float* Uf, const float* bias, const float* residual, float* out, const float* scale,
+                   const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin, int Cout, unsigned flags, float alpha,
+                   int in_up, int out_pool, float* V, void* stream);
 /* Weight gradient from the V planes the FORWARD pass of the same layer left in its workspace: icg_conv2d_wino4_fprop,
  * icg_conv2d_up_wino_fprop and icg_conv2d_down_wino_fprop write V = transform(act(x)) to the first
  * planes * T * Cin floats of the workspace (T = B * H/4 * W/4 at the FULL resolution H x W; planes = 36 / 25).  A caller that

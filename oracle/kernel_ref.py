@@ -376,6 +376,67 @@ def icg_conv2d_down_wino_wgrad(x, dy, dw, B, Hp, Wp, Cin, Cout, flags, workspace
     mem(dw)[: 9 * Cin * Cout].copy_(gw.permute(2, 3, 1, 0).reshape(-1))       # HWIO
 
 
+# ---- fused F(4x4,3x3) kernel for the narrow layers (csrc/fwino.hip): the same op graph, evaluated directly
+def icg_fwino_applies(B, H, W, Cin, Cout):
+    import os
+    env = lambda k, d: int(os.environ.get(k, d))
+    if not env("ICG_FWINO", 1):
+        return 0
+    if Cin % 32 or Cin > env("ICG_FWINO_MAXK", 192) or Cout % 96 or Cout > env("ICG_FWINO_MAXN", 192) or H % 16 or W % 16:
+        return 0
+    wgs = B * (H // 16) * (W // 16) * (Cout // 96)
+    return 1 if env("ICG_FWINO_MIN_WGS", 512) <= wgs < 0x7FFFFFFF else 0
+
+
+def icg_fwino_weight_bytes(planes, Cin, Cout):
+    return planes * Cin * Cout * 4
+
+
+def icg_fwino_pack_weights(U, Uf, planes, Cin, Cout):
+    """Uf[((p NT + jt) KG + kg) 64 + l][e] = U[p][16 jt + (l & 15)][16 kg + 4 (l >> 4) + e]"""
+    u = mem(U)[: planes * Cout * Cin].view(planes, Cout // 16, 16, Cin // 16, 4, 4)          # [p][jt][n][kg][kq][e]
+    mem(Uf)[: planes * Cout * Cin].copy_(u.permute(0, 1, 3, 4, 2, 5).reshape(-1))           # [p][jt][kg][kq][n][e]
+
+
+def _fwino_unpack(Uf, planes, Cin, Cout):
+    uf = mem(Uf)[: planes * Cout * Cin].view(planes, Cout // 16, Cin // 16, 4, 16, 4)        # [p][jt][kg][kq][n][e]
+    return uf.permute(0, 1, 4, 2, 3, 5).reshape(planes * Cout * Cin).contiguous()
+
+
+def icg_fwino_conv(x, Uf, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, flags, alpha, in_up, out_pool, V):
+    planes = 25 if (in_up or out_pool) else 36
+    U = _fwino_unpack(Uf, planes, Cin, Cout)
+    if planes == 25:
+        g = _w4r_kernel(U, Cout, Cin)
+    else:
+        u = U.view(6, 6, Cout, Cin).double()
+        inv = torch.tensor([[4.0, 0, 0, 0, 0, 0], [0, -3.0, 3.0, 0, 0, 0], [0, 0, 0, 0, 0, 1.0]], dtype=torch.float64)
+        g = torch.einsum("ra,abnk,sb->nrsk", inv, u, inv).float().contiguous()
+    a = _act(x, scale, shift, ss_bstride, flags | (UPSAMPLE2X if in_up else 0), B, H >> (1 if in_up else 0), W >> (1 if in_up else 0), Cin)
+    y = F.conv2d(a, g.permute(0, 3, 1, 2), None, 1, 1)
+    Ho, Wo = H, W
+    if out_pool:
+        y = F.avg_pool2d(y, 2) * 4.0
+        Ho, Wo = H // 2, W // 2
+    y = y * alpha
+    if bias is not None:
+        y = y + mem(bias)[:Cout].view(1, -1, 1, 1)
+    if flags & RES_RELU_MASK:
+        r = _nhwc(residual, B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+        y = torch.where(r > 0, y, torch.zeros((), dtype=y.dtype))
+    elif residual is not None:
+        if flags & RES_UPSAMPLE2X:
+            y = y + F.interpolate(_nhwc(residual, B, Ho // 2, Wo // 2, Cout).permute(0, 3, 1, 2), scale_factor=2)
+        else:
+            y = y + _nhwc(residual, B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    mem(out)[: B * Ho * Wo * Cout].copy_(y.permute(0, 2, 3, 1).reshape(-1))
+    if V is not None:
+        n = planes * B * (H // 4) * (W // 4) * Cin
+        tmp = torch.empty(n * 4, dtype=torch.uint8)
+        _w4_store_v(tmp, a, planes)
+        mem(V)[:n].copy_(tmp.view(torch.float32))
+
+
 def icg_gemm_batched(A, Bm, C, M, N, K, transA, transB, strideA, strideB, strideC, batch, alpha):
     a, b, c = mem(A), mem(Bm), mem(C)
     for z in range(batch):

@@ -1,0 +1,276 @@
+"""GPU parity of the fused F(4x4,3x3) kernel for the narrow 3x3 layers (csrc/fwino.hip): the kernel as its own entry point and
+behind the layer entry points it takes over (icg_conv2d_wino4_fprop, icg_conv2d_{up,down}_wino_{fprop,dgrad[_relu]}), against
+the plain-PyTorch references of oracle/kernel_ref.py AND against the three-kernel composite it replaces (ICG_FWINO=0), at small
+shapes and at the layer shapes of the bench configuration.  Reference layers: BigGAN_PyTorch/layers.py:144-153, 542-552, 587-613.
+Tolerances: 2e-4 of max|ref| against the direct convolution (fp32 Winograd transforms with entries up to 8, as for the
+composite); 2e-5 against the composite itself (same transforms, different summation order of the K chain)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernel_ref as R
+from tests.test_kernels_gpu import PRE_AFFINE, PRE_RELU, RES_MASK, RES_UP, _L, cl, close, rnd, run_pair
+
+pytestmark = pytest.mark.gpu
+KEEP_V = 32
+
+
+@pytest.fixture
+def fwino_small(monkeypatch):
+    """let the layer entry points route small test shapes to the fused kernel"""
+    monkeypatch.setenv("ICG_FWINO", "1")
+    monkeypatch.setenv("ICG_FWINO_MIN_WGS", "1")
+
+
+def _weights(Cin, Cout, planes, seed=5):
+    """-> (w_ohwi, U [planes][Cout][Cin], Uf fragment-major), all CPU"""
+    w = rnd(Cout, 3, 3, Cin, seed=seed, scale=1 / np.sqrt(9 * Cin))
+    U = torch.empty(planes * Cout * Cin)
+    (R.icg_wino4_weight_transform if planes == 36 else R.icg_wino4r_weight_transform)(w, U, Cout, Cin)
+    Uf = torch.empty_like(U)
+    R.icg_fwino_pack_weights(U, Uf, planes, Cin, Cout)
+    return w, U, Uf
+
+
+@pytest.mark.parametrize("planes,Cin,Cout", [(36, 32, 96), (25, 96, 192), (36, 192, 96)])
+def test_fwino_pack_weights_bitwise(planes, Cin, Cout):
+    U = rnd(planes * Cout * Cin, seed=3)
+    (p,) = run_pair("icg_fwino_pack_weights", [U, torch.empty_like(U), planes, Cin, Cout], [1])
+    assert torch.equal(p[0].cpu(), p[1])
+
+
+FW_CASES = [
+    # B, H, W (Winograd domain), Cin, Cout, flags, residual (0 none / 1 same / 2 half-res upsampled / 3 ReLU mask), bias
+    (1, 16, 16, 32, 96, 0, 0, True),
+    (2, 16, 32, 96, 96, PRE_AFFINE | PRE_RELU, 1, True),
+    (1, 32, 16, 64, 192, PRE_RELU, 2, False),
+    (2, 32, 32, 192, 96, PRE_AFFINE, 3, True),
+    (3, 48, 16, 96, 192, PRE_AFFINE | PRE_RELU, 0, False),
+]
+
+
+def _inputs(case, in_up, out_pool, seed=10):
+    B, H, W, Cin, Cout, flags, res, has_bias = case
+    Hx, Wx = (H // 2, W // 2) if in_up else (H, W)
+    Ho, Wo = (H // 2, W // 2) if out_pool else (H, W)
+    x = cl(B, Cin, Hx, Wx, seed=seed)
+    bias = rnd(Cout, seed=seed + 1) if has_bias else None
+    sc = sh = None
+    ssb = 0
+    if flags & PRE_AFFINE:
+        sc, sh, ssb = (1 + 0.3 * rnd(B, Cin, seed=seed + 2)).contiguous(), (0.3 * rnd(B, Cin, seed=seed + 3)).contiguous(), Cin
+    r = None
+    rflags = flags
+    if res == 1 or (res == 2 and out_pool):
+        r = cl(B, Cout, Ho, Wo, seed=seed + 4)
+    elif res == 2:
+        r = cl(B, Cout, Ho // 2, Wo // 2, seed=seed + 4)
+        rflags |= RES_UP
+    elif res == 3:
+        r = cl(B, Cout, Ho, Wo, seed=seed + 4)
+        rflags |= RES_MASK
+    out = torch.empty(B, Cout, Ho, Wo).contiguous(memory_format=torch.channels_last)
+    return x, bias, r, out, sc, sh, ssb, rflags
+
+
+@pytest.mark.parametrize("form", [(0, 0), (1, 0), (0, 1)])
+@pytest.mark.parametrize("case", FW_CASES)
+def test_fwino_conv_entry(case, form):
+    """the kernel itself: plain / upsample-on-read / pooled-output forms, every prologue and epilogue mode, V by-product"""
+    in_up, out_pool = form
+    B, H, W, Cin, Cout, flags, res, has_bias = case
+    planes = 25 if (in_up or out_pool) else 36
+    _, U, Uf = _weights(Cin, Cout, planes)
+    x, bias, r, out, sc, sh, ssb, rflags = _inputs(case, in_up, out_pool)
+    alpha = 0.25 if out_pool else 1.0
+    V = torch.empty(planes * B * (H // 4) * (W // 4) * Cin)
+    pout, pv = run_pair("icg_fwino_conv", [x, Uf, bias, r, out, sc, sh, ssb, B, H, W, Cin, Cout, rflags, alpha, in_up, out_pool, V],
+                        [4, 17])
+    close(*pout, rtol=2e-4, atol_rel=2e-4, what=f"fwino_conv {case} {form}")
+    close(*pv, rtol=1e-5, atol_rel=1e-5, what=f"fwino_conv V planes {case} {form}")
+    # V = nullptr: same output, bitwise
+    out2 = torch.empty_like(out).cuda()
+    L = _L()
+    L.call("icg_fwino_conv", x.cuda(), Uf.cuda(), None if bias is None else bias.cuda(), None if r is None else r.cuda(), out2,
+           None if sc is None else sc.cuda(), None if sh is None else sh.cuda(), ssb, B, H, W, Cin, Cout, rflags, alpha, in_up,
+           out_pool, None)
+    torch.cuda.synchronize()
+    assert torch.equal(out2.cpu(), pout[0].cpu())
+
+
+def _ab(name, args, out_idx, monkeypatch):
+    """run a layer entry point on the fused route and on the composite (ICG_FWINO=0); -> (fused, composite, reference)"""
+    L = _L()
+    res = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("ICG_FWINO", on)
+        dargs = [a.cuda() if isinstance(a, torch.Tensor) else a for a in args]
+        L.call(name, *dargs)
+        torch.cuda.synchronize()
+        res.append(dargs)
+    monkeypatch.setenv("ICG_FWINO", "1")
+    getattr(R, name)(*args)
+    return [(res[0][i].cpu(), res[1][i].cpu(), args[i]) for i in out_idx]
+
+
+@pytest.mark.parametrize("case", FW_CASES)
+def test_fwino_behind_wino4_fprop(case, fwino_small, monkeypatch):
+    B, H, W, Cin, Cout, flags, res, has_bias = case
+    L = _L()
+    assert L.lib().icg_fwino_applies(B, H, W, Cin, Cout) == 1
+    _, U, _ = _weights(Cin, Cout, 36)
+    x, bias, r, out, sc, sh, ssb, rflags = _inputs(case, 0, 0)
+    nb = L.query("icg_conv2d_wino4_workspace_bytes", B, H, W, Cin, Cout)
+    ws = torch.zeros(nb, dtype=torch.uint8)
+    ((f, c, ref), (wf, wc, wref)) = _ab("icg_conv2d_wino4_fprop", [x, U, bias, r, out, sc, sh, ssb, B, H, W, Cin, Cout, rflags | KEEP_V,
+                                                                   1.0, ws, nb], [4, 15], monkeypatch)
+    close(f, ref, rtol=2e-4, atol_rel=2e-4, what=f"fused wino4_fprop vs direct conv {case}")
+    close(f, c, rtol=2e-5, atol_rel=2e-5, what=f"fused vs composite {case}")
+    nv = 36 * B * (H // 4) * (W // 4) * Cin * 4
+    close(wf[:nv].view(torch.float32), wc[:nv].view(torch.float32), rtol=1e-6, atol_rel=1e-6, what="V planes: fused vs composite")
+    close(wf[:nv].view(torch.float32), wref[:nv].view(torch.float32), rtol=1e-5, atol_rel=1e-5, what="V planes vs reference")
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 96, 96, PRE_AFFINE | PRE_RELU), (1, 16, 8, 192, 96, PRE_RELU), (2, 8, 16, 96, 192, 0)])
+def test_fwino_behind_resample_entries(case, fwino_small, monkeypatch):
+    """GBlock conv1 (upsample-fused) and DBlock conv2 (pool-fused): forward and data gradients through the fused kernel"""
+    B, Hl, Wl, Cin, Cout, flags = case
+    L = _L()
+    H, W = 2 * Hl, 2 * Wl
+    assert L.lib().icg_fwino_applies(B, H, W, Cin, Cout) == 1 and L.lib().icg_fwino_applies(B, H, W, Cout, Cin) == 1
+    w = rnd(Cout, 3, 3, Cin, seed=5, scale=1 / np.sqrt(9 * Cin))
+    wd = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+    U, Ud = torch.empty(25 * Cout * Cin), torch.empty(25 * Cout * Cin)
+    R.icg_wino4r_weight_transform(w, U, Cout, Cin)
+    R.icg_wino4r_weight_transform(wd, Ud, Cin, Cout)
+    bias = rnd(Cout, seed=7)
+    sc = sh = None
+    ssb = 0
+    if flags & PRE_AFFINE:
+        sc, sh, ssb = (1 + 0.3 * rnd(B, Cin, seed=8)).contiguous(), (0.3 * rnd(B, Cin, seed=9)).contiguous(), Cin
+    nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cin, Cout)
+    nbd = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cout, Cin)
+    tol = dict(rtol=2e-4, atol_rel=2e-4)
+    # upsample-fused layer
+    xs = cl(B, Cin, Hl, Wl, seed=6)
+    out = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
+    ((f, c, ref),) = _ab("icg_conv2d_up_wino_fprop", [xs, U, bias, out, sc, sh, ssb, B, Hl, Wl, Cin, Cout, flags,
+                                                     torch.zeros(nb, dtype=torch.uint8), nb], [3], monkeypatch)
+    close(f, ref, what=f"up_wino_fprop fused {case}", **tol); close(f, c, what="up_wino_fprop fused vs composite")
+    dy = cl(B, Cout, H, W, seed=11)
+    da = torch.empty(B, Cin, Hl, Wl).contiguous(memory_format=torch.channels_last)
+    ((f, c, ref),) = _ab("icg_conv2d_up_wino_dgrad", [dy, Ud, da, B, Hl, Wl, Cin, Cout, torch.zeros(nbd, dtype=torch.uint8), nbd], [2],
+                         monkeypatch)
+    close(f, ref, what=f"up_wino_dgrad fused {case}", **tol); close(f, c, what="up_wino_dgrad fused vs composite")
+    # pool-fused layer
+    xf = cl(B, Cin, H, W, seed=12)
+    res = cl(B, Cout, Hl, Wl, seed=13)
+    outp = torch.empty(B, Cout, Hl, Wl).contiguous(memory_format=torch.channels_last)
+    ((f, c, ref),) = _ab("icg_conv2d_down_wino_fprop", [xf, U, bias, res, outp, B, Hl, Wl, Cin, Cout, flags & PRE_RELU,
+                                                       torch.zeros(nb, dtype=torch.uint8), nb], [4], monkeypatch)
+    close(f, ref, what=f"down_wino_fprop fused {case}", **tol); close(f, c, what="down_wino_fprop fused vs composite")
+    dyp = cl(B, Cout, Hl, Wl, seed=14)
+    daf = torch.empty(B, Cin, H, W).contiguous(memory_format=torch.channels_last)
+    ((f, c, ref),) = _ab("icg_conv2d_down_wino_dgrad", [dyp, Ud, daf, B, Hl, Wl, Cin, Cout, torch.zeros(nbd, dtype=torch.uint8), nbd],
+                         [2], monkeypatch)
+    close(f, ref, what=f"down_wino_dgrad fused {case}", **tol); close(f, c, what="down_wino_dgrad fused vs composite")
+    ((fm, cm, refm),) = _ab("icg_conv2d_down_wino_dgrad_relu", [dyp, Ud, xf, torch.empty_like(daf), B, Hl, Wl, Cin, Cout,
+                                                               torch.zeros(nbd, dtype=torch.uint8), nbd], [3], monkeypatch)
+    close(fm, refm, what=f"down_wino_dgrad_relu fused {case}", **tol)
+    assert torch.equal(fm, torch.where(xf > 0, f, torch.zeros(()))), "ReLU mask epilogue == mask of the unmasked result, bitwise"
+
+
+def test_fwino_saved_v_feeds_the_weight_gradient(fwino_small, monkeypatch):
+    """ICG_WINO_KEEP_V on the fused route: the weight gradient from the kept V planes == the one from a fresh transform of x"""
+    B, H, W, Cin, Cout, flags = 2, 32, 32, 96, 96, PRE_AFFINE | PRE_RELU
+    L = _L()
+    _, U, _ = _weights(Cin, Cout, 36)
+    x = cl(B, Cin, H, W, seed=21).cuda()
+    sc, sh = (1 + 0.3 * rnd(B, Cin, seed=22)).cuda(), (0.3 * rnd(B, Cin, seed=23)).cuda()
+    dy = cl(B, Cout, H, W, seed=24).cuda()
+    out = torch.empty(B, Cout, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    nb = L.query("icg_conv2d_wino4_workspace_bytes", B, H, W, Cin, Cout)
+    ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    L.call("icg_conv2d_wino4_fprop", x, U.cuda(), None, None, out, sc, sh, Cin, B, H, W, Cin, Cout, flags | KEEP_V, 1.0, ws, nb)
+    v = ws[: 36 * B * (H // 4) * (W // 4) * Cin * 4].view(torch.float32)
+    nbw = L.query("icg_conv2d_wino4_wgrad_from_v_workspace_bytes", B, H, W, Cin, Cout, 36)
+    dw_v = torch.empty(9 * Cin * Cout, device="cuda")
+    L.call("icg_conv2d_wino4_wgrad_from_v", v, dy, dw_v, B, H, W, Cin, Cout, 36, 0, 1.0, torch.empty(nbw, dtype=torch.uint8, device="cuda"), nbw)
+    nbx = L.query("icg_conv2d_wino4_wgrad_workspace_bytes", B, H, W, Cin, Cout)
+    dw_x = torch.empty(9 * Cin * Cout, device="cuda")
+    L.call("icg_conv2d_wino4_wgrad", x, dy, dw_x, sc, sh, Cin, B, H, W, Cin, Cout, flags, torch.empty(nbx, dtype=torch.uint8, device="cuda"), nbx)
+    torch.cuda.synchronize()
+    close(dw_v, dw_x, rtol=1e-5, atol_rel=1e-5, what="wgrad from the fused kernel's V planes vs from x")
+    # without the flag the fused route leaves the V region untouched
+    ws2 = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    L.call("icg_conv2d_wino4_fprop", x, U.cuda(), None, None, out, sc, sh, Cin, B, H, W, Cin, Cout, flags, 1.0, ws2, nb)
+    torch.cuda.synchronize()
+    assert int(ws2[: 36 * B * (H // 4) * (W // 4) * Cin * 4].count_nonzero()) == 0
+
+
+BENCH_LAYERS = [   # name, kind, B, H, W (Winograd domain), Cin, Cout -- the cfg3 layers icg_fwino_applies takes (reduced batch)
+    ("G.b5.conv2 96->96 @256", "plain", 4, 256, 256, 96, 96),
+    ("G.b4.conv2 192->192 @128", "plain", 4, 128, 128, 192, 192),
+    ("D.b1.conv1 96->192 @128", "plain", 4, 128, 128, 96, 192),
+    ("G.b5.conv1 192->96 up@256", "up", 4, 256, 256, 192, 96),
+    ("D.b1.conv2 192->192 pool@128", "down", 4, 128, 128, 192, 192),
+]
+
+
+@pytest.mark.parametrize("layer", BENCH_LAYERS, ids=[l[0] for l in BENCH_LAYERS])
+def test_fwino_at_bench_layer_shapes(layer, monkeypatch):
+    """default routing (no test switches) at the layer shapes of cfg3: fused == composite to summation-order accuracy, and both
+    within the Winograd tolerance of an fp64 direct convolution on a pixel sample"""
+    name, kind, B, H, W, Cin, Cout = layer
+    L = _L()
+    assert L.lib().icg_fwino_applies(B, H, W, Cin, Cout) == 1
+    planes = 36 if kind == "plain" else 25
+    w, U, _ = _weights(Cin, Cout, planes)
+    bias = rnd(Cout, seed=7)
+    sc, sh = (1 + 0.3 * rnd(B, Cin, seed=8)).contiguous(), (0.3 * rnd(B, Cin, seed=9)).contiguous()
+    dargs = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("ICG_FWINO", on)
+        if kind == "plain":
+            x = cl(B, Cin, H, W, seed=6)
+            res = cl(B, Cout, H, W, seed=10)
+            out = torch.empty(B, Cout, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+            nb = L.query("icg_conv2d_wino4_workspace_bytes", B, H, W, Cin, Cout)
+            L.call("icg_conv2d_wino4_fprop", x.cuda(), U.cuda(), bias.cuda(), res.cuda(), out, sc.cuda(), sh.cuda(), Cin, B, H, W, Cin,
+                   Cout, PRE_AFFINE | PRE_RELU, 1.0, torch.empty(nb, dtype=torch.uint8, device="cuda"), nb)
+        elif kind == "up":
+            x = cl(B, Cin, H // 2, W // 2, seed=6)
+            res = None
+            out = torch.empty(B, Cout, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+            nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cin, Cout)
+            L.call("icg_conv2d_up_wino_fprop", x.cuda(), U.cuda(), bias.cuda(), out, sc.cuda(), sh.cuda(), Cin, B, H // 2, W // 2, Cin,
+                   Cout, PRE_AFFINE | PRE_RELU, torch.empty(nb, dtype=torch.uint8, device="cuda"), nb)
+        else:
+            x = cl(B, Cin, H, W, seed=6)
+            res = cl(B, Cout, H // 2, W // 2, seed=10)
+            out = torch.empty(B, Cout, H // 2, W // 2, device="cuda").contiguous(memory_format=torch.channels_last)
+            nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cin, Cout)
+            L.call("icg_conv2d_down_wino_fprop", x.cuda(), U.cuda(), bias.cuda(), res.cuda(), out, B, H // 2, W // 2, Cin, Cout, PRE_RELU,
+                   torch.empty(nb, dtype=torch.uint8, device="cuda"), nb)
+        torch.cuda.synchronize()
+        dargs[on] = out.cpu()
+    f, c = dargs["1"], dargs["0"]
+    close(f, c, rtol=2e-5, atol_rel=2e-5, what=f"{name}: fused vs composite")
+    # fp64 direct evaluation of image 0
+    import torch.nn.functional as F
+    a = x[:1].double()
+    if kind != "down":
+        a = a * sc[:1].double().view(1, -1, 1, 1) + sh[:1].double().view(1, -1, 1, 1)
+    a = F.relu(a)
+    if kind == "up":
+        a = F.interpolate(a, scale_factor=2)
+    y = F.conv2d(a, w.double().permute(0, 3, 1, 2), bias.double(), 1, 1)
+    if kind == "down":
+        y = F.avg_pool2d(F.conv2d(a, w.double().permute(0, 3, 1, 2), None, 1, 1), 2) + bias.double().view(1, -1, 1, 1)
+    if res is not None:
+        y = y + res[:1].double()
+    ef = float((f[:1].double() - y).norm() / y.norm())
+    ec = float((c[:1].double() - y).norm() / y.norm())
+    assert ef < 5e-6 and ef < 1.5 * ec + 1e-7, (name, ef, ec)
