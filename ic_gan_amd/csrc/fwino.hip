@@ -30,6 +30,11 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// measurement builds only (tools/build_dbg.sh FWA<n>): 1 producers idle, 2 no MFMAs, 4 no weight loads in the loop, 8 no output stage
+#ifndef FWINO_ABLATE
+#define FWINO_ABLATE 0
+#endif
+
 struct FwinoP {
   const float* x;
   const float* Uf;       // fragment-major Winograd weights (icg_fwino_pack_kernel)
@@ -147,6 +152,9 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
   // ---- output side, shared by both roles: item -> (tile, column) of a 48-column round (768 items per round)
   const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
   auto output_item = [&](int round, int item) {
+#if FWINO_ABLATE & 8
+    return;
+#endif
     const int otile = item / 48, ocol = item - 48 * otile;
     const int oty = 4 * by + (otile >> 2), otx = 4 * bx + (otile & 3);
     const int n = nb * 96 + round * 48 + ocol;
@@ -285,15 +293,19 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
       }
     };
 
+#if !(FWINO_ABLATE & 1)
     load_chunk(0);
     transform_chunk(0, 0u);
     if (nc > 1) load_chunk(1);
+#endif
     fw_barrier();
     for (int ck = 0; ck < nc; ++ck) {
+#if !(FWINO_ABLATE & 1)
       if (ck + 1 < nc) {
         transform_chunk(ck + 1, ((ck + 1) & 1) ? (unsigned)VBUF : 0u);
         if (ck + 2 < nc) load_chunk(ck + 2);
       }
+#endif
       fw_barrier();
     }
     // output: the consumers hand their accumulators over in two 48-column rounds (the V buffers are dead: every wave has passed
@@ -315,25 +327,30 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned apos[2] = {(unsigned)((kq * 16 + (it ^ kq)) * 16), (unsigned)((64 + kq * 16 + (it ^ (kq + 4))) * 16)};
-    // weight fragments: wave-uniform base (column block, column group, plane group, chunk -- all scalar arithmetic) + 16 B x lane
+    // weight fragments: buffer loads through ONE wave-uniform descriptor over Uf (SGPRs), the per-lane part of the address is
+    // 16 B x lane in voffset and everything else (column block, column group, plane, chunk) is scalar arithmetic in soffset
     const int NT = N >> 4, KG = K >> 4;
     const unsigned pstride = (unsigned)NT * (unsigned)KG * 1024u;    // bytes per plane of Uf
     const unsigned jstride = (unsigned)KG * 1024u;
-    const char* __restrict__ ub = reinterpret_cast<const char*>(p.Uf) + (size_t)(nb * 6 + ng * 3) * jstride + (size_t)pg * pstride;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Uf), 0, (int)((unsigned)NPL * (unsigned)N * (unsigned)K * 4u),
+                                                      0x00020000);
+    const unsigned ubase = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(nb * 6 + ng * 3) * jstride + (unsigned)pg * pstride));
     const unsigned lane16 = (unsigned)lane * 16u;
     auto load_b = [&](f32x4 (&bf)[3], unsigned ckoff, int i, int sgg) {      // ckoff = 2048 x chunk (bytes)
-      const char* src = ub + (size_t)(4u * (unsigned)i * pstride + ckoff + (unsigned)sgg * 1024u);
+      const unsigned so = ubase + 4u * (unsigned)i * pstride + ckoff + (unsigned)sgg * 1024u;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const f32x4*>(src + (size_t)((unsigned)j * jstride) + lane16);
+      for (int j = 0; j < 3; ++j)
+        bf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane16, (int)(so + (unsigned)j * jstride), 0));
     };
     auto valid = [&](int i) -> bool { return NPL % 4 == 0 || i < NPW - 1 || pg + 4 * i < NPL; };
 
+    __builtin_amdgcn_s_setprio(1);              // the MFMA waves go first on their SIMD (one producer wave shares it)
     f32x4 bcur[3], acur;
     load_b(bcur, 0u, 0, 0);
     fw_barrier();
     for (int ck = 0; ck < nc; ++ck) {
       unsigned ckoff = (unsigned)ck * 2048u, ckoff_next = (unsigned)min(ck + 1, nc - 1) * 2048u;
-      asm volatile("" : "+s"(ckoff), "+s"(ckoff_next));            // (addresses are rebuilt per chunk, not hoisted as 54 pointers)
+      asm volatile("" : "+s"(ckoff), "+s"(ckoff_next));            // (offsets are rebuilt per chunk, not hoisted)
       const char* vbase = lds + ((ck & 1) ? VBUF : 0) + pg * 2048;
       acur = *reinterpret_cast<const f32x4*>(vbase + apos[0]);
 #pragma unroll
@@ -342,23 +359,33 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
         f32x4 bnext[3], anext;
         const bool last = (q + 1 == 2 * NPW);
         const int ni = last ? 0 : (q + 1) >> 1, nsg = last ? 0 : (q + 1) & 1;
+        // the next half-step's operands first: a full half-step (12 MFMAs of this wave + those of its SIMD neighbour) of distance
         if (valid(ni)) {
+#if !(FWINO_ABLATE & 4)
           load_b(bnext, last ? ckoff_next : ckoff, ni, nsg);
+#else
+#pragma unroll
+          for (int j = 0; j < 3; ++j) bnext[j] = bcur[j];
+#endif
           if (!last) anext = *reinterpret_cast<const f32x4*>(vbase + ni * 4 * 2048 + apos[nsg]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#if !(FWINO_ABLATE & 2)
         if (valid(i)) {
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[j][s], acur[s], acc[i][j], 0, 0, 0);
         }
+#endif
 #pragma unroll
         for (int j = 0; j < 3; ++j) bcur[j] = bnext[j];
         acur = anext;
-        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch distance at one half-step (register budget: 168)
+        __builtin_amdgcn_sched_barrier(0);      // one half-step of prefetch distance, no more (register budget: 168)
       }
       fw_barrier();
     }
+    __builtin_amdgcn_s_setprio(0);
     auto hand_over = [&]() {
 #pragma unroll
       for (int i = 0; i < NPW; ++i) {

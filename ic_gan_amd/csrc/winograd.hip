@@ -751,9 +751,15 @@ extern "C" int icg_wino_weight_transform_multi(const icg_wino_weight* items, int
   return icg_check_launch();
 }
 
+// room for the fragment-major weight copy of the fused narrow-layer kernel (fwino.hip), behind the V and M regions: present for
+// every shape that kernel can take, whether or not a given call routes to it (the size is a pure function of the shape)
+static size_t fwino_ws_extra(int planes, int H, int W, int Cin, int Cout) {
+  return (Cin % 32 == 0 && Cout % 96 == 0 && H % 16 == 0 && W % 16 == 0) ? (size_t)planes * Cin * Cout * sizeof(float) : 0;
+}
+
 extern "C" size_t icg_conv2d_wino4_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   const size_t T = (size_t)B * (H / 4) * (W / 4);
-  return 36 * T * ((size_t)Cin + (size_t)Cout) * sizeof(float);
+  return 36 * T * ((size_t)Cin + (size_t)Cout) * sizeof(float) + fwino_ws_extra(36, H, W, Cin, Cout);
 }
 
 // fwino.hip: the fused kernel for the narrow layers
@@ -774,9 +780,9 @@ static int wino4_run(const float* x, int in_up, const float* U, const float* bia
   float* Mb = V + (long)np * np * T * Cin;
   const bool keep_v = (flags & ICG_WINO_KEEP_V) != 0;
   if (icg_fwino_applies(B, H, W, Cin, Cout) && (!keep_v || (double)np * np * T * Cin * 4.0 < 4294967296.0)) {
-    // narrow layer: one fused kernel (fwino.hip).  The M region of the workspace (np^2 T Cout floats, T >= 8192 there) holds the
-    // fragment-major copy of U; V is written only when the caller keeps it for the weight gradient.
-    float* Uf = Mb;
+    // narrow layer: one fused kernel (fwino.hip).  The fragment-major copy of U goes behind the (unused) M region
+    // (fwino_ws_extra); V is written only when the caller keeps it for the weight gradient.
+    float* Uf = Mb + (long)np * np * T * Cout;
     int rc = icg_fwino_pack_weights(U, Uf, np * np, Cin, Cout, stream);
     if (rc != ICG_OK) return rc;
     return icg_fwino_run(x, in_up, Uf, bias, residual, res_up, out, out_pool, scale, shift, ssb, B, H, W, Cin, Cout, flags, alpha,
@@ -806,7 +812,7 @@ extern "C" int icg_conv2d_wino4_fprop(const float* x, const float* U, const floa
 // ---- resample-fused layers in the 25-plane domain (H, W below are always the FULL resolution of the layer) -----------------
 extern "C" size_t icg_conv2d_rs_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   const size_t T = (size_t)B * (H / 4) * (W / 4);
-  return 25 * T * ((size_t)Cin + (size_t)Cout) * sizeof(float);
+  return 25 * T * ((size_t)Cin + (size_t)Cout) * sizeof(float) + fwino_ws_extra(25, H, W, Cin, Cout);
 }
 
 #define ICG_RS_REQUIRE(B, Hl, Wl, Cin, Cout)                                                                           \

@@ -109,8 +109,13 @@ def icg_wino4_weight_transform(w, U, N, K):
     mem(U)[: 36 * N * K].copy_(u.reshape(-1).float())
 
 
+def _fwino_ws_extra(planes, H, W, Cin, Cout):
+    """room for the fragment-major weight copy of the fused narrow-layer kernel (csrc/fwino.hip)"""
+    return planes * Cin * Cout * 4 if (Cin % 32 == 0 and Cout % 96 == 0 and H % 16 == 0 and W % 16 == 0) else 0
+
+
 def icg_conv2d_wino4_workspace_bytes(B, H, W, Cin, Cout):
-    return 36 * B * (H // 4) * (W // 4) * (Cin + Cout) * 4
+    return 36 * B * (H // 4) * (W // 4) * (Cin + Cout) * 4 + _fwino_ws_extra(36, H, W, Cin, Cout)
 
 
 def icg_conv2d_wino4_fprop(x, U, bias, residual, out, scale, shift, ss_bstride, B, H, W, Cin, Cout, flags, alpha, workspace,
@@ -320,7 +325,7 @@ def _w4r_kernel(U, N, K):
 
 
 def icg_conv2d_rs_wino_workspace_bytes(B, H, W, Cin, Cout):
-    return 25 * B * (H // 4) * (W // 4) * (Cin + Cout) * 4
+    return 25 * B * (H // 4) * (W // 4) * (Cin + Cout) * 4 + _fwino_ws_extra(25, H, W, Cin, Cout)
 
 
 def icg_conv2d_rs_wino_wgrad_workspace_bytes(B, H, W, Cin, Cout):

@@ -25,6 +25,7 @@ for v in "$@"; do
     L1_384) build_variant L1_384 -DICG_PLANES_1LEVEL_MAX_K=384 gemm_conv ;;
     NOPERSIST) build_variant NOPERSIST -DICG_PLANES_PERSISTENT=0 gemm_conv ;;
     LB3) build_variant LB3 -DICG_PLANES_TN4_MIN_WAVES=3 gemm_conv ;;
+    FWA*) build_variant "$v" "-DFWINO_ABLATE=${v#FWA}" fwino ;;      # fused Winograd kernel, ablation bits (csrc/fwino.hip)
     *) echo "unknown variant $v"; exit 1 ;;
   esac
 done
