@@ -34,6 +34,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef FWINO_ABLATE
 #define FWINO_ABLATE 0
 #endif
+// FWINO_TRACE (measurement builds): workgroup 0 records shader-clock timestamps of its wave 0 (consumer) and wave 8 (producer) at
+// every barrier arrival / departure into the buffer named by the environment variable ICG_FWINO_TRACE_PTR (tools/fwino_trace.py)
+#ifndef FWINO_TRACE
+#define FWINO_TRACE 0
+#endif
+#ifndef FWINO_MASKBITS
+#define FWINO_MASKBITS 0
+#endif
 
 struct FwinoP {
   const float* x;
@@ -44,6 +52,7 @@ struct FwinoP {
   const float* scale;
   const float* shift;
   float* V;              // optional: the V planes [NP*NP][T][K] as a by-product (nullptr: not written)
+  unsigned long long* trace;   // FWINO_TRACE builds only
   long ssb;              // per-sample stride of scale / shift (elements)
   long planeV;           // T * K
   int B, H, W;           // resolution of the Winograd domain (the conv's full resolution)
@@ -97,6 +106,21 @@ __device__ __forceinline__ void fw_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+#if FWINO_TRACE
+#define FW_BARRIER()                                                                                  \
+  do {                                                                                                \
+    if (tr_on && tr_n < 250) tr_buf[tr_n++] = clock64();                                              \
+    fw_barrier();                                                                                     \
+    if (tr_on && tr_n < 250) tr_buf[tr_n++] = clock64();                                              \
+  } while (0)
+#define FW_MARK()                                                                                     \
+  do {                                                                                                \
+    if (tr_on && tr_n < 250) tr_buf[tr_n++] = clock64() | (1ull << 63);                               \
+  } while (0)
+#else
+#define FW_BARRIER() fw_barrier()
+#define FW_MARK() do {} while (0)
+#endif
 
 // Uf[((p * NT + jt) * KG + kg) * 64 + l][e] = U[p][16 jt + (l & 15)][16 kg + 4 (l >> 4) + e]      (U: [planes][N][K])
 __global__ __launch_bounds__(256) void icg_fwino_pack_kernel(const float* __restrict__ U, float* __restrict__ Uf, int planes, int N,
@@ -115,6 +139,31 @@ __global__ __launch_bounds__(256) void icg_fwino_pack_kernel(const float* __rest
   }
 }
 
+// transforms on channel PAIRS (v_pk_* arithmetic): the producers' instruction count is what they cost the MFMA waves they share a
+// SIMD with
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fw2(float a) { return f32x2{a, a}; }
+__device__ __forceinline__ f32x2 fw_fma(f32x2 a, float b, f32x2 c) { return __builtin_elementwise_fma(a, fw2(b), c); }
+__device__ __forceinline__ void fw_in6(const f32x2 d[6], f32x2 t[6]) {
+  t[0] = fw_fma(d[2], -5.f, d[0] * 4.f) + d[4];
+  const f32x2 a = fw_fma(d[2], -4.f, d[4]), b = fw_fma(d[1], -4.f, d[3]);
+  t[1] = a + b;
+  t[2] = a - b;
+  const f32x2 c = d[4] - d[2], e = (d[3] - d[1]) * 2.f;
+  t[3] = c + e;
+  t[4] = c - e;
+  t[5] = fw_fma(d[3], -5.f, d[1] * 4.f) + d[5];
+}
+__device__ __forceinline__ void fw_in_up(const f32x2 l[4], f32x2 t[6]) {
+  t[0] = fw_fma(l[1], -5.f, l[0] * 4.f) + l[2];
+  t[1] = fw_fma(l[1], -8.f, l[2] * 2.f);
+  t[2] = fw2(0.f);
+  const f32x2 c = l[2] - l[1];
+  t[3] = c * 3.f;
+  t[4] = c * -1.f;
+  t[5] = fw_fma(l[2], -5.f, l[1] * 4.f) + l[3];
+}
+
 template <int UP, int POOL, int NP>
 __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
   static_assert(!(UP && POOL), "no layer is resampled on both sides");
@@ -131,33 +180,54 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..11
+#if FWINO_TRACE
+  const bool tr_on = p.trace && blockIdx.x == 0 && (tid == 0 || tid == 512);
+  unsigned long long* tr_buf = p.trace + (tid == 0 ? 0 : 256);
+  int tr_n = 0;
+#endif
 
-  // ---- this workgroup: (image b, tile block (by, bx), column block nb); XCD-aware order as in pgemm.hip
-  unsigned t = blockIdx.x;
+  // ---- this workgroup's RUN of work items (image b, tile block (by, bx), column block nb), XCD-aware as in pgemm.hip's streaming
+  // kernel: each XCD owns a contiguous range of the item order and its workgroups stride through it
+  const unsigned tot = p.total, lin = blockIdx.x;
+  unsigned first, last, vstep;
   if (p.swz) {
-    const unsigned tot = p.total, q = tot >> 3, rr = tot & 7u, xcd = t & 7u;
-    t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
+    const unsigned q = tot >> 3, rr = tot & 7u, xcd = lin & 7u;
+    const unsigned base = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+    vstep = gridDim.x >> 3;
+    first = base + (lin >> 3);
+    last = base + q + (xcd < rr ? 1u : 0u);
+  } else {
+    vstep = gridDim.x;
+    first = lin;
+    last = tot;
   }
-  const int nb = (int)(t % (unsigned)p.nblk);
-  unsigned tb = t / (unsigned)p.nblk;
-  const int bx = (int)(tb % (unsigned)p.tbw);
-  tb /= (unsigned)p.tbw;
-  const int by = (int)(tb % (unsigned)p.tbh);
-  const int b = (int)(tb / (unsigned)p.tbh);
+  if (first >= last) return;
 
   const int K = p.K, N = p.N, H = p.H, W = p.W;
   const int nc = K >> 5;                                            // 32-channel chunks
   const int th = H >> 2, tw = W >> 2;
+  struct Item { int nb, bx, by, b; };
+  auto decode = [&](unsigned t) -> Item {
+    Item it;
+    it.nb = (int)(t % (unsigned)p.nblk);
+    unsigned tb = t / (unsigned)p.nblk;
+    it.bx = (int)(tb % (unsigned)p.tbw);
+    tb /= (unsigned)p.tbw;
+    it.by = (int)(tb % (unsigned)p.tbh);
+    it.b = (int)(tb / (unsigned)p.tbh);
+    return it;
+  };
 
   // ---- output side, shared by both roles: item -> (tile, column) of a 48-column round (768 items per round)
   const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
-  auto output_item = [&](int round, int item) {
+  auto output_item = [&](const Item& w, int round, int item) {
 #if FWINO_ABLATE & 8
     return;
 #endif
+    asm volatile("" : "+v"(item));              // (per-item address arithmetic stays here: hoisted out of the persistent loop it spills)
     const int otile = item / 48, ocol = item - 48 * otile;
-    const int oty = 4 * by + (otile >> 2), otx = 4 * bx + (otile & 3);
-    const int n = nb * 96 + round * 48 + ocol;
+    const int oty = 4 * w.by + (otile >> 2), otx = 4 * w.bx + (otile & 3);
+    const int n = w.nb * 96 + round * 48 + ocol;
     const float* mp = reinterpret_cast<const float*>(lds) + otile * MROW + ocol;
     // y = A^T M A accumulated column by column: for column j of M the 1-D transform yy = A^T M[:, j], then
     // y[a][c] += yy[a] * A[j][c] with the constants of A folded (rows of A^T: [1 1 1 1 1 0], [0 1 -1 2 -2 0], [0 1 1 4 4 0],
@@ -180,23 +250,23 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
       for (int a = 0; a < NO; ++a)
 #pragma unroll
         for (int c = 0; c < NO; ++c) {
-          const float w = POOL ? ATP[c][j] : AT4[c][j];
-          if (w == 1.f) y[a][c] += yy[a];
-          else if (w == -1.f) y[a][c] -= yy[a];
-          else if (w != 0.f) y[a][c] = fmaf(yy[a], w, y[a][c]);
+          const float cw = POOL ? ATP[c][j] : AT4[c][j];
+          if (cw == 1.f) y[a][c] += yy[a];
+          else if (cw == -1.f) y[a][c] -= yy[a];
+          else if (cw != 0.f) y[a][c] = fmaf(yy[a], cw, y[a][c]);
         }
     }
     const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
     for (int a = 0; a < NO; ++a) {
       const int oy = NO * oty + a;
-      const long p0 = (((long)b * Ho + oy) * Wo + NO * otx) * N + n;
+      const long p0 = (((long)w.b * Ho + oy) * Wo + NO * otx) * N + n;
 #pragma unroll
       for (int c = 0; c < NO; ++c) {
         float v = p.alpha * y[a][c] + bv;
         if (p.res) {
           const long rp = (!POOL && p.res_mode == 1)
-                              ? (((long)b * (H >> 1) + (oy >> 1)) * (W >> 1) + ((4 * otx + c) >> 1)) * N + n
+                              ? (((long)w.b * (H >> 1) + (oy >> 1)) * (W >> 1) + ((4 * otx + c) >> 1)) * N + n
                               : p0 + (long)c * N;
           const float r = p.res[rp];
           v = (p.res_mode == 2) ? (r > 0.f ? v : 0.f) : v + r;
@@ -205,127 +275,154 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
       }
     }
   };
+
+  // Barriers per work item, the same sequence in every role: [T(0) written] [chunk 0 consumed / T(1) written] ... [chunk nc-1
+  // consumed] [round-0 accumulators handed over] [round-0 items done] [round-1 handed over] [round-1 items done: LDS free].
   if (wv >= 8) {
     // =========================================================== producers ===========================================================
-    // Addressing: wave-uniform base pointer + ONE 32-bit lane offset per access (saddr + voffset loads / stores); the offsets are
-    // rebuilt from 6 + 6 row / column terms at every use (fw_opaque keeps the compiler from hoisting 36 + 36 + 36 precomputed
-    // 64-bit addresses out of the chunk loop, which is what spilled this branch).
+    // lane = (tile ti, channel pair cp) of a 32-channel chunk: ONE item per lane and chunk, everything on float2.
+    // Addressing: wave-uniform base pointer + a 32-bit lane offset per access, rebuilt from row / column terms at every use
+    // (opaque to the optimiser on purpose: hoisted 64-bit addresses are what spilled this branch).
+    // Priority: a producer wave's ~500 instructions per chunk go FIRST on its SIMD.  The two MFMA waves it shares the SIMD with
+    // have slack (they wait for this wave at every chunk barrier); measured with tools/fwino_trace.py the other way round
+    // (MFMA waves at priority 1): the producer was not issued for ~10 000 clocks after each barrier and the MFMA waves then idled
+    // ~15 000 clocks per chunk at the next one.
+    __builtin_amdgcn_s_setprio(3);
     const int pl = tid - 512;
-    const int tc = pl & 31, tq = pl >> 5;                           // channel of the chunk; items: tiles tq and tq + 8
     const int Hx = UP ? (H >> 1) : H, Wx = UP ? (W >> 1) : W;       // stored tensor
-    const int txg = 4 * bx + (tq & 3), tyg = 4 * by + (tq >> 2);    // second item: tyg + 2
-    const int w0 = UP ? 2 * txg - 1 : 4 * txg - 1;
-    const float* __restrict__ xb = p.x + (long)b * Hx * Wx * K;     // this image (uniform)
     const unsigned WxK = (unsigned)(Wx * K);
-    unsigned coloff[NL];
-    unsigned colok = 0;
-#pragma unroll
-    for (int s = 0; s < NL; ++s) {
-      const int w = w0 + s;
-      coloff[s] = (unsigned)(min(max(w, 0), Wx - 1) * K + tc);
-      colok |= ((unsigned)w < (unsigned)Wx ? 1u : 0u) << s;
-    }
-    // LDS position of this lane's values inside a plane's 2 KiB: [sg][kq*16 + (tile ^ (kq + 4 sg))][s4]
-    const int sg = tc >> 4, kq = (tc >> 2) & 3, s4 = tc & 3;
-    const bool wantV = (p.V != nullptr) && nb == 0;
+    // LDS position of a lane's pair inside a plane's 2 KiB: [sg][kq*16 + (tile ^ (kq + 4 sg))][s4], channel = 16 sg + 4 kq + s4
 
-    float d[2][NL][NL];
-    auto load_chunk = [&](int ck) {
-      const float* xc = xb + 32 * ck;                               // uniform
+    f32x2 d[NL][NL];
+    Item cur = decode(first);                                        // item whose chunks are being loaded / transformed
+    auto load_chunk = [&](const Item& w, int ck) {
+      int cp = pl & 15, ti = pl >> 4;
+      asm volatile("" : "+v"(cp), "+v"(ti));
+      const int txg = 4 * w.bx + (ti & 3), tyg = 4 * w.by + (ti >> 2);
+      const int w0 = UP ? 2 * txg - 1 : 4 * txg - 1, h0 = UP ? 2 * tyg - 1 : 4 * tyg - 1;
+      const float* xc = p.x + (long)w.b * Hx * Wx * K + 32 * ck;    // this image, this chunk (uniform)
+      unsigned coloff[NL];
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int h0 = UP ? 2 * (tyg + 2 * it) - 1 : 4 * (tyg + 2 * it) - 1;
+      for (int s = 0; s < NL; ++s) coloff[s] = (unsigned)(min(max(w0 + s, 0), Wx - 1) * K + 2 * cp);
 #pragma unroll
-        for (int r = 0; r < NL; ++r) {
-          unsigned ro = (unsigned)min(max(h0 + r, 0), Hx - 1) * WxK;
-          asm volatile("" : "+v"(ro));
+      for (int r = 0; r < NL; ++r) {
+        unsigned ro = (unsigned)min(max(h0 + r, 0), Hx - 1) * WxK;
+        asm volatile("" : "+v"(ro));
 #pragma unroll
-          for (int s = 0; s < NL; ++s) d[it][r][s] = xc[ro + coloff[s]];
-        }
+        for (int s = 0; s < NL; ++s) d[r][s] = *reinterpret_cast<const f32x2*>(xc + ro + coloff[s]);
       }
     };
-    auto transform_chunk = [&](int ck, unsigned vb) {
-      float sc = 1.f, sh = 0.f;
+    auto transform_chunk = [&](const Item& w, int ck, unsigned vb) {
+      int cp = pl & 15, ti = pl >> 4;
+      asm volatile("" : "+v"(cp), "+v"(ti));
+      const int sg = cp >> 3, kq = (cp >> 1) & 3;
+      const unsigned wpos0 = (unsigned)((sg * 64 + kq * 16 + (ti ^ (kq + 4 * sg))) * 16 + (cp & 1) * 8);
+      const int txg = 4 * w.bx + (ti & 3), tyg = 4 * w.by + (ti >> 2);
+      const int w0 = UP ? 2 * txg - 1 : 4 * txg - 1, h0 = UP ? 2 * tyg - 1 : 4 * tyg - 1;
+      f32x2 sc = fw2(1.f), sh = fw2(0.f);
       if (p.affine) {
-        sc = p.scale[(long)b * p.ssb + 32 * ck + tc];
-        sh = p.shift[(long)b * p.ssb + 32 * ck + tc];
+        sc = *reinterpret_cast<const f32x2*>(p.scale + (long)w.b * p.ssb + 32 * ck + 2 * cp);
+        sh = *reinterpret_cast<const f32x2*>(p.shift + (long)w.b * p.ssb + 32 * ck + 2 * cp);
       }
+      FW_MARK();
+      // row pass, in place where the window is 6 wide (d[r][.] <- (d[r][.] B): the inputs are dead once their row is transformed);
+      // the 4-wide upsampled window expands to 6 components and gets its own array
+      constexpr int EW = UP ? 6 : 1;
+      f32x2 Eu[UP ? NL : 1][EW];
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int ty = tyg + 2 * it;
-        const int h0 = UP ? 2 * ty - 1 : 4 * ty - 1;
-        float E[NL][6];
+      for (int r = 0; r < NL; ++r) {
+        const bool rok = (unsigned)(h0 + r) < (unsigned)Hx;
+        f32x2 row[NL], t6[6];
+#pragma unroll
+        for (int s = 0; s < NL; ++s) {
+          f32x2 v = d[r][s];
+          if (p.affine) v = __builtin_elementwise_fma(v, sc, sh);
+          if (p.relu) v = f32x2{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)};
+#if FWINO_MASKBITS
+          // zero padding as a bit mask (a select here becomes a divergent branch around the whole row)
+          const unsigned okm = 0u - (unsigned)(rok & ((unsigned)(w0 + s) < (unsigned)Wx));
+          row[s] = f32x2{__builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.x) & okm),
+                         __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.y) & okm)};
+#else
+          row[s] = (rok && (unsigned)(w0 + s) < (unsigned)Wx) ? v : fw2(0.f);
+#endif
+        }
+        if constexpr (UP) {
+          fw_in_up(row, t6);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) Eu[r][j] = t6[j];
+        } else {
+          fw_in6(row, t6);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) d[r][j] = t6[j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      FW_MARK();
+      unsigned wpos = vb + wpos0;
+      unsigned vpos = (unsigned)((((w.b * th + tyg) * tw + txg) * K + 2 * cp)) * 4u;       // byte offset inside a V plane
+      unsigned pv4 = (unsigned)p.planeV * 4u;                       // bytes per plane; planes x pv4 < 2^32 (icg_fwino_conv)
+      asm volatile("" : "+v"(wpos), "+v"(vpos), "+s"(pv4));
+      const bool wantV = (p.V != nullptr) && w.nb == 0;
+      char* vplane = reinterpret_cast<char*>(p.V + 32 * ck);        // uniform
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (!fw_has<NP>(j)) continue;
+        f32x2 col[NL], o[6];
 #pragma unroll
         for (int r = 0; r < NL; ++r) {
-          const bool rok = (unsigned)(h0 + r) < (unsigned)Hx;
-          float row[NL];
-#pragma unroll
-          for (int s = 0; s < NL; ++s) {
-            float v = d[it][r][s];
-            if (p.affine) v = fmaf(v, sc, sh);
-            if (p.relu) v = fmaxf(v, 0.f);
-            row[s] = (rok && ((colok >> s) & 1u)) ? v : 0.f;
-          }
-          if constexpr (UP) fw_in_up(row, E[r]); else fw_in6(row, E[r]);
+          if constexpr (UP) col[r] = Eu[r][j]; else col[r] = d[r][j];
         }
-        const int ti = tq + 8 * it;
-        unsigned wpos = vb + (unsigned)((sg * 64 + kq * 16 + (ti ^ (kq + 4 * sg))) * 16 + s4 * 4);
-        unsigned vpos = (unsigned)((((b * th + ty) * tw + txg) * K + tc)) * 4u;     // byte offset inside a V plane
-        unsigned pv4 = (unsigned)p.planeV * 4u;                     // bytes per plane; planes x pv4 < 2^32 (icg_fwino_applies)
-        asm volatile("" : "+v"(wpos), "+v"(vpos), "+s"(pv4));
-        char* vplane = reinterpret_cast<char*>(p.V + 32 * ck);      // uniform
+        if constexpr (UP) fw_in_up(col, o); else fw_in6(col, o);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          if (!fw_has<NP>(j)) continue;
-          float col[NL], o[6];
-#pragma unroll
-          for (int r = 0; r < NL; ++r) col[r] = E[r][j];
-          if constexpr (UP) fw_in_up(col, o); else fw_in6(col, o);
-#pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            if (!fw_has<NP>(r)) continue;
-            const int plane = fw_slot<NP>(r) * NP + fw_slot<NP>(j);
-            *reinterpret_cast<float*>(lds + wpos + plane * 2048) = o[r];
-            if (wantV) *reinterpret_cast<float*>(vplane + (size_t)((unsigned)plane * pv4 + vpos)) = o[r];
-          }
+        for (int r = 0; r < 6; ++r) {
+          if (!fw_has<NP>(r)) continue;
+          const int plane = fw_slot<NP>(r) * NP + fw_slot<NP>(j);
+          *reinterpret_cast<f32x2*>(lds + wpos + plane * 2048) = o[r];
+          if (wantV) *reinterpret_cast<f32x2*>(vplane + (size_t)((unsigned)plane * pv4 + vpos)) = o[r];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
 
 #if !(FWINO_ABLATE & 1)
-    load_chunk(0);
-    transform_chunk(0, 0u);
-    if (nc > 1) load_chunk(1);
+    load_chunk(cur, 0);
 #endif
-    fw_barrier();
-    for (int ck = 0; ck < nc; ++ck) {
+    for (unsigned v = first; v < last; v += vstep) {
+      const Item w = cur;                                            // the item of this iteration (output coordinates)
+      const bool has_next = v + vstep < last;
 #if !(FWINO_ABLATE & 1)
-      if (ck + 1 < nc) {
-        transform_chunk(ck + 1, ((ck + 1) & 1) ? (unsigned)VBUF : 0u);
-        if (ck + 2 < nc) load_chunk(ck + 2);
-      }
+      transform_chunk(w, 0, 0u);
+      FW_MARK();
+      if (nc > 1) load_chunk(w, 1);
+      else if (has_next) { cur = decode(v + vstep); load_chunk(cur, 0); }
 #endif
-      fw_barrier();
+      FW_BARRIER();
+      for (int ck = 0; ck < nc; ++ck) {
+#if !(FWINO_ABLATE & 1)
+        if (ck + 1 < nc) {
+          transform_chunk(w, ck + 1, ((ck + 1) & 1) ? (unsigned)VBUF : 0u);
+          FW_MARK();
+          if (ck + 2 < nc) load_chunk(w, ck + 2);
+          else if (has_next) { cur = decode(v + vstep); load_chunk(cur, 0); }    // the next item's first chunk: in flight during
+        }                                                                         // this item's last MFMAs and its output stage
+#endif
+        FW_BARRIER();
+      }
+      // Round 0 is worked by the 512 threads that hold no accumulators any more (first-round consumers + producers), the
+      // second-round consumers wait with theirs: no point of the program has 108 accumulators AND an output transform live.
+      FW_BARRIER();
+      output_item(w, 0, tid - 256);                                  // items 256..511 (the first-round consumers: 0..255, 512..767)
+      FW_BARRIER();
+      FW_BARRIER();
+      output_item(w, 1, tid);
+      FW_BARRIER();
     }
-    // output: the consumers hand their accumulators over in two 48-column rounds (the V buffers are dead: every wave has passed
-    // the barrier that closes the last chunk)
-    // Round 0 is worked by the 512 threads that hold no accumulators any more (first-round consumers + producers), the
-    // second-round consumers wait with theirs: no point of the program has 108 accumulators AND an output transform live.
-    fw_barrier();
-    output_item(0, tid - 256);                                      // items 256..511 (the first-round consumers: 0..255, 512..767)
-    fw_barrier();
-    fw_barrier();
-    output_item(1, tid);
   } else {
     // =========================================================== consumers ===========================================================
     const int pg = wv & 3, ng = wv >> 2;
     const int it = lane & 15, kq = lane >> 4;
     f32x4 acc[NPW][3];
-#pragma unroll
-    for (int i = 0; i < NPW; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned apos[2] = {(unsigned)((kq * 16 + (it ^ kq)) * 16), (unsigned)((64 + kq * 16 + (it ^ (kq + 4))) * 16)};
     // weight fragments: buffer loads through ONE wave-uniform descriptor over Uf (SGPRs), the per-lane part of the address is
     // 16 B x lane in voffset and everything else (column block, column group, plane, chunk) is scalar arithmetic in soffset
@@ -334,9 +431,11 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
     const unsigned jstride = (unsigned)KG * 1024u;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Uf), 0, (int)((unsigned)NPL * (unsigned)N * (unsigned)K * 4u),
                                                       0x00020000);
-    const unsigned ubase = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(nb * 6 + ng * 3) * jstride + (unsigned)pg * pstride));
     const unsigned lane16 = (unsigned)lane * 16u;
-    auto load_b = [&](f32x4 (&bf)[3], unsigned ckoff, int i, int sgg) {      // ckoff = 2048 x chunk (bytes)
+    auto ubase_of = [&](int nb) -> unsigned {
+      return (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(nb * 6 + ng * 3) * jstride + (unsigned)pg * pstride));
+    };
+    auto load_b = [&](f32x4 (&bf)[3], unsigned ubase, unsigned ckoff, int i, int sgg) {      // ckoff = 2048 x chunk (bytes)
       const unsigned so = ubase + 4u * (unsigned)i * pstride + ckoff + (unsigned)sgg * 1024u;
 #pragma unroll
       for (int j = 0; j < 3; ++j)
@@ -344,74 +443,90 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
     };
     auto valid = [&](int i) -> bool { return NPL % 4 == 0 || i < NPW - 1 || pg + 4 * i < NPL; };
 
-    __builtin_amdgcn_s_setprio(1);              // the MFMA waves go first on their SIMD (one producer wave shares it)
     f32x4 bcur[3], acur;
-    load_b(bcur, 0u, 0, 0);
-    fw_barrier();
-    for (int ck = 0; ck < nc; ++ck) {
-      unsigned ckoff = (unsigned)ck * 2048u, ckoff_next = (unsigned)min(ck + 1, nc - 1) * 2048u;
-      asm volatile("" : "+s"(ckoff), "+s"(ckoff_next));            // (offsets are rebuilt per chunk, not hoisted)
-      const char* vbase = lds + ((ck & 1) ? VBUF : 0) + pg * 2048;
-      acur = *reinterpret_cast<const f32x4*>(vbase + apos[0]);
+    Item w = decode(first);
+    unsigned ubase = ubase_of(w.nb);
+    load_b(bcur, ubase, 0u, 0, 0);
+    for (unsigned v = first; v < last; v += vstep) {
+      const bool has_next = v + vstep < last;
+      Item wn = w;
+      if (has_next) wn = decode(v + vstep);
+      const unsigned ubase_next = ubase_of(wn.nb);
 #pragma unroll
-      for (int q = 0; q < 2 * NPW; ++q) {
-        const int i = q >> 1, sgg = q & 1;
-        f32x4 bnext[3], anext;
-        const bool last = (q + 1 == 2 * NPW);
-        const int ni = last ? 0 : (q + 1) >> 1, nsg = last ? 0 : (q + 1) & 1;
-        // the next half-step's operands first: a full half-step (12 MFMAs of this wave + those of its SIMD neighbour) of distance
-        if (valid(ni)) {
+      for (int i = 0; i < NPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      FW_BARRIER();
+      for (int ck = 0; ck < nc; ++ck) {
+        unsigned ckoff = (unsigned)ck * 2048u;
+        // the prefetch past this chunk: the next chunk, or the first fragments of the next work item
+        unsigned ckoff_next = (ck + 1 < nc) ? ckoff + 2048u : 0u, ub_next = (ck + 1 < nc) ? ubase : ubase_next;
+        asm volatile("" : "+s"(ckoff), "+s"(ckoff_next), "+s"(ub_next));   // (offsets are rebuilt per chunk, not hoisted)
+        const char* vbase = lds + ((ck & 1) ? VBUF : 0) + pg * 2048;
+        acur = *reinterpret_cast<const f32x4*>(vbase + apos[0]);
+#pragma unroll
+        for (int q = 0; q < 2 * NPW; ++q) {
+          const int i = q >> 1, sgg = q & 1;
+          f32x4 bnext[3], anext;
+          const bool lastq = (q + 1 == 2 * NPW);
+          const int ni = lastq ? 0 : (q + 1) >> 1, nsg = lastq ? 0 : (q + 1) & 1;
+          // the next half-step's operands first: a full half-step (12 MFMAs of this wave + those of its SIMD neighbour) of distance
+          if (valid(ni)) {
 #if !(FWINO_ABLATE & 4)
-          load_b(bnext, last ? ckoff_next : ckoff, ni, nsg);
+            if (lastq) load_b(bnext, ub_next, ckoff_next, 0, 0);
+            else load_b(bnext, ubase, ckoff, ni, nsg);
 #else
 #pragma unroll
-          for (int j = 0; j < 3; ++j) bnext[j] = bcur[j];
+            for (int j = 0; j < 3; ++j) bnext[j] = bcur[j];
 #endif
-          if (!last) anext = *reinterpret_cast<const f32x4*>(vbase + ni * 4 * 2048 + apos[nsg]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            if (!lastq) anext = *reinterpret_cast<const f32x4*>(vbase + ni * 4 * 2048 + apos[nsg]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #if !(FWINO_ABLATE & 2)
-        if (valid(i)) {
+          if (valid(i)) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[j][s], acur[s], acc[i][j], 0, 0, 0);
-        }
+              for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[j][s], acur[s], acc[i][j], 0, 0, 0);
+          }
 #endif
 #pragma unroll
-        for (int j = 0; j < 3; ++j) bcur[j] = bnext[j];
-        acur = anext;
-        __builtin_amdgcn_sched_barrier(0);      // one half-step of prefetch distance, no more (register budget: 168)
+          for (int j = 0; j < 3; ++j) bcur[j] = bnext[j];
+          acur = anext;
+          __builtin_amdgcn_sched_barrier(0);    // one half-step of prefetch distance, no more (register budget: 168)
+        }
+        FW_BARRIER();
       }
-      fw_barrier();
-    }
-    __builtin_amdgcn_s_setprio(0);
-    auto hand_over = [&]() {
+      auto hand_over = [&]() {
+        int hb = (it * MROW + 4 * kq) * 4;
+        asm volatile("" : "+v"(hb));
 #pragma unroll
-      for (int i = 0; i < NPW; ++i) {
-        const int plane = pg + 4 * i;
-        if (NPL % 4 != 0 && i == NPW - 1 && plane >= NPL) continue;
+        for (int i = 0; i < NPW; ++i) {
+          const int plane = pg + 4 * i;
+          if (NPL % 4 != 0 && i == NPW - 1 && plane >= NPL) continue;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-          *reinterpret_cast<f32x4*>(lds + ((plane * 16 + it) * MROW + 16 * j + 4 * kq) * 4) = acc[i][j];
+          for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(lds + hb + (plane * 16 * MROW + 16 * j) * 4) = acc[i][j];
+        }
+      };
+      if (ng == 0) {
+        hand_over();
+        FW_BARRIER();
+        output_item(w, 0, tid);                                      // items 0..255 and 512..767
+        output_item(w, 0, tid + 512);
+        FW_BARRIER();
+        FW_BARRIER();
+      } else {
+        FW_BARRIER();
+        FW_BARRIER();
+        hand_over();
+        FW_BARRIER();
       }
-    };
-    if (ng == 0) {
-      hand_over();
-      fw_barrier();
-      output_item(0, tid);                                          // items 0..255 (+ 512..767 below)
-      output_item(0, tid + 512);
-      fw_barrier();
-      fw_barrier();
-    } else {
-      fw_barrier();
-      fw_barrier();
-      hand_over();
-      fw_barrier();
+      output_item(w, 1, tid);
+      FW_BARRIER();                                                  // the exchange region is the V ring again
+      w = wn;
+      ubase = ubase_next;
     }
-    output_item(1, tid);
   }
-
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
@@ -450,6 +565,10 @@ int icg_fwino_run(const float* x, int in_up, const float* Uf, const float* bias,
                   unsigned flags, float alpha, int np, float* V, void* stream) {
   static const bool no_swz = [] { const char* e = getenv("ICG_NO_XCD_SWIZZLE"); return e && e[0] == '1'; }();
   FwinoP p;
+  p.trace = nullptr;
+#if FWINO_TRACE
+  if (const char* e = getenv("ICG_FWINO_TRACE_PTR")) p.trace = (unsigned long long*)strtoull(e, nullptr, 0);
+#endif
   p.x = x; p.Uf = Uf; p.bias = bias; p.res = residual; p.out = out; p.scale = scale; p.shift = shift; p.V = V;
   p.ssb = (long)ssb;
   p.planeV = (long)B * (H / 4) * (W / 4) * Cin;
@@ -460,9 +579,17 @@ int icg_fwino_run(const float* x, int in_up, const float* Uf, const float* bias,
   p.alpha = alpha;
   p.tbw = W / 16; p.tbh = H / 16; p.nblk = Cout / 96;
   p.total = (unsigned)((long)B * p.tbw * p.tbh * p.nblk);
-  p.swz = (p.total >= 16 && !no_swz) ? 1 : 0;
+  // persistent workgroups: one per CU (147 KiB of LDS and 12 x 168 registers each), striding through the work items of its XCD
+  static const int n_cu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n - n % 8;
+  }();
+  unsigned grid = p.total < (unsigned)n_cu ? p.total : (unsigned)n_cu;
+  p.swz = (p.total >= 16 && grid % 8 == 0 && !no_swz) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 g(p.total), blk(768);
+  const dim3 g(grid), blk(768);
   icg_gemm_set_last_variant(5, in_up ? 1 : 0, out_pool ? 1 : 0, np);
   if (in_up) {
     if (np != 5 || out_pool) return ICG_ERR_ARG;

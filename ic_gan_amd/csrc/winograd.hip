@@ -7,6 +7,7 @@
 // Same mathematical result as the direct convolution; rounding differs at the 1e-6 level (fp32 transforms).
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
 #include "icg_common.h"
+#include <stdlib.h>
 #include <vector>
 #include <atomic>
 #include <mutex>
@@ -779,7 +780,10 @@ static int wino4_run(const float* x, int in_up, const float* U, const float* bia
   float* V = (float*)workspace;
   float* Mb = V + (long)np * np * T * Cin;
   const bool keep_v = (flags & ICG_WINO_KEEP_V) != 0;
-  if (icg_fwino_applies(B, H, W, Cin, Cout) && (!keep_v || (double)np * np * T * Cin * 4.0 < 4294967296.0)) {
+  // (measured, tools/fwino_bench.py -> profiles/r04_fwino_microbench.txt: the fused kernel wins 1.2 - 1.6x everywhere except the
+  // 25-plane forms at 192 -> 192 channels: 1.01x / 0.90x, left on the composite)
+  const bool fused_wins = !(np == 5 && Cin == 192 && Cout == 192) || getenv("ICG_FWINO_ALL");
+  if (fused_wins && icg_fwino_applies(B, H, W, Cin, Cout) && (!keep_v || (double)np * np * T * Cin * 4.0 < 4294967296.0)) {
     // narrow layer: one fused kernel (fwino.hip).  The fragment-major copy of U goes behind the (unused) M region
     // (fwino_ws_extra); V is written only when the caller keeps it for the weight gradient.
     float* Uf = Mb + (long)np * np * T * Cout;

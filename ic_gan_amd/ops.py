@@ -278,7 +278,15 @@ def winograd_applies(cin, cout, h, w, batch):
 # wgrad 1.2 / 1.9 / 2.1 / 2.2 / 2.0x;  pool-fused fprop 0.7 / 1.1 / 1.6 / 1.9 / 2.2x, dgrad 0.9 / 1.3 / 1.7 / 2.1 / 2.3x, wgrad 0.7 / 1.05 / 1.6 / 1.8 / 2.1x
 # round 3, against the second-generation kernels (profiles/r03_rs_winograd_thresholds.txt): upsample-fused 192 -> 96 @256: fprop 1.39x, dgrad 1.13x,
 # wgrad 1.42x; pool-fused 96 -> 96 @256: 0.97 / 1.05 / 0.98x (stays on the 4x4-stride-2 form), 192 -> 192 @128: 1.49 / 1.51 / 1.37x
-RS_WINOGRAD_MIN_CHANNELS = {True: (96, 96, 96), False: (192, 192, 192)}       # upsample?: (fprop, dgrad, wgrad)
+# round 4: with the fused narrow-layer kernel (csrc/fwino.hip) behind the same entry points the pool-fused 96 -> 96 @256 layer runs
+# 1.26x faster in the 25-plane domain than on the 4x4-stride-2 form (profiles/r04_fwino_microbench.txt): forward and data gradient
+# from 96 channels; its weight gradient stays on the direct kernel (no V planes are kept for it)
+RS_WINOGRAD_MIN_CHANNELS = {True: (96, 96, 96), False: (96, 96, 192)}         # upsample?: (fprop, dgrad, wgrad)
+
+
+def fwino_applies(B, H, W, Cin, Cout) -> bool:
+    """does the fused F(4x4,3x3) kernel take this layer (H, W: its full resolution)?  (icg_fwino_applies, csrc/fwino.hip)"""
+    return bool(L.query("icg_fwino_applies", B, H, W, Cin, Cout))
 
 
 def resample_winograd_applies(cin, cout, h, w, batch):
@@ -432,9 +440,13 @@ class FusedConvFn(Function):
             assert res is None, "the upsample-fused path has no residual epilogue (GBlock conv1 has none)"
             nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cin, Cout)
             ws = _bytes(nb, dev)
+            # V planes for the weight gradient: the composite leaves them in the workspace anyway; as a by-product of the fused
+            # kernel the 25-plane V of an upsampled input costs more (+1.4 ms at 192 -> 96 @256) than transforming x again in the
+            # backward pass (1.0 ms), so it is not kept there
+            keep_up = bool(keep_v and sn.rs[2] and not fwino_applies(B, H, W, Cin, Cout))
             L.call("icg_conv2d_up_wino_fprop", x, sn.w_wino, bias, out, scale, shift, ssb, B, Hs, Ws, Cin, Cout,
-                   (flags & ~L.ICG_UPSAMPLE2X) | (L.ICG_WINO_KEEP_V if (keep_v and sn.rs[2]) else 0), ws, nb)
-            if keep_v and sn.rs[2]:
+                   (flags & ~L.ICG_UPSAMPLE2X) | (L.ICG_WINO_KEEP_V if keep_up else 0), ws, nb)
+            if keep_up:
                 saved_v = (_saved_v(ws, 25, B, H, W, Cin), 25)
         elif phase:
             # nearest-x2 + 3x3 as 4 phases of 2x2 taps on the source tensor (2.25x fewer MACs)

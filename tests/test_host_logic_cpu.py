@@ -263,7 +263,8 @@ def test_winograd_routing_rules(monkeypatch):
     assert ops.resample_winograd_applies(192, 96, 6, 6, 64) == 0
     assert ops.resample_winograd_directions(192, 96, True) == (True, True, True)       # upsample-fused: fprop / dgrad / wgrad (round 3: dgrad too)
     assert ops.resample_winograd_directions(192, 64, True) == (False, False, False)
-    assert ops.resample_winograd_directions(96, 96, False) == (False, False, False)    # pool-fused pays from 192 channels
+    assert ops.resample_winograd_directions(96, 96, False) == (True, True, False)      # pool-fused: forward / data gradient from 96 channels
+    assert ops.resample_winograd_directions(64, 96, False) == (False, False, False)    # (round 4, fused narrow-layer kernel), weight gradient from 192
     assert ops.resample_winograd_directions(384, 192, False) == (True, True, True)
     # the strict route
     for k in ("WINOGRAD_MIN_CHANNELS", "WINOGRAD2_MIN_CHANNELS", "WINOGRAD4_MIN_CHANNELS", "WINOGRAD4_WGRAD_MIN_CHANNELS",

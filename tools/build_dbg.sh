@@ -26,6 +26,8 @@ for v in "$@"; do
     NOPERSIST) build_variant NOPERSIST -DICG_PLANES_PERSISTENT=0 gemm_conv ;;
     LB3) build_variant LB3 -DICG_PLANES_TN4_MIN_WAVES=3 gemm_conv ;;
     FWA*) build_variant "$v" "-DFWINO_ABLATE=${v#FWA}" fwino ;;      # fused Winograd kernel, ablation bits (csrc/fwino.hip)
+    FWM) build_variant FWM -DFWINO_MASKBITS=1 fwino ;;
+    FWT) build_variant FWT -DFWINO_TRACE=1 fwino ;;                    # ... with barrier timestamps of workgroup 0 (tools/fwino_trace.py)
     *) echo "unknown variant $v"; exit 1 ;;
   esac
 done
