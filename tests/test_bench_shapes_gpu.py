@@ -96,7 +96,7 @@ def test_plain_winograd4_at_bench_shape(B, H, Cin, Cout):
     nb = L.query("icg_conv2d_wino4_workspace_bytes", B, H, H, Cin, Cout)
     ws = _bytes(nb)
     out = torch.empty_like(dy)
-    L.call("icg_conv2d_wino4_fprop", x, U, bias.cuda(), None, out, None, None, 0, B, H, H, Cin, Cout, PRE_RELU, 1.0, ws, nb)
+    L.call("icg_conv2d_wino4_fprop", x, U, bias.cuda(), None, out, None, None, 0, B, H, H, Cin, Cout, PRE_RELU | L.ICG_WINO_KEEP_V, 1.0, ws, nb)   # V is read back below
     v_saved = ws[: 36 * B * (H // 4) * (H // 4) * Cin * 4].view(torch.float32)
     # data gradient = the same entry on dy with the dgrad-layout weights
     nbd = L.query("icg_conv2d_wino4_workspace_bytes", B, H, H, Cout, Cin)
@@ -142,7 +142,7 @@ def test_upsample_fused_25plane_at_bench_shape(B, Hs, Cin, Cout):
     nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, H, Cin, Cout)
     ws = _bytes(nb)
     out = torch.empty_like(dy)
-    L.call("icg_conv2d_up_wino_fprop", x, U, bias.cuda(), out, sc.cuda(), sh.cuda(), Cin, B, Hs, Hs, Cin, Cout, flags, ws, nb)
+    L.call("icg_conv2d_up_wino_fprop", x, U, bias.cuda(), out, sc.cuda(), sh.cuda(), Cin, B, Hs, Hs, Cin, Cout, flags | L.ICG_WINO_KEEP_V, ws, nb)
     v_saved = ws[: 25 * B * (H // 4) * (H // 4) * Cin * 4].view(torch.float32)
     nbd = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, H, Cout, Cin)
     da = torch.empty_like(x)
@@ -183,7 +183,7 @@ def test_avgpool_fused_25plane_at_bench_shape():
     nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, H, Cin, Cout)
     ws = _bytes(nb)
     out = torch.empty_like(dy)
-    L.call("icg_conv2d_down_wino_fprop", x, U, bias.cuda(), res, out, B, Hp, Hp, Cin, Cout, PRE_RELU, ws, nb)
+    L.call("icg_conv2d_down_wino_fprop", x, U, bias.cuda(), res, out, B, Hp, Hp, Cin, Cout, PRE_RELU | L.ICG_WINO_KEEP_V, ws, nb)
     v_saved = ws[: 25 * B * (H // 4) * (H // 4) * Cin * 4].view(torch.float32)
     nbd = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, H, Cout, Cin)
     da = torch.empty_like(x)

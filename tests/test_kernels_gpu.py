@@ -412,7 +412,7 @@ def test_conv2d_winograd4_wgrad_from_saved_v(case, kind):
         nb = L.query("icg_conv2d_wino4_workspace_bytes", B, H, W, Cin, Cout)
         ws = torch.zeros(nb, dtype=torch.uint8)
         out = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
-        pairs = run_pair("icg_conv2d_wino4_fprop", [x, U, bias, None, out, None, None, 0, B, H, W, Cin, Cout, flags, 1.0, ws, nb], [15])
+        pairs = run_pair("icg_conv2d_wino4_fprop", [x, U, bias, None, out, None, None, 0, B, H, W, Cin, Cout, flags | 32, 1.0, ws, nb], [15])    # 32: ICG_WINO_KEEP_V
         dy = cl(B, Cout, H, W, seed=11)
         ref_args = ("icg_conv2d_wino4_wgrad", [x, dy, None, None, None, 0, B, H, W, Cin, Cout, flags, None, 0])
         dy_up, alpha = 0, 1.0
@@ -421,7 +421,7 @@ def test_conv2d_winograd4_wgrad_from_saved_v(case, kind):
         nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cin, Cout)
         ws = torch.zeros(nb, dtype=torch.uint8)
         out = torch.empty(B, Cout, H, W).contiguous(memory_format=torch.channels_last)
-        pairs = run_pair("icg_conv2d_up_wino_fprop", [x, U25, bias, out, None, None, 0, B, Hl, Wl, Cin, Cout, flags, ws, nb], [13])
+        pairs = run_pair("icg_conv2d_up_wino_fprop", [x, U25, bias, out, None, None, 0, B, Hl, Wl, Cin, Cout, flags | 32, ws, nb], [13])
         dy = cl(B, Cout, H, W, seed=11)
         ref_args = ("icg_conv2d_up_wino_wgrad", [x, dy, None, None, None, 0, B, Hl, Wl, Cin, Cout, flags, None, 0])
         dy_up, alpha = 0, 1.0
@@ -430,7 +430,7 @@ def test_conv2d_winograd4_wgrad_from_saved_v(case, kind):
         nb = L.query("icg_conv2d_rs_wino_workspace_bytes", B, H, W, Cin, Cout)
         ws = torch.zeros(nb, dtype=torch.uint8)
         out = torch.empty(B, Cout, Hl, Wl).contiguous(memory_format=torch.channels_last)
-        pairs = run_pair("icg_conv2d_down_wino_fprop", [x, U25, bias, None, out, B, Hl, Wl, Cin, Cout, flags, ws, nb], [11])
+        pairs = run_pair("icg_conv2d_down_wino_fprop", [x, U25, bias, None, out, B, Hl, Wl, Cin, Cout, flags | 32, ws, nb], [11])
         dy = cl(B, Cout, Hl, Wl, seed=11)
         ref_args = ("icg_conv2d_down_wino_wgrad", [x, dy, None, B, Hl, Wl, Cin, Cout, flags, None, 0])
         dy_up, alpha = 1, 0.25
