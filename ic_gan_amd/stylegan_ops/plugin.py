@@ -61,9 +61,19 @@ def _ptr(t):
     return t if t.numel() else None
 
 
+def _on_device(t) -> bool:
+    """`x must reside on CUDA device` (bias_act.cpp:38, upfirdn2d.cpp:22).  A seam of its own so that the CPU binding test
+    (tests/test_reference_binding_cpu.py: the reference's own callers over this module, kernels emulated) can lift it."""
+    return t.is_cuda
+
+
+def _device_of(t):
+    return torch.cuda.device(t.device)
+
+
 def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
     """y = clamp(gain * act(x + b[dim])) (grad = 0), its first (1) or second (2) derivative pass — bias_act.cu:26-150."""
-    _check(x.is_cuda, "x must reside on CUDA device")
+    _check(_on_device(x), "x must reside on CUDA device")
     _check(b.numel() == 0 or (b.dtype == x.dtype and b.device == x.device), "b must have the same dtype and device as x")
     for name, t in (("xref", xref), ("yref", yref)):
         _check(t.numel() == 0 or (t.shape == x.shape and t.dtype == x.dtype and t.device == x.device),
@@ -86,7 +96,7 @@ def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
     if x.numel() == 0:
         return y
     step_b = int(x.stride(dim)) if b.numel() else 1
-    with torch.cuda.device(x.device):
+    with _device_of(x):
         L.call("icg_bias_act_typed", x, _ptr(b), _ptr(xref), _ptr(yref), _ptr(dy), y, x.numel(), step_b,
                max(int(b.numel()), 1), int(grad), int(act), float(alpha), float(gain), float(clamp), _DTYPES[x.dtype])
     return y
@@ -94,7 +104,7 @@ def bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp):
 
 def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain):
     """zero-insert upsample -> pad / crop -> 2-D FIR -> decimate -> gain, per channel — upfirdn2d.cu:32-203."""
-    _check(x.is_cuda, "x must reside on CUDA device")
+    _check(_on_device(x), "x must reside on CUDA device")
     _check(f.device == x.device, "f must reside on the same device as x")
     _check(f.dtype == torch.float32, "f must be float32")
     _check(x.numel() <= _INT_MAX, "x is too large")
@@ -119,7 +129,7 @@ def upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, ga
     y = torch.empty((n, c, out_h, out_w), device=x.device, dtype=x.dtype,
                     memory_format=torch.channels_last if cl else torch.contiguous_format)
     _check(y.numel() <= _INT_MAX, "output is too large")
-    with torch.cuda.device(x.device):
+    with _device_of(x):
         L.call("icg_upfirdn2d_typed", x, f.contiguous(), y, n, c, h, w, fh, fw, int(upx), int(upy), int(downx), int(downy),
                int(padx0), int(padx1), int(pady0), int(pady1), int(bool(flip)), float(gain), out_h, out_w, _DTYPES[x.dtype],
                int(cl))
