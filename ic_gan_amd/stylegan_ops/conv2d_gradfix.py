@@ -106,7 +106,9 @@ class _GatherConv(torch.autograd.Function):
             return y
         if half:      # shapes the fp16 kernel does not serve: exact-fp32 kernel between two casts (layout glue)
             return _GatherConv._forward_f32(_ops._cl(x), w.float().contiguous(), geo).to(torch.float16)
-        return _GatherConv._forward_f32(_ops._cl(x), w.contiguous(), geo)
+        # the fp32 kernels read raw fp32 buffers: both operands are normalised here (an fp16 weight next to fp32 activations would
+        # otherwise be reinterpreted); fp64 operands are computed in fp32
+        return _GatherConv._forward_f32(_ops._cl(x), w.float().contiguous(), geo)
 
     @staticmethod
     def _forward_f32(x, w, geo):
@@ -226,6 +228,9 @@ class _Matmul(torch.autograd.Function):
         _ops._require_gpu(a)
         ctx.mode = mode
         ctx.save_for_backward(a, b)
+        ctx.out_dtype = torch.promote_types(a.dtype, b.dtype)      # the reference's addmm / matmul return the operands' dtype
+        if ctx.out_dtype == torch.float64:
+            raise TypeError("linear_nt / _Matmul: fp64 operands are not supported on this path (fp32 GEMM)")
         a, b = a.contiguous().float(), b.contiguous().float()
         if mode == 1 and a.shape[0] <= 32 and a.shape[1] >= 128:
             # a handful of rows (batch 16): the row-streaming kernel behind mode 0 (gemm_conv.hip: smallm_nt_kernel) wants K contiguous
@@ -242,7 +247,7 @@ class _Matmul(torch.autograd.Function):
             assert b.shape == (k, n)
         c = torch.empty(m, n, device=a.device, dtype=torch.float32)
         L.call("icg_gemm_batched", a, b, c, m, n, k, 1 if mode == 2 else 0, 1 if mode == 0 else 0, 0, 0, 0, 1, 1.0)
-        return c
+        return c if ctx.out_dtype == torch.float32 else c.to(ctx.out_dtype)
 
     @staticmethod
     def backward(ctx, dc):

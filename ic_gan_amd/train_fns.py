@@ -18,7 +18,13 @@ the reference's pattern):
       could ship the 100 M unused parameters (400 MB per step at cfg3); torch 2.10's does not (no autograd hook of the wrapper
       fires, so nothing is marked ready) -- measured by tests/test_ddp_gloo_cpu.py with a counting communication hook -- and the
       explicit no_sync() keeps it that way independently of the reducer's internals.
-Neither changes a result: same losses, replicas bit-identical, bucket traffic counted in the tests.
+Neither changes a loss or a parameter: same losses, parameters of the replicas bit-identical, bucket traffic counted in the tests.
+Side effect on BUFFERS: DistributedDataParallel broadcasts rank 0's buffers (BN running statistics, the spectral-norm `u` /
+`sv`) at the start of a forward only when the previous forward was a synchronising one (`require_forward_param_sync`), so under
+(1) and (2) the replicas' buffers are re-aligned less often than in the reference: between two such broadcasts every rank
+advances its own running statistics / power iteration from its own shard.  Training does not read another rank's buffers; before
+anything that does -- evaluation or a checkpoint written from a rank other than 0 -- call `utils.sync_buffers(module)` (an
+explicit rank-0 broadcast; tests/test_ddp_gloo_cpu.py::test_ddp_buffers_after_accumulation).
 """
 from __future__ import annotations
 

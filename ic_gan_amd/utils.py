@@ -128,3 +128,16 @@ def load_weights(G, D, state_dict, weights_root, experiment_name, name_suffix=No
         print("No values to load")
     if G_ema is not None:
         G_ema.load_state_dict(load("G_ema"), strict=strict)
+
+
+def sync_buffers(module, src: int = 0):
+    """Broadcast `src`'s buffers (BN running statistics, spectral-norm u / sv) to every rank -- what DistributedDataParallel does
+    before a synchronising forward (trainer.py:196-210 wraps with broadcast_buffers on).  For use before evaluation or a
+    checkpoint on ranks other than `src` when the step ran with train_fns.COMM_SAVINGS (forwards under no_sync() skip DDP's own
+    broadcast).  No-op without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    m = module.module if hasattr(module, "module") and hasattr(module, "no_sync") else module
+    for b in m.buffers():
+        dist.broadcast(b, src)

@@ -97,7 +97,16 @@ def _worker_step(rank, world, port, out, savings=True, accumulations=1):
     flat = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
+    bufs = lambda: torch.cat([b.detach().reshape(-1).float() for b in list(G.buffers()) + list(D.buffers())])
+    bg = [torch.empty_like(bufs()) for _ in range(world)]
+    dist.all_gather(bg, bufs())
+    utils.sync_buffers(Gd); utils.sync_buffers(Dd)                  # the explicit rank-0 broadcast (train_fns docstring)
+    bs = [torch.empty_like(bufs()) for _ in range(world)]
+    dist.all_gather(bs, bufs())
     if rank == 0:
+        out["buffers_identical_after_step"] = all(bool(torch.equal(bg[0], g)) for g in bg[1:])
+        out["buffers_identical_after_sync"] = all(bool(torch.equal(bs[0], g)) for g in bs[1:])
+        out["buffers_rank0_unchanged_by_sync"] = bool(torch.equal(bs[0], bg[0]))
         out["identical"] = all(bool(torch.equal(gathered[0], g)) for g in gathered[1:])
         out["finite"] = bool(torch.isfinite(flat).all())
         out["loss"] = m
@@ -188,6 +197,17 @@ def test_ddp_accumulation_allreduces_once_per_phase():
 
 
 @pytest.mark.timeout(900)
+def test_ddp_buffers_after_accumulation():
+    """COMM_SAVINGS runs D in the G phase and the early accumulation rounds under no_sync(): DDP then skips its rank-0 buffer
+    broadcast at the next forward, so after a step the replicas' BUFFERS (running statistics, u / sv: each rank's own shard) may
+    differ although every parameter is bit-identical; utils.sync_buffers re-aligns them on rank 0's values."""
+    out = _spawn(_worker_step, True, 2)
+    assert out["identical"] and out["finite"]
+    assert out["buffers_identical_after_sync"] and out["buffers_rank0_unchanged_by_sync"]
+    ref = _spawn(_worker_step, False, 2)           # the reference pattern: every forward synchronises
+    assert ref["identical"] and ref["buffers_identical_after_sync"]
+
+
 def test_ddp_step_world_size_4():
     out = _spawn(_worker_step, True, 1, world=4)
     assert out["finite"] and out["identical"], out
