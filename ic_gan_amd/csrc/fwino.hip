@@ -293,7 +293,7 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
     const unsigned WxK = (unsigned)(Wx * K);
     // LDS position of a lane's pair inside a plane's 2 KiB: [sg][kq*16 + (tile ^ (kq + 4 sg))][s4], channel = 16 sg + 4 kq + s4
 
-    f32x2 d[NL][NL];
+    f32x2 d[NL][NL], d_sc = fw2(1.f), d_sh = fw2(0.f);
     Item cur = decode(first);                                        // item whose chunks are being loaded / transformed
     auto load_chunk = [&](const Item& w, int ck) {
       int cp = pl & 15, ti = pl >> 4;
@@ -311,6 +311,12 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
 #pragma unroll
         for (int s = 0; s < NL; ++s) d[r][s] = *reinterpret_cast<const f32x2*>(xc + ro + coloff[s]);
       }
+      // the chunk's BN scale / shift travel with the window: issued at the start of the transform their full latency
+      // (~11 000 clocks under the weight stream, tools/fwino_trace.py) would sit in front of the first multiply
+      if (p.affine) {
+        d_sc = *reinterpret_cast<const f32x2*>(p.scale + (long)w.b * p.ssb + 32 * ck + 2 * cp);
+        d_sh = *reinterpret_cast<const f32x2*>(p.shift + (long)w.b * p.ssb + 32 * ck + 2 * cp);
+      }
     };
     auto transform_chunk = [&](const Item& w, int ck, unsigned vb) {
       int cp = pl & 15, ti = pl >> 4;
@@ -319,11 +325,9 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
       const unsigned wpos0 = (unsigned)((sg * 64 + kq * 16 + (ti ^ (kq + 4 * sg))) * 16 + (cp & 1) * 8);
       const int txg = 4 * w.bx + (ti & 3), tyg = 4 * w.by + (ti >> 2);
       const int w0 = UP ? 2 * txg - 1 : 4 * txg - 1, h0 = UP ? 2 * tyg - 1 : 4 * tyg - 1;
-      f32x2 sc = fw2(1.f), sh = fw2(0.f);
-      if (p.affine) {
-        sc = *reinterpret_cast<const f32x2*>(p.scale + (long)w.b * p.ssb + 32 * ck + 2 * cp);
-        sh = *reinterpret_cast<const f32x2*>(p.shift + (long)w.b * p.ssb + 32 * ck + 2 * cp);
-      }
+      const f32x2 sc = d_sc, sh = d_sh;
+      // tile blocks off the image border need no zero-padding masks (workgroup-uniform; 144 of ~500 producer instructions)
+      const bool interior = w.bx > 0 && w.bx < p.tbw - 1 && w.by > 0 && w.by < p.tbh - 1;
       FW_MARK();
       // row pass, in place where the window is 6 wide (d[r][.] <- (d[r][.] B): the inputs are dead once their row is transformed);
       // the 4-wide upsampled window expands to 6 components and gets its own array
@@ -338,14 +342,7 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
           f32x2 v = d[r][s];
           if (p.affine) v = __builtin_elementwise_fma(v, sc, sh);
           if (p.relu) v = f32x2{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)};
-#if FWINO_MASKBITS
-          // zero padding as a bit mask (a select here becomes a divergent branch around the whole row)
-          const unsigned okm = 0u - (unsigned)(rok & ((unsigned)(w0 + s) < (unsigned)Wx));
-          row[s] = f32x2{__builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.x) & okm),
-                         __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.y) & okm)};
-#else
-          row[s] = (rok && (unsigned)(w0 + s) < (unsigned)Wx) ? v : fw2(0.f);
-#endif
+          row[s] = (interior || (rok && (unsigned)(w0 + s) < (unsigned)Wx)) ? v : fw2(0.f);
         }
         if constexpr (UP) {
           fw_in_up(row, t6);
