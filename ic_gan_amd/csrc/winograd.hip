@@ -780,9 +780,9 @@ static int wino4_run(const float* x, int in_up, const float* U, const float* bia
   float* V = (float*)workspace;
   float* Mb = V + (long)np * np * T * Cin;
   const bool keep_v = (flags & ICG_WINO_KEEP_V) != 0;
-  // (measured, tools/fwino_bench.py -> profiles/r04_fwino_microbench.txt: the fused kernel wins 1.2 - 1.6x everywhere except the
-  // 25-plane forms at 192 -> 192 channels: 1.01x / 0.90x, left on the composite)
-  const bool fused_wins = !(np == 5 && Cin == 192 && Cout == 192) || getenv("ICG_FWINO_ALL");
+  // (measured, tools/fwino_bench.py -> profiles/r04_fwino_microbench.txt: the fused kernel wins 1.1 - 1.7x everywhere except the
+  // upsample-on-read 25-plane form at 192 -> 192 channels (the data gradient of DBlock 1's pooled conv2): 0.94x, left on the composite)
+  const bool fused_wins = !(np == 5 && in_up && Cin == 192 && Cout == 192) || getenv("ICG_FWINO_ALL");
   if (fused_wins && icg_fwino_applies(B, H, W, Cin, Cout) && (!keep_v || (double)np * np * T * Cin * 4.0 < 4294967296.0)) {
     // narrow layer: one fused kernel (fwino.hip).  The fragment-major copy of U goes behind the (unused) M region
     // (fwino_ws_extra); V is written only when the caller keeps it for the weight gradient.
