@@ -29,6 +29,13 @@ static inline int icg_res_mode(unsigned flags) {
 
 static inline int64_t icg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Launch geometry of the streaming kernels (transforms, elementwise, bias_act / upfirdn2d): a FULL grid -- one block-iteration per
+// workgroup -- up to 2^22 workgroups.  Hand-written copies (tools/hbm_copy.hip, tools/hbm_bench.py) stream at 6.35 TB/s that way on
+// MI355X and at 4.8 - 5.5 TB/s as grid-stride loops over 2048 - 8192 workgroups; the kernels keep their loops for larger problems.
+#ifndef ICG_GRID_CAP
+#define ICG_GRID_CAP (1L << 22)
+#endif
+
 // 64-wide wavefront reductions (gfx950: wave = 64 lanes)
 // Ordering point for LDS data exchanged between the lanes of ONE wavefront (wave-private LDS regions): tells the compiler that
 // the LDS stores before it are visible to the LDS loads after it.  A wave executes in lockstep and the LDS queue is in order

@@ -5,7 +5,9 @@
 // Everything is NHWC fp32; kernels are grid-stride with 16-byte-per-lane accesses where C % 4 == 0.
 #include "icg_common.h"
 
-#define GRID_1D(n, per) ((unsigned)(icg_cdiv((n), (per)) > 4096 ? 4096 : (icg_cdiv((n), (per)) < 1 ? 1 : icg_cdiv((n), (per)))))
+// a FULL grid (one block-iteration per workgroup) up to 2^22 workgroups: measured with hand-written copies (tools/hbm_bench.py) a
+// one-iteration grid streams at 6.35 TB/s on MI355X, grid-stride loops over 2048 - 8192 workgroups at 4.8 - 5.5
+#define GRID_1D(n, per) ((unsigned)(icg_cdiv((n), (per)) > ICG_GRID_CAP ? ICG_GRID_CAP : (icg_cdiv((n), (per)) < 1 ? 1 : icg_cdiv((n), (per)))))
 
 // ---------------------------------------------------------------- batched transpose  [b][R][S] -> [b][S][R]
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int R,
@@ -48,29 +50,52 @@ extern "C" int icg_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, i
 
 // ---------------------------------------------------------------- elementwise
 template <int OP>
+__device__ __forceinline__ float4 ew_apply(const float4 va, const float4 vb) {
+  float4 o;
+  if (OP == 0) {  // tanh
+    o.x = tanhf(va.x); o.y = tanhf(va.y); o.z = tanhf(va.z); o.w = tanhf(va.w);
+  } else if (OP == 1) {  // tanh bwd: a = y, b = dy
+    o.x = vb.x * (1.f - va.x * va.x); o.y = vb.y * (1.f - va.y * va.y);
+    o.z = vb.z * (1.f - va.z * va.z); o.w = vb.w * (1.f - va.w * va.w);
+  } else if (OP == 2) {  // relu bwd: a = x, b = dy
+    o.x = va.x > 0.f ? vb.x : 0.f; o.y = va.y > 0.f ? vb.y : 0.f;
+    o.z = va.z > 0.f ? vb.z : 0.f; o.w = va.w > 0.f ? vb.w : 0.f;
+  } else if (OP == 3) {  // relu
+    o.x = fmaxf(va.x, 0.f); o.y = fmaxf(va.y, 0.f); o.z = fmaxf(va.z, 0.f); o.w = fmaxf(va.w, 0.f);
+  } else {  // add
+    o.x = va.x + vb.x; o.y = va.y + vb.y; o.z = va.z + vb.z; o.w = va.w + vb.w;
+  }
+  return o;
+}
+
+// EW_U float4 per thread and block-iteration, every load of the iteration issued before the first store: one 16-byte load per
+// thread in flight (the round-1 form) keeps ~32 KB per CU on the wire, short of what 6 TB/s x ~2 us of latency needs
+// (tools/hbm_bench.py: hand-written copies x1 / x4)
+#define EW_U 4
+template <int OP>
 __global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                  float* __restrict__ y, long n) {
   const long stride = (long)gridDim.x * blockDim.x;
   const long n4 = n >> 2;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const float4 va = reinterpret_cast<const float4*>(a)[i];
-    float4 vb = make_float4(0, 0, 0, 0);
-    if (OP != 0 && OP != 3) vb = reinterpret_cast<const float4*>(b)[i];
-    float4 o;
-    if (OP == 0) {  // tanh
-      o.x = tanhf(va.x); o.y = tanhf(va.y); o.z = tanhf(va.z); o.w = tanhf(va.w);
-    } else if (OP == 1) {  // tanh bwd: a = y, b = dy
-      o.x = vb.x * (1.f - va.x * va.x); o.y = vb.y * (1.f - va.y * va.y);
-      o.z = vb.z * (1.f - va.z * va.z); o.w = vb.w * (1.f - va.w * va.w);
-    } else if (OP == 2) {  // relu bwd: a = x, b = dy
-      o.x = va.x > 0.f ? vb.x : 0.f; o.y = va.y > 0.f ? vb.y : 0.f;
-      o.z = va.z > 0.f ? vb.z : 0.f; o.w = va.w > 0.f ? vb.w : 0.f;
-    } else if (OP == 3) {  // relu
-      o.x = fmaxf(va.x, 0.f); o.y = fmaxf(va.y, 0.f); o.z = fmaxf(va.z, 0.f); o.w = fmaxf(va.w, 0.f);
-    } else {  // add
-      o.x = va.x + vb.x; o.y = va.y + vb.y; o.z = va.z + vb.z; o.w = va.w + vb.w;
+  const long step = stride * EW_U;
+  long base = (long)blockIdx.x * blockDim.x * EW_U + threadIdx.x;
+  for (; base + (long)(EW_U - 1) * 256 < n4; base += step) {
+    float4 va[EW_U], vb[EW_U];
+#pragma unroll
+    for (int u = 0; u < EW_U; ++u) {
+      va[u] = reinterpret_cast<const float4*>(a)[base + u * 256];
+      vb[u] = (OP != 0 && OP != 3) ? reinterpret_cast<const float4*>(b)[base + u * 256] : make_float4(0, 0, 0, 0);
     }
-    reinterpret_cast<float4*>(y)[i] = o;
+#pragma unroll
+    for (int u = 0; u < EW_U; ++u) reinterpret_cast<float4*>(y)[base + u * 256] = ew_apply<OP>(va[u], vb[u]);
+  }
+  for (int u = 0; u < EW_U; ++u) {          // ragged end of the float4 range
+    const long i = base + u * 256;
+    if (i < n4) {
+      const float4 va = reinterpret_cast<const float4*>(a)[i];
+      const float4 vb = (OP != 0 && OP != 3) ? reinterpret_cast<const float4*>(b)[i] : make_float4(0, 0, 0, 0);
+      reinterpret_cast<float4*>(y)[i] = ew_apply<OP>(va, vb);
+    }
   }
   // tail
   for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -91,7 +116,7 @@ static int launch_ew(const float* a, const float* b, float* y, int64_t n, void* 
   if (!a || !y || n <= 0) return ICG_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b)) & 15)
     return ICG_ERR_ARG;
-  hipLaunchKernelGGL(ew_kernel<OP>, dim3(GRID_1D(n, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long)n);
+  hipLaunchKernelGGL(ew_kernel<OP>, dim3(GRID_1D(n, 1024 * EW_U)), dim3(256), 0, (hipStream_t)stream, a, b, y, (long)n);
   return icg_check_launch();
 }
 
@@ -301,7 +326,7 @@ static bool softmax_reg_ok(const void* a, const void* b, const void* c, int cols
 extern "C" int icg_softmax_fwd(const float* x, float* y, int64_t rows, int cols, void* stream) {
   ICG_REQUIRE(x && y && rows > 0 && cols > 0);
   long blocks = icg_cdiv(rows, 4);
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > ICG_GRID_CAP) blocks = ICG_GRID_CAP;
   if (softmax_reg_ok(x, y, nullptr, cols)) {
     const dim3 grid((unsigned)blocks), blk(256);
     hipStream_t st = (hipStream_t)stream;
@@ -320,7 +345,7 @@ extern "C" int icg_softmax_fwd(const float* x, float* y, int64_t rows, int cols,
 extern "C" int icg_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int cols, void* stream) {
   ICG_REQUIRE(y && dy && dx && rows > 0 && cols > 0);
   long blocks = icg_cdiv(rows, 4);
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > ICG_GRID_CAP) blocks = ICG_GRID_CAP;
   if (softmax_reg_ok(y, dy, dx, cols)) {
     const dim3 grid((unsigned)blocks), blk(256);
     hipStream_t st = (hipStream_t)stream;

@@ -192,7 +192,7 @@ extern "C" int icg_bias_act(const float* x, const float* b, const float* xref, c
     return icg_check_launch();
   }
   long blocks = icg_cdiv(n, 1024);
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > ICG_GRID_CAP) blocks = ICG_GRID_CAP;
   hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, b, xref, yref, dy,
                      y, (long)n, (long)step_b, size_b, grad, act, alpha, gain, clamp);
   return icg_check_launch();
@@ -368,7 +368,7 @@ extern "C" int icg_upfirdn2d_nhwc(const float* x, const float* f, float* y, int 
   constexpr int TY = 4;
   const long total = (long)N * ((outH + TY - 1) / TY) * outW * (C / 4);
   long blocks = icg_cdiv(total, 256);
-  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (blocks > ICG_GRID_CAP) blocks = ICG_GRID_CAP;
   if (fh == 4 && fw == 4 && upx == 1 && upy == 1 && downx == downy && (downx == 1 || downx == 2)) {
     if (downx == 1)
       hipLaunchKernelGGL((upfirdn2d_nhwc_f4_kernel<1, TY>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, f,
@@ -450,7 +450,7 @@ extern "C" int icg_upfirdn2d(const float* x, const float* f, float* y, int N, in
     constexpr int TY = 4;
     const long tot = (long)N * C * ((outH + TY - 1) / TY) * outW;
     long nb = icg_cdiv(tot, 256);
-    if (nb > 256 * 32) nb = 256 * 32;
+    if (nb > ICG_GRID_CAP) nb = ICG_GRID_CAP;
     if (downx == 1)
       hipLaunchKernelGGL((upfirdn2d_nchw_f4_kernel<1, TY>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, f, y,
                          N * C, H, W, padx0, pady0, flip, gain, outH, outW);
@@ -461,7 +461,7 @@ extern "C" int icg_upfirdn2d(const float* x, const float* f, float* y, int N, in
   }
   const long total = (long)N * C * outH * outW;
   long blocks = icg_cdiv(total, 256);
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > ICG_GRID_CAP) blocks = ICG_GRID_CAP;
   hipLaunchKernelGGL(upfirdn2d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, f, y, N * C, H, W,
                      fh, fw, upx, upy, downx, downy, padx0, pady0, flip, gain, outH, outW);
   return icg_check_launch();

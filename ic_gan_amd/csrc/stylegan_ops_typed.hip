@@ -201,7 +201,7 @@ static int launch_bias_act_typed(const void* x, const void* b, const void* xref,
   else if (step_b == 1 && size_b % VEC == 0 && t_al16(b)) bmode = 2;
   if (!vec || bmode < 0) {       // general form, one element per thread
     long blocks = icg_cdiv((long)n, 256);
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > ICG_GRID_CAP) blocks = ICG_GRID_CAP;
     if (b)
       hipLaunchKernelGGL((bias_act_typed_kernel<T, 1, 3>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (const T*)b,
                          (const T*)xref, (const T*)yref, (const T*)dy, (T*)y, (long)n, (long)step_b, size_b, grad, act, alpha,
@@ -213,7 +213,7 @@ static int launch_bias_act_typed(const void* x, const void* b, const void* xref,
   }
   const long npack = n / VEC;
   long blocks = icg_cdiv(npack, 256);
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks > ICG_GRID_CAP) blocks = ICG_GRID_CAP;
 #define ICG_TBA(BM)                                                                                                       \
   hipLaunchKernelGGL((bias_act_typed_kernel<T, VEC, BM>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (const T*)b, \
                      (const T*)xref, (const T*)yref, (const T*)dy, (T*)y, npack, (long)(BM == 1 ? step_b / VEC : 1), size_b,  \
@@ -347,14 +347,14 @@ static int launch_upfirdn2d_typed(const void* x, const float* f, void* y, int N,
     constexpr int TY = 4;
     const long total = (long)N * ((outH + TY - 1) / TY) * outW * (C / VEC);
     long blocks = icg_cdiv(total, 256);
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks > ICG_GRID_CAP) blocks = ICG_GRID_CAP;
     hipLaunchKernelGGL((upfirdn2d_nhwc_typed_kernel<T, VEC, TY>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, f, (T*)y,
                        N, H, W, C / VEC, fh, fw, upx, upy, downx, downy, padx0, pady0, flip, gain, outH, outW);
     return icg_check_launch();
   }
   const long total = (long)N * C * outH * outW;
   long blocks = icg_cdiv(total, 256);
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > ICG_GRID_CAP) blocks = ICG_GRID_CAP;
   hipLaunchKernelGGL((upfirdn2d_typed_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, f, (T*)y, N * C, H, W, fh,
                      fw, upx, upy, downx, downy, padx0, pady0, flip, gain, outH, outW);
   return icg_check_launch();

@@ -378,11 +378,11 @@ extern "C" int icg_conv2d_wino_wgrad(const float* x, const float* dy, float* dw,
   void* gws = base;
   const size_t gws_bytes = icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)T, 16);
   long nb = icg_cdiv(T * (Cin / 4), 256);
-  if (nb > 256 * 64) nb = 256 * 64;
+  if (nb > ICG_GRID_CAP) nb = ICG_GRID_CAP;
   hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, (long)ss_bstride, V, B, H, W,
                      Cin / 4, (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0);
   nb = icg_cdiv(T * (Cout / 4), 256);
-  if (nb > 256 * 64) nb = 256 * 64;
+  if (nb > ICG_GRID_CAP) nb = ICG_GRID_CAP;
   hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, DY, B, H, W, Cout / 4);
   int rc;
   { PlanesScope ps(stream, 16, Cin, Cout, (double)T, 1); rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, 16, gws, gws_bytes, stream); }
@@ -425,14 +425,14 @@ extern "C" int icg_conv2d_wino_fprop(const float* x, const float* U, const float
   float* V = (float*)workspace;
   float* Mb = V + 16 * T * Cin;
   long nb = icg_cdiv(T * (Cin / 4), 256);
-  if (nb > 256 * 64) nb = 256 * 64;
+  if (nb > ICG_GRID_CAP) nb = ICG_GRID_CAP;
   hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, scale, shift, (long)ss_bstride, V, B, H, W,
                      Cin / 4, (flags & ICG_PRE_AFFINE) ? 1 : 0, (flags & ICG_PRE_RELU) ? 1 : 0);
   int rc;
   { PlanesScope ps(stream, 16, (double)T, Cout, Cin); rc = icg_gemm_batched(V, U, Mb, (int)T, Cout, Cin, 0, 1, T * Cin, (long)Cout * Cin, T * Cout, 16, 1.0f, stream); }
   if (rc != ICG_OK) return rc;
   nb = icg_cdiv(T * (Cout / 4), 256);
-  if (nb > 256 * 64) nb = 256 * 64;
+  if (nb > ICG_GRID_CAP) nb = ICG_GRID_CAP;
   hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)Mb, bias, residual,
                      icg_res_mode(flags), alpha, out, B, H, W, Cout / 4);
   return icg_check_launch();
@@ -696,7 +696,7 @@ static void launch_wino4_input(hipStream_t st, int up, int np, const float* x, c
                                float* V, int B, int H, int W, int Cin, unsigned flags) {
   const long T = (long)B * (H / 4) * (W / 4);
   long nb = icg_cdiv(T * (Cin / 4), 256);
-  if (nb > 256 * 64) nb = 256 * 64;
+  if (nb > ICG_GRID_CAP) nb = ICG_GRID_CAP;
   const int aff = (flags & ICG_PRE_AFFINE) ? 1 : 0, relu = (flags & ICG_PRE_RELU) ? 1 : 0;
   const dim3 g((unsigned)nb), blk(256);
   if (up) hipLaunchKernelGGL((wino4_input_kernel<1, 5>), g, blk, 0, st, x, scale, shift, ssb, V, B, H, W, Cin / 4, aff, relu);
@@ -708,7 +708,7 @@ static void launch_wino4_output(hipStream_t st, int pool, int np, const float* M
                                 float alpha, float* y, int B, int H, int W, int Cout) {
   const long T = (long)B * (H / 4) * (W / 4);
   long nb = icg_cdiv(T * (Cout / 4), 256);
-  if (nb > 256 * 64) nb = 256 * 64;
+  if (nb > ICG_GRID_CAP) nb = ICG_GRID_CAP;
   const dim3 g((unsigned)nb), blk(256);
   if (pool) hipLaunchKernelGGL((wino4_output_kernel<1, 5>), g, blk, 0, st, Mb, bias, res, res_up, alpha, y, B, H, W, Cout / 4);
   else if (np == 5) hipLaunchKernelGGL((wino4_output_kernel<0, 5>), g, blk, 0, st, Mb, bias, res, res_up, alpha, y, B, H, W, Cout / 4);
@@ -1036,7 +1036,7 @@ static size_t wino4_wgrad_bytes(int np, int B, int H, int W, int Cin, int Cout) 
 // dU[xi] = V[xi]^T DY[xi], dw = G^T dU G.  H, W: full resolution.
 static long wino4_dy_blocks(long T, int Cout) {
   long nb = icg_cdiv(T * (Cout / 4), 256);
-  return nb > 256 * 64 ? 256 * 64 : nb;
+  return nb > ICG_GRID_CAP ? ICG_GRID_CAP : nb;
 }
 
 static int wino4_wgrad_run(const float* x, int x_up, const float* dy, int dy_up, float dy_alpha, float* dw, const float* scale,

@@ -37,6 +37,27 @@ def main():
     # reference point: device copy
     a = torch.empty(256 << 20, device=dev); b = torch.empty_like(a)
     report("copy (torch) 1 GiB", 2 * a.numel() * 4, ev(lambda: b.copy_(a)))
+    # ... and hand-written float4 copies (tools/hbm_copy.hip): this box's ceiling for a read + write stream and how the access shape
+    # moves it -- U float4 in flight per thread, one block-iteration per workgroup (grid = n / (256 U)) or a grid-stride loop over a
+    # fixed grid, non-temporal hints
+    import ctypes, subprocess
+    so = os.path.join(ROOT, "tools", "hbm_copy.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC",
+                               os.path.join(ROOT, "tools", "hbm_copy.hip"), "-o", so])
+    lib = ctypes.CDLL(so)
+    n4 = a.numel() // 4
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    best = 0.0
+    for name, var, u, byt in (("copy float4 x1", 0, 1, 8), ("copy float4 x2", 1, 2, 8), ("copy float4 x4", 2, 4, 8), ("copy float4 x8", 3, 8, 8),
+                              ("copy float4 x4 non-temporal", 4, 4, 8), ("read-only float4 x4", 5, 4, 4), ("write-only float4 x4", 6, 4, 4)):
+        for grid_name, blocks in (("full grid", (n4 + 256 * u - 1) // (256 * u)), ("2048 blocks", 2048), ("8192 blocks", 8192)):
+            t = ev(lambda: lib.hbm_copy_launch(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), ctypes.c_long(n4), var,
+                                               int(blocks), st()))
+            report(f"{name}, {grid_name}", byt * a.numel(), t)
+            if byt == 8:
+                best = max(best, 4.0 * a.numel() * 2 / t / 1e9)
+    print(f"# copy ceiling of this box: {best:.0f} GB/s = {best / PEAK:.2f} of 8 TB/s", flush=True)
     del a, b
 
     # ---- BigGAN cfg3: largest BN layer [64, 96, 256, 256] ----
