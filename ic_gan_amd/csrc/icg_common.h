@@ -32,9 +32,13 @@ static inline int64_t icg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Launch geometry of the streaming kernels (transforms, elementwise, bias_act / upfirdn2d): a FULL grid -- one block-iteration per
 // workgroup -- up to 2^22 workgroups.  Hand-written copies (tools/hbm_copy.hip, tools/hbm_bench.py) stream at 6.35 TB/s that way on
 // MI355X and at 4.8 - 5.5 TB/s as grid-stride loops over 2048 - 8192 workgroups; the kernels keep their loops for larger problems.
-#ifndef ICG_GRID_CAP
-#define ICG_GRID_CAP (1L << 22)
-#endif
+// (ICG_GRID_CAP in the environment: measurement switch, read once per process)
+#include <stdlib.h>
+static inline long icg_grid_cap() {
+  static const long cap = [] { const char* e = getenv("ICG_GRID_CAP"); const long v = e ? atol(e) : 0; return v > 0 ? v : (1L << 22); }();
+  return cap;
+}
+#define ICG_GRID_CAP icg_grid_cap()
 
 // 64-wide wavefront reductions (gfx950: wave = 64 lanes)
 // Ordering point for LDS data exchanged between the lanes of ONE wavefront (wave-private LDS regions): tells the compiler that
