@@ -14,7 +14,11 @@ affine / epilogue heads -> icg_gemm_batched (`conv2d_gradfix.linear_nt`; no vend
 gradients (R1 and path-length regularisation differentiate twice).  `num_fp16_res` / `conv_clamp` (the reference's
 `cfg=auto` uses 4 / 256, train.py:297-310): the highest-resolution blocks keep their activations in fp16 exactly where the
 reference does (networks.py:505-515, 581-600, 793-870) -- fp16 storage through bias_act / upfirdn2d / the modulation glue,
-fp16-rounded weights, exact-fp32 MFMA arithmetic inside the convolutions, one rounding per convolution output.
+fp16 weights, and convolutions on the fp16-input MFMA kernels (csrc/hconv.hip, csrc/hwgrad.hip: exact fp16 products, fp32
+accumulation, one rounding per convolution output -- the reference's cuDNN arithmetic there); layers those kernels do not serve
+(3-channel toRGB / fromRGB) run on the exact-fp32 kernels between two casts.
+Not fused (SURVEY 8(f) N1 asks for it, VERDICT r03 missing 2): style modulation, demodulation, noise and the per-pass weight
+preparation are PyTorch elementwise ops around the convolution (stylegan_ops/modconv.py).
 """
 import numpy as np
 import torch

@@ -4,7 +4,8 @@
   (3) size-independent properties at BASELINE.json's full sizes (adjoint identities of the convolution
       triplet, normalisation statistics, value range / finiteness of a full cfg3-shaped step).
 Tolerances: forward activations / losses ~1e-4 relative (north_star: samples within 1e-3 rel L2);
-gradients and post-step parameters are compared through fingerprints at 5e-3 of the tensor rms."""
+gradients and post-step parameters are compared through fingerprints at tests/helpers.py's GRAD_RTOL / STATE_RTOL of the
+tensor rms (+ the conditioning slack of the real-width cases; the dense 4096-sample groups by check_group's four-part rule)."""
 import json
 
 import numpy as np
