@@ -137,3 +137,111 @@ extern "C" int icg_attn_scores_softmax(const float* theta, const float* phi, flo
   }
   return icg_check_launch();
 }
+
+
+// =====================================================================================================================
+// Backward of the same block: dS = beta .* (dbeta - rowsum(beta .* dbeta)),  dbeta[b][i][j] = sum_c dO[b][i][c] V[b][j][c]
+// (autograd of layers.py:237-243: o = bmm(g, beta^T), beta = softmax(scores)).  The three-kernel form writes dbeta [B][n][m]
+// (1 - 2 GiB), reads it back together with beta in icg_softmax_bwd and writes dS.  Here the dbeta tile never leaves the
+// registers: a workgroup owns 32 query rows and all m keys (wave w: keys [128 w, 128 w + 128), 64 accumulator registers), the
+// 32 x dv rows of dO are staged once in LDS (row stride = 32 bytes mod 256: the four ds_read_b128 service groups of the
+// 16x16x4 operand pattern then see 16 distinct 16-byte slots), the V fragments come straight from L2 (every CU streams the
+// same m x dv matrix of its image), beta is read once with 16-byte loads in the accumulator layout, the row dot products go
+// through two wave shuffles and one LDS exchange in a fixed order, dS is written once.
+template <int DV>
+__global__ __launch_bounds__(512, 2) void icg_attn_dscores_kernel(const float* __restrict__ dO, const float* __restrict__ Vg,
+                                                                const float* __restrict__ beta, float* __restrict__ dS, int n, int m) {
+  constexpr int STRIDE = DV + (((DV * 4) % 256 == 128) ? 40 : 8);   // floats per staged row: 544 / 800 bytes = 32 mod 256 for DV = 96 / 192
+  static_assert((DV % 16) == 0 && ((STRIDE * 4) % 256) == 32, "LDS row stride must be 32 bytes mod 256");
+  __shared__ __attribute__((aligned(16))) float qs[32 * STRIDE];
+  __shared__ float red[8][32];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+  const int r = lane & 15, kk = lane >> 4;
+  const int rows_per_img = n >> 5;
+  const int b = blockIdx.x / rows_per_img, row0 = (blockIdx.x - b * rows_per_img) << 5;
+  const float* __restrict__ Q = dO + ((long)b * n + row0) * DV;
+  const float* __restrict__ Kp = Vg + ((long)b * m + 128 * wv) * DV;
+
+  // stage the 32 x DV rows of dO (float4 per thread-iteration)
+  for (int i = tid; i < 32 * (DV / 4); i += blockDim.x) {
+    const int row = i / (DV / 4), c4 = i - row * (DV / 4);
+    *reinterpret_cast<float4*>(qs + row * STRIDE + 4 * c4) = *reinterpret_cast<const float4*>(Q + row * DV + 4 * c4);
+  }
+  __syncthreads();
+
+  at_f32x4 acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = at_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int t = 0; t < DV / 16; ++t) {               // K-tile of 16 channels: a lane's 4 consecutive channels feed 4 MFMAs
+    float4 qa[2], kb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kb[j] = *reinterpret_cast<const float4*>(Kp + (16 * j + r) * DV + 16 * t + 4 * kk);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) qa[i] = *reinterpret_cast<const float4*>(qs + (16 * i + r) * STRIDE + 16 * t + 4 * kk);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(at_get(kb[j], s), at_get(qa[i], s), acc[i][j], 0, 0, 0);
+  }
+
+  // ---- epilogue: lane (r, kk) holds dbeta[row 16 i + r][key 128 wv + 16 j + 4 kk .. + 3]
+  const long off = ((long)b * n + row0) * m + 128 * wv + 4 * kk;
+  float dot[2];
+  at_f32x4 bt[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bt[i][j] = *reinterpret_cast<const at_f32x4*>(beta + off + (long)(16 * i + r) * m + 16 * j);
+      const at_f32x4 pr = bt[i][j] * acc[i][j];
+      s += (pr[0] + pr[1]) + (pr[2] + pr[3]);
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (kk == 0) red[wv][16 * i + r] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float s = red[0][16 * i + r];
+    for (int w = 1; w < nw; ++w) s += red[w][16 * i + r];
+    dot[i] = s;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      at_f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = bt[i][j][e] * (acc[i][j][e] - dot[i]);
+      *reinterpret_cast<at_f32x4*>(dS + off + (long)(16 * i + r) * m + 16 * j) = o;
+    }
+}
+
+// 1 when the fused backward serves the shape: n a multiple of 32, m a multiple of 128 up to 1024, dv in {96, 192}
+extern "C" int icg_attn_dscores_applies(int n, int m, int dv) {
+  if (n < 32 || n % 32 != 0 || m < 128 || m % 128 != 0 || m > 1024) return 0;
+  return (dv == 96 || dv == 192) ? 1 : 0;
+}
+
+// dS [B][n][m] from dO [B][n][dv], V = g [B][m][dv] and beta [B][n][m]
+extern "C" int icg_attn_dscores(const float* dO, const float* V, const float* beta, float* dS, int B, int n, int m, int dv,
+                                void* stream) {
+  ICG_REQUIRE(dO && V && beta && dS && B > 0);
+  ICG_REQUIRE(icg_attn_dscores_applies(n, m, dv));
+  ICG_REQUIRE(((uintptr_t)dO % 16) == 0 && ((uintptr_t)V % 16) == 0 && ((uintptr_t)beta % 16) == 0 && ((uintptr_t)dS % 16) == 0);
+  const long blocks = (long)B * (n / 32);
+  ICG_REQUIRE(blocks < 0x7fffffffL);
+  const dim3 grid((unsigned)blocks), block((unsigned)(64 * (m / 128)));
+  hipStream_t st = (hipStream_t)stream;
+  if (dv == 96) hipLaunchKernelGGL((icg_attn_dscores_kernel<96>), grid, block, 0, st, dO, V, beta, dS, n, m);
+  else hipLaunchKernelGGL((icg_attn_dscores_kernel<192>), grid, block, 0, st, dO, V, beta, dS, n, m);
+  return icg_check_launch();
+}

@@ -981,11 +981,15 @@ class AttnCoreFn(Function):
         do = _cl(do)
         dg = torch.empty_like(g)           # dV = beta^T dO
         L.call("icg_gemm_batched", beta, do, dg, m, dv, n, 1, 0, n * m, n * dv, m * dv, B, 1.0)
-        dbeta = torch.empty_like(beta)     # dP = dO V^T
-        L.call("icg_gemm_batched", do, g, dbeta, n, m, dv, 0, 1, n * dv, m * dv, n * m, B, 1.0)
         ds = torch.empty_like(beta)
-        L.call("icg_softmax_bwd", beta, dbeta, ds, B * n, m)
-        del dbeta
+        if FUSED_ATTENTION_SCORES and L.query("icg_attn_dscores_applies", n, m, dv):
+            # dP = dO V^T with the softmax backward in its epilogue (csrc/attn.hip): the [B][n][m] dP tensor is never written
+            L.call("icg_attn_dscores", do, g, beta, ds, B, n, m, dv)
+        else:
+            dbeta = torch.empty_like(beta)     # dP = dO V^T
+            L.call("icg_gemm_batched", do, g, dbeta, n, m, dv, 0, 1, n * dv, m * dv, n * m, B, 1.0)
+            L.call("icg_softmax_bwd", beta, dbeta, ds, B * n, m)
+            del dbeta
         dtheta = torch.empty_like(theta)   # dQ = dS K
         L.call("icg_gemm_batched", ds, phi, dtheta, n, d, m, 0, 0, n * m, m * d, n * d, B, 1.0)
         dphi = torch.empty_like(phi)       # dK = dS^T Q

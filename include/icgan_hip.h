@@ -483,6 +483,12 @@ int icg_softmax_fwd(const float* x, float* y, int64_t rows, int cols, void* stre
 int icg_attn_scores_softmax_applies(int n, int m, int d);
 int icg_attn_scores_softmax(const float* theta, const float* phi, float* beta, int B, int n, int m, int d, void* stream);
 int icg_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, int cols, void* stream);
+/* Backward of the attention block's softmax with the dbeta GEMM in front of it (autograd of layers.py:237-243):
+ *   dS[b][i][j] = beta[b][i][j] * (dbeta[b][i][j] - sum_j' beta[b][i][j'] dbeta[b][i][j']),  dbeta[b][i][j] = sum_c dO[b][i][c] V[b][j][c]
+ * in one kernel -- dbeta [B][n][m] (1 - 2 GiB) is never written.  dO [B][n][dv], V = g [B][m][dv], beta / dS [B][n][m];
+ * `_applies` -> 1 for n % 32 == 0, m % 128 == 0, m <= 1024, dv in {96, 192} (the two attention blocks of the 64 x 64 models). */
+int icg_attn_dscores_applies(int n, int m, int dv);
+int icg_attn_dscores(const float* dO, const float* V, const float* beta, float* dS, int B, int n, int m, int dv, void* stream);
 /* h[b][c] = sum_hw relu(x[b,h,w,c])   (BigGAN.py:625) and its backward */
 int icg_relu_sumpool_fwd(const float* x, float* y, int B, int HW, int C, void* stream);
 int icg_relu_sumpool_bwd(const float* x, const float* dy, float* dx, int B, int HW, int C, void* stream);

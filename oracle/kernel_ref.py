@@ -787,6 +787,18 @@ def icg_softmax_bwd(y, dy, dx, rows, cols):
     mem(dx)[: rows * cols].copy_((yy * (g - (yy * g).sum(-1, keepdim=True))).reshape(-1))
 
 
+def icg_attn_dscores_applies(n, m, dv):
+    return int(n >= 32 and n % 32 == 0 and m >= 128 and m % 128 == 0 and m <= 1024 and dv in (96, 192))
+
+
+def icg_attn_dscores(dO, V, beta, dS, B, n, m, dv):
+    do = mem(dO)[: B * n * dv].view(B, n, dv)
+    v = mem(V)[: B * m * dv].view(B, m, dv)
+    bt = mem(beta)[: B * n * m].view(B, n, m)
+    g = torch.bmm(do, v.transpose(1, 2))
+    mem(dS)[: B * n * m].copy_((bt * (g - (bt * g).sum(-1, keepdim=True))).reshape(-1))
+
+
 def icg_relu_sumpool_fwd(x, y, B, HW, C):
     mem(y)[: B * C].copy_(F.relu(mem(x)[: B * HW * C].view(B, HW, C)).sum(1).reshape(-1))
 

@@ -1201,6 +1201,23 @@ def test_attn_scores_softmax(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 128, 96), (1, 96, 1024, 192), (3, 32, 512, 96), (2, 128, 1024, 96), (1, 4096, 1024, 192)])
+def test_attn_dscores(case):
+    """icg_attn_dscores (csrc/attn.hip: dP = dO V^T with the softmax backward in the epilogue) against bmm + the softmax backward
+    formula in fp32 on the CPU; beta from a softmax of scores of a few units (probabilities over many decades)."""
+    B, n, m, dv = case
+    assert _L().query("icg_attn_dscores_applies", n, m, dv) == 1 and R.icg_attn_dscores_applies(n, m, dv) == 1
+    assert _L().query("icg_attn_dscores_applies", n, m, 48) == 0
+    do = rnd(B, n, dv, seed=1)
+    v = rnd(B, m, dv, seed=2, scale=0.5)
+    beta = torch.softmax(rnd(B, n, m, seed=3, scale=2.0), -1).contiguous()
+    ds = torch.zeros(B, n, m)
+    (p,) = run_pair("icg_attn_dscores", [do, v, beta, ds, B, n, m, dv], [3])
+    close(*p, rtol=1e-4, atol_rel=2e-5, what="attention dS %r" % (case,))
+    assert float(p[0].cpu().sum(-1).abs().max()) < 1e-4 * float(p[1].abs().max()) * m ** 0.5 + 1e-5      # rows of dS sum to zero
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rows,C", [(1000, 64), (37, 8), (5000, 512), (70000, 128), (300, 2048), (4 * 129 * 129, 256)])
 def test_colsum_f16(rows, C):
     """icg_colsum_f16 (bias gradient of bias_act in StyleGAN2's fp16 blocks): fp32 column sums of an fp16 [rows][C] tensor against fp64."""
