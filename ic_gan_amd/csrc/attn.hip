@@ -149,7 +149,7 @@ extern "C" int icg_attn_scores_softmax(const float* theta, const float* phi, flo
 // same m x dv matrix of its image), beta is read once with 16-byte loads in the accumulator layout, the row dot products go
 // through two wave shuffles and one LDS exchange in a fixed order, dS is written once.
 template <int DV>
-__global__ __launch_bounds__(512, 2) void icg_attn_dscores_kernel(const float* __restrict__ dO, const float* __restrict__ Vg,
+__global__ __launch_bounds__(512) void icg_attn_dscores_kernel(const float* __restrict__ dO, const float* __restrict__ Vg,
                                                                 const float* __restrict__ beta, float* __restrict__ dS, int n, int m) {
   constexpr int STRIDE = DV + (((DV * 4) % 256 == 128) ? 40 : 8);   // floats per staged row: 544 / 800 bytes = 32 mod 256 for DV = 96 / 192
   static_assert((DV % 16) == 0 && ((STRIDE * 4) % 256) == 32, "LDS row stride must be 32 bytes mod 256");
@@ -174,32 +174,48 @@ __global__ __launch_bounds__(512, 2) void icg_attn_dscores_kernel(const float* _
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = at_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int t = 0; t < DV / 16; ++t) {               // K-tile of 16 channels: a lane's 4 consecutive channels feed 4 MFMAs
-    float4 qa[2], kb[8];
+  // K-tiles of 16 channels (a lane's 4 consecutive channels feed 4 MFMAs); the V fragments of the next K-tile are loaded before the
+  // 64 MFMAs of the current one are issued, and beta -- the epilogue's operand, independent of the GEMM -- during the last K-tile
+  // (one workgroup per CU: 64 accumulator + 64 V-fragment + 64 beta registers; the first version loaded and consumed each K-tile
+  // in turn and ran at 70 TF)
+  constexpr int NKT = DV / 16;
+  const long off = ((long)b * n + row0) * m + 128 * wv + 4 * kk;
+  at_f32x4 bt[2][8];
+  float4 kb[2][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) kb[j] = *reinterpret_cast<const float4*>(Kp + (16 * j + r) * DV + 16 * t + 4 * kk);
+  for (int j = 0; j < 8; ++j) kb[0][j] = *reinterpret_cast<const float4*>(Kp + (16 * j + r) * DV + 4 * kk);
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    if (t + 1 < NKT) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kb[(t + 1) & 1][j] = *reinterpret_cast<const float4*>(Kp + (16 * j + r) * DV + 16 * (t + 1) + 4 * kk);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bt[i][j] = *reinterpret_cast<const at_f32x4*>(beta + off + (long)(16 * i + r) * m + 16 * j);
+    }
+    float4 qa[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) qa[i] = *reinterpret_cast<const float4*>(qs + (16 * i + r) * STRIDE + 16 * t + 4 * kk);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(at_get(kb[j], s), at_get(qa[i], s), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(at_get(kb[t & 1][j], s), at_get(qa[i], s), acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- epilogue: lane (r, kk) holds dbeta[row 16 i + r][key 128 wv + 16 j + 4 kk .. + 3]
-  const long off = ((long)b * n + row0) * m + 128 * wv + 4 * kk;
   float dot[2];
-  at_f32x4 bt[2][8];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      bt[i][j] = *reinterpret_cast<const at_f32x4*>(beta + off + (long)(16 * i + r) * m + 16 * j);
       const at_f32x4 pr = bt[i][j] * acc[i][j];
       s += (pr[0] + pr[1]) + (pr[2] + pr[3]);
     }
