@@ -27,6 +27,7 @@
 // Chains are single-level over K <= 192 (48 MFMA steps); the routes through this kernel are gated on that (fwino_applies).
 #include "icg_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -141,9 +142,24 @@ __global__ __launch_bounds__(256) void icg_fwino_pack_kernel(const float* __rest
 
 // transforms on channel PAIRS (v_pk_* arithmetic): the producers' instruction count is what they cost the MFMA waves they share a
 // SIMD with
+// FWINO_SCALAR (measurement builds, tools/build_dbg.sh FWS): the same arithmetic on two plain floats (compile with
+// -fno-slp-vectorize) -- packed fp32 VALU beside MFMAs has an issue cost of its own (MI355X_MICROARCH.md)
+#ifndef FWINO_SCALAR
+#define FWINO_SCALAR 0
+#endif
+#if FWINO_SCALAR
+struct f32x2 { float x, y; };
+__device__ __forceinline__ f32x2 operator+(f32x2 a, f32x2 b) { return f32x2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f32x2 operator-(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f32x2 operator*(f32x2 a, float b) { return f32x2{a.x * b, a.y * b}; }
+__device__ __forceinline__ f32x2 fw2(float a) { return f32x2{a, a}; }
+__device__ __forceinline__ f32x2 fw_fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#else
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fw2(float a) { return f32x2{a, a}; }
-__device__ __forceinline__ f32x2 fw_fma(f32x2 a, float b, f32x2 c) { return __builtin_elementwise_fma(a, fw2(b), c); }
+__device__ __forceinline__ f32x2 fw_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+__device__ __forceinline__ f32x2 fw_fma(f32x2 a, float b, f32x2 c) { return fw_fma2(a, fw2(b), c); }
 __device__ __forceinline__ void fw_in6(const f32x2 d[6], f32x2 t[6]) {
   t[0] = fw_fma(d[2], -5.f, d[0] * 4.f) + d[4];
   const f32x2 a = fw_fma(d[2], -4.f, d[4]), b = fw_fma(d[1], -4.f, d[3]);
@@ -163,6 +179,13 @@ __device__ __forceinline__ void fw_in_up(const f32x2 l[4], f32x2 t[6]) {
   t[4] = c * -1.f;
   t[5] = fw_fma(l[2], -5.f, l[1] * 4.f) + l[3];
 }
+
+// the prologue operands of a layer without ICG_PRE_AFFINE: scale 1, shift 0 (the kernel loads them unconditionally, see load_affine)
+#define FW_R8(x) x, x, x, x, x, x, x, x
+#define FW_R64(x) FW_R8(x), FW_R8(x), FW_R8(x), FW_R8(x), FW_R8(x), FW_R8(x), FW_R8(x), FW_R8(x)
+#define FW_R512(x) FW_R64(x), FW_R64(x), FW_R64(x), FW_R64(x), FW_R64(x), FW_R64(x), FW_R64(x), FW_R64(x)
+__device__ float g_fw_ones[2048] = {FW_R512(1.f), FW_R512(1.f), FW_R512(1.f), FW_R512(1.f)};
+__device__ float g_fw_zeros[2048] = {0.f};
 
 template <int UP, int POOL, int NP>
 __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
@@ -293,127 +316,212 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
     const unsigned WxK = (unsigned)(Wx * K);
     // LDS position of a lane's pair inside a plane's 2 KiB: [sg][kq*16 + (tile ^ (kq + 4 sg))][s4], channel = 16 sg + 4 kq + s4
 
-    f32x2 d[NL][NL], d_sc = fw2(1.f), d_sh = fw2(0.f);
-    Item cur = decode(first);                                        // item whose chunks are being loaded / transformed
-    auto load_chunk = [&](const Item& w, int ck) {
-      int cp = pl & 15, ti = pl >> 4;
-      asm volatile("" : "+v"(cp), "+v"(ti));
+    f32x2 d[NL][NL], d_sc, d_sh;
+    // Window loads: buffer loads through ONE descriptor over x, everything in voffset = the lane's window origin + a wave-uniform
+    // (row, column) term.  No clamping: rows / columns outside the image land in the neighbouring row / image (valid memory, the
+    // transform zeroes them) or outside the tensor, where the range check of the buffer load returns 0 instead of faulting
+    // (offsets wrap modulo 2^32; x is < 2^32 - 2^24 bytes, icg_fwino_applies).
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((unsigned)(p.B * Hx * Wx) * (unsigned)K * 4u),
+                                                       0x00020000);
+    const unsigned RowB = WxK * 4u, ColB = (unsigned)K * 4u;
+    // byte offset of window element (0, 0) of this lane's tile in work item w, chunk ck, channel pair cp
+    auto win_base = [&](const Item& w, int ck, int cp, int ti) -> unsigned {
       const int txg = 4 * w.bx + (ti & 3), tyg = 4 * w.by + (ti >> 2);
       const int w0 = UP ? 2 * txg - 1 : 4 * txg - 1, h0 = UP ? 2 * tyg - 1 : 4 * tyg - 1;
-      const float* xc = p.x + (long)w.b * Hx * Wx * K + 32 * ck;    // this image, this chunk (uniform)
-      unsigned coloff[NL];
-#pragma unroll
-      for (int s = 0; s < NL; ++s) coloff[s] = (unsigned)(min(max(w0 + s, 0), Wx - 1) * K + 2 * cp);
-#pragma unroll
-      for (int r = 0; r < NL; ++r) {
-        unsigned ro = (unsigned)min(max(h0 + r, 0), Hx - 1) * WxK;
-        asm volatile("" : "+v"(ro));
-#pragma unroll
-        for (int s = 0; s < NL; ++s) d[r][s] = *reinterpret_cast<const f32x2*>(xc + ro + coloff[s]);
-      }
-      // the chunk's BN scale / shift travel with the window: issued at the start of the transform their full latency
-      // (~11 000 clocks under the weight stream, tools/fwino_trace.py) would sit in front of the first multiply
-      if (p.affine) {
-        d_sc = *reinterpret_cast<const f32x2*>(p.scale + (long)w.b * p.ssb + 32 * ck + 2 * cp);
-        d_sh = *reinterpret_cast<const f32x2*>(p.shift + (long)w.b * p.ssb + 32 * ck + 2 * cp);
-      }
+      unsigned wb = (((unsigned)(w.b * Hx + h0) * (unsigned)Wx + (unsigned)w0) * (unsigned)K + (unsigned)(32 * ck + 2 * cp)) * 4u;
+      asm volatile("" : "+v"(wb));               // (opaque: hoisted address arithmetic is what spilled this branch)
+      return wb;
     };
-    auto transform_chunk = [&](const Item& w, int ck, unsigned vb) {
+    auto load_px = [&](unsigned wb, int r, int s) -> f32x2 {
+      return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, (int)(wb + (unsigned)r * RowB + (unsigned)s * ColB), 0, 0));
+    };
+    // The chunk's prologue scale / shift travel with its window and go FIRST (one order of the in-order vmcnt queue on every path);
+    // unconditional -- without ICG_PRE_AFFINE they come from a row of ones / zeros: a load under a run-time flag
+    // is a phi of registers, i.e. a copy of the loaded value, i.e. a full wait right behind the load.
+    const float* const scale_p = p.affine ? p.scale : g_fw_ones;     // (uniform, once per kernel)
+    const float* const shift_p = p.affine ? p.shift : g_fw_zeros;
+    const long ssb_p = p.affine ? p.ssb : 0;
+    auto load_affine = [&](const Item& w, int ck, int cp) {
+      d_sc = *reinterpret_cast<const f32x2*>(scale_p + (long)w.b * ssb_p + 32 * ck + 2 * cp);
+      d_sh = *reinterpret_cast<const f32x2*>(shift_p + (long)w.b * ssb_p + 32 * ck + 2 * cp);
+    };
+    auto load_chunk = [&](const Item& w, int ck) {                   // the whole window at once (first chunk of the run; UP form)
+      int cp = pl & 15, ti = pl >> 4;
+      asm volatile("" : "+v"(cp), "+v"(ti));
+      const unsigned wb = win_base(w, ck, cp, ti);
+      load_affine(w, ck, cp);
+#pragma unroll
+      for (int r = 0; r < NL; ++r)
+#pragma unroll
+        for (int s = 0; s < NL; ++s) d[r][s] = load_px(wb, r, s);
+    };
+
+    // A chunk = FIRST pass (1-D transform in place; prologue: scale / shift, ReLU, zero padding) + SECOND pass (the other dimension:
+    // a window line in, a line of V out to LDS / HBM).  The second pass retires the window line by line, and every retired line is
+    // refilled at once with the matching line of the NEXT chunk's window (same registers), so that the loads have half a transform
+    // of distance instead of none (measured before, tools/fwino_trace.py: the producer waited ~16 000 clocks for its window after
+    // every barrier, the MFMA waves the same time for the producer).  A window refilled by COLUMNS can only be transformed
+    // columns-first, one refilled by rows rows-first: the two orders alternate (YV); B^T (d B) and (B^T d) B differ in rounding
+    // order only.  The 4 x 4 window of the upsample-fused form is dead after its first pass (it expands into Eu) and is refilled as
+    // a whole at the start of the second.
+    constexpr int EW = UP ? 6 : 1;
+    f32x2 Eu[UP ? NL : 1][EW];
+    auto first_pass = [&](auto yv, const Item& w) {
+      constexpr bool YV = decltype(yv)::value;      // false: rows then columns (window arrived by rows); true: columns then rows
+      static_assert(!(UP && YV), "the upsample-fused form has one order");
+      int ti = pl >> 4;
+      asm volatile("" : "+v"(ti));
+      const int txg = 4 * w.bx + (ti & 3), tyg = 4 * w.by + (ti >> 2);
+      const int w0 = UP ? 2 * txg - 1 : 4 * txg - 1, h0 = UP ? 2 * tyg - 1 : 4 * tyg - 1;
+      const f32x2 sc = d_sc, sh = d_sh;                             // (1, 0) without ICG_PRE_AFFINE
+      const float lo = p.relu ? 0.f : -__builtin_inff();
+      FW_MARK();
+      // (the zero-padding masks run for every tile block: a workgroup-uniform branch around a mask-free copy for the blocks off
+      // the image border -- 72 of ~520 instructions -- does not compile in this loop shape: "illegal VGPR to SGPR copy")
+#pragma unroll
+      for (int a = 0; a < NL; ++a) {                                 // a: window row (rows first) / window column (columns first)
+        const bool aok = YV ? (unsigned)(w0 + a) < (unsigned)Wx : (unsigned)(h0 + a) < (unsigned)Hx;
+        f32x2 line[NL], t6[6];
+#pragma unroll
+        for (int b = 0; b < NL; ++b) {
+          const bool bok = YV ? (unsigned)(h0 + b) < (unsigned)Hx : (unsigned)(w0 + b) < (unsigned)Wx;
+          // branch-free prologue: scale 1 / shift 0 without ICG_PRE_AFFINE (exact), ReLU floor -inf without ICG_PRE_RELU
+          // (if-converted run-time flags cost a v_cndmask per value and flag: 144 of this loop's instructions)
+          f32x2 v = fw_fma2(YV ? d[b][a] : d[a][b], sc, sh);
+          v = f32x2{fmaxf(v.x, lo), fmaxf(v.y, lo)};
+          line[b] = (aok && bok) ? v : fw2(0.f);
+        }
+        if constexpr (UP) {
+          fw_in_up(line, t6);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) Eu[a][j] = t6[j];
+        } else {
+          fw_in6(line, t6);
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            if constexpr (YV) d[j][a] = t6[j]; else d[a][j] = t6[j];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      FW_MARK();
+    };
+    // second pass of chunk (w, ck) into the V buffer at vb; refill with the window of chunk (wl, ckl)
+    auto second_pass = [&](auto yv, const Item& w, int ck, unsigned vb, const Item& wl, int ckl) {
+      constexpr bool YV = decltype(yv)::value;
       int cp = pl & 15, ti = pl >> 4;
       asm volatile("" : "+v"(cp), "+v"(ti));
       const int sg = cp >> 3, kq = (cp >> 1) & 3;
       const unsigned wpos0 = (unsigned)((sg * 64 + kq * 16 + (ti ^ (kq + 4 * sg))) * 16 + (cp & 1) * 8);
       const int txg = 4 * w.bx + (ti & 3), tyg = 4 * w.by + (ti >> 2);
-      const int w0 = UP ? 2 * txg - 1 : 4 * txg - 1, h0 = UP ? 2 * tyg - 1 : 4 * tyg - 1;
-      const f32x2 sc = d_sc, sh = d_sh;
-      // tile blocks off the image border need no zero-padding masks (workgroup-uniform; 144 of ~500 producer instructions)
-      const bool interior = w.bx > 0 && w.bx < p.tbw - 1 && w.by > 0 && w.by < p.tbh - 1;
-      FW_MARK();
-      // row pass, in place where the window is 6 wide (d[r][.] <- (d[r][.] B): the inputs are dead once their row is transformed);
-      // the 4-wide upsampled window expands to 6 components and gets its own array
-      constexpr int EW = UP ? 6 : 1;
-      f32x2 Eu[UP ? NL : 1][EW];
-#pragma unroll
-      for (int r = 0; r < NL; ++r) {
-        const bool rok = (unsigned)(h0 + r) < (unsigned)Hx;
-        f32x2 row[NL], t6[6];
-#pragma unroll
-        for (int s = 0; s < NL; ++s) {
-          f32x2 v = d[r][s];
-          if (p.affine) v = __builtin_elementwise_fma(v, sc, sh);
-          if (p.relu) v = f32x2{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)};
-          row[s] = (interior || (rok && (unsigned)(w0 + s) < (unsigned)Wx)) ? v : fw2(0.f);
-        }
-        if constexpr (UP) {
-          fw_in_up(row, t6);
-#pragma unroll
-          for (int j = 0; j < 6; ++j) Eu[r][j] = t6[j];
-        } else {
-          fw_in6(row, t6);
-#pragma unroll
-          for (int j = 0; j < 6; ++j) d[r][j] = t6[j];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      unsigned wbn = 0u;
+      if constexpr (UP) {
+        load_chunk(wl, ckl);
+      } else {
+        load_affine(wl, ckl, cp);
+        wbn = win_base(wl, ckl, cp, ti);
       }
-      FW_MARK();
       unsigned wpos = vb + wpos0;
       unsigned vpos = (unsigned)((((w.b * th + tyg) * tw + txg) * K + 2 * cp)) * 4u;       // byte offset inside a V plane
-      unsigned pv4 = (unsigned)p.planeV * 4u;                       // bytes per plane; planes x pv4 < 2^32 (icg_fwino_conv)
-      asm volatile("" : "+v"(wpos), "+v"(vpos), "+s"(pv4));
+      const unsigned pv4 = (unsigned)p.planeV * 4u;                 // bytes per plane; planes x pv4 < 2^32 (icg_fwino_conv)
+      asm volatile("" : "+v"(wpos), "+v"(vpos));
       const bool wantV = (p.V != nullptr) && w.nb == 0;
       char* vplane = reinterpret_cast<char*>(p.V + 32 * ck);        // uniform
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        if (!fw_has<NP>(j)) continue;
-        f32x2 col[NL], o[6];
+      for (int j = 0; j < 6; ++j) {             // line j of the transformed domain (rows first: column j; columns first: row j)
+        if (fw_has<NP>(j)) {
+          f32x2 col[NL], o[6];
 #pragma unroll
-        for (int r = 0; r < NL; ++r) {
-          if constexpr (UP) col[r] = Eu[r][j]; else col[r] = d[r][j];
+          for (int r = 0; r < NL; ++r) {
+            if constexpr (UP) col[r] = Eu[r][j]; else col[r] = YV ? d[j][r] : d[r][j];
+          }
+          if constexpr (UP) fw_in_up(col, o); else fw_in6(col, o);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            if (!fw_has<NP>(r)) continue;
+            const int plane = YV ? fw_slot<NP>(j) * NP + fw_slot<NP>(r) : fw_slot<NP>(r) * NP + fw_slot<NP>(j);
+            *reinterpret_cast<f32x2*>(lds + wpos + plane * 2048) = o[r];
+            if (wantV) *reinterpret_cast<f32x2*>(vplane + (size_t)((unsigned)plane * pv4 + vpos)) = o[r];
+          }
         }
-        if constexpr (UP) fw_in_up(col, o); else fw_in6(col, o);
+        if constexpr (!UP) {                                         // register line j is retired: the next window's line j
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          if (!fw_has<NP>(r)) continue;
-          const int plane = fw_slot<NP>(r) * NP + fw_slot<NP>(j);
-          *reinterpret_cast<f32x2*>(lds + wpos + plane * 2048) = o[r];
-          if (wantV) *reinterpret_cast<f32x2*>(vplane + (size_t)((unsigned)plane * pv4 + vpos)) = o[r];
+          for (int q = 0; q < NL; ++q) {
+            if constexpr (YV) d[j][q] = load_px(wbn, j, q); else d[q][j] = load_px(wbn, q, j);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      FW_MARK();
     };
 
+    // ---- the run.  Straight-line code per pair of chunks, rotated so that the loop's back edge (and its entry) sit BEHIND a first
+    // pass: where two code paths join, the register allocator moves values between the registers each side keeps them in, and a
+    // move of a window element that is still in flight is a full wait -- behind a first pass nothing is in flight.  (One call site
+    // behind a flag instead of the two orders in sequence: 9 - 36 spilled VGPRs.)
+    unsigned v = first;
+    Item cur = decode(first), w = cur;                               // w: the item whose chunk ck is in work; cur: the item after it
+    int ck = 0;
+    bool has_next = v + vstep < last;
+    if (has_next) cur = decode(v + vstep);
+    // (w, cur, ck are loop-carried state; the compiler wants them in SGPRs at their uses and needs to be told it may)
+    auto uni = [&](const Item& x) -> Item {
+      Item y;
+      y.nb = __builtin_amdgcn_readfirstlane(x.nb); y.bx = __builtin_amdgcn_readfirstlane(x.bx);
+      y.by = __builtin_amdgcn_readfirstlane(x.by); y.b = __builtin_amdgcn_readfirstlane(x.b);
+      return y;
+    };
+    auto second = [&](auto yv) {
 #if !(FWINO_ABLATE & 1)
-    load_chunk(cur, 0);
+      // the refill: the next chunk of this item, else the next item's first one -- in flight during this item's last MFMAs and its
+      // output stage -- else (end of the run) this chunk again: unconditional, see load_affine
+      const int cku = __builtin_amdgcn_readfirstlane(ck);
+      const bool same = cku + 1 < nc;
+      const Item wu = uni(w), wl = uni(same ? w : cur);
+      second_pass(yv, wu, cku, (cku & 1) ? (unsigned)VBUF : 0u, wl, same ? cku + 1 : (has_next ? 0 : cku));
 #endif
-    for (unsigned v = first; v < last; v += vstep) {
-      const Item w = cur;                                            // the item of this iteration (output coordinates)
-      const bool has_next = v + vstep < last;
+    };
+    auto first_of = [&](auto yv) {
 #if !(FWINO_ABLATE & 1)
-      transform_chunk(w, 0, 0u);
-      FW_MARK();
-      if (nc > 1) load_chunk(w, 1);
-      else if (has_next) { cur = decode(v + vstep); load_chunk(cur, 0); }
+      first_pass(yv, uni(w));
 #endif
+    };
+    // after a chunk: barrier k of the item (T(k) written, chunk k - 1 consumed); behind the last chunk the rest of the item's
+    // barrier sequence and this role's share of the output stage.  false: the run is over
+    auto post = [&]() -> bool {
       FW_BARRIER();
-      for (int ck = 0; ck < nc; ++ck) {
-#if !(FWINO_ABLATE & 1)
-        if (ck + 1 < nc) {
-          transform_chunk(w, ck + 1, ((ck + 1) & 1) ? (unsigned)VBUF : 0u);
-          FW_MARK();
-          if (ck + 2 < nc) load_chunk(w, ck + 2);
-          else if (has_next) { cur = decode(v + vstep); load_chunk(cur, 0); }    // the next item's first chunk: in flight during
-        }                                                                         // this item's last MFMAs and its output stage
-#endif
-        FW_BARRIER();
-      }
+      if (++ck < nc) return true;
+      FW_BARRIER();                                                  // chunk nc - 1 consumed
       // Round 0 is worked by the 512 threads that hold no accumulators any more (first-round consumers + producers), the
       // second-round consumers wait with theirs: no point of the program has 108 accumulators AND an output transform live.
       FW_BARRIER();
-      output_item(w, 0, tid - 256);                                  // items 256..511 (the first-round consumers: 0..255, 512..767)
+      const Item wo = uni(w);
+      output_item(wo, 0, tid - 256);                                 // items 256..511 (the first-round consumers: 0..255, 512..767)
       FW_BARRIER();
       FW_BARRIER();
-      output_item(w, 1, tid);
+      output_item(wo, 1, tid);
       FW_BARRIER();
+      v += vstep;
+      if (v >= last) return false;
+      w = cur;
+      ck = 0;
+      has_next = v + vstep < last;
+      if (has_next) cur = decode(v + vstep);
+      return true;
+    };
+#if !(FWINO_ABLATE & 1)
+    load_chunk(w, 0);
+#endif
+    first_of(std::false_type{});
+    for (;;) {
+      second(std::false_type{});
+      if (!post()) break;
+      if constexpr (!UP) {
+        first_of(std::true_type{});
+        second(std::true_type{});
+        if (!post()) break;
+      }
+      first_of(std::false_type{});
     }
   } else {
     // =========================================================== consumers ===========================================================
@@ -537,6 +645,7 @@ extern "C" int icg_fwino_applies(int B, int H, int W, int Cin, int Cout) {
   if (!fwino_env("ICG_FWINO", 1)) return 0;
   if (Cin % 32 || Cin > fwino_env("ICG_FWINO_MAXK", 192) || Cout % 96 || Cout > fwino_env("ICG_FWINO_MAXN", 192) || H % 16 || W % 16)
     return 0;
+  if ((double)B * H * W * Cin * 4.0 >= 4278190080.0) return 0;       // x behind ONE buffer descriptor with 32-bit offsets (2^32 - 2^24)
   const long wgs = (long)B * (H / 16) * (W / 16) * (Cout / 96);
   return (wgs >= fwino_env("ICG_FWINO_MIN_WGS", 512) && wgs < 0x7fffffffL) ? 1 : 0;
 }
@@ -554,6 +663,7 @@ extern "C" int icg_fwino_pack_weights(const float* U, float* Uf, int planes, int
 }
 
 void icg_gemm_set_last_variant(int a, int b, int c, int d);     // gemm_conv.hip: the label bench.py reads back
+
 
 // The fused forward: out = epilogue(conv3x3(prologue(x))) with x / out resampled as (in_up, out_pool) say; Uf from
 // icg_fwino_pack_weights; V (optional) receives the transformed input planes [np*np][T][Cin] as a by-product.
@@ -615,6 +725,7 @@ extern "C" int icg_fwino_conv(const float* x, const float* Uf, const float* bias
   const double T = (double)B * (H / 4) * (W / 4);
   ICG_REQUIRE(T * (Cout / 96) / 16 < 2147483647.0);
   if (V) ICG_REQUIRE((double)np * np * T * Cin * 4.0 < 4294967296.0);
+  ICG_REQUIRE((double)B * H * W * Cin * 4.0 < 4278190080.0 && Cin <= 2048);
   return icg_fwino_run(x, in_up, Uf, bias, residual, icg_res_mode(flags), out, out_pool, scale, shift, ss_bstride, B, H, W, Cin,
                        Cout, flags, alpha, np, V, stream);
 }

@@ -9,7 +9,7 @@ SRC="$HERE/../ic_gan_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-sometimes-uninitialized -Wno-uninitialized"
 mkdir -p "$HERE/obj"
 build_variant() {   # name, define, source file
-  /opt/rocm/bin/hipcc $FLAGS "$2" -c "$SRC/$3.hip" -o "$HERE/obj/$3_$1.o"
+  /opt/rocm/bin/hipcc $FLAGS $2 -c "$SRC/$3.hip" -o "$HERE/obj/$3_$1.o"
   objs=""
   for o in "$SRC"/obj/*.o; do
     [ "$(basename "$o")" = "$3.o" ] || objs="$objs $o"
@@ -27,6 +27,7 @@ for v in "$@"; do
     LB3) build_variant LB3 -DICG_PLANES_TN4_MIN_WAVES=3 gemm_conv ;;
     FWA*) build_variant "$v" "-DFWINO_ABLATE=${v#FWA}" fwino ;;      # fused Winograd kernel, ablation bits (csrc/fwino.hip)
     FWM) build_variant FWM -DFWINO_MASKBITS=1 fwino ;;
+    FWS) build_variant FWS "-DFWINO_SCALAR=1 -fno-slp-vectorize" fwino ;;      # ... producers on plain floats instead of float2 (v_pk_*)
     FWT) build_variant FWT -DFWINO_TRACE=1 fwino ;;                    # ... with barrier timestamps of workgroup 0 (tools/fwino_trace.py)
     *) echo "unknown variant $v"; exit 1 ;;
   esac
