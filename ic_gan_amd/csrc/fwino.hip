@@ -252,6 +252,28 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
     const int oty = 4 * w.by + (otile >> 2), otx = 4 * w.bx + (otile & 3);
     const int n = w.nb * 96 + round * 48 + ocol;
     const float* mp = reinterpret_cast<const float*>(lds) + otile * MROW + ocol;
+    // bias and the residual operand (plain, upsample-on-read, ReLU mask) FIRST and unconditionally -- all of them in flight under
+    // the LDS reads and the transform below; without a residual / bias they read one zero.  (Loaded one by one where they are
+    // used, each behind an `if (p.res)`, every one of the 16 loads was a full s_waitcnt vmcnt(0) round trip: the output stage
+    // of an item cost 18 000 of its 71 000 clocks, tools/fwino_trace.py.)
+    // 32-bit byte offsets throughout (out and the residual operand are < 2^32 - 2^24 bytes, icg_fwino_applies); the residual's
+    // geometry (same as out / half resolution, nearest upsampling on read / none: offset 0 into one zero) as uniform selects
+    const float* const resp = p.res ? p.res : g_fw_zeros;
+    const float bv = (p.bias ? p.bias : g_fw_zeros)[p.bias ? n : 0];
+    const bool rup = !POOL && p.res_mode == 1;
+    const unsigned N4 = (unsigned)N * 4u, rN4 = p.res ? N4 : 0u;
+    const int rH = rup ? (H >> 1) : Ho, rW = rup ? (W >> 1) : Wo, rx = rup ? 2 * otx : NO * otx;
+    unsigned pb[NO];
+    float rv[NO][NO];
+#pragma unroll
+    for (int a = 0; a < NO; ++a) {
+      const int oy = NO * oty + a;
+      pb[a] = (unsigned)(((w.b * Ho + oy) * Wo + NO * otx) * N + n) * 4u;
+      const unsigned rb = p.res ? (unsigned)(((w.b * rH + (rup ? (oy >> 1) : oy)) * rW + rx) * N + n) * 4u : 0u;
+#pragma unroll
+      for (int c = 0; c < NO; ++c)
+        rv[a][c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(resp) + (rb + (unsigned)(rup ? (c >> 1) : c) * rN4));
+    }
     // y = A^T M A accumulated column by column: for column j of M the 1-D transform yy = A^T M[:, j], then
     // y[a][c] += yy[a] * A[j][c] with the constants of A folded (rows of A^T: [1 1 1 1 1 0], [0 1 -1 2 -2 0], [0 1 1 4 4 0],
     // [0 1 -1 8 -8 1]; pooled: [1 2 0 3 -1 0], [0 2 0 12 -4 1]) -- 16 + 6 + 4 live values instead of 36 + 24
@@ -279,22 +301,13 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
           else if (cw != 0.f) y[a][c] = fmaf(yy[a], cw, y[a][c]);
         }
     }
-    const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
     for (int a = 0; a < NO; ++a) {
-      const int oy = NO * oty + a;
-      const long p0 = (((long)w.b * Ho + oy) * Wo + NO * otx) * N + n;
 #pragma unroll
       for (int c = 0; c < NO; ++c) {
         float v = p.alpha * y[a][c] + bv;
-        if (p.res) {
-          const long rp = (!POOL && p.res_mode == 1)
-                              ? (((long)w.b * (H >> 1) + (oy >> 1)) * (W >> 1) + ((4 * otx + c) >> 1)) * N + n
-                              : p0 + (long)c * N;
-          const float r = p.res[rp];
-          v = (p.res_mode == 2) ? (r > 0.f ? v : 0.f) : v + r;
-        }
-        p.out[p0 + (long)c * N] = v;
+        if (p.res) v = (p.res_mode == 2) ? (rv[a][c] > 0.f ? v : 0.f) : v + rv[a][c];
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + (pb[a] + (unsigned)c * N4)) = v;
       }
     }
   };
@@ -486,28 +499,38 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
       first_pass(yv, uni(w));
 #endif
     };
-    // after a chunk: barrier k of the item (T(k) written, chunk k - 1 consumed); behind the last chunk the rest of the item's
-    // barrier sequence and this role's share of the output stage.  false: the run is over
-    auto post = [&]() -> bool {
+    // after a chunk: barrier k of the item (T(k) written, chunk k - 1 consumed), then the FIRST pass of the chunk that follows
+    // (`next_first`); behind an item's last chunk the rest of its barrier sequence and this role's share of the output stage --
+    // with the first pass of the next item's chunk 0 (its window arrived long ago) in front of it, in the time the first-round
+    // consumers need to hand their accumulators over, instead of behind it where the MFMA waves wait for T(0).  false: run over
+    auto post = [&](auto next_first) -> bool {
       FW_BARRIER();
-      if (++ck < nc) return true;
-      FW_BARRIER();                                                  // chunk nc - 1 consumed
-      // Round 0 is worked by the 512 threads that hold no accumulators any more (first-round consumers + producers), the
-      // second-round consumers wait with theirs: no point of the program has 108 accumulators AND an output transform live.
-      FW_BARRIER();
-      const Item wo = uni(w);
-      output_item(wo, 0, tid - 256);                                 // items 256..511 (the first-round consumers: 0..255, 512..767)
-      FW_BARRIER();
-      FW_BARRIER();
-      output_item(wo, 1, tid);
-      FW_BARRIER();
-      v += vstep;
-      if (v >= last) return false;
-      w = cur;
-      ck = 0;
-      has_next = v + vstep < last;
-      if (has_next) cur = decode(v + vstep);
-      return true;
+      const bool item_done = ++ck >= nc;
+      Item wo = uni(w);                                              // the item whose outputs are due
+      bool more = true;
+      if (item_done) {
+        FW_BARRIER();                                                // chunk nc - 1 consumed
+        v += vstep;
+        more = v < last;
+        if (more) {
+          w = cur;
+          ck = 0;
+          has_next = v + vstep < last;
+          if (has_next) cur = decode(v + vstep);
+        }
+      }
+      if (more) next_first();                                        // (ONE call site: see the note on joins above)
+      if (item_done) {
+        // Round 0 is worked by the 512 threads that hold no accumulators any more (first-round consumers + producers), the
+        // second-round consumers wait with theirs: no point of the program has 108 accumulators AND an output transform live.
+        FW_BARRIER();
+        output_item(wo, 0, tid - 256);                               // items 256..511 (the first-round consumers: 0..255, 512..767)
+        FW_BARRIER();
+        FW_BARRIER();
+        output_item(wo, 1, tid);
+        FW_BARRIER();
+      }
+      return more;
     };
 #if !(FWINO_ABLATE & 1)
     load_chunk(w, 0);
@@ -515,13 +538,13 @@ __global__ __launch_bounds__(768) void icg_fwino_kernel(FwinoP p) {
     first_of(std::false_type{});
     for (;;) {
       second(std::false_type{});
-      if (!post()) break;
-      if constexpr (!UP) {
-        first_of(std::true_type{});
+      if constexpr (UP) {
+        if (!post([&] { first_of(std::false_type{}); })) break;
+      } else {
+        if (!post([&] { first_of(std::true_type{}); })) break;
         second(std::true_type{});
-        if (!post()) break;
+        if (!post([&] { first_of(std::false_type{}); })) break;
       }
-      first_of(std::false_type{});
     }
   } else {
     // =========================================================== consumers ===========================================================
@@ -645,7 +668,8 @@ extern "C" int icg_fwino_applies(int B, int H, int W, int Cin, int Cout) {
   if (!fwino_env("ICG_FWINO", 1)) return 0;
   if (Cin % 32 || Cin > fwino_env("ICG_FWINO_MAXK", 192) || Cout % 96 || Cout > fwino_env("ICG_FWINO_MAXN", 192) || H % 16 || W % 16)
     return 0;
-  if ((double)B * H * W * Cin * 4.0 >= 4278190080.0) return 0;       // x behind ONE buffer descriptor with 32-bit offsets (2^32 - 2^24)
+  // x behind ONE buffer descriptor with 32-bit offsets, 32-bit byte offsets into out / the residual operand (2^32 - 2^24)
+  if ((double)B * H * W * Cin * 4.0 >= 4278190080.0 || (double)B * H * W * Cout * 4.0 >= 4278190080.0) return 0;
   const long wgs = (long)B * (H / 16) * (W / 16) * (Cout / 96);
   return (wgs >= fwino_env("ICG_FWINO_MIN_WGS", 512) && wgs < 0x7fffffffL) ? 1 : 0;
 }
@@ -725,7 +749,7 @@ extern "C" int icg_fwino_conv(const float* x, const float* Uf, const float* bias
   const double T = (double)B * (H / 4) * (W / 4);
   ICG_REQUIRE(T * (Cout / 96) / 16 < 2147483647.0);
   if (V) ICG_REQUIRE((double)np * np * T * Cin * 4.0 < 4294967296.0);
-  ICG_REQUIRE((double)B * H * W * Cin * 4.0 < 4278190080.0 && Cin <= 2048);
+  ICG_REQUIRE((double)B * H * W * Cin * 4.0 < 4278190080.0 && (double)B * H * W * Cout * 4.0 < 4278190080.0 && Cin <= 2048);
   return icg_fwino_run(x, in_up, Uf, bias, residual, icg_res_mode(flags), out, out_pool, scale, shift, ss_bstride, B, H, W, Cin,
                        Cout, flags, alpha, np, V, stream);
 }

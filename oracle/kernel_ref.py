@@ -389,7 +389,7 @@ def icg_fwino_applies(B, H, W, Cin, Cout):
         return 0
     if Cin % 32 or Cin > env("ICG_FWINO_MAXK", 192) or Cout % 96 or Cout > env("ICG_FWINO_MAXN", 192) or H % 16 or W % 16:
         return 0
-    if B * H * W * Cin * 4 >= 4278190080:          # x behind one buffer descriptor with 32-bit offsets
+    if B * H * W * Cin * 4 >= 4278190080 or B * H * W * Cout * 4 >= 4278190080:      # 32-bit byte offsets into x / out
         return 0
     wgs = B * (H // 16) * (W // 16) * (Cout // 96)
     return 1 if env("ICG_FWINO_MIN_WGS", 512) <= wgs < 0x7FFFFFFF else 0
