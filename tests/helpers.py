@@ -64,7 +64,7 @@ def _fail(cond, msg, ratio):
 
 
 DENSE_EXCEED_SHARE = 1.0 / 64     # dense groups: share of a tensor's samples that may exceed the per-element tolerance ...
-DENSE_MAX_MULT = 3.5              # ... by at most this factor (round 4: 4.0 -> 3.5; measured worst 2.95, profiles/r04_parity_report.txt),
+DENSE_MAX_MULT = 3.25             # ... by at most this factor (round 4: 4.0 -> 3.25; measured worst 2.95, profiles/r04_parity_report.txt),
 DENSE_RMS_FRAC = 0.3              # ... while the rms of the differences stays below this fraction of the tolerance (0.5 -> 0.3; worst 0.22)
 
 

@@ -22,7 +22,7 @@ for path in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv")
 rows = []
 for k, c in tot.items():
     busy = c.get("SQ_BUSY_CU_CYCLES", 0.0)
-    if busy > 0 and any(t in k for t in ("icg_gemm", "icg_pgemm", "icg_pconv")):
+    if busy > 0 and any(t in k for t in ("icg_gemm", "icg_pgemm", "icg_pconv", "icg_fwino_kernel", "icg_attn", "thin_", "narrow_")):
         rows.append((c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * busy), busy, cnt[k], k))
 for util, busy, n, k in sorted(rows, key=lambda r: -r[1]):
     print(f"{util:6.3f} MFMA-pipe utilisation  {n:5d} launches  {k}")
