@@ -45,7 +45,11 @@ class StyleGAN2Loss:
                 cutoff = torch.empty([], dtype=torch.int64, device=ws.device).random_(1, ws.shape[1])
                 cutoff = torch.where(torch.rand([], device=ws.device) < self.style_mixing_prob, cutoff,
                                      torch.full_like(cutoff, ws.shape[1]))
-                ws[:, cutoff:] = self.G_mapping(_randn_like(z), c, h, skip_w_avg_update=True)[:, cutoff:]
+                # ws[:, cutoff:] = mixed[:, cutoff:] (loss.py:52) as a select: slicing with a device scalar reads it back to the
+                # host -- a device synchronisation per generator pass, and not capturable in a HIP graph; same values
+                mixed = self.G_mapping(_randn_like(z), c, h, skip_w_avg_update=True)
+                layer = torch.arange(ws.shape[1], device=ws.device).reshape(1, -1, 1)
+                ws = torch.where(layer >= cutoff, mixed, ws)
         with _ddp_sync(self.G_synthesis, sync):
             img = self.G_synthesis(ws)
         return img, ws

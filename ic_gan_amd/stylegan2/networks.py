@@ -45,14 +45,13 @@ class FullyConnectedLayer(torch.nn.Module):
         self.bias_gain = lr_multiplier
 
     def forward(self, x):
-        w = self.weight * self.weight_gain
         b = self.bias
         if b is not None and self.bias_gain != 1:
             b = b * self.bias_gain
         # x @ w^T on the hand-written GEMM (conv2d_gradfix._Matmul: closed under differentiation, so the layer has gradients of
         # every order like the rest of the network -- path-length regularisation differentiates the affine layers twice);
         # the reference's addmm / matmul (networks.py:99-107) are cuBLAS calls
-        y = linear_nt(x, w)
+        y = linear_nt(x, self.weight, alpha=self.weight_gain)            # (w * gain) folded into the GEMM's alpha
         if self.activation == "linear" and b is not None:
             return y + b.unsqueeze(0)
         return bias_act.bias_act(y, b, act=self.activation)

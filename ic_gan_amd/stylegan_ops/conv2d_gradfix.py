@@ -73,11 +73,16 @@ def _adjoint_weight(w):
     return w.permute(3, 1, 2, 0).flip(1, 2).contiguous()
 
 
+_PHASE_TAPS = {}      # device -> index tensor (made once: a host list -> device copy is not capturable in a HIP graph)
+
+
 def _phase_weights(w):
     """[Cout][3][3][Cin] (gather form) -> wp[al][be][Cout][2][2][Cin] of icg_conv2d_tr2_fprop: an even output coordinate
     meets taps {0, 2}, an odd one tap {1} (second slot zero)."""
     w4 = torch.nn.functional.pad(w, (0, 0, 0, 1, 0, 1))                  # tap index 3 = zero
-    idx = torch.tensor([0, 2, 1, 3], device=w.device)                    # (al, u) -> tap: (0,0)->0 (0,1)->2 (1,0)->1 (1,1)->zero
+    idx = _PHASE_TAPS.get(w.device)                                      # (al, u) -> tap: (0,0)->0 (0,1)->2 (1,0)->1 (1,1)->zero
+    if idx is None:
+        idx = _PHASE_TAPS[w.device] = torch.tensor([0, 2, 1, 3], device=w.device)
     g = w4.index_select(1, idx).index_select(2, idx)                     # [Cout][al,u][be,v][Cin]
     Cout, Cin = w.shape[0], w.shape[3]
     return g.view(Cout, 2, 2, 2, 2, Cin).permute(1, 3, 0, 2, 4, 5).contiguous()
@@ -224,9 +229,9 @@ class _Matmul(torch.autograd.Function):
     (each gradient is another mode of the same Function), so gradients of every order exist, as for the convolutions."""
 
     @staticmethod
-    def forward(ctx, a, b, mode):
+    def forward(ctx, a, b, mode, alpha=1.0):
         _ops._require_gpu(a)
-        ctx.mode = mode
+        ctx.mode, ctx.alpha = mode, float(alpha)
         ctx.save_for_backward(a, b)
         ctx.out_dtype = torch.promote_types(a.dtype, b.dtype)      # the reference's addmm / matmul return the operands' dtype
         if ctx.out_dtype == torch.float64:
@@ -246,35 +251,37 @@ class _Matmul(torch.autograd.Function):
             (k, m), n = a.shape, b.shape[1]
             assert b.shape == (k, n)
         c = torch.empty(m, n, device=a.device, dtype=torch.float32)
-        L.call("icg_gemm_batched", a, b, c, m, n, k, 1 if mode == 2 else 0, 1 if mode == 0 else 0, 0, 0, 0, 1, 1.0)
+        L.call("icg_gemm_batched", a, b, c, m, n, k, 1 if mode == 2 else 0, 1 if mode == 0 else 0, 0, 0, 0, 1, ctx.alpha)
         return c if ctx.out_dtype == torch.float32 else c.to(ctx.out_dtype)
 
     @staticmethod
     def backward(ctx, dc):
         a, b = ctx.saved_tensors
-        mode = ctx.mode
+        mode, al = ctx.mode, ctx.alpha
         da = db = None
-        if mode == 0:        # C = A B^T:  dA = dC B,  dB = dC^T A
+        if mode == 0:        # C = al A B^T:  dA = al dC B,  dB = al dC^T A
             if ctx.needs_input_grad[0]:
-                da = _Matmul.apply(dc, b, 1)
+                da = _Matmul.apply(dc, b, 1, al)
             if ctx.needs_input_grad[1]:
-                db = _Matmul.apply(dc, a, 2)
-        elif mode == 1:      # C = A B:  dA = dC B^T,  dB = A^T dC
+                db = _Matmul.apply(dc, a, 2, al)
+        elif mode == 1:      # C = al A B:  dA = al dC B^T,  dB = al A^T dC
             if ctx.needs_input_grad[0]:
-                da = _Matmul.apply(dc, b, 0)
+                da = _Matmul.apply(dc, b, 0, al)
             if ctx.needs_input_grad[1]:
-                db = _Matmul.apply(a, dc, 2)
-        else:                # C = A^T B:  dA = B dC^T,  dB = A dC
+                db = _Matmul.apply(a, dc, 2, al)
+        else:                # C = al A^T B:  dA = al B dC^T,  dB = al A dC
             if ctx.needs_input_grad[0]:
-                da = _Matmul.apply(b, dc, 0)
+                da = _Matmul.apply(b, dc, 0, al)
             if ctx.needs_input_grad[1]:
-                db = _Matmul.apply(a, dc, 1)
-        return da, db, None
+                db = _Matmul.apply(a, dc, 1, al)
+        return da, db, None, None
 
 
-def linear_nt(x, w):
-    """x [M][K] @ w [N][K]^T -> [M][N] (F.linear without the bias), arbitrary-order gradients."""
-    return _Matmul.apply(x, w, 0)
+def linear_nt(x, w, alpha=1.0):
+    """alpha * x [M][K] @ w [N][K]^T -> [M][N] (F.linear without the bias), arbitrary-order gradients.  `alpha`: the equalised-
+    learning-rate gain of a FullyConnectedLayer (networks.py:99-107 multiplies the weight by it first: one elementwise kernel
+    forward and one backward per layer; here it rides in the GEMM's epilogue)."""
+    return _Matmul.apply(x, w, 0, alpha)
 
 
 def _one(v, what):

@@ -208,3 +208,28 @@ def test_phase_gradients_hip(name, monkeypatch):
 @pytest.mark.parametrize("name", CASES + REAL_CASES)
 def test_training_iterations_hip(name, monkeypatch):
     _iterations(name, "cuda:0", monkeypatch)
+
+
+def test_style_mixing_select_equals_the_slice_assignment():
+    """loss.py:49-53 `ws[:, cutoff:] = mixed[:, cutoff:]` is computed as a select over the layer index (no device -> host read of
+    the cutoff): same ws for every cutoff, incl. 'no mixing' (cutoff = num_ws)."""
+    from ic_gan_amd.stylegan2.loss import StyleGAN2Loss
+    num_ws, calls = 6, []
+    a, b = torch.randn(3, num_ws, 4), torch.randn(3, num_ws, 4)
+
+    def mapping(z, c, h, skip_w_avg_update=False):
+        calls.append(skip_w_avg_update)
+        return (b if skip_w_avg_update else a).clone()
+
+    for seed in range(12):
+        for prob in (0.9, 1.0):
+            loss = StyleGAN2Loss("cpu", mapping, lambda ws: ws, None, style_mixing_prob=prob)
+            torch.manual_seed(seed)
+            _, ws = loss.run_G(torch.zeros(3, 2), None, None, sync=True)
+            torch.manual_seed(seed)                       # the reference's own lines, same RNG draws
+            cutoff = torch.empty([], dtype=torch.int64).random_(1, num_ws)
+            cutoff = torch.where(torch.rand([]) < prob, cutoff, torch.full_like(cutoff, num_ws))
+            want = a.clone()
+            want[:, cutoff:] = b[:, cutoff:]
+            assert torch.equal(ws, want), (seed, prob, int(cutoff))
+    assert calls[:2] == [False, True]
