@@ -4,8 +4,9 @@ A piece's forward + backward is run eagerly twice, captured in a HIP graph, and 
 whose gradient is not bit-identical to the eager one are listed.  Finding of round 4 (MI355X, ROCm 7.0, torch 2.10): every single
 operation replays exactly, and so do modulated convolutions without a noise operand; modulated_conv2d with demodulation AND a noise
 operand (+ bias_act) -- i.e. a SynthesisLayer -- is exact in replay 0 and differs from replay 1 on, in fp16 and in fp32 storage,
-in gradients that vary with the memory layout.  Replay 0 runs on fresh (zero) pool memory, later replays on the previous replay's
-leftovers: the signature of a read past the end of a tensor somewhere in that composition."""
+in gradients that vary with the memory layout -- also with the convolution replaced by an ATen einsum (case 3c: no kernel of this
+repository in that position), not with the convolution removed (3b).  Replay 0 runs on fresh (zero) pool memory, later replays on
+the previous replay's leftovers: something in that composition reads memory it did not write in the same replay."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -83,3 +84,18 @@ check("2 modconv(demod=True, noise=None)", lambda m: MC.modulated_conv2d(xcl(m),
 check("3 modconv(demod=True, noise = nz * strength)", lambda m: MC.modulated_conv2d(xcl(m), m.w, sty(m), noise=nz * m.ns, padding=1, demodulate=True), ns=torch.full([], 0.3), **L)
 check("4 3 + bias_act(lrelu, clamp)", lambda m: BA.bias_act(MC.modulated_conv2d(xcl(m), m.w, sty(m), noise=nz * m.ns, padding=1, demodulate=True), m.bb.to(torch.float16), act="lrelu", gain=1.4, clamp=256), ns=torch.full([], 0.3), bb=pn((C,), 8.5), **L)
 check("5 fp32 storage: modconv(demod=True, noise) + bias_act", lambda m: BA.bias_act(MC.modulated_conv2d(m.x.contiguous(memory_format=torch.channels_last), m.w, sty(m), noise=nz * m.ns, padding=1, demodulate=True), m.bb, act="lrelu", gain=1.4), ns=torch.full([], 0.3), bb=pn((C,), 8.5), **L)
+
+# ---- case 3 with the convolution replaced / removed
+def mod_noconv(m, conv):
+    x, wgt, styles = xcl(m), m.w, sty(m)
+    wgt = wgt * (1 / np.sqrt(C * 9) / wgt.norm(float("inf"), dim=[1, 2, 3], keepdim=True))
+    styles = styles / styles.norm(float("inf"), dim=1, keepdim=True)
+    wsq = wgt.square().sum(dim=[2, 3])
+    dco = (CG.linear_nt(styles.square().float(), wsq.float()) + 1e-8).rsqrt()
+    y = x * styles.to(x.dtype).reshape(B, -1, 1, 1)
+    y = conv(y, wgt)
+    return torch.addcmul((nz * m.ns).to(y.dtype), y, dco.to(y.dtype).reshape(B, -1, 1, 1))
+check("3a case 3 spelled out (our conv)", lambda m: mod_noconv(m, lambda y, wgt: CG.conv2d(y, wgt.to(y.dtype), padding=1)), ns=torch.full([], 0.3), **L)
+check("3b no convolution at all (identity)", lambda m: mod_noconv(m, lambda y, wgt: y * 1.0 + 0 * wgt.sum().to(y.dtype)), ns=torch.full([], 0.3), **L)
+check("3c conv as an fp32 einsum over the centre tap", lambda m: mod_noconv(m, lambda y, wgt: torch.einsum("nchw,oc->nohw", y.float(), wgt[:, :, 1, 1]).to(y.dtype).contiguous(memory_format=torch.channels_last)), ns=torch.full([], 0.3), **L)
+check("3d our conv, noise without the strength parameter", lambda m: mod_noconv(m, lambda y, wgt: CG.conv2d(y, wgt.to(y.dtype), padding=1)) + 0 * m.ns.to(torch.float16), ns=torch.full([], 0.3), **L)
