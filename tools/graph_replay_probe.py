@@ -4,8 +4,8 @@ A piece's forward + backward is run eagerly twice, captured in a HIP graph, and 
 whose gradient is not bit-identical to the eager one are listed.  Finding of round 4 (MI355X, ROCm 7.0, torch 2.10): every single
 operation replays exactly, and so do modulated convolutions without a noise operand; modulated_conv2d with demodulation AND a noise
 operand (+ bias_act) -- i.e. a SynthesisLayer -- is exact in replay 0 and differs from replay 1 on, in fp16 and in fp32 storage,
-in gradients that vary with the memory layout -- also with the convolution replaced by an ATen einsum (case 3c: no kernel of this
-repository in that position), not with the convolution removed (3b).  Replay 0 runs on fresh (zero) pool memory, later replays on
+in gradients that vary with the memory layout -- also with the convolution replaced by an ATen einsum (case 3c) and with the WHOLE
+composition written in ATen operations (3e / 3f: no kernel of this repository in the graph), not with the convolution removed (3b).  Replay 0 runs on fresh (zero) pool memory, later replays on
 the previous replay's leftovers: something in that composition reads memory it did not write in the same replay."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -52,7 +52,8 @@ def check(tag, fwd, **leaves):
     bits = lambda t: t.contiguous().view(torch.int32)
     for rep in range(3):
         g.replay(); torch.cuda.synchronize()
-        res.append([n for (n, _), r, h in zip(named, ref, held) if not torch.equal(bits(r), bits(h))])
+        res.append([(n if r.numel() > 1 else "%s: eager %.6g graph %.6g" % (n, float(r), float(h))) for (n, _), r, h in zip(named, ref, held)
+                    if not torch.equal(bits(r), bits(h))])
     print("%-64s differing: %s" % (tag, res), flush=True)
 
 B, C, H = 2, 512, 32
@@ -99,3 +100,16 @@ check("3a case 3 spelled out (our conv)", lambda m: mod_noconv(m, lambda y, wgt:
 check("3b no convolution at all (identity)", lambda m: mod_noconv(m, lambda y, wgt: y * 1.0 + 0 * wgt.sum().to(y.dtype)), ns=torch.full([], 0.3), **L)
 check("3c conv as an fp32 einsum over the centre tap", lambda m: mod_noconv(m, lambda y, wgt: torch.einsum("nchw,oc->nohw", y.float(), wgt[:, :, 1, 1]).to(y.dtype).contiguous(memory_format=torch.channels_last)), ns=torch.full([], 0.3), **L)
 check("3d our conv, noise without the strength parameter", lambda m: mod_noconv(m, lambda y, wgt: CG.conv2d(y, wgt.to(y.dtype), padding=1)) + 0 * m.ns.to(torch.float16), ns=torch.full([], 0.3), **L)
+
+# ---- 3c with every operation in ATen (no kernel of this repository at all): F.linear for the affine layer and the demodulation
+def mod_aten(m):
+    x = xcl(m)
+    styles = torch.nn.functional.linear(m.wl, m.aw * (1 / np.sqrt(512)), m.ab)
+    wgt = m.w * (1 / np.sqrt(C * 9) / m.w.norm(float("inf"), dim=[1, 2, 3], keepdim=True))
+    styles = styles / styles.norm(float("inf"), dim=1, keepdim=True)
+    dco = (torch.nn.functional.linear(styles.square(), wgt.square().sum(dim=[2, 3])) + 1e-8).rsqrt()
+    y = x * styles.to(x.dtype).reshape(B, -1, 1, 1)
+    y = torch.einsum("nchw,oc->nohw", y.float(), wgt[:, :, 1, 1]).to(x.dtype).contiguous(memory_format=torch.channels_last)
+    return torch.addcmul((nz * m.ns).to(y.dtype), y, dco.to(y.dtype).reshape(B, -1, 1, 1))
+check("3e the same composition in ATen only", mod_aten, ns=torch.full([], 0.3), **L)
+check("3f ATen only, fp32 storage", lambda m: mod_aten(type("M", (), dict(x=m.x, w=m.w, wl=m.wl, aw=m.aw, ab=m.ab, ns=m.ns))) if False else mod_aten(m).float(), ns=torch.full([], 0.3), **L)
