@@ -11,19 +11,23 @@
 // (the register file, not the LDS, is what bounds the tile count: 37 tiles would fill the CU's 512 KB).
 //
 // Warp specialisation (12 waves = 768 threads, 3 per SIMD):
-//   * waves 8..11, PRODUCERS: lane = (tile, channel) of a 32-channel chunk; 6 x 6 (4 x 4 source pixels, upsample-fused form)
-//     window loads straight from x (128-byte segments), BN / ccbn affine + ReLU + zero padding, B^T d B in registers, the 36
-//     values go to LDS in the MFMA operand order (one ds_write_b32 each, conflict-free through an XOR of the tile index with the
-//     channel quad); optionally also to HBM as the V planes the weight gradient wants (icg_conv2d_wino4_wgrad_from_v).
-//     Their global loads are HBM-latency loads; keeping them in waves of their own keeps the in-order vmcnt queue of the MFMA
-//     waves free of them.
+//   * waves 8..11, PRODUCERS: lane = (tile, channel PAIR) of a 32-channel chunk; the 6 x 6 (4 x 4 source pixels, upsample-fused
+//     form) window lives in registers as float2: BN / ccbn affine + ReLU + zero padding, B^T d B with v_pk_* arithmetic, the 36
+//     values go to LDS in the MFMA operand order (ds_write_b64, conflict-free through an XOR of the tile index with the channel
+//     quad); optionally also to HBM as the V planes the weight gradient wants (icg_conv2d_wino4_wgrad_from_v).  The window is
+//     REFILLED IN PLACE: the second 1-D pass retires it line by line and each retired line's registers are loaded at once with
+//     the matching line of the next chunk's window (buffer loads through one descriptor over x), so the loads have half a
+//     transform of distance without a second set of 72 registers; the two pass orders alternate (see transform notes below).
+//     Their loads are HBM-latency loads; keeping them in waves of their own keeps the in-order vmcnt queue of the MFMA waves
+//     free of them.
 //   * waves 0..7, CONSUMERS: wave (pg, ng) owns planes pg, pg+4, ... and 48 of the 96 columns: per plane and 16-channel
 //     group ONE ds_read_b128 (the tile operand of four k-steps) and three 16-byte global loads of the fragment-major weights
 //     (icg_fwino_pack_kernel: every wave-load is 1 KiB contiguous = 8 full cache lines from L2) feed 12
 //     v_mfma_f32_16x16x4_f32.  Weight fragments are prefetched one half-step (12 MFMAs) ahead.
 //   * double-buffered V chunk in LDS (2 x 72 KiB), ONE raw s_barrier per 32-channel chunk.
 //   * output: accumulators -> LDS (the V buffers are dead by then) in two 48-column rounds, every thread then owns one
-//     (tile, column): A^T m A from 36 LDS reads, alpha / bias / residual (plain, upsample-on-read, ReLU mask) and the stores.
+//     (tile, column): bias and the residual operand first (all loads in flight), A^T m A from 36 LDS reads, alpha / bias /
+//     residual (plain, upsample-on-read, ReLU mask) and the stores.
 // Chains are single-level over K <= 192 (48 MFMA steps); the routes through this kernel are gated on that (fwino_applies).
 #include "icg_common.h"
 #include <stdlib.h>
