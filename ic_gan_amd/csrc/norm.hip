@@ -83,15 +83,18 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-// sums[2][C] (double) = sum over chunks of partial[chunk][2][C]; block = 32 channels x 8 chunk slices
-__global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __restrict__ partial, int nchunks, int C,
-                                                                 double* __restrict__ sums) {
-  __shared__ double red[2][8][32];
+// sums[2][C] (double) = sum over chunks of partial[chunk][2][C]; block = 32 channels x 32 chunk slices (8 slices until round 4: with
+// C / 32 = 3 ... 6 workgroups for the 96- / 192-channel layers each thread walked 128 of the 1024 chunks serially: 35 us per launch,
+// 26 launches per step)
+__global__ __launch_bounds__(1024) void bn_reduce_partials_kernel(const float* __restrict__ partial, int nchunks, int C,
+                                                                  double* __restrict__ sums) {
+  constexpr int SL = 32;
+  __shared__ double red[2][SL][32];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double a = 0.0, b = 0.0;
   if (c < C) {
-    for (int k = sl; k < nchunks; k += 8) {
+    for (int k = sl; k < nchunks; k += SL) {
       a += (double)partial[(long)k * 2 * C + c];
       b += (double)partial[(long)k * 2 * C + C + c];
     }
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void bn_reduce_partials_kernel(const float* __
   red[1][sl][cl] = b;
   __syncthreads();
   if (sl == 0 && c < C) {
-    for (int k = 1; k < 8; ++k) {
+    for (int k = 1; k < SL; ++k) {
       a += red[0][k][cl];
       b += red[1][k][cl];
     }
@@ -165,7 +168,7 @@ extern "C" int icg_bn_partial_stats(const float* x, const float* shift_k, int64_
 extern "C" int icg_bn_reduce_partials(const void* workspace, int64_t rows, int C, double* sums, void* stream) {
   ICG_REQUIRE(workspace && sums && rows > 0 && C > 0 && (C % 4) == 0);
   ColPlan pl = col_plan(rows, C, 1024);
-  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((unsigned)icg_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3((unsigned)icg_cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream,
                      (const float*)workspace, pl.nchunks, C, sums);
   return icg_check_launch();
 }
