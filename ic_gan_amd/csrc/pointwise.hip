@@ -514,19 +514,19 @@ static int colsum4_blocks(int64_t rows, int C) {
   return (int)want;
 }
 
-// out[c] = sum_k part[k][c]; block = 32 channels x 8 slices of k (deterministic order)
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nblocks, int C,
-                                                           float* __restrict__ out) {
-  __shared__ double red[8][32];
+// out[c] = sum_k part[k][c]; block = 32 channels x 32 slices of k (deterministic order)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nblocks, int C,
+                                                            float* __restrict__ out) {
+  __shared__ double red[32][33];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s = 0.0;
   if (c < C)
-    for (int k = sl; k < nblocks; k += 8) s += (double)part[(long)k * C + c];
+    for (int k = sl; k < nblocks; k += 32) s += (double)part[(long)k * C + c];
   red[sl][cl] = s;
   __syncthreads();
   if (sl == 0 && c < C) {
-    for (int k = 1; k < 8; ++k) s += red[k][cl];
+    for (int k = 1; k < 32; ++k) s += red[k][cl];
     out[c] = (float)s;
   }
 }
@@ -581,7 +581,7 @@ extern "C" int icg_colsum(const float* x, int64_t rows, int C, float* out, void*
     const int chunks = (int)icg_cdiv(rows, rpc);
     hipLaunchKernelGGL(colsum_wide_partial_kernel, dim3((unsigned)icg_cdiv(C, 256), chunks), dim3(256), 0, st, x,
                        (long)rows, C, rpc, (float*)workspace);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)icg_cdiv(C, 32)), dim3(256), 0, st,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)icg_cdiv(C, 32)), dim3(1024), 0, st,
                        (const float*)workspace, chunks, C, out);
     return icg_check_launch();
   }
@@ -590,14 +590,14 @@ extern "C" int icg_colsum(const float* x, int64_t rows, int C, float* out, void*
     if (workspace_bytes < (size_t)blocks * C * sizeof(float)) return ICG_ERR_WORKSPACE;
     hipLaunchKernelGGL(colsum_partial4_kernel, dim3(blocks), dim3(256), 0, st, (const float4*)x, (long)rows * (C / 4),
                        C / 4, (float*)workspace);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)icg_cdiv(C, 32)), dim3(256), 0, st, (const float*)workspace,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)icg_cdiv(C, 32)), dim3(1024), 0, st, (const float*)workspace,
                        blocks, C, out);
     return icg_check_launch();
   }
   const int blocks = colsum_blocks(rows, C);
   if (workspace_bytes < (size_t)blocks * C * sizeof(float)) return ICG_ERR_WORKSPACE;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(blocks), dim3(256), 0, st, x, (long)rows * C, C, (float*)workspace);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)icg_cdiv(C, 32)), dim3(256), 0, st, (const float*)workspace,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)icg_cdiv(C, 32)), dim3(1024), 0, st, (const float*)workspace,
                      blocks, C, out);
   return icg_check_launch();
 }

@@ -980,17 +980,22 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
   }
 }
 
-// dbias[c] = sum over blocks of part[block][c]: one workgroup per channel, lanes stride over the blocks in fixed order
-__global__ __launch_bounds__(256) void wino_db_final_kernel(const float* __restrict__ part, int nblocks, int C,
-                                                            float* __restrict__ dbias) {
-  __shared__ float red[4];
-  const int c = blockIdx.x;
-  float a = 0.f;
-  for (int k = threadIdx.x; k < nblocks; k += 256) a += part[(long)k * C + c];
-  a = wave_sum(a);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+// dbias[c] = sum over blocks of part[block][c]: block = 32 channels x 32 slices of the partial rows (128-byte row segments per
+// wave half, fixed order), folded through LDS
+__global__ __launch_bounds__(1024) void wino_db_final_kernel(const float* __restrict__ part, int nblocks, int C,
+                                                             float* __restrict__ dbias) {
+  __shared__ double red[32][33];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double a = 0.0;
+  if (c < C)
+    for (int k = sl; k < nblocks; k += 32) a += (double)part[(long)k * C + c];
+  red[sl][cl] = a;
   __syncthreads();
-  if (threadIdx.x == 0) dbias[c] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (sl == 0 && c < C) {
+    for (int k = 1; k < 32; ++k) a += red[k][cl];
+    dbias[c] = (float)a;
+  }
 }
 
 __device__ __forceinline__ void w4_gt3(const float u[6], float g[3]) {
@@ -1061,7 +1066,7 @@ static int wino4_wgrad_run(const float* x, int x_up, const float* dy, int dy_up,
   else if (np == 5) hipLaunchKernelGGL((wino4_dy_kernel<0, 5>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha, db_part);
   else hipLaunchKernelGGL((wino4_dy_kernel<0, 6>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha, db_part);
   if (db_part)
-    hipLaunchKernelGGL(wino_db_final_kernel, dim3((unsigned)Cout), dim3(256), 0, st, (const float*)db_part, (int)nb, Cout, dbias);
+    hipLaunchKernelGGL(wino_db_final_kernel, dim3((unsigned)icg_cdiv(Cout, 32)), dim3(1024), 0, st, (const float*)db_part, (int)nb, Cout, dbias);
   int rc;
   { PlanesScope ps(stream, (int)P, Cin, Cout, (double)T, 1); rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, (int)P, gws, gws_bytes, stream); }
   if (rc != ICG_OK) return rc;
