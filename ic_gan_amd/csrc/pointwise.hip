@@ -402,30 +402,52 @@ __global__ void scale_add_fwd_kernel(const float* __restrict__ gamma, const floa
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = fmaf(g, o[i], x[i]);
 }
+// 16-byte loads when the three arrays allow it (two quads in flight per thread); the per-thread sum stays fp64 and the order fixed
 __global__ __launch_bounds__(256) void scale_add_bwd_kernel(const float* __restrict__ gamma,
                                                             const float* __restrict__ o,
                                                             const float* __restrict__ dout, float* __restrict__ d_o,
-                                                            double* __restrict__ part, long n) {
+                                                            double* __restrict__ part, long n, int vec) {
   __shared__ double red[4];
   const float g = gamma[0];
   const long stride = (long)gridDim.x * blockDim.x;
+  const long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
   double acc = 0.0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float d = dout[i];
-    acc += (double)d * (double)o[i];
-    d_o[i] = g * d;
+  if (vec) {
+    const long n4 = n >> 2;
+    const float4* __restrict__ o4 = reinterpret_cast<const float4*>(o);
+    const float4* __restrict__ d4 = reinterpret_cast<const float4*>(dout);
+    float4* __restrict__ r4 = reinterpret_cast<float4*>(d_o);
+    long i = g0;
+    for (; i + stride < n4; i += 2 * stride) {
+      const float4 da = d4[i], db = d4[i + stride], oa = o4[i], ob = o4[i + stride];
+      acc += ((double)da.x * (double)oa.x + (double)da.y * (double)oa.y) + ((double)da.z * (double)oa.z + (double)da.w * (double)oa.w);
+      acc += ((double)db.x * (double)ob.x + (double)db.y * (double)ob.y) + ((double)db.z * (double)ob.z + (double)db.w * (double)ob.w);
+      r4[i] = make_float4(g * da.x, g * da.y, g * da.z, g * da.w);
+      r4[i + stride] = make_float4(g * db.x, g * db.y, g * db.z, g * db.w);
+    }
+    if (i < n4) {
+      const float4 da = d4[i], oa = o4[i];
+      acc += ((double)da.x * (double)oa.x + (double)da.y * (double)oa.y) + ((double)da.z * (double)oa.z + (double)da.w * (double)oa.w);
+      r4[i] = make_float4(g * da.x, g * da.y, g * da.z, g * da.w);
+    }
+  } else {
+    for (long i = g0; i < n; i += stride) {
+      const float d = dout[i];
+      acc += (double)d * (double)o[i];
+      d_o[i] = g * d;
+    }
   }
   acc = wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void sum_parts_kernel(const double* __restrict__ part, int n, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int k = 0; k < n; ++k) s += part[k];
-    out[0] = (float)s;
-  }
+// out[0] = sum of n block partials: one wave, lane l takes partials l, l + 64, ... in order, then the wave fold
+__global__ __launch_bounds__(64) void sum_parts_kernel(const double* __restrict__ part, int n, float* __restrict__ out) {
+  double s = 0.0;
+  for (int k = threadIdx.x; k < n; k += 64) s += part[k];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[0] = (float)s;
 }
 extern "C" int icg_scale_add_fwd(const float* gamma, const float* o, const float* x, float* out, int64_t n,
                                  void* stream) {
@@ -437,10 +459,13 @@ extern "C" int icg_scale_add_fwd(const float* gamma, const float* o, const float
 extern "C" int icg_scale_add_bwd(const float* gamma, const float* o, const float* dout, float* d_o, float* dgamma,
                                  int64_t n, void* scratch, size_t scratch_bytes, void* stream) {
   ICG_REQUIRE(gamma && o && dout && d_o && dgamma && scratch && n > 0);
-  int blocks = (int)(icg_cdiv(n, 1024) > 512 ? 512 : icg_cdiv(n, 1024));
-  if (scratch_bytes < (size_t)blocks * sizeof(double)) return ICG_ERR_WORKSPACE;
+  if (scratch_bytes < 512 * sizeof(double)) return ICG_ERR_WORKSPACE;
+  long cap = (long)(scratch_bytes / sizeof(double));       // 512 partials at least; up to 2048 when the scratch holds them
+  if (cap > 2048) cap = 2048;
+  const int blocks = (int)(icg_cdiv(n, 2048) > cap ? cap : icg_cdiv(n, 2048));
+  const int vec = ((n & 3) == 0) && ((((uintptr_t)o) | ((uintptr_t)dout) | ((uintptr_t)d_o)) & 15) == 0;
   hipLaunchKernelGGL(scale_add_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gamma, o, dout, d_o,
-                     (double*)scratch, (long)n);
+                     (double*)scratch, (long)n, vec);
   hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)scratch, blocks,
                      dgamma);
   return icg_check_launch();

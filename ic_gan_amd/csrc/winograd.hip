@@ -980,21 +980,24 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
   }
 }
 
-// dbias[c] = sum over blocks of part[block][c]: block = 32 channels x 32 slices of the partial rows (128-byte row segments per
-// wave half, fixed order), folded through LDS
-__global__ __launch_bounds__(1024) void wino_db_final_kernel(const float* __restrict__ part, int nblocks, int C,
-                                                             float* __restrict__ dbias) {
+// out[y][c] = sum of the partial rows [y * rows_per_y, (y + 1) * rows_per_y) of part[.][c]: block = 32 channels x 32 row slices
+// (128-byte row segments, fixed order), folded through LDS.  The bias gradient runs it twice -- the wino4_dy pass leaves up to
+// T * C / 1024 partial rows (24576 x 96 at 256^2: 9.4 MB) -- WINO_DB_ROWS2 row groups first, then those rows into dbias.
+#define WINO_DB_ROWS2 64
+__global__ __launch_bounds__(1024) void wino_db_final_kernel(const float* __restrict__ part, int nblocks, int rows_per_y, int C,
+                                                             float* __restrict__ out) {
   __shared__ double red[32][33];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
+  const int k0 = blockIdx.y * rows_per_y, k1 = min(nblocks, k0 + rows_per_y);
   double a = 0.0;
   if (c < C)
-    for (int k = sl; k < nblocks; k += 32) a += (double)part[(long)k * C + c];
+    for (int k = k0 + sl; k < k1; k += 32) a += (double)part[(long)k * C + c];
   red[sl][cl] = a;
   __syncthreads();
   if (sl == 0 && c < C) {
     for (int k = 1; k < 32; ++k) a += red[k][cl];
-    dbias[c] = (float)a;
+    out[(long)blockIdx.y * C + c] = (float)a;
   }
 }
 
@@ -1065,8 +1068,17 @@ static int wino4_wgrad_run(const float* x, int x_up, const float* dy, int dy_up,
   if (dy_up) hipLaunchKernelGGL((wino4_dy_kernel<1, 5>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha, db_part);
   else if (np == 5) hipLaunchKernelGGL((wino4_dy_kernel<0, 5>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha, db_part);
   else hipLaunchKernelGGL((wino4_dy_kernel<0, 6>), g, blk, 0, st, dy, DY, B, H, W, Cout / 4, dy_alpha, db_part);
-  if (db_part)
-    hipLaunchKernelGGL(wino_db_final_kernel, dim3((unsigned)icg_cdiv(Cout, 32)), dim3(1024), 0, st, (const float*)db_part, (int)nb, Cout, dbias);
+  if (db_part) {
+    const dim3 cg((unsigned)icg_cdiv(Cout, 32));
+    if (nb <= 32 * 8) {
+      hipLaunchKernelGGL(wino_db_final_kernel, cg, dim3(1024), 0, st, (const float*)db_part, (int)nb, (int)nb, Cout, dbias);
+    } else {                                   // two levels: the second level's rows sit behind the nb partial rows
+      float* part2 = db_part + nb * Cout;
+      const int rpy = (int)icg_cdiv(nb, WINO_DB_ROWS2), ny = (int)icg_cdiv(nb, rpy);
+      hipLaunchKernelGGL(wino_db_final_kernel, dim3(cg.x, (unsigned)ny), dim3(1024), 0, st, (const float*)db_part, (int)nb, rpy, Cout, part2);
+      hipLaunchKernelGGL(wino_db_final_kernel, cg, dim3(1024), 0, st, (const float*)part2, ny, ny, Cout, dbias);
+    }
+  }
   int rc;
   { PlanesScope ps(stream, (int)P, Cin, Cout, (double)T, 1); rc = icg_gemm_tn_batched(V, DY, dU, Cin, Cout, (int)T, T * Cin, T * Cout, (long)Cin * Cout, (int)P, gws, gws_bytes, stream); }
   if (rc != ICG_OK) return rc;
@@ -1131,7 +1143,7 @@ extern "C" size_t icg_conv2d_wino4_wgrad_from_v_workspace_bytes(int B, int H, in
 extern "C" size_t icg_conv2d_wino4_wgrad_from_v_db_workspace_bytes(int B, int H, int W, int Cin, int Cout, int planes) {
   const long T = (long)B * (H / 4) * (W / 4);
   return icg_conv2d_wino4_wgrad_from_v_workspace_bytes(B, H, W, Cin, Cout, planes) +
-         wino_al((size_t)wino4_dy_blocks(T, Cout) * Cout * sizeof(float));
+         wino_al((size_t)(wino4_dy_blocks(T, Cout) + WINO_DB_ROWS2) * Cout * sizeof(float));
 }
 
 extern "C" int icg_conv2d_wino4_wgrad_from_v_db(const float* V, const float* dy, float* dw, float* dbias, int B, int H, int W,

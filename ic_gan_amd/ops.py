@@ -937,7 +937,7 @@ class ScaleAddFn(Function):
         dout = _cl(dout)
         d_o = torch.empty_like(o)
         dgamma = _f32(1, o.device)
-        nb = 512 * 8
+        nb = 2048 * 8
         L.call("icg_scale_add_bwd", g, o, dout, d_o, dgamma, o.numel(), _bytes(nb, o.device), nb)
         return dgamma.view(ctx.gshape), d_o, dout
 
