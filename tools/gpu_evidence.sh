@@ -16,3 +16,12 @@ timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_final.log 2
 tail -n 1 gpurun_out/bench_final.log | cut -c1-3000
 timeout 300 python tools/block_profile.py > gpurun_out/block_profile.txt 2>&1
 tail -n 30 gpurun_out/block_profile.txt | cut -c1-200
+if [ "$1" = "secondary" ]; then
+  # the secondary workloads' lines at the same kernels (profiles/rNN_bench_{cfg2,cfg4_fp16,cfg5,sample,cfg3_acc4x16}.json.log)
+  timeout 300 python bench.py --workload cfg2 --no-cpu-baseline > gpurun_out/bench_cfg2.log 2>&1
+  timeout 300 python bench.py --workload cfg4 --fp16 --steps 16 --warmup 4 --no-cpu-baseline > gpurun_out/bench_cfg4_fp16.log 2>&1
+  timeout 300 python bench.py --workload sample --no-cpu-baseline > gpurun_out/bench_sample.log 2>&1
+  timeout 300 python bench.py --accumulate 4 --batch 16 --no-cpu-baseline > gpurun_out/bench_cfg3_acc4x16.log 2>&1
+  timeout 400 python bench.py --workload cfg5 --no-cpu-baseline > gpurun_out/bench_cfg5.log 2>&1
+  for f in cfg2 cfg4_fp16 sample cfg3_acc4x16 cfg5; do tail -n 1 gpurun_out/bench_$f.log | cut -c1-200; done
+fi
