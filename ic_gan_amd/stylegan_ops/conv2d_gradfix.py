@@ -16,8 +16,8 @@ and the family is closed under differentiation:
 so both autograd Functions below express their backward with each other and gradients of any order exist.
 
 Tensors are logical NCHW fp32 stored channels-last (NHWC in memory), weights are handed to the kernel as
-[Cout][R][R][Cin].  groups > 1, dilation > 1 and non-square stride/padding are not supported (StyleGAN2 training uses
-none of them: `fused_modconv` — the only groups>1 user — is off in training mode, networks.py:440-444).
+[Cout][R][R][Cin].  dilation > 1 and non-square stride/padding are not supported (StyleGAN2 uses neither); groups > 1 — only
+`fused_modconv`, off in training mode (networks.py:440-444) — runs as one groups=1 call per group (`_per_group`).
 
 fp16 (the reference's `num_fp16_res` blocks, training/networks.py:77-91, 581-601: activations and weights cast to fp16, cuDNN
 convolves in fp16 with fp32 accumulation): G runs on icg_conv2d_g_fprop_f16 -- fp16 operands straight into
@@ -294,10 +294,23 @@ def _one(v, what):
 
 def _check(input, weight, dilation, groups):
     assert isinstance(input, torch.Tensor) and input.ndim == 4 and weight.ndim == 4
-    if _one(dilation, "dilation") != 1 or groups != 1:
-        raise NotImplementedError("conv2d_gradfix on HIP supports dilation=1, groups=1 (got %r, %r)" % (dilation, groups))
+    if _one(dilation, "dilation") != 1:
+        raise NotImplementedError("conv2d_gradfix on HIP supports dilation=1 (got %r)" % (dilation,))
     if weight.shape[2] != weight.shape[3]:
         raise NotImplementedError("square kernels only")
+    groups = int(groups)
+    if groups < 1 or int(input.shape[1]) % groups or int(weight.shape[0]) % groups:
+        raise ValueError("groups=%d does not divide the channel counts %d / %d" % (groups, input.shape[1], weight.shape[0]))
+
+
+def _per_group(op, input, weight, bias, groups, **kw):
+    """groups > 1 (the reference's only user: fused_modconv, one group per sample, networks.py:100-114): one call of the groups=1
+    operator per group on channel slices, outputs concatenated -- F.conv2d's / F.conv_transpose2d's layout in both cases (group g
+    owns input channels [g*Cin/G, (g+1)*Cin/G) and the weight's rows [g*W0/G, (g+1)*W0/G)).  Every order of gradient follows
+    from the groups=1 operator's own."""
+    xs, ws = input.chunk(groups, dim=1), weight.chunk(groups, dim=0)
+    y = torch.cat([op(x, w, **kw) for x, w in zip(xs, ws)], dim=1)
+    return _with_bias(y, bias)
 
 
 def _with_bias(y, bias):
@@ -307,6 +320,8 @@ def _with_bias(y, bias):
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     """F.conv2d semantics; weight [Cout][Cin][R][R]  (conv2d_gradfix.py:43-64)."""
     _check(input, weight, dilation, groups)
+    if groups != 1:
+        return _per_group(conv2d, input, weight, bias, int(groups), stride=stride, padding=padding)
     s, p, R = _one(stride, "stride"), _one(padding, "padding"), int(weight.shape[2])
     H, W = int(input.shape[2]), int(input.shape[3])
     out = ((H + 2 * p - R) // s + 1, (W + 2 * p - R) // s + 1)
@@ -327,6 +342,9 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
     """F.conv_transpose2d semantics; weight [Cin][Cout][R][R]  (conv2d_gradfix.py:67-99)."""
     _check(input, weight, dilation, groups)
+    if groups != 1:
+        return _per_group(conv_transpose2d, input, weight, bias, int(groups), stride=stride, padding=padding,
+                          output_padding=output_padding)
     s, p, op, R = _one(stride, "stride"), _one(padding, "padding"), _one(output_padding, "output_padding"), int(weight.shape[2])
     H, W = int(input.shape[2]), int(input.shape[3])
     out = ((H - 1) * s - 2 * p + R + op, (W - 1) * s - 2 * p + R + op)

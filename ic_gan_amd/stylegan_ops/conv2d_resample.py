@@ -9,7 +9,7 @@ is defined on that op graph:
     no resampling  : conv(padding)                                          (200-204)
     otherwise      : upfirdn2d(up) -> conv -> upfirdn2d(down)               (207-216)
 Convolutions run on icg_conv2d_g_fprop / icg_conv2d_g_wgrad (conv2d_gradfix.py here), FIR resampling on
-icg_upfirdn2d.  groups > 1 is not supported (see conv2d_gradfix)."""
+icg_upfirdn2d.  groups > 1: one convolution per group (conv2d_gradfix._per_group)."""
 import torch
 
 from . import conv2d_gradfix, upfirdn2d
@@ -31,9 +31,8 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
     assert isinstance(w, torch.Tensor) and w.ndim == 4 and w.dtype == x.dtype
     assert f is None or (isinstance(f, torch.Tensor) and f.ndim in [1, 2] and f.dtype == torch.float32)
     assert isinstance(up, int) and up >= 1 and isinstance(down, int) and down >= 1
-    if groups != 1:
-        raise NotImplementedError("grouped convolution (fused_modconv) is not supported; use fused_modconv=False")
-    out_channels, in_channels, kh, kw = (int(s) for s in w.shape)
+    groups = int(groups)
+    out_channels, in_channels, kh, kw = (int(s) for s in w.shape)          # in_channels: per group
     fw, fh = _get_filter_size(f)
     px0, px1, py0, py1 = _parse_padding(padding)
 
@@ -50,25 +49,29 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
 
     if kw == 1 and kh == 1 and down > 1 and up == 1:
         x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-        return _conv(x, w, flip_weight=flip_weight)
+        return _conv(x, w, groups=groups, flip_weight=flip_weight)
 
     if kw == 1 and kh == 1 and up > 1 and down == 1:
-        x = _conv(x, w, flip_weight=flip_weight)
+        x = _conv(x, w, groups=groups, flip_weight=flip_weight)
         return upfirdn2d.upfirdn2d(x=x, f=f, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter)
 
     if down > 1 and up == 1:
         x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-        return _conv(x, w, stride=down, flip_weight=flip_weight)
+        return _conv(x, w, stride=down, groups=groups, flip_weight=flip_weight)
 
     if up > 1:
-        wt = w.transpose(0, 1)
+        if groups == 1:
+            wt = w.transpose(0, 1)
+        else:     # F.conv_transpose2d's grouped layout [G * Cin_g][Cout_g][k][k]: swap the two channel axes inside every group
+            wt = w.reshape(groups, out_channels // groups, in_channels, kh, kw).transpose(1, 2)
+            wt = wt.reshape(groups * in_channels, out_channels // groups, kh, kw)
         px0 -= kw - 1
         px1 -= kw - up
         py0 -= kh - 1
         py1 -= kh - up
         pxt = max(min(-px0, -px1), 0)
         pyt = max(min(-py0, -py1), 0)
-        x = _conv(x, wt, stride=up, padding=[pyt, pxt], transpose=True, flip_weight=(not flip_weight))
+        x = _conv(x, wt, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight))
         x = upfirdn2d.upfirdn2d(x=x, f=f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up ** 2,
                                 flip_filter=flip_filter)
         if down > 1:
@@ -76,11 +79,11 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
         return x
 
     if up == 1 and down == 1 and px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:
-        return _conv(x, w, padding=[py0, px0], flip_weight=flip_weight)
+        return _conv(x, w, padding=[py0, px0], groups=groups, flip_weight=flip_weight)
 
     x = upfirdn2d.upfirdn2d(x=x, f=(f if up > 1 else None), up=up, padding=[px0, px1, py0, py1], gain=up ** 2,
                             flip_filter=flip_filter)
-    x = _conv(x, w, flip_weight=flip_weight)
+    x = _conv(x, w, groups=groups, flip_weight=flip_weight)
     if down > 1:
         x = upfirdn2d.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
     return x

@@ -3,12 +3,17 @@
 Style modulation, convolution (with optional resampling), demodulation and noise.  Executed as "scale the activations
 before and after the convolution" (the reference's fused_modconv=False branch, networks.py:78-97, which is what training
 uses); `fused_modconv=True` — a grouped convolution over per-sample weights in the reference, used in eval mode — is
-computed through the same branch: x*s -> conv(w) -> *d equals conv(w*s*d) exactly in real arithmetic and to fp32 rounding
-here, and needs no per-sample weight tensor [N, O, I, k, k] in HBM."""
+computed through the same branch by default: x*s -> conv(w) -> *d equals conv(w*s*d) exactly in real arithmetic and to fp32
+rounding here, and needs no per-sample weight tensor [N, O, I, k, k] in HBM.  `GROUPED_FUSED_MODCONV = True` switches a
+`fused_modconv=True` call to the reference's literal formulation (networks.py:64-73,100-117: per-sample weights, one group per
+sample through `conv2d_resample(groups=N)`) — N convolutions of batch 1 instead of one of batch N, there for parity checks
+against the reference's fused goldens and for callers who ask for exactly that op graph."""
 import numpy as np
 import torch
 
 from . import conv2d_gradfix, conv2d_resample, fma
+
+GROUPED_FUSED_MODCONV = False        # True: fused_modconv=True runs the reference's grouped convolution (see the module docstring)
 
 
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
@@ -23,6 +28,16 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     if x.dtype == torch.float16 and demodulate:
         weight = weight * (1 / np.sqrt(in_channels * kh * kw) / weight.norm(float("inf"), dim=[1, 2, 3], keepdim=True))
         styles = styles / styles.norm(float("inf"), dim=1, keepdim=True)
+
+    if fused_modconv and GROUPED_FUSED_MODCONV:
+        w = weight.unsqueeze(0) * styles.reshape(batch_size, 1, -1, 1, 1)                        # [N, O, I, k, k]
+        if demodulate:
+            w = w * (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt().reshape(batch_size, -1, 1, 1, 1)
+        x = x.reshape(1, -1, *x.shape[2:])                                                      # one group per sample
+        x = conv2d_resample.conv2d_resample(x=x, w=w.reshape(-1, in_channels, kh, kw).to(x.dtype), f=resample_filter, up=up,
+                                            down=down, padding=padding, groups=batch_size, flip_weight=flip_weight)
+        x = x.reshape(batch_size, -1, *x.shape[2:])
+        return x if noise is None else x + noise.to(x.dtype)
 
     dcoefs = None
     if demodulate:

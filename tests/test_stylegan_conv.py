@@ -124,10 +124,67 @@ def test_no_weight_gradients_context(emu):
         gx, gw = torch.autograd.grad(y.sum(), (x, w), allow_unused=True)
     assert gx is not None and gw is None
     assert cg.weight_gradients_disabled is False
-    with pytest.raises(NotImplementedError):
-        cg.conv2d(x, w, padding=1, groups=2)
+    with pytest.raises(ValueError):
+        cg.conv2d(x, w, padding=1, groups=3)
     with pytest.raises(NotImplementedError):
         cg.conv2d(x, w, padding=1, dilation=2)
+
+
+@pytest.mark.parametrize("transpose", [False, True])
+@pytest.mark.parametrize("dev", ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)])
+def test_grouped_convolution_equals_torch(dev, transpose, monkeypatch):
+    """conv2d / conv_transpose2d with groups > 1 (conv2d_gradfix.py:43-99 hands `groups` to cuDNN; here one groups=1 call per group):
+    values, first- and second-order gradients against F.conv2d / F.conv_transpose2d on the same fp32 tensors."""
+    from ic_gan_amd.stylegan_ops import conv2d_gradfix as cg
+    if dev == "cpu":
+        kernel_ref.install(monkeypatch)
+    G, cin_g, cout_g = 3, 4, 8
+    x = rnd((2, G * cin_g, 6, 6), 11).to(dev).requires_grad_(True)
+    shape = (G * cin_g, cout_g, 3, 3) if transpose else (G * cout_g, cin_g, 3, 3)
+    w = (rnd(shape, 12) * 0.2).to(dev).requires_grad_(True)
+    b = rnd((G * cout_g,), 13).to(dev).requires_grad_(True)
+    xr, wr, br = (t.detach().cpu().clone().requires_grad_(True) for t in (x, w, b))
+    if transpose:
+        y = cg.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1, groups=G)
+        ref = torch.nn.functional.conv_transpose2d(xr, wr, br, stride=2, padding=1, output_padding=1, groups=G)
+    else:
+        y = cg.conv2d(x, w, b, stride=1, padding=1, groups=G)
+        ref = torch.nn.functional.conv2d(xr, wr, br, stride=1, padding=1, groups=G)
+    assert y.shape == ref.shape
+    dy = rnd(tuple(ref.shape), 14)
+    g = torch.autograd.grad(y, (x, w, b), dy.to(dev), create_graph=True)
+    gr = torch.autograd.grad(ref, (xr, wr, br), dy, create_graph=True)
+    p, q = rnd(tuple(x.shape), 15), rnd(tuple(w.shape), 16)
+    g2 = torch.autograd.grad((g[0] * p.to(dev)).sum() + (g[1] * q.to(dev)).sum(), (x, w))
+    g2r = torch.autograd.grad((gr[0] * p).sum() + (gr[1] * q).sum(), (xr, wr))
+    for name, u, v in zip(("y", "dx", "dw", "db", "ddx", "ddw"), (y,) + tuple(g) + tuple(g2), (ref,) + tuple(gr) + tuple(g2r)):
+        err = float((u.detach().cpu() - v.detach()).abs().max())
+        assert err <= 2e-5 * max(1.0, float(v.detach().abs().max())), "%s: %.3e" % (name, err)
+
+
+@pytest.mark.parametrize("i", [k for k, c in enumerate(MODCONV) if c[-1]])
+@pytest.mark.parametrize("dev", ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)])
+def test_fused_modconv_as_the_reference_grouped_convolution(dev, i, monkeypatch):
+    """`fused_modconv=True` in the reference's literal form (per-sample weights, groups = batch: networks.py:64-73,100-117) against
+    the goldens the reference produced on exactly that path, outputs and gradients of both orders -- and against the default
+    route (activations scaled before and after one convolution) on the same inputs."""
+    from ic_gan_amd.stylegan_ops import modconv, modulated_conv2d, upfirdn2d as up_
+    if dev == "cpu":
+        kernel_ref.install(monkeypatch)
+    monkeypatch.setattr(modconv, "GROUPED_FUSED_MODCONV", True)
+    _modconv_case(i, dev)
+    n, ci, h, w, co, k, up, demod, noise, fused = MODCONV[i]
+    x = rnd((n, ci, h, w), 700 + i).to(dev)
+    wt = rnd((co, ci, k, k), 800 + i).to(dev)
+    st = (rnd((n, ci), 900 + i) * 0.5 + 1.0).to(dev)
+    nz = (rnd((n, 1, h * up, w * up), 950 + i) * 0.1).to(dev) if noise else None
+    f = up_.setup_filter([1, 3, 3, 1], device=dev)
+    kw = dict(x=x, weight=wt, styles=st, noise=nz, up=up, padding=k // 2, resample_filter=f, demodulate=demod, flip_weight=(up == 1),
+              fused_modconv=True)
+    grouped = modulated_conv2d(**kw)
+    monkeypatch.setattr(modconv, "GROUPED_FUSED_MODCONV", False)
+    plain = modulated_conv2d(**kw)
+    assert float((grouped - plain).abs().max()) <= 2e-5 * float(plain.abs().max())
 
 
 @pytest.mark.parametrize("m", [2, 4])
