@@ -46,6 +46,10 @@ class EmaTensor(ctypes.Structure):
     _fields_ = [("target", ctypes.c_void_p), ("source", ctypes.c_void_p), ("numel", ctypes.c_int64)]
 
 
+class F32Buffer(ctypes.Structure):        # icg_f32_buffer
+    _fields_ = [("data", ctypes.c_void_p), ("numel", ctypes.c_int64)]
+
+
 def parse_header(path: str = HEADER) -> Dict[str, Tuple[str, List[Tuple[str, str]]]]:
     """-> {function name: (return type, [(arg type, arg name), ...])} for every prototype."""
     src = open(path).read()

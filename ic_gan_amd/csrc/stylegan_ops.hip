@@ -466,3 +466,69 @@ extern "C" int icg_upfirdn2d(const float* x, const float* f, float* y, int N, in
                      fh, fw, upx, upy, downx, downy, padx0, pady0, flip, gain, outH, outW);
   return icg_check_launch();
 }
+
+// ---------------------------------------------------------------- gradient sanitising of the training loop, all parameters at once
+// training_loop.py:511-515 runs torch.nan_to_num(param.grad, nan=0, posinf=1e5, neginf=-1e5, out=param.grad) per parameter: 144
+// launches per iteration at cfg4 for 60 MB of gradients, in a loop that is bound by the host.  Same packing as icg_adam_multi
+// (optim.hip): up to NTN_MAX tensors per launch, descriptors in the kernel arguments, a block owns NTN_CHUNK elements of one tensor.
+#define NTN_MAX 64
+#define NTN_CHUNK 4096
+struct NtnPack {
+  icg_f32_buffer t[NTN_MAX];
+  int blk_start[NTN_MAX + 1];
+  int n;
+};
+__device__ __forceinline__ float ntn_one(float v, float nan_v, float posinf, float neginf) {
+  // isnan / isinf spelled on the bits: immune to any finite-math assumption of the build
+  const unsigned u = __float_as_uint(v), mag = u & 0x7fffffffu;
+  if (mag > 0x7f800000u) return nan_v;
+  if (mag == 0x7f800000u) return (u >> 31) ? neginf : posinf;
+  return v;
+}
+__global__ __launch_bounds__(256) void nan_to_num_multi_kernel(NtnPack p, float nan_v, float posinf, float neginf) {
+  int lo = 0, hi = p.n - 1;                       // the tensor whose block range holds blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= p.blk_start[mid]) lo = mid; else hi = mid - 1;
+  }
+  const icg_f32_buffer t = p.t[lo];
+  const long base = (long)((int)blockIdx.x - p.blk_start[lo]) * NTN_CHUNK;
+  const long end = min((long)t.numel, base + NTN_CHUNK);
+  if ((((uintptr_t)t.data & 15) == 0) && end - base == NTN_CHUNK) {
+#pragma unroll
+    for (int u = 0; u < NTN_CHUNK / 4 / 256; ++u) {
+      float4* q = reinterpret_cast<float4*>(t.data) + (base >> 2) + threadIdx.x + u * 256;
+      float4 v = *q;
+      v.x = ntn_one(v.x, nan_v, posinf, neginf); v.y = ntn_one(v.y, nan_v, posinf, neginf);
+      v.z = ntn_one(v.z, nan_v, posinf, neginf); v.w = ntn_one(v.w, nan_v, posinf, neginf);
+      *q = v;
+    }
+    return;
+  }
+  for (long i = base + threadIdx.x; i < end; i += 256) t.data[i] = ntn_one(t.data[i], nan_v, posinf, neginf);
+}
+
+extern "C" int icg_nan_to_num_multi(const icg_f32_buffer* tensors, int n, float nan_v, float posinf, float neginf, void* stream) {
+  ICG_REQUIRE(tensors && n >= 0);
+  int done = 0;
+  while (done < n) {
+    NtnPack p;
+    p.n = 0;
+    int blocks = 0;
+    while (done < n && p.n < NTN_MAX) {
+      const icg_f32_buffer& t = tensors[done++];
+      if (t.numel <= 0) continue;
+      ICG_REQUIRE(t.data);
+      p.t[p.n] = t;
+      p.blk_start[p.n] = blocks;
+      blocks += (int)icg_cdiv(t.numel, NTN_CHUNK);
+      p.n++;
+    }
+    if (p.n == 0) break;
+    p.blk_start[p.n] = blocks;
+    hipLaunchKernelGGL(nan_to_num_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, nan_v, posinf, neginf);
+    const int rc = icg_check_launch();
+    if (rc != ICG_OK) return rc;
+  }
+  return ICG_OK;
+}

@@ -1028,6 +1028,24 @@ def adam_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step
     bump_version(*params)
 
 
+def nan_to_num_multi(tensors, nan=0.0, posinf=None, neginf=None):
+    """torch.nan_to_num(t, nan, posinf, neginf, out=t) for every fp32 tensor of `tensors` in one launch per 64 tensors
+    (icg_nan_to_num_multi; stylegan2_ada_pytorch/training/training_loop.py:511-515 does it per parameter gradient)."""
+    import ctypes
+    tensors = [t for t in tensors if t is not None and t.numel()]
+    if not tensors:
+        return
+    _require_gpu(tensors[0])
+    fmax = torch.finfo(torch.float32).max                 # torch.nan_to_num's defaults for None
+    posinf, neginf = (fmax if posinf is None else posinf), (-fmax if neginf is None else neginf)
+    arr = (L.F32Buffer * len(tensors))()
+    for i, t in enumerate(tensors):
+        assert t.dtype == torch.float32 and t.is_contiguous(), "nan_to_num_multi: contiguous fp32 tensors"
+        arr[i].data, arr[i].numel = t.data_ptr(), t.numel()
+    L.call("icg_nan_to_num_multi", ctypes.cast(arr, ctypes.c_void_p), len(tensors), float(nan), float(posinf), float(neginf))
+    bump_version(*tensors)
+
+
 def ema_multi(targets, sources, decay):
     import ctypes
     n = len(targets)

@@ -30,6 +30,7 @@ class FusedAdam(Optimizer):
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             by_step = {}
+            live = []
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -40,8 +41,15 @@ class FusedAdam(Optimizer):
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                k = int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])
+                live.append((p, st))
+            # the per-parameter `step` counters (host tensors, kept for torch.optim.Adam's state_dict layout) advance in one call
+            counters = [st["step"] for _, st in live if torch.is_tensor(st["step"])]
+            if counters:
+                torch._foreach_add_(counters, 1.0)
+            for p, st in live:
+                if not torch.is_tensor(st["step"]):
+                    st["step"] += 1
+                k = int(st["step"])
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 by_step.setdefault(k, ([], [], [], []))
                 lst = by_step[k]

@@ -66,9 +66,14 @@ class TrainingStep:
                 self.loss.accumulate_gradients(phase=phase.name, real_img=x, real_c=c, real_h=h, gen_z=gz, gen_c=gc,
                                                gen_h=gh, sync=(r == rounds - 1), gain=phase.interval)
             phase.module.requires_grad_(False)
-            for p in phase.module.parameters():        # training_loop.py:511-515
-                if p.grad is not None:
-                    torch.nan_to_num(p.grad, nan=0, posinf=1e5, neginf=-1e5, out=p.grad)
+            # training_loop.py:511-515 (torch.nan_to_num(param.grad, nan=0, posinf=1e5, neginf=-1e5, out=param.grad) per parameter):
+            # every fp32 gradient in one multi-tensor launch -- the loop is bound by the host, 144 launches per iteration at cfg4
+            grads = [p.grad for p in phase.module.parameters() if p.grad is not None]
+            from .. import ops as _ops
+            _ops.nan_to_num_multi([g for g in grads if g.dtype == torch.float32 and g.is_contiguous()], nan=0, posinf=1e5, neginf=-1e5)
+            for g in grads:
+                if not (g.dtype == torch.float32 and g.is_contiguous()):
+                    torch.nan_to_num(g, nan=0, posinf=1e5, neginf=-1e5, out=g)
             phase.opt.step()
             ran.append(phase.name)
         self.update_ema()

@@ -578,6 +578,15 @@ int icg_upfirdn2d_nhwc(const float* x, const float* f, float* y, int N, int C, i
                        int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1,
                        int flip, float gain, int outH, int outW, void* stream);
 
+/* ---- gradient sanitising of the StyleGAN2 training loop  (training/training_loop.py:511-515) ---- */
+/* data[i] <- nan_v for NaN, posinf / neginf for +inf / -inf, unchanged otherwise, in place, for n tensors in ceil(n / 64) launches:
+ * what the reference's loop `torch.nan_to_num(param.grad, nan=0, posinf=1e5, neginf=-1e5, out=param.grad)` does per parameter. */
+typedef struct {
+  float* data;
+  int64_t numel;
+} icg_f32_buffer;
+int icg_nan_to_num_multi(const icg_f32_buffer* tensors, int n, float nan_v, float posinf, float neginf, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

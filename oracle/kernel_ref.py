@@ -1084,6 +1084,13 @@ def icg_knn_l2(feats, N, D, k, idx, d2, workspace, workspace_bytes):
     mem(d2)[: N * k].copy_(order.values[:, :k].clamp(min=0).float().reshape(-1))
 
 
+def nan_to_num_multi_ref(tensors, nan=0.0, posinf=None, neginf=None):
+    """ops.nan_to_num_multi (icg_nan_to_num_multi) as the per-tensor torch call it batches (training_loop.py:511-515)"""
+    for t in tensors:
+        if t is not None and t.numel():
+            torch.nan_to_num(t, nan=nan, posinf=posinf, neginf=neginf, out=t)
+
+
 def install(monkeypatch):
     """Route ic_gan_amd._lib.call / query to this module (CPU host-logic tests only)."""
     import ic_gan_amd._lib as L
@@ -1101,5 +1108,6 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "_require_gpu", lambda t: None)
     monkeypatch.setattr(ops, "adam_multi", adam_multi_ref)
     monkeypatch.setattr(ops, "ema_multi", ema_multi_ref)
+    monkeypatch.setattr(ops, "nan_to_num_multi", nan_to_num_multi_ref)
     monkeypatch.setattr(ops, "sn_prepare_many", lambda items, eps, training: [
         ops.sn_prepare(w, u, sv, eps, training, nd, up, dn, *rest) for (w, u, sv, nd, up, dn, *rest) in items])

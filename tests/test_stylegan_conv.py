@@ -279,3 +279,19 @@ def test_linear_nt_all_orders(m, emu):
     s2 = (r[0] * rnd((m, 160), 7)).sum() + (r[1] * rnd((24, 160), 8)).sum()
     for a, b in zip(torch.autograd.grad(s, (x, w)), torch.autograd.grad(s2, (x2, w2))):
         assert float((a - b).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(6, 3, 3, 4), (5, 1, 1, 7), (4, 4, 4, 8)])
+def test_adjoint_weight_is_transpose_and_tap_flip(shape, dtype):
+    """conv2d_gradfix._adjoint_weight (one gather along the reversed flattened tap axis) = permute + flip of both tap axes, values and
+    the gradient that flows back through it (second-order terms of the data gradient)."""
+    from ic_gan_amd.stylegan_ops import conv2d_gradfix as cg
+    w = rnd(shape, 21).to(dtype).requires_grad_(True)
+    got = cg._adjoint_weight(w)
+    want = w.permute(3, 1, 2, 0).flip(1, 2).contiguous()
+    assert got.shape == want.shape and got.is_contiguous() and torch.equal(got, want)
+    p = rnd(tuple(want.shape), 22).to(dtype)
+    (ga,) = torch.autograd.grad((got * p).sum(), w)
+    (gb,) = torch.autograd.grad((want * p).sum(), w)
+    assert torch.equal(ga, gb)

@@ -159,3 +159,36 @@ def test_bias_act_vectorised_paths(act, cl):
     if ddx is not None:
         K.icg_bias_act(d2, b, x, yr, dy, g2, n, step, 8, 2, act_id, alpha, gain, 0.9)
         torch.testing.assert_close(ddx.detach().cpu().contiguous(), g2, rtol=1e-3, atol=1e-4)
+
+
+def _nan_to_num_tensors(dev):
+    """gradient-like tensors: vector-path sizes (multiples of 4096), ragged tails, a scalar, an empty one, > 64 tensors (two launches)"""
+    sizes = [4096, 8192 + 3, 1, 0, 5000, 12288, 17] + [33 + k for k in range(70)]
+    out = []
+    for i, n in enumerate(sizes):
+        t = rnd((n,), 300 + i, 3.0)
+        if n:
+            k = max(n // 7, 1)
+            t[::k] = float("nan")
+            t[1::k + 1] = float("inf")
+            t[2::k + 2] = float("-inf")
+        out.append(t.to(dev))
+    return out
+
+
+@pytest.mark.parametrize("dev", ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("args", [dict(nan=0, posinf=1e5, neginf=-1e5), dict(nan=2.5)])
+def test_nan_to_num_multi_equals_torch(dev, args, monkeypatch):
+    """ops.nan_to_num_multi (icg_nan_to_num_multi: every gradient of a network in one launch per 64 tensors) against
+    torch.nan_to_num per tensor -- the reference's loop, training_loop.py:511-515 -- bit for bit, NaN / +inf / -inf in the vector and
+    the ragged parts of the tensors; None = torch's defaults (the largest finite fp32)."""
+    import ic_gan_amd.ops as ops
+    if dev == "cpu":
+        R.install(monkeypatch)
+    ts = _nan_to_num_tensors(dev)
+    want = [torch.nan_to_num(t.cpu(), **args) for t in ts]
+    versions = [t._version for t in ts]
+    ops.nan_to_num_multi(ts, **args)
+    for t, w, v in zip(ts, want, versions):
+        assert torch.equal(t.cpu(), w)
+        assert t.numel() == 0 or t._version > v

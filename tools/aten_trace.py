@@ -98,5 +98,73 @@ def main(case="cc_ic_r64"):
         print("%5d  %-34s %-5s %s" % (n, name, size, site))
 
 
+def main_sg2(case="ic_r32_fp16"):
+    """the same for one StyleGAN2 training iteration (Gmain + Dmain: the iteration without the lazy regularisers)"""
+    import copy
+    import ic_gan_amd._lib as L
+    import ic_gan_amd.ops as ops
+    from ic_gan_amd.stylegan2 import networks as N
+    from ic_gan_amd.stylegan2.training_step import TrainingStep
+    from tests.stylegan_cases import SG2_NETS, SG2_LOSS, SG2_OPT, sg2_inputs, sg2_state
+    from tests import stylegan_cases as SC
+    kernel_ref.install(Patch())
+    tr = Trace()
+    for mod, names in ((L, ("call", "query")), (ops, ("adam_multi", "ema_multi"))):
+        for n in names:
+            f = getattr(mod, n)
+
+            def wrapped(*a, _f=f, **k):
+                tr.off += 1
+                try:
+                    return _f(*a, **k)
+                finally:
+                    tr.off -= 1
+            setattr(mod, n, wrapped)
+    nets = dict(SG2_NETS)
+    nets.update(getattr(SC, "SG2_REAL_NETS", {}))
+    cfg = nets[case]
+    G = N.Generator(**cfg["G"]).train().requires_grad_(False)
+    D = N.Discriminator(**cfg["D"]).train().requires_grad_(False)
+    for m, seed in ((G, 1), (D, 2)):
+        sd = sg2_state([[k, list(v.shape)] for k, v in m.state_dict().items()], seed)
+        cur = m.state_dict()
+        m.load_state_dict({k: (cur[k] if v is None else v) for k, v in sd.items()})
+    G_ema = copy.deepcopy(G).eval()
+    b = cfg["batch"]
+    step = TrainingStep(G, D, G_ema, "cpu", batch_size=b, batch_gpu=b, loss_kwargs=SG2_LOSS, G_opt_kwargs=SG2_OPT, D_opt_kwargs=SG2_OPT,
+                        G_reg_interval=4, D_reg_interval=16, ema_kimg=0.02)
+    for it in range(2):                    # iteration 0 runs the regularisers too; iteration 1 (Gmain + Dmain) is counted
+        z, gc, gh, img, rc, rh = sg2_inputs(cfg, 20 + it, 4)
+        if it == 1:
+            with tr:
+                ran = step(img, rc, rh, z, gc, gh)
+        else:
+            ran = step(img, rc, rh, z, gc, gh)
+    total = sum(tr.rows.values())
+    print("%s %s: %d ATen operations outside the C-ABI calls in one iteration" % (case, ran, total))
+    by_site = collections.Counter()
+    for (name, site, size), n in tr.rows.items():
+        by_site[site] += n
+    print("-- by call site")
+    for site, n in by_site.most_common(40):
+        print("%5d  %s" % (n, site))
+    print("-- operations of the five largest sites")
+    for site, n in by_site.most_common(5):
+        ops_here = collections.Counter()
+        for (name, st, size), k in tr.rows.items():
+            if st == site:
+                ops_here[name + " " + size] += k
+        print("  %s: %s" % (site, ", ".join("%s x%d" % kv for kv in ops_here.most_common(14))))
+    print("-- by operation")
+    by_op = collections.Counter()
+    for (name, site, size), n in tr.rows.items():
+        by_op[name] += n
+    for name, n in by_op.most_common(30):
+        print("%5d  %s" % (n, name))
+
+
 if __name__ == "__main__":
-    main(*sys.argv[1:])
+    if len(sys.argv) > 1 and sys.argv[1] == "sg2":
+        main_sg2(*sys.argv[2:])
+    else:
+        main(*sys.argv[1:])
