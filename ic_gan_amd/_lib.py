@@ -46,6 +46,12 @@ class EmaTensor(ctypes.Structure):
     _fields_ = [("target", ctypes.c_void_p), ("source", ctypes.c_void_p), ("numel", ctypes.c_int64)]
 
 
+class Sg2Weight(ctypes.Structure):        # icg_sg2_weight
+    _fields_ = [(n, ctypes.c_void_p) for n in ("w", "w_fwd", "w_adj", "wsq", "wscale", "warg")] + \
+               [("O", ctypes.c_int), ("I", ctypes.c_int), ("R", ctypes.c_int), ("prenorm", ctypes.c_int), ("gain", ctypes.c_float),
+                ("flip", ctypes.c_int), ("dtype", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
 class F32Buffer(ctypes.Structure):        # icg_f32_buffer
     _fields_ = [("data", ctypes.c_void_p), ("numel", ctypes.c_int64)]
 

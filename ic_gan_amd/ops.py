@@ -1046,6 +1046,28 @@ def nan_to_num_multi(tensors, nan=0.0, posinf=None, neginf=None):
     bump_version(*tensors)
 
 
+def sg2_weight_prep_multi(items):
+    """icg_sg2_weight_prep_multi: the per-pass weight preparation of StyleGAN2 layers (gain or fp16 pre-normalisation, cast, the
+    gather-convolution layout and its adjoint, the demodulation table) for ALL given layers in two launches.  items: dicts with the
+    tensors w [O][I][R][R], w_fwd, w_adj / None, wsq / None, wscale, warg / None and prenorm, gain, flip."""
+    import ctypes
+    if not items:
+        return
+    _require_gpu(items[0]["w"])
+    arr = (L.Sg2Weight * len(items))()
+    for i, it in enumerate(items):
+        w = it["w"]
+        assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4 and w.shape[2] == w.shape[3]
+        a = arr[i]
+        a.w, a.w_fwd, a.wscale = w.data_ptr(), it["w_fwd"].data_ptr(), it["wscale"].data_ptr()
+        a.w_adj = it["w_adj"].data_ptr() if it["w_adj"] is not None else None
+        a.wsq = it["wsq"].data_ptr() if it["wsq"] is not None else None
+        a.warg = it["warg"].data_ptr() if it["warg"] is not None else None
+        a.O, a.I, a.R, a.prenorm = int(w.shape[0]), int(w.shape[1]), int(w.shape[2]), int(bool(it["prenorm"]))
+        a.gain, a.flip, a.dtype = float(it["gain"]), int(bool(it["flip"])), 1 if it["w_fwd"].dtype == torch.float16 else 0
+    L.call("icg_sg2_weight_prep_multi", ctypes.cast(arr, ctypes.c_void_p), len(items))
+
+
 def ema_multi(targets, sources, decay):
     import ctypes
     n = len(targets)

@@ -8,10 +8,12 @@
     Dreg   R1: (gamma/2) |dD(x)/dx|^2                            (180-194)  — second-order through the discriminator
 `Gboth` / `Dboth` combine main and regulariser.  ADA augmentation (`augment_pipe`) is not part of this engine.
 """
+import contextlib
+
 import numpy as np
 import torch
 
-from ..stylegan_ops import conv2d_gradfix
+from ..stylegan_ops import conv2d_gradfix, fused_layers
 
 
 def _randn_like(t):
@@ -20,7 +22,6 @@ def _randn_like(t):
 
 
 def _ddp_sync(module, sync):
-    import contextlib
     if sync or not isinstance(module, torch.nn.parallel.DistributedDataParallel):
         return contextlib.nullcontext()
     return module.no_sync()
@@ -65,13 +66,18 @@ class StyleGAN2Loss:
         do_Gpl = phase in ["Greg", "Gboth"] and self.pl_weight != 0
         do_Dr1 = phase in ["Dreg", "Dboth"] and self.r1_gamma != 0
         softplus = torch.nn.functional.softplus
+        # Gmain / Dmain differentiate once: every layer is ONE autograd node there (stylegan_ops/fused_layers.py); the regularisers
+        # differentiate twice and keep the composed operators.  The weights both networks' layers read were prepared for the
+        # previous optimiser step: re-prepare all of them in one launch pair
+        fused_layers.refresh(self.G_mapping, self.G_synthesis, self.D)
 
         if do_Gmain:
-            gen_img, _ = self.run_G(gen_z, gen_c, gen_h, sync=(sync and not do_Gpl))
-            gen_logits = self.run_D(gen_img, gen_c, gen_h, sync=False)
-            loss_Gmain = softplus(-gen_logits)
-            self.stats["Loss/G/loss"] = loss_Gmain.detach()
-            loss_Gmain.mean().mul(gain).backward()
+            with fused_layers.first_order():
+                gen_img, _ = self.run_G(gen_z, gen_c, gen_h, sync=(sync and not do_Gpl))
+                gen_logits = self.run_D(gen_img, gen_c, gen_h, sync=False)
+                loss_Gmain = softplus(-gen_logits)
+                self.stats["Loss/G/loss"] = loss_Gmain.detach()
+                loss_Gmain.mean().mul(gain).backward()
 
         if do_Gpl:
             n = gen_z.shape[0] // self.pl_batch_shrink
@@ -90,14 +96,16 @@ class StyleGAN2Loss:
 
         loss_Dgen = 0
         if do_Dmain:
-            gen_img, _ = self.run_G(gen_z, gen_c, gen_h, sync=False)
-            gen_logits = self.run_D(gen_img, gen_c, gen_h, sync=False)
-            loss_Dgen = softplus(gen_logits)
-            loss_Dgen.mean().mul(gain).backward()
+            with fused_layers.first_order():
+                gen_img, _ = self.run_G(gen_z, gen_c, gen_h, sync=False)
+                gen_logits = self.run_D(gen_img, gen_c, gen_h, sync=False)
+                loss_Dgen = softplus(gen_logits)
+                loss_Dgen.mean().mul(gain).backward()
 
         if do_Dmain or do_Dr1:
             real_img_tmp = real_img.detach().requires_grad_(do_Dr1)
-            real_logits = self.run_D(real_img_tmp, real_c, real_h, sync=sync)
+            with (fused_layers.first_order() if not do_Dr1 else contextlib.nullcontext()):
+                real_logits = self.run_D(real_img_tmp, real_c, real_h, sync=sync)
             loss_Dreal = 0
             if do_Dmain:
                 loss_Dreal = softplus(-real_logits)

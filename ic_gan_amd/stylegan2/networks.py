@@ -23,7 +23,7 @@ preparation are PyTorch elementwise ops around the convolution (stylegan_ops/mod
 import numpy as np
 import torch
 
-from ..stylegan_ops import bias_act, conv2d_gradfix, conv2d_resample, modulated_conv2d, upfirdn2d
+from ..stylegan_ops import bias_act, conv2d_gradfix, conv2d_resample, fused_layers, modulated_conv2d, upfirdn2d
 
 _DEF_GAIN = {name: spec[2] for name, spec in bias_act.activation_funcs.items()}
 
@@ -46,6 +46,8 @@ class FullyConnectedLayer(torch.nn.Module):
 
     def forward(self, x):
         b = self.bias
+        if fused_layers.fc_applies(x, self.weight, self.activation):       # one autograd node: GEMM, bias + activation
+            return fused_layers.fc_layer(x, self.weight, b, self.activation, self.weight_gain, self.bias_gain, _DEF_GAIN[self.activation])
         if b is not None and self.bias_gain != 1:
             b = b * self.bias_gain
         # x @ w^T on the hand-written GEMM (conv2d_gradfix._Matmul: closed under differentiation, so the layer has gradients of
@@ -79,6 +81,11 @@ class Conv2dLayer(torch.nn.Module):
                 self.bias = None
 
     def forward(self, x, gain=1):
+        pl = fused_layers.conv_applies(x, self.weight, self.activation, self.up, self.down, self.padding,
+                                       int(self.resample_filter.shape[-1]), self.up == 1)
+        if pl is not None:      # one autograd node: [FIR] convolution [FIR], bias + activation + clamp; weights prepared once per step
+            return fused_layers.conv_layer(self, x, self.weight, self.bias, self.resample_filter, pl, self.activation, self.weight_gain,
+                                           self.act_gain * gain, self.conv_clamp * gain if self.conv_clamp is not None else None)
         x = conv2d_resample.conv2d_resample(x=x, w=(self.weight * self.weight_gain).to(x.dtype), f=self.resample_filter,
                                             up=self.up, down=self.down, padding=self.padding, flip_weight=(self.up == 1))
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
@@ -154,6 +161,17 @@ class SynthesisLayer(torch.nn.Module):
     def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1):
         assert noise_mode in ["random", "const", "none"]
         assert x.shape[1] == self.weight.shape[1] and x.shape[2] == self.resolution // self.up
+        pl = fused_layers.modconv_applies(x, self.weight, w, self.affine.weight, self.up, self.padding,
+                                          int(self.resample_filter.shape[-1]), self.up == 1)
+        if pl is not None:      # one autograd node for the whole layer (stylegan_ops/fused_layers.py)
+            base, bstride = None, 0
+            if self.use_noise and noise_mode == "random":
+                base, bstride = _randn([x.shape[0], 1, self.resolution, self.resolution], x.device), self.resolution ** 2
+            if self.use_noise and noise_mode == "const":
+                base = self.noise_const
+            return fused_layers.modconv_layer(self, x, w, self.affine, self.weight, self.noise_strength if self.use_noise else None,
+                                              self.bias, base, bstride, self.resample_filter, pl, self.act_gain * gain,
+                                              self.conv_clamp * gain if self.conv_clamp is not None else None)
         styles = self.affine(w)
         noise = None
         if self.use_noise and noise_mode == "random":
@@ -181,10 +199,16 @@ class ToRGBLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
-    def forward(self, x, w, fused_modconv=True):
+    def forward(self, x, w, fused_modconv=True, img=None):
+        """`img` (an extension of the reference signature, networks.py:476): the fp32 image to accumulate into; returns img + y"""
+        if fused_layers.torgb_applies(x, self.weight, w):      # one pass over x, image accumulation included
+            return fused_layers.torgb_layer(x, w, self.affine, self.weight, self.bias, img, self.weight_gain, self.conv_clamp)
         styles = self.affine(w) * self.weight_gain
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
-        return bias_act.bias_act(x, self.bias, clamp=self.conv_clamp)
+        y = bias_act.bias_act(x, self.bias, clamp=self.conv_clamp)
+        if img is None:
+            return y
+        return img + y.to(torch.float32)
 
 
 class SynthesisBlock(torch.nn.Module):
@@ -237,9 +261,8 @@ class SynthesisBlock(torch.nn.Module):
         if img is not None:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == "skip":
-            y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv)
-            y = y.to(torch.float32)                  # the image accumulates in fp32 (networks.py:630)
-            img = img + y if img is not None else y
+            # the image accumulates in fp32 (networks.py:630); the addition rides in the toRGB layer
+            img = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, img=img).to(torch.float32)
         assert x.dtype == dtype and (img is None or img.dtype == torch.float32)
         return x, img
 

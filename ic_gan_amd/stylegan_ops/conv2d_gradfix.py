@@ -98,63 +98,92 @@ def _phase_weights(w):
     return g.view(Cout, 2, 2, 2, 2, Cin).permute(1, 3, 0, 2, 4, 5).contiguous()
 
 
-class _GatherConv(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, w, geo):
-        _ops._require_gpu(x)
-        # the autograd inputs themselves are saved (not their re-laid-out copies): the backward differentiates through them
-        ctx.geo = geo
-        ctx.save_for_backward(x, w)
-        half = x.dtype == torch.float16
-        if half and w.dtype == torch.float16 and FP16_MFMA and \
-                L.query("icg_conv2d_g_fprop_f16_applies", int(x.shape[1]), int(w.shape[0]), geo.R, geo.stride, geo.zins):
-            # the reference's fp16 arithmetic: fp16 operands, fp32 accumulation, one rounding (csrc/hconv.hip)
-            x = x.contiguous(memory_format=torch.channels_last)
-            w = w.contiguous()
-            B, Cin, H, W = x.shape
-            Cout = w.shape[0]
-            assert (H, W) == geo.src and w.shape == (Cout, geo.R, geo.R, Cin), (x.shape, w.shape, geo)
-            y = torch.empty((B, Cout, geo.out[0], geo.out[1]), device=x.device, dtype=torch.float16,
-                            memory_format=torch.channels_last)
-            L.call("icg_conv2d_g_fprop_f16", x, w, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout, geo.R, geo.stride, geo.pad,
-                   geo.zins)
-            return y
-        if half:      # shapes the fp16 kernel does not serve: exact-fp32 kernel between two casts (layout glue)
-            return _GatherConv._forward_f32(_ops._cl(x), w.float().contiguous(), geo).to(torch.float16)
-        # the fp32 kernels read raw fp32 buffers: both operands are normalised here (an fp16 weight next to fp32 activations would
-        # otherwise be reinterpreted); fp64 operands are computed in fp32
-        return _GatherConv._forward_f32(_ops._cl(x), w.float().contiguous(), geo)
-
-    @staticmethod
-    def _forward_f32(x, w, geo):
+def gather_conv(x, w, geo, cache=None):
+    """G[geo](x, w) as plain kernel calls (no autograd): x logical NCHW (fp16 / fp32), w [Cout][R][R][Cin].  `cache`: a dict owned by
+    the caller that lives as long as `w` keeps its values -- derived weight forms (phase weights, Winograd transforms) are kept
+    there instead of being rebuilt per call (stylegan_ops/fused_layers.py prepares a layer's weights once per optimiser step)."""
+    _ops._require_gpu(x)
+    half = x.dtype == torch.float16
+    if half and w.dtype == torch.float16 and FP16_MFMA and \
+            L.query("icg_conv2d_g_fprop_f16_applies", int(x.shape[1]), int(w.shape[0]), geo.R, geo.stride, geo.zins):
+        # the reference's fp16 arithmetic: fp16 operands, fp32 accumulation, one rounding (csrc/hconv.hip)
+        x = x.contiguous(memory_format=torch.channels_last)
+        w = w.contiguous()
         B, Cin, H, W = x.shape
         Cout = w.shape[0]
         assert (H, W) == geo.src and w.shape == (Cout, geo.R, geo.R, Cin), (x.shape, w.shape, geo)
-        y = _ops._empty_cl(B, Cout, geo.out[0], geo.out[1], x.device)
-        if geo.zins == 2 and geo.R == 3 and geo.pad == 2 and geo.out[0] <= 2 * H + 2 and geo.out[1] <= 2 * W + 2:
-            # stride-2 transposed 3x3 convolution: 4 phases of 2x2 taps instead of a gather over the zero-inserted source
-            L.call("icg_conv2d_tr2_fprop", x, _phase_weights(w), None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout)
-            return y
-        if geo.R == 3 and geo.stride == 1 and geo.pad == 1 and geo.zins == 0 and geo.out == (H, W) and \
-                _ops.winograd_applies(Cin, Cout, H, W, B):
-            # wide 3x3 'same' convolution (synthesis conv1 / discriminator conv0 and the data gradients of both):
-            # Winograd F(2x2,3x3), 16/36 of the multiply-adds and 16x the parallelism at low resolutions
-            m = _ops.winograd_applies(Cin, Cout, H, W, B)
-            v = "wino4" if m == 4 else "wino"
+        y = torch.empty((B, Cout, geo.out[0], geo.out[1]), device=x.device, dtype=torch.float16,
+                        memory_format=torch.channels_last)
+        L.call("icg_conv2d_g_fprop_f16", x, w, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout, geo.R, geo.stride, geo.pad,
+               geo.zins)
+        return y
+    if half:      # shapes the fp16 kernel does not serve: exact-fp32 kernel between two casts (layout glue)
+        return _forward_f32(_ops._cl(x), _f32_weight(w, cache), geo, cache).to(torch.float16)
+    # the fp32 kernels read raw fp32 buffers: both operands are normalised here (an fp16 weight next to fp32 activations would
+    # otherwise be reinterpreted, ADVICE r03); fp64 operands are computed in fp32
+    return _forward_f32(_ops._cl(x), _f32_weight(w, cache), geo, cache)
+
+
+def _f32_weight(w, cache):
+    if w.dtype == torch.float32 and w.is_contiguous():
+        return w
+    if cache is None:
+        return w.float().contiguous()
+    key = ("f32", w.data_ptr())
+    if key not in cache:
+        cache[key] = w.float().contiguous()
+    return cache[key]
+
+
+def _forward_f32(x, w, geo, cache=None):
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    assert (H, W) == geo.src and w.shape == (Cout, geo.R, geo.R, Cin), (x.shape, w.shape, geo)
+    y = _ops._empty_cl(B, Cout, geo.out[0], geo.out[1], x.device)
+    if geo.zins == 2 and geo.R == 3 and geo.pad == 2 and geo.out[0] <= 2 * H + 2 and geo.out[1] <= 2 * W + 2:
+        # stride-2 transposed 3x3 convolution: 4 phases of 2x2 taps instead of a gather over the zero-inserted source
+        key = ("phase", w.data_ptr())
+        wp = cache.get(key) if cache is not None else None
+        if wp is None:
+            wp = _phase_weights(w)
+            if cache is not None:
+                cache[key] = wp
+        L.call("icg_conv2d_tr2_fprop", x, wp, None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout)
+        return y
+    if geo.R == 3 and geo.stride == 1 and geo.pad == 1 and geo.zins == 0 and geo.out == (H, W) and \
+            _ops.winograd_applies(Cin, Cout, H, W, B):
+        # wide 3x3 'same' convolution (synthesis conv1 / discriminator conv0 and the data gradients of both):
+        # Winograd F(2x2,3x3), 16/36 of the multiply-adds and 16x the parallelism at low resolutions
+        m = _ops.winograd_applies(Cin, Cout, H, W, B)
+        v = "wino4" if m == 4 else "wino"
+        key = (v, w.data_ptr())
+        U = cache.get(key) if cache is not None else None
+        if U is None:
             U = torch.empty((36 if m == 4 else 16) * Cout * Cin, device=x.device, dtype=torch.float32)
             L.call("icg_%s_weight_transform" % v, w, U, Cout, Cin)
-            nbw = L.query("icg_conv2d_%s_workspace_bytes" % v, B, H, W, Cin, Cout)
-            L.call("icg_conv2d_%s_fprop" % v, x, U, None, None, y, None, None, 0, B, H, W, Cin, Cout, 0, 1.0,
-                   _ops._bytes(nbw, x.device), nbw)
-            return y
-        nb = L.query("icg_conv2d_g_fprop_workspace_bytes", B, geo.out[0], geo.out[1], Cin, Cout, geo.R, geo.zins)
-        if nb:    # too few output tiles to fill the chip: split-K
-            L.call("icg_conv2d_g_fprop_ws", x, w, None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout, geo.R, geo.stride,
-                   geo.pad, geo.zins, _ops._bytes(nb, x.device), nb)
-        else:
-            L.call("icg_conv2d_g_fprop", x, w, None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout, geo.R, geo.stride,
-                   geo.pad, geo.zins)
+            if cache is not None:
+                cache[key] = U
+        nbw = L.query("icg_conv2d_%s_workspace_bytes" % v, B, H, W, Cin, Cout)
+        L.call("icg_conv2d_%s_fprop" % v, x, U, None, None, y, None, None, 0, B, H, W, Cin, Cout, 0, 1.0,
+               _ops._bytes(nbw, x.device), nbw)
         return y
+    nb = L.query("icg_conv2d_g_fprop_workspace_bytes", B, geo.out[0], geo.out[1], Cin, Cout, geo.R, geo.zins)
+    if nb:    # too few output tiles to fill the chip: split-K
+        L.call("icg_conv2d_g_fprop_ws", x, w, None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout, geo.R, geo.stride,
+               geo.pad, geo.zins, _ops._bytes(nb, x.device), nb)
+    else:
+        L.call("icg_conv2d_g_fprop", x, w, None, y, B, H, W, Cin, geo.out[0], geo.out[1], Cout, geo.R, geo.stride,
+               geo.pad, geo.zins)
+    return y
+
+
+class _GatherConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, geo):
+        # the autograd inputs themselves are saved (not their re-laid-out copies): the backward differentiates through them
+        ctx.geo = geo
+        ctx.save_for_backward(x, w)
+        return gather_conv(x, w, geo)
 
     @staticmethod
     def backward(ctx, dy):
@@ -168,56 +197,63 @@ class _GatherConv(torch.autograd.Function):
         return dx, dw, None
 
 
+def gather_wgrad_raw(x, dy, geo):
+    """Weight gradient of y = G[geo](x, w) given dy, as the kernels write it (fp32, no autograd): (t, layout) with layout 0:
+    t [R][R][Cin][Cout] = d w[co][r][s][ci];  layout 1 (zero-inserted direction -- dy is the gathered tensor): t [R][R][Cout][Cin] =
+    d w[co][R-1-r][R-1-s][ci], i.e. indexed by the taps of the transposed convolution's own (un-flipped) weight."""
+    _ops._require_gpu(x)
+    B, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    assert (H, W) == geo.src and tuple(dy.shape[2:]) == geo.out, (x.shape, dy.shape, geo)
+    R = geo.R
+    if x.dtype == torch.float16 and dy.dtype == torch.float16 and FP16_MFMA and \
+            L.query("icg_conv2d_g_wgrad_f16_applies", int(Cin), int(Cout), R, geo.zins if geo.zins else geo.stride):
+        # fp16 operands straight into the MFMA (csrc/hwgrad.hip); fp32 accumulation, fp32 HWIO result
+        x = x.contiguous(memory_format=torch.channels_last)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if geo.zins:      # zero-inserted direction: dy is the gathered tensor, x lives on the pixel grid
+            adj = geo.adjoint()
+            nb = L.query("icg_conv2d_g_wgrad_f16_workspace_bytes", B, H, W, Cout, Cin, R)
+            t = torch.empty(R, R, Cout, Cin, device=x.device, dtype=torch.float32)
+            L.call("icg_conv2d_g_wgrad_f16", dy, x, t, B, geo.out[0], geo.out[1], Cout, H, W, Cin, R, adj.stride, adj.pad,
+                   _ops._bytes(nb, x.device), nb)
+            return t, 1
+        nb = L.query("icg_conv2d_g_wgrad_f16_workspace_bytes", B, geo.out[0], geo.out[1], Cin, Cout, R)
+        t = torch.empty(R, R, Cin, Cout, device=x.device, dtype=torch.float32)
+        L.call("icg_conv2d_g_wgrad_f16", x, dy, t, B, H, W, Cin, geo.out[0], geo.out[1], Cout, R, geo.stride, geo.pad,
+               _ops._bytes(nb, x.device), nb)
+        return t, 0
+    x, dy = _ops._cl(x), _ops._cl(dy)
+    if geo.zins:      # zero-inserted direction: dy is the gathered tensor, x lives on the pixel grid
+        adj = geo.adjoint()
+        ws_bytes = L.query("icg_conv2d_g_wgrad_workspace_bytes", B, H, W, Cout, Cin, R)
+        t = torch.empty(R, R, Cout, Cin, device=x.device, dtype=torch.float32)
+        L.call("icg_conv2d_g_wgrad", dy, x, t, B, geo.out[0], geo.out[1], Cout, H, W, Cin, R, adj.stride, adj.pad,
+               _ops._bytes(ws_bytes, x.device), ws_bytes)
+        return t, 1
+    if R == 3 and geo.stride == 1 and geo.pad == 1 and geo.out == (H, W) and _ops.winograd_wgrad_tile(Cin, Cout, H, W, B):
+        v = "wino4" if _ops.winograd_wgrad_tile(Cin, Cout, H, W, B) == 4 else "wino"      # Winograd-domain wgrad
+        nbw = L.query("icg_conv2d_%s_wgrad_workspace_bytes" % v, B, H, W, Cin, Cout)
+        t = torch.empty(R, R, Cin, Cout, device=x.device, dtype=torch.float32)
+        L.call("icg_conv2d_%s_wgrad" % v, x, dy, t, None, None, 0, B, H, W, Cin, Cout, 0, _ops._bytes(nbw, x.device), nbw)
+        return t, 0
+    ws_bytes = L.query("icg_conv2d_g_wgrad_workspace_bytes", B, geo.out[0], geo.out[1], Cin, Cout, R)
+    t = torch.empty(R, R, Cin, Cout, device=x.device, dtype=torch.float32)
+    L.call("icg_conv2d_g_wgrad", x, dy, t, B, H, W, Cin, geo.out[0], geo.out[1], Cout, R, geo.stride, geo.pad,
+           _ops._bytes(ws_bytes, x.device), ws_bytes)
+    return t, 0
+
+
 class _GatherWgrad(torch.autograd.Function):
     """dw[Cout][R][R][Cin] of y = G[geo](x, w) given dy."""
 
     @staticmethod
     def forward(ctx, x, dy, geo):
-        _ops._require_gpu(x)
         ctx.geo = geo
         ctx.save_for_backward(x, dy)
         out_dtype = x.dtype                       # fp16 blocks: the gradient of an fp16 weight is fp16 (rounded once, from fp32)
-        B, Cin, H, W = x.shape
-        Cout = dy.shape[1]
-        assert (H, W) == geo.src and tuple(dy.shape[2:]) == geo.out, (x.shape, dy.shape, geo)
-        R = geo.R
-        if x.dtype == torch.float16 and dy.dtype == torch.float16 and FP16_MFMA and \
-                L.query("icg_conv2d_g_wgrad_f16_applies", int(Cin), int(Cout), R, geo.zins if geo.zins else geo.stride):
-            # fp16 operands straight into the MFMA (csrc/hwgrad.hip); fp32 accumulation, fp32 HWIO result, rounded to fp16 once
-            x = x.contiguous(memory_format=torch.channels_last)
-            dy = dy.contiguous(memory_format=torch.channels_last)
-            if geo.zins:      # zero-inserted direction: dy is the gathered tensor, x lives on the pixel grid
-                adj = geo.adjoint()
-                nb = L.query("icg_conv2d_g_wgrad_f16_workspace_bytes", B, H, W, Cout, Cin, R)
-                t = torch.empty(R, R, Cout, Cin, device=x.device, dtype=torch.float32)
-                L.call("icg_conv2d_g_wgrad_f16", dy, x, t, B, geo.out[0], geo.out[1], Cout, H, W, Cin, R, adj.stride, adj.pad,
-                       _ops._bytes(nb, x.device), nb)
-                return t.flip(0, 1).permute(2, 0, 1, 3).contiguous().to(out_dtype)
-            nb = L.query("icg_conv2d_g_wgrad_f16_workspace_bytes", B, geo.out[0], geo.out[1], Cin, Cout, R)
-            t = torch.empty(R, R, Cin, Cout, device=x.device, dtype=torch.float32)
-            L.call("icg_conv2d_g_wgrad_f16", x, dy, t, B, H, W, Cin, geo.out[0], geo.out[1], Cout, R, geo.stride, geo.pad,
-                   _ops._bytes(nb, x.device), nb)
-            return t.permute(3, 0, 1, 2).contiguous().to(out_dtype)
-        x, dy = _ops._cl(x), _ops._cl(dy)
-        if geo.zins:      # zero-inserted direction: dy is the gathered tensor, x lives on the pixel grid
-            adj = geo.adjoint()
-            ws_bytes = L.query("icg_conv2d_g_wgrad_workspace_bytes", B, H, W, Cout, Cin, R)
-            t = torch.empty(R, R, Cout, Cin, device=x.device, dtype=torch.float32)
-            L.call("icg_conv2d_g_wgrad", dy, x, t, B, geo.out[0], geo.out[1], Cout, H, W, Cin, R, adj.stride, adj.pad,
-                   _ops._bytes(ws_bytes, x.device), ws_bytes)
-            dw = t.flip(0, 1).permute(2, 0, 1, 3).contiguous()
-        elif R == 3 and geo.stride == 1 and geo.pad == 1 and geo.out == (H, W) and _ops.winograd_wgrad_tile(Cin, Cout, H, W, B):
-            v = "wino4" if _ops.winograd_wgrad_tile(Cin, Cout, H, W, B) == 4 else "wino"      # Winograd-domain wgrad
-            nbw = L.query("icg_conv2d_%s_wgrad_workspace_bytes" % v, B, H, W, Cin, Cout)
-            t = torch.empty(R, R, Cin, Cout, device=x.device, dtype=torch.float32)
-            L.call("icg_conv2d_%s_wgrad" % v, x, dy, t, None, None, 0, B, H, W, Cin, Cout, 0, _ops._bytes(nbw, x.device), nbw)
-            dw = t.permute(3, 0, 1, 2).contiguous()
-        else:
-            ws_bytes = L.query("icg_conv2d_g_wgrad_workspace_bytes", B, geo.out[0], geo.out[1], Cin, Cout, R)
-            t = torch.empty(R, R, Cin, Cout, device=x.device, dtype=torch.float32)
-            L.call("icg_conv2d_g_wgrad", x, dy, t, B, H, W, Cin, geo.out[0], geo.out[1], Cout, R, geo.stride, geo.pad,
-                   _ops._bytes(ws_bytes, x.device), ws_bytes)
-            dw = t.permute(3, 0, 1, 2).contiguous()
+        t, layout = gather_wgrad_raw(x, dy, geo)
+        dw = t.flip(0, 1).permute(2, 0, 1, 3).contiguous() if layout else t.permute(3, 0, 1, 2).contiguous()
         return dw if out_dtype == torch.float32 else dw.to(out_dtype)
 
     @staticmethod

@@ -587,6 +587,88 @@ typedef struct {
 } icg_f32_buffer;
 int icg_nan_to_num_multi(const icg_f32_buffer* tensors, int n, float nan_v, float posinf, float neginf, void* stream);
 
+
+/* ==== fused StyleGAN2 layers: stylegan2_ada_pytorch/training/networks.py:37-117 (modulated_conv2d), 361-444
+ * (SynthesisLayer), 450-486 (ToRGBLayer), 171-242 (Conv2dLayer), 121-165 (FullyConnectedLayer) =====================================
+ * What those layers do AROUND their contraction, as a few launches per layer and pass.  Activations are NHWC [N][HW][C] with
+ * storage `dtype` 0 = fp32 / 1 = fp16; per-sample vectors (styles s, demodulation coefficients d) and all reductions are fp32.
+ * fp16 storage rounds where the reference's fp16 tensors do (x * s, the convolution output, x * d + noise, the activation and their
+ * gradients).  Reductions use per-block partial sums in the caller's workspace and a fixed-order final pass (no atomics). */
+
+/* Weight preparation of n layers in two launches (per <= 40 layers).  Per layer, from the parameter w [O][I][R][R] (R <= 3):
+ *   scale[o] = prenorm ? gain * (1 / max_{i,k} |w[o]|) : gain     prenorm: the fp16 pre-normalisation of networks.py:57-63 with
+ *                                                                  gain = 1 / sqrt(I R R); otherwise the equalised-lr gain
+ *   w_fwd [O][R][R][I]  = w * scale, taps reversed when flip       the gather-convolution weight of icg_conv2d_g_fprop(_f16)
+ *   w_adj [I][R][R][O]  = w_fwd with both roles swapped and taps reversed (its data-gradient weight); may be NULL
+ *   wsq   [O][I]        = sum_k (w * scale)^2                      for the demodulation coefficients; may be NULL
+ *   wscale [O], warg [O] (flat (i, k) index of the maximum; prenorm only)                       kept for icg_sg2_weight_bwd */
+typedef struct {
+  const float* w;
+  void* w_fwd;
+  void* w_adj;
+  float* wsq;
+  float* wscale;
+  int* warg;
+  int O, I, R, prenorm;
+  float gain;
+  int flip, dtype, reserved;
+} icg_sg2_weight;
+int icg_sg2_weight_prep_multi(const icg_sg2_weight* layers, int n, void* stream);
+
+/* styles of one modulated convolution from its affine layer's GEMM output lin [N][I]  (networks.py:409, 57-75):
+ *   s0 = (lin + bias * bias_gain) * post_gain;   s = prenorm ? s0 / max_i |s0| : s0   (smax [N] = s0 at the maximum, sarg [N] its index)
+ *   d[n][o] = rsqrt(sum_i s[n][i]^2 wsq[o][i] + 1e-8)      when wsq != NULL (demodulate) */
+int icg_sg2_style_prep(const float* lin, const float* bias, float bias_gain, float post_gain, const float* wsq, int N, int I, int O,
+                       int prenorm, float* s, float* smax, int* sarg, float* d, void* stream);
+
+/* 1 when the row kernels below take C channels at this storage type (C / (16 bytes) a power of two <= 256) */
+int icg_sg2_rows_applies(int C, int dtype);
+/* xs = x * s[n][c]   (networks.py:78) */
+int icg_sg2_modulate(const void* x, const float* s, void* xs, int N, int64_t HW, int C, int dtype, void* stream);
+/* y = clamp(gain * act(c * d[n][o] + noise[n * noise_bstride + p] * strength[0] + bias[o]))   act: 1 linear, 3 lrelu(alpha)
+ * (networks.py:86-94 fma / add, 432-442 bias_act).  d, noise, bias may be NULL; clamp < 0: none. */
+int icg_sg2_act_fwd(const void* c, const float* d, const float* noise, int64_t noise_bstride, const float* strength, const float* bias,
+                    void* y, int N, int64_t HW, int O, int act, float alpha, float gain, float clamp, int dtype, void* stream);
+size_t icg_sg2_rows_workspace_bytes(int N, int64_t HW, int C, int ncols, int dtype);
+/* gradient of icg_sg2_act_fwd: dz = dy * gain * act'(y) [|y| < clamp] (bias_act.cu's grad = 1 pass);  dc = dz * d (may be NULL);
+ * sums [N][2 O + 1] per sample and tot [2 O + 1] over the batch of (dz | dz * c | dz * noise):  d bias = tot[0 .. O),
+ * d d[n][o] = sums[n][O + o], d strength = tot[2 O].  workspace: icg_sg2_rows_workspace_bytes(N, HW, O, 2 O + 1, dtype). */
+int icg_sg2_act_bwd(const void* dy, const void* y, const void* c, const float* d, const float* noise, int64_t noise_bstride, void* dc,
+                    float* sums, float* tot, int N, int64_t HW, int O, int act, float alpha, float gain, float clamp, int dtype,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* gradient of icg_sg2_modulate: dx = dxs * s (may be NULL), ds[n][c] = sum_p dxs * x.  workspace: (N, HW, C, C, dtype). */
+int icg_sg2_modulate_bwd(const void* dxs, const void* x, const float* s, void* dx, float* ds, int N, int64_t HW, int C, int dtype,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* styles, backward through the demodulation: t[n][o] = -dd d^3;  g[n][i] = ds_mod[n][i] + s[n][i] sum_o t[n][o] wsq[o][i];
+ * pdot[n][ceil(I / 64)] = partial sums of g s (for the pre-normalisation's gradient).  dd == NULL: no demodulation (g = ds_mod). */
+int icg_sg2_style_bwd(const float* ds_mod, int64_t ds_stride, const float* dd, int64_t dd_stride, const float* d, const float* s,
+                      const float* wsq, int N, int I, int O, float* g, float* pdot, float* t, void* stream);
+/* backward of a fully-connected layer at a small batch (N <= 64):  lin = wgain x W^T + bias_gain b,  x [N][K], W [I][K].
+ * dlin = post_gain * g, or through the style pre-normalisation when smax != NULL:
+ *   dlin[n][i] = post_gain (g[n][i] - [i == sarg[n]] sign(smax[n]) sum_k pdot[n][k]) / |smax[n]|
+ * dW [I][K] = wgain dlin^T x, db [I] = bias_gain sum_n dlin, dx [N][K] = wgain dlin W   (each may be NULL) */
+int icg_sg2_fc_bwd(const float* g, const float* smax, const int* sarg, const float* pdot, int npdot, float post_gain, const float* x,
+                   const float* W, int N, int I, int K, float wgain, float bias_gain, float* dW, float* db, float* dx, void* stream);
+/* weight gradient of a layer from the convolution's weight gradient dw_conv (fp32; layout 0: [R][R][I][O] as icg_conv2d_g_wgrad(_f16)
+ * writes it, 1: [R][R][O][I] -- the zero-inserted direction) plus the demodulation term w scale sum_n t[n][o] s[n][i]^2 (t may be
+ * NULL), back through scale[o] (gain, or the pre-normalisation's c0 / max|w[o]|): dw [O][I][R][R].  round_f16: dw_conv is rounded to
+ * fp16 first (the gradient of an fp16 weight tensor).  workspace (prenorm only): icg_sg2_weight_bwd_workspace_bytes(O, I). */
+size_t icg_sg2_weight_bwd_workspace_bytes(int O, int I);
+int icg_sg2_weight_bwd(const float* dw_conv, int layout, const float* t, const float* s, int N, const float* w, const float* wscale,
+                       const int* warg, int prenorm, float c0, int round_f16, float* dw, int O, int I, int R, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* ToRGB (networks.py:450-486) as one pass over x: y[n][p][o] = clamp(sum_c (x * s)[n][p][c] w[o][c] + bias[o]), o < 3, stored in the
+ * activation type (kept for the backward) and accumulated into the fp32 NCHW image: img_out = img_in + y (img_in may be NULL). */
+int icg_sg2_torgb_applies(int C, int dtype);
+int icg_sg2_torgb_fwd(const void* x, const float* s, const float* w, const float* bias, float clamp, const float* img_in, float* img_out,
+                      void* y, int N, int64_t HW, int C, int dtype, void* stream);
+size_t icg_sg2_torgb_bwd_workspace_bytes(int N, int64_t HW, int C, int dtype);
+/* its gradient from dimg [N][3][HW] fp32: dx (may be NULL), sums [N][4 C + 3] (ds = sums[:, 0 .. C)), tot [4 C + 3]
+ * (dw[o][c] = tot[(1 + o) C + c], d bias[o] = tot[4 C + o]).  mask_clamp 0: the reference CUDA plugin's unmasked gradient of a
+ * clamped linear bias_act (bias_act.py:262-266). */
+int icg_sg2_torgb_bwd(const float* dimg, const void* y, const void* x, const float* s, const float* w, float clamp, int mask_clamp, void* dx,
+                      float* sums, float* tot, int N, int64_t HW, int C, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1084,6 +1084,259 @@ def icg_knn_l2(feats, N, D, k, idx, d2, workspace, workspace_bytes):
     mem(d2)[: N * k].copy_(order.values[:, :k].clamp(min=0).float().reshape(-1))
 
 
+# ---------------------------------------------------------------- fused StyleGAN2 layers (csrc/sg2_fused.hip)
+def _rt(v, dtype):
+    """round to the storage type and come back to fp32 (dtype 1 = fp16)"""
+    return v.half().float() if dtype == 1 else v
+
+
+def sg2_weight_prep_ref(items):
+    """ops.sg2_weight_prep_multi (icg_sg2_weight_prep_multi): items = dicts with w, w_fwd, w_adj, wsq, wscale, warg, prenorm, gain, flip."""
+    for it in items:
+        w = it["w"].detach().float()
+        O, I, R, _ = w.shape
+        if it["prenorm"]:
+            flat = w.reshape(O, -1).abs()
+            m, arg = flat.max(dim=1)
+            scale = (1.0 / m) * torch.tensor(it["gain"], dtype=torch.float32)
+            it["warg"].copy_(arg.to(torch.int32))
+        else:
+            scale = torch.full((O,), it["gain"], dtype=torch.float32)
+        it["wscale"].copy_(scale)
+        wn = w * scale.view(O, 1, 1, 1)
+        if it["wsq"] is not None:
+            it["wsq"].copy_(wn.square().sum(dim=[2, 3]))
+        g = wn.permute(0, 2, 3, 1)                         # [O][R][R][I]
+        if it["flip"]:
+            g = g.flip(1, 2)
+        mem(it["w_fwd"])[: g.numel()].copy_(g.reshape(-1).to(it["w_fwd"].dtype))
+        if it["w_adj"] is not None:
+            a = g.flip(1, 2).permute(3, 1, 2, 0)           # [I][R][R][O], taps reversed
+            mem(it["w_adj"])[: a.numel()].copy_(a.reshape(-1).to(it["w_adj"].dtype))
+
+
+def icg_sg2_style_prep(lin, bias, bias_gain, post_gain, wsq, N, I, O, prenorm, s, smax, sarg, d):
+    s0 = mem(lin)[: N * I].view(N, I)
+    if bias is not None:
+        s0 = s0 + mem(bias)[:I] * bias_gain
+    s0 = s0 * post_gain
+    sv = s0
+    if prenorm:
+        m, arg = s0.abs().max(dim=1)
+        mem(smax)[:N].copy_(s0.gather(1, arg[:, None])[:, 0])
+        mem(sarg)[:N].copy_(arg.to(torch.int32))
+        sv = s0 / m[:, None]
+    mem(s)[: N * I].copy_(sv.reshape(-1))
+    if wsq is not None:
+        q = sv.square() @ mem(wsq)[: O * I].view(O, I).t()
+        mem(d)[: N * O].copy_((q + 1e-8).rsqrt().reshape(-1))
+
+
+def icg_sg2_rows_applies(C, dtype):
+    vec = 8 if dtype == 1 else 4
+    if dtype not in (0, 1) or C < vec or C % vec:
+        return 0
+    v = C // vec
+    return int(v <= 256 and (v & (v - 1)) == 0)
+
+
+def icg_sg2_modulate(x, s, xs, N, HW, C, dtype):
+    xv = mem(x)[: N * HW * C].view(N, HW, C).float()
+    sv = _rt(mem(s)[: N * C].view(N, 1, C), dtype)
+    mem(xs)[: N * HW * C].copy_((xv * sv).reshape(-1).to(xs.dtype))
+
+
+def _sg2_act(v, act, alpha):
+    return torch.where(v < 0, v * alpha, v) if act == 3 else v
+
+
+def icg_sg2_act_fwd(c, d, noise, noise_bstride, strength, bias, y, N, HW, O, act, alpha, gain, clamp, dtype):
+    z = mem(c)[: N * HW * O].view(N, HW, O).float()
+    nz = None
+    if noise is not None:
+        st = mem(strength)[0] if strength is not None else 1.0
+        nb = mem(noise)
+        nz = torch.stack([nb[n * noise_bstride: n * noise_bstride + HW] for n in range(N)]) * st
+        nz = _rt(nz, dtype).view(N, HW, 1)
+    if d is not None:
+        dv = _rt(mem(d)[: N * O].view(N, 1, O), dtype)
+        z = _rt(z * dv + (nz if nz is not None else 0.0), dtype)
+    elif nz is not None:
+        z = _rt(z + nz, dtype)
+    if bias is not None:
+        z = z + _rt(mem(bias)[:O], dtype)
+    o = _sg2_act(z, act, alpha) * gain
+    if clamp >= 0:
+        o = o.clamp(-clamp, clamp)
+    mem(y)[: N * HW * O].copy_(o.reshape(-1).to(y.dtype))
+
+
+def _rows_geometry(HW, V):
+    nrl = 256 // V
+    r = max(-(-HW // 64), nrl)
+    r = -(-r // nrl) * nrl
+    return r, -(-HW // r)
+
+
+def icg_sg2_rows_workspace_bytes(N, HW, C, ncols, dtype):
+    if not icg_sg2_rows_applies(C, dtype):
+        return 0
+    _, chunks = _rows_geometry(HW, C // (8 if dtype == 1 else 4))
+    return N * chunks * ncols * 4
+
+
+def icg_sg2_act_bwd(dy, y, c, d, noise, noise_bstride, dc, sums, tot, N, HW, O, act, alpha, gain, clamp, dtype, workspace, workspace_bytes):
+    g = mem(dy)[: N * HW * O].view(N, HW, O).float()
+    yv = mem(y)[: N * HW * O].view(N, HW, O).float()
+    slope = torch.where(yv > 0, torch.ones_like(yv), torch.full_like(yv, alpha)) if act == 3 else torch.ones_like(yv)
+    dz = g * (gain * slope)
+    if clamp >= 0:
+        dz = torch.where((yv > -clamp) & (yv < clamp), dz, torch.zeros_like(dz))
+    dz = _rt(dz, dtype)
+    out = torch.zeros(N, 2 * O + 1, dtype=torch.float64)
+    out[:, :O] = dz.double().sum(1)
+    if c is not None:
+        out[:, O:2 * O] = (dz.double() * mem(c)[: N * HW * O].view(N, HW, O).double()).sum(1)
+    if noise is not None:
+        nb = mem(noise)
+        nz = torch.stack([nb[n * noise_bstride: n * noise_bstride + HW] for n in range(N)]).double()
+        out[:, 2 * O] = (dz.double().sum(2) * nz).sum(1)
+    if sums is not None:
+        mem(sums)[: N * (2 * O + 1)].copy_(out.float().reshape(-1))
+    if tot is not None:
+        mem(tot)[: 2 * O + 1].copy_(out.sum(0).float())
+    if dc is not None:
+        o = _rt(dz * _rt(mem(d)[: N * O].view(N, 1, O), dtype), dtype) if d is not None else dz
+        mem(dc)[: N * HW * O].copy_(o.reshape(-1).to(dc.dtype))
+
+
+def icg_sg2_modulate_bwd(dxs, x, s, dx, ds, N, HW, C, dtype, workspace, workspace_bytes):
+    g = mem(dxs)[: N * HW * C].view(N, HW, C).float()
+    xv = mem(x)[: N * HW * C].view(N, HW, C).float()
+    mem(ds)[: N * C].copy_((g.double() * xv.double()).sum(1).float().reshape(-1))
+    if dx is not None:
+        sv = _rt(mem(s)[: N * C].view(N, 1, C), dtype)
+        mem(dx)[: N * HW * C].copy_((g * sv).reshape(-1).to(dx.dtype))
+
+
+def _raw(t):
+    """the memory behind a pointer argument that is a strided view (row n at p + n * stride): flat from the view's first element"""
+    n = t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+    return t.as_strided((n,), (1,))
+
+
+def icg_sg2_style_bwd(ds_mod, ds_stride, dd, dd_stride, d, s, wsq, N, I, O, g, pdot, t):
+    dsm = torch.stack([_raw(ds_mod)[n * ds_stride: n * ds_stride + I] for n in range(N)])
+    sv = mem(s)[: N * I].view(N, I)
+    gv = dsm
+    if dd is not None:
+        ddv = torch.stack([_raw(dd)[n * dd_stride: n * dd_stride + O] for n in range(N)])
+        dv = mem(d)[: N * O].view(N, O)
+        tv = -ddv * dv * dv * dv
+        mem(t)[: N * O].copy_(tv.reshape(-1))
+        gv = dsm + sv * (tv @ mem(wsq)[: O * I].view(O, I))
+    mem(g)[: N * I].copy_(gv.reshape(-1))
+    nb = -(-I // 64)
+    pad = F.pad(gv * sv, (0, nb * 64 - I)).view(N, nb, 64).sum(2)
+    mem(pdot)[: N * nb].copy_(pad.reshape(-1))
+
+
+def _sg2_dlin(g, smax, sarg, pdot, npdot, post_gain, N, I):
+    gv = mem(g)[: N * I].view(N, I).clone()
+    if smax is not None:
+        sm = mem(smax)[:N]
+        P = mem(pdot)[: N * npdot].view(N, npdot).sum(1)
+        arg = mem(sarg)[:N].long()
+        gv[torch.arange(N), arg] -= torch.sign(sm) * P
+        gv = gv / sm.abs()[:, None]
+    return gv * post_gain
+
+
+def icg_sg2_fc_bwd(g, smax, sarg, pdot, npdot, post_gain, x, W, N, I, K, wgain, bias_gain, dW, db, dx):
+    dl = _sg2_dlin(g, smax, sarg, pdot, npdot, post_gain, N, I)
+    if dW is not None:
+        mem(dW)[: I * K].copy_((dl.t() @ mem(x)[: N * K].view(N, K) * wgain).reshape(-1))
+    if db is not None:
+        mem(db)[:I].copy_(dl.sum(0) * bias_gain)
+    if dx is not None:
+        mem(dx)[: N * K].copy_((dl @ mem(W)[: I * K].view(I, K) * wgain).reshape(-1))
+
+
+def icg_sg2_weight_bwd_workspace_bytes(O, I):
+    return O * (-(-I // 32)) * 4
+
+
+def icg_sg2_weight_bwd(dw_conv, layout, t, s, N, w, wscale, warg, prenorm, c0, round_f16, dw, O, I, R, workspace, workspace_bytes):
+    RR = R * R
+    dc = mem(dw_conv)[: RR * I * O]
+    dc = dc.view(RR, I, O).permute(2, 1, 0) if layout == 0 else dc.view(RR, O, I).permute(1, 2, 0)      # -> [O][I][RR]
+    if round_f16:
+        dc = dc.half().float()
+    wv = mem(w)[: O * I * RR].view(O, I, RR)
+    sc = mem(wscale)[:O].view(O, 1, 1)
+    g = dc
+    if t is not None:
+        q = mem(t)[: N * O].view(N, O).t() @ mem(s)[: N * I].view(N, I).square()                 # [O][I]
+        g = dc + wv * sc * q[:, :, None]
+    out = g * sc
+    if prenorm:
+        D = (g * wv).sum(dim=[1, 2])
+        arg = mem(warg)[:O].long()
+        flat = out.reshape(O, -1).clone()
+        wa = wv.reshape(O, -1)[torch.arange(O), arg]
+        flat[torch.arange(O), arg] -= torch.sign(wa) * D * sc.view(O) * sc.view(O) / c0
+        out = flat
+    mem(dw)[: O * I * RR].copy_(out.reshape(-1))
+
+
+def icg_sg2_torgb_applies(C, dtype):
+    vec = 8 if dtype == 1 else 4
+    if dtype not in (0, 1) or C < vec or C % vec:
+        return 0
+    v = C // vec
+    return int((v & (v - 1)) == 0 and (v <= 64 or v in (128, 256)))
+
+
+def icg_sg2_torgb_fwd(x, s, w, bias, clamp, img_in, img_out, y, N, HW, C, dtype):
+    xv = mem(x)[: N * HW * C].view(N, HW, C).float()
+    xs = _rt(xv * _rt(mem(s)[: N * C].view(N, 1, C), dtype), dtype)
+    o = _rt(xs @ _rt(mem(w)[: 3 * C].view(3, C), dtype).t(), dtype)
+    if bias is not None:
+        o = o + _rt(mem(bias)[:3], dtype)
+    if clamp >= 0:
+        o = o.clamp(-clamp, clamp)
+    o = _rt(o, dtype)
+    mem(y)[: N * HW * 3].copy_(o.reshape(-1).to(y.dtype))
+    im = o.permute(0, 2, 1)                                # [N][3][HW]
+    if img_in is not None:
+        im = im + mem(img_in)[: N * 3 * HW].view(N, 3, HW)
+    mem(img_out)[: N * 3 * HW].copy_(im.reshape(-1))
+
+
+def icg_sg2_torgb_bwd_workspace_bytes(N, HW, C, dtype):
+    return 16 if icg_sg2_torgb_applies(C, dtype) else 0
+
+
+def icg_sg2_torgb_bwd(dimg, y, x, s, w, clamp, mask_clamp, dx, sums, tot, N, HW, C, dtype, workspace, workspace_bytes):
+    dz = _rt(mem(dimg)[: N * 3 * HW].view(N, 3, HW).permute(0, 2, 1), dtype)                      # [N][HW][3]
+    if mask_clamp and clamp >= 0:
+        yv = mem(y)[: N * HW * 3].view(N, HW, 3).float()
+        dz = torch.where((yv > -clamp) & (yv < clamp), dz, torch.zeros_like(dz))
+    xv = mem(x)[: N * HW * C].view(N, HW, C).float()
+    sv = _rt(mem(s)[: N * C].view(N, 1, C), dtype)
+    wv = _rt(mem(w)[: 3 * C].view(3, C), dtype)
+    dxs = _rt(dz @ wv, dtype)
+    xs = _rt(xv * sv, dtype)
+    per = torch.zeros(N, 4 * C + 3, dtype=torch.float64)
+    per[:, :C] = (dxs.double() * xv.double()).sum(1)
+    per[:, C:4 * C] = torch.einsum("npo,npc->noc", dz.double(), xs.double()).reshape(N, 3 * C)
+    per[:, 4 * C:] = dz.double().sum(1)
+    mem(sums)[: N * (4 * C + 3)].copy_(per.float().reshape(-1))
+    mem(tot)[: 4 * C + 3].copy_(per.sum(0).float())
+    if dx is not None:
+        mem(dx)[: N * HW * C].copy_(_rt(dxs * sv, dtype).reshape(-1).to(dx.dtype))
+
+
 def nan_to_num_multi_ref(tensors, nan=0.0, posinf=None, neginf=None):
     """ops.nan_to_num_multi (icg_nan_to_num_multi) as the per-tensor torch call it batches (training_loop.py:511-515)"""
     for t in tensors:
@@ -1109,5 +1362,8 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "adam_multi", adam_multi_ref)
     monkeypatch.setattr(ops, "ema_multi", ema_multi_ref)
     monkeypatch.setattr(ops, "nan_to_num_multi", nan_to_num_multi_ref)
+    monkeypatch.setattr(ops, "sg2_weight_prep_multi", sg2_weight_prep_ref)
+    import ic_gan_amd.stylegan_ops.fused_layers as FL
+    monkeypatch.setattr(FL, "_EMULATED", True)
     monkeypatch.setattr(ops, "sn_prepare_many", lambda items, eps, training: [
         ops.sn_prepare(w, u, sv, eps, training, nd, up, dn, *rest) for (w, u, sv, nd, up, dn, *rest) in items])

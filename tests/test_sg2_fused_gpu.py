@@ -1,0 +1,299 @@
+"""GPU parity of the fused StyleGAN2 layer kernels (csrc/sg2_fused.hip): every C-ABI entry point against its CPU
+restatement (oracle/kernel_ref.py) on the same seeded inputs, fp32 and fp16 storage, at toy shapes and at the layer shapes of
+BASELINE.json configs[3] (64 ... 512 channels); then each fused layer (one autograd node) against the composed operator graph on the
+GPU -- outputs and all first-order gradients."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernel_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _L():
+    import ic_gan_amd._lib as L
+    return L
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(got, ref, tol, what):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what + ": non-finite"
+    scale = float(ref.abs().max()) + 1e-30
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, "%s: max err %.3e of max|ref| %.3e (%.2e rel), rel L2 %.2e" % (
+        what, err, scale, err / scale, float((got - ref).norm() / (ref.norm() + 1e-30)))
+
+
+def run_pair(name, args, outs):
+    L = _L()
+    dargs = [a.cuda() if isinstance(a, torch.Tensor) else a for a in args]
+    L.call(name, *dargs)
+    torch.cuda.synchronize()
+    getattr(R, name)(*args)
+    return [(dargs[i], args[i]) for i in outs]
+
+
+def act(n, hw, c, half, seed, scale=1.0):
+    t = rnd(n, hw, c, seed=seed, scale=scale)
+    return t.half() if half else t
+
+
+SHAPES = [(2, 64, 16), (3, 100, 32), (2, 37, 64), (2, 1024, 512), (2, 4096, 64), (4, 16, 512)]      # N, HW, C
+
+
+@pytest.mark.parametrize("shape", [(24, 16, 3, 1, 0), (40, 24, 3, 1, 1), (16, 33, 1, 0, 0), (512, 512, 3, 1, 1), (64, 128, 3, 0, 0), (3, 64, 1, 0, 0)])
+@pytest.mark.parametrize("half", [False, True])
+def test_weight_prep(shape, half):
+    from ic_gan_amd import ops
+    O, I, Rk, prenorm, flip = shape
+    dt = torch.float16 if half else torch.float32
+    w = rnd(O, I, Rk, Rk, seed=1)
+    gain = float(np.float32(1 / np.sqrt(I * Rk * Rk))) if prenorm else 0.37
+
+    def bufs(dev):
+        return dict(w=w.to(dev), w_fwd=torch.empty(O, Rk, Rk, I, dtype=dt, device=dev), w_adj=torch.empty(I, Rk, Rk, O, dtype=dt, device=dev),
+                    wsq=torch.empty(O, I, device=dev), wscale=torch.empty(O, device=dev),
+                    warg=torch.empty(O, dtype=torch.int32, device=dev) if prenorm else None, prenorm=prenorm, gain=gain, flip=flip)
+    g, c = bufs("cuda"), bufs("cpu")
+    ops.sg2_weight_prep_multi([g, dict(g, w_adj=None, wsq=None)])          # two layers in one call (the second rewrites the same outputs)
+    torch.cuda.synchronize()
+    R.sg2_weight_prep_ref([c])
+    close(g["wscale"], c["wscale"], 1e-6, "wscale")
+    close(g["wsq"], c["wsq"], 1e-5, "wsq")
+    close(g["w_fwd"].float(), c["w_fwd"].float(), 1e-3 if half else 1e-6, "w_fwd")
+    close(g["w_adj"].float(), c["w_adj"].float(), 1e-3 if half else 1e-6, "w_adj")
+    if prenorm:
+        assert torch.equal(g["warg"].cpu(), c["warg"])
+
+
+@pytest.mark.parametrize("N,I,O,prenorm,demod", [(3, 16, 24, 0, 1), (4, 100, 33, 1, 1), (16, 512, 512, 1, 1), (2, 64, 0, 0, 0), (16, 512, 256, 0, 1)])
+def test_style_prep(N, I, O, prenorm, demod):
+    lin, bias = rnd(N, I, seed=1), rnd(I, seed=2) + 1
+    wsq = rnd(max(O, 1), I, seed=3).square() if demod else None
+    s, smax, sarg, d = torch.empty(N, I), torch.empty(N), torch.empty(N, dtype=torch.int32), torch.empty(N, max(O, 1))
+    args = [lin, bias, 1.0, 0.7, wsq, N, I, O, prenorm, s, smax if prenorm else None, sarg if prenorm else None, d if demod else None]
+    outs = [9] + ([10, 11] if prenorm else []) + ([12] if demod else [])
+    for k, (g, r) in zip(outs, run_pair("icg_sg2_style_prep", args, outs)):
+        if k == 11:
+            assert torch.equal(g.cpu(), r)
+        else:
+            close(g, r, 2e-5, "style_prep out %d" % k)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("half", [False, True])
+def test_modulate_and_its_gradient(shape, half):
+    N, HW, C = shape
+    dt = 1 if half else 0
+    x, s = act(N, HW, C, half, 1), rnd(N, C, seed=2)
+    xs = torch.empty_like(x)
+    ((g, r),) = run_pair("icg_sg2_modulate", [x, s, xs, N, HW, C, dt], [2])
+    close(g.float(), r.float(), 1e-3 if half else 1e-6, "modulate")
+    dxs = act(N, HW, C, half, 3)
+    dx, ds = torch.empty_like(x), torch.empty(N, C)
+    nb = R.icg_sg2_rows_workspace_bytes(N, HW, C, C, dt)
+    assert nb == _L().query("icg_sg2_rows_workspace_bytes", N, HW, C, C, dt)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8)
+    (gdx, rdx), (gds, rds) = run_pair("icg_sg2_modulate_bwd", [dxs, x, s, dx, ds, N, HW, C, dt, ws, nb], [3, 4])
+    close(gdx.float(), rdx.float(), 1e-3 if half else 1e-6, "modulate_bwd dx")
+    close(gds, rds, 2e-5, "modulate_bwd ds")
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("variant", ["full", "per_sample_noise", "bias_act_only", "noise_only", "demod_only"])
+def test_act_forward_and_backward(shape, half, variant):
+    N, HW, O = shape
+    dt = 1 if half else 0
+    c = act(N, HW, O, half, 1)
+    d = rnd(N, O, seed=2).abs() + 0.5 if variant in ("full", "per_sample_noise", "demod_only") else None
+    noise = None
+    bstride = 0
+    if variant in ("full", "noise_only"):
+        noise = rnd(HW, seed=3)
+    if variant == "per_sample_noise":
+        noise, bstride = rnd(N, HW, seed=3), HW
+    strength = torch.tensor([0.3]) if noise is not None else None
+    bias = rnd(O, seed=4) if variant != "demod_only" else None
+    act_id, gain, clamp = (3, float(np.sqrt(2)), 1.5) if variant != "noise_only" else (1, 1.0, -1.0)
+    y = torch.empty_like(c)
+    ((g, r),) = run_pair("icg_sg2_act_fwd", [c, d, noise, bstride, strength, bias, y, N, HW, O, act_id, 0.2, gain, clamp, dt], [6])
+    close(g.float(), r.float(), 2e-3 if half else 2e-6, "act_fwd")
+    dy = act(N, HW, O, half, 5)
+    dc, sums, tot = torch.empty_like(c), torch.empty(N, 2 * O + 1), torch.empty(2 * O + 1)
+    nb = R.icg_sg2_rows_workspace_bytes(N, HW, O, 2 * O + 1, dt)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8)
+    args = [dy, r, c if d is not None else None, d, noise, bstride, dc, sums, tot, N, HW, O, act_id, 0.2, gain, clamp, dt, ws, nb]
+    (gdc, rdc), (gs, rs), (gt, rt) = run_pair("icg_sg2_act_bwd", args, [6, 7, 8])
+    close(gdc.float(), rdc.float(), 2e-3 if half else 2e-6, "act_bwd dc")
+    close(gs, rs, 3e-5, "act_bwd per-sample sums")
+    close(gt, rt, 3e-5, "act_bwd batch sums")
+
+
+@pytest.mark.parametrize("N,I,O,demod", [(3, 16, 24, 1), (4, 100, 33, 1), (16, 512, 512, 1), (2, 64, 0, 0)])
+def test_style_backward(N, I, O, demod):
+    ds = rnd(N, I + 5, seed=1)
+    dd, d, s = rnd(N, 2 * max(O, 1) + 1, seed=2), rnd(N, max(O, 1), seed=3).abs() + 0.5, rnd(N, I, seed=4)
+    wsq = rnd(max(O, 1), I, seed=5).square()
+    nblk = (I + 63) // 64
+    g, pdot, t = torch.empty(N, I), torch.empty(N, nblk), torch.empty(N, max(O, 1))
+    args = [ds, I + 5, dd if demod else None, 2 * O + 1, d if demod else None, s, wsq if demod else None, N, I, O, g, pdot, t if demod else None]
+    outs = [10, 11] + ([12] if demod else [])
+    for k, (a, b) in zip(outs, run_pair("icg_sg2_style_bwd", args, outs)):
+        close(a, b, 3e-5, "style_bwd out %d" % k)
+
+
+@pytest.mark.parametrize("N,I,K,norm", [(3, 16, 24, 0), (4, 100, 33, 1), (16, 512, 512, 1), (16, 512, 2048, 0), (16, 1, 512, 0), (64, 300, 40, 0)])
+def test_fc_backward(N, I, K, norm):
+    g, x, W = rnd(N, I, seed=1), rnd(N, K, seed=2), rnd(I, K, seed=3)
+    nblk = (I + 63) // 64
+    smax = rnd(N, seed=4) + 0.1
+    sarg = torch.randint(0, I, (N,), generator=torch.Generator().manual_seed(5), dtype=torch.int32)
+    pdot = rnd(N, nblk, seed=6)
+    dW, db, dx = torch.empty(I, K), torch.empty(I), torch.empty(N, K)
+    args = [g, smax if norm else None, sarg if norm else None, pdot if norm else None, nblk if norm else 0, 0.6, x, W, N, I, K, 0.3, 1.7, dW, db, dx]
+    for k, (a, b) in zip([13, 14, 15], run_pair("icg_sg2_fc_bwd", args, [13, 14, 15])):
+        close(a, b, 3e-5, "fc_bwd out %d" % k)
+
+
+@pytest.mark.parametrize("O,I,Rk,layout,demod,prenorm,round16", [(24, 16, 3, 0, 1, 0, 0), (40, 33, 3, 1, 1, 1, 1), (512, 512, 3, 0, 1, 1, 1), (64, 128, 3, 1, 0, 0, 0),
+                                                                  (33, 16, 1, 0, 0, 0, 1), (3, 64, 1, 0, 1, 1, 0)])
+def test_weight_backward(O, I, Rk, layout, demod, prenorm, round16):
+    N, RR = 5, Rk * Rk
+    dwc = rnd(RR, I, O, seed=1) if layout == 0 else rnd(RR, O, I, seed=1)
+    t, s, w = rnd(N, O, seed=2), rnd(N, I, seed=3), rnd(O, I, Rk, Rk, seed=4)
+    c0 = float(np.float32(1 / np.sqrt(I * RR)))
+    m, arg = w.reshape(O, -1).abs().max(dim=1)
+    wscale = (1.0 / m) * c0 if prenorm else torch.full((O,), 0.37)
+    warg = arg.to(torch.int32)
+    dw = torch.empty(O, I, Rk, Rk)
+    nb = R.icg_sg2_weight_bwd_workspace_bytes(O, I)
+    assert nb == _L().query("icg_sg2_weight_bwd_workspace_bytes", O, I)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8)
+    args = [dwc, layout, t if demod else None, s if demod else None, N if demod else 0, w, wscale, warg if prenorm else None, prenorm, c0, round16,
+            dw, O, I, Rk, ws if prenorm else None, nb if prenorm else 0]
+    ((a, b),) = run_pair("icg_sg2_weight_bwd", args, [11])
+    close(a, b, 3e-5, "weight_bwd")
+
+
+@pytest.mark.parametrize("N,HW,C", [(2, 64, 16), (3, 100, 32), (2, 4096, 64), (2, 1024, 512), (2, 256, 1024)])
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("clamp,with_img", [(-1.0, False), (0.8, True)])
+def test_torgb_forward_and_backward(N, HW, C, half, clamp, with_img):
+    dt = 1 if half else 0
+    if not R.icg_sg2_torgb_applies(C, dt):
+        assert not _L().query("icg_sg2_torgb_applies", C, dt)
+        pytest.skip("shape not served")
+    assert _L().query("icg_sg2_torgb_applies", C, dt)
+    x, s, w, bias = act(N, HW, C, half, 1), rnd(N, C, seed=2), rnd(3, C, seed=3, scale=0.1), rnd(3, seed=4)
+    img = rnd(N, 3, HW, seed=5) if with_img else None
+    out, y = torch.empty(N, 3, HW), torch.empty(N, HW, 3, dtype=x.dtype)
+    (go, ro), (gy, ry) = run_pair("icg_sg2_torgb_fwd", [x, s, w, bias, clamp, img, out, y, N, HW, C, dt], [6, 7])
+    close(go, ro, 2e-3 if half else 1e-5, "torgb img")
+    close(gy.float(), ry.float(), 2e-3 if half else 1e-5, "torgb y")
+    dimg = rnd(N, 3, HW, seed=6)
+    dx, sums, tot = torch.empty_like(x), torch.empty(N, 4 * C + 3), torch.empty(4 * C + 3)
+    nb = _L().query("icg_sg2_torgb_bwd_workspace_bytes", N, HW, C, dt)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8)
+    args = [dimg, ry, x, s, w, clamp, 1, dx, sums, tot, N, HW, C, dt, ws, nb]
+    (gdx, rdx), (gs, rs), (gt, rt) = run_pair("icg_sg2_torgb_bwd", args, [7, 8, 9])
+    close(gdx.float(), rdx.float(), 2e-3 if half else 2e-6, "torgb_bwd dx")
+    close(gs, rs, 5e-5, "torgb_bwd per-sample sums")
+    close(gt, rt, 5e-5, "torgb_bwd batch sums")
+
+
+# ------------------------------------------------------------------------------------------------ whole layers, fused vs composed
+def _init(mod, seed):
+    for i, (n, p) in enumerate(mod.named_parameters()):
+        with torch.no_grad():
+            v = rnd(*p.shape, seed=seed * 100 + i) if p.dim() else rnd(1, seed=seed * 100 + i)[0]
+            if n.endswith("bias"):
+                v = 0.3 * v + (1.0 if "affine" in n else 0.0)
+            if n.endswith("noise_strength"):
+                v = 0.3 * v
+            p.copy_(v)
+
+
+def _grads(fn, params, inputs, fused):
+    from ic_gan_amd.stylegan_ops import fused_layers as FL
+    for p in params:
+        p.grad = None
+    ins = [t.detach().clone().requires_grad_(True) for t in inputs]
+    if fused:
+        with FL.first_order():
+            y = fn(*ins)
+    else:
+        y = fn(*ins)
+    r = rnd(*y.shape, seed=99).to(y.device)
+    (y.float() * r).sum().backward()
+    return y.detach().float(), [t.grad.float() for t in ins], [p.grad.float() if p.grad is not None else None for p in params]
+
+
+def _check(fn, mod, inputs, half):
+    params, names = list(mod.parameters()), [n for n, _ in mod.named_parameters()]
+    y0, gi0, gp0 = _grads(fn, params, inputs, False)
+    y1, gi1, gp1 = _grads(fn, params, inputs, True)
+    close(y1, y0, 2e-3 if half else 2e-5, "output")
+    for i, (a, b) in enumerate(zip(gi1, gi0)):
+        close(a, b, 6e-3 if half else 5e-5, "grad input %d" % i)
+    for n, a, b in zip(names, gp1, gp0):
+        assert (a is None) == (b is None), n
+        if a is not None:
+            close(a, b, 6e-3 if half else 5e-5, "grad " + n)
+
+
+@pytest.mark.parametrize("cin,cout,res,up,half,noise_mode,n", [(512, 512, 16, 1, False, "random", 4), (512, 512, 16, 2, False, "const", 4),
+                                                                (512, 512, 32, 2, True, "random", 4), (512, 256, 64, 2, True, "const", 2),
+                                                                (128, 64, 64, 2, True, "random", 2), (64, 64, 64, 1, True, "const", 2),
+                                                                (32, 32, 16, 1, False, "none", 3)])
+def test_synthesis_layer_fused_equals_composed_hip(cin, cout, res, up, half, noise_mode, n, monkeypatch):
+    from ic_gan_amd.stylegan2 import networks as N
+    layer = N.SynthesisLayer(cin, cout, w_dim=512, resolution=res, up=up, conv_clamp=256).cuda()
+    _init(layer, 3)
+    draws = rnd(n, 1, res, res, seed=77).cuda()
+    monkeypatch.setattr(N, "_randn", lambda shape, device: draws.clone())
+    x = rnd(n, cin, res // up, res // up, seed=5).cuda().contiguous(memory_format=torch.channels_last)
+    w = rnd(n, 512, seed=6).cuda()
+    if half:
+        x = x.half()
+    _check(lambda x, w: layer(x, w, noise_mode=noise_mode, fused_modconv=False), layer, [x, w], half)
+
+
+@pytest.mark.parametrize("cin,res,half", [(512, 16, False), (64, 64, True), (256, 32, True)])
+def test_torgb_layer_fused_equals_composed_hip(cin, res, half):
+    from ic_gan_amd.stylegan2 import networks as N
+    layer = N.ToRGBLayer(cin, 3, w_dim=512, conv_clamp=256).cuda()
+    _init(layer, 4)
+    x = rnd(2, cin, res, res, seed=5).cuda().contiguous(memory_format=torch.channels_last)
+    if half:
+        x = x.half()
+    w, img = rnd(2, 512, seed=6).cuda(), rnd(2, 3, res, res, seed=8).cuda()
+    _check(lambda x, w, img: layer(x, w, fused_modconv=False, img=img), layer, [x, w, img], half)
+
+
+@pytest.mark.parametrize("cin,cout,k,down,act,bias,gain,half,res", [(64, 64, 3, 1, "lrelu", True, 1.0, True, 64), (64, 128, 3, 2, "lrelu", True, 0.7071, True, 64),
+                                                                    (64, 128, 1, 2, "linear", False, 0.7071, True, 64), (512, 512, 3, 2, "lrelu", True, 0.7071, False, 16),
+                                                                    (512, 512, 3, 1, "lrelu", True, 1.0, False, 8), (3, 64, 1, 1, "lrelu", True, 1.0, True, 64)])
+def test_conv2d_layer_fused_equals_composed_hip(cin, cout, k, down, act, bias, gain, half, res):
+    from ic_gan_amd.stylegan2 import networks as N
+    layer = N.Conv2dLayer(cin, cout, kernel_size=k, bias=bias, activation=act, down=down, conv_clamp=256 if bias else None).cuda()
+    _init(layer, 5)
+    x = rnd(2, cin, res, res, seed=5).cuda().contiguous(memory_format=torch.channels_last)
+    if half:
+        x = x.half()
+    _check(lambda x: layer(x, gain=gain), layer, [x], half)
+
+
+def test_fully_connected_fused_equals_composed_hip():
+    from ic_gan_amd.stylegan2 import networks as N
+    for act, fin, fout in (("lrelu", 512, 512), ("linear", 2048, 512), ("linear", 512, 1)):
+        layer = N.FullyConnectedLayer(fin, fout, activation=act, lr_multiplier=0.01 if act == "lrelu" else 1).cuda()
+        _init(layer, 6)
+        _check(lambda x: layer(x), layer, [rnd(16, fin, seed=5).cuda()], False)
