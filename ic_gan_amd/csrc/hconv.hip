@@ -35,6 +35,17 @@ struct HconvP {
   // zs = 1: four phases; phase ph = 2 al + be owns the output pixels (2 my + al, 2 mx + be), my < (Ho - al + 1) / 2, and the
   // workgroup tiles [ph_tile0[ph], ph_tile0[ph + 1]) of the launch (pixel-tile major, column-tile minor inside a phase)
   unsigned ph_tile0[5];
+  // EP = 1 (zs = 0 only): the layer's epilogue on the accumulators -- y = clamp(gain * act(c * d[b][n] + noise[b][p] * strength + bias[n]))
+  // with the fp16 rounding points of the reference's op graph (conv output, fma, bias_act: networks.py:86-94, 432-442) -- stored to Y;
+  // the convolution output itself still goes to C when C != null (the demodulation gradient needs it)
+  const float* ep_d;
+  const float* ep_noise;
+  const float* ep_strength;
+  const float* ep_bias;
+  _Float16* Y;
+  long ep_nbs;
+  int ep_act;
+  float ep_alpha, ep_gain, ep_clamp;
 };
 
 __device__ __attribute__((aligned(64))) _Float16 g_hc_zero_page[32];      // zero-initialised: DMA source of the padding taps
@@ -68,7 +79,7 @@ __device__ __forceinline__ void hc_dma16_ptr(const void* lane_src, unsigned lds_
 }
 
 // NT: 16-column MFMA tiles per wave (workgroup tile 128 x 32 NT; 8 waves as 4 x 2, wave tile 32 x 16 NT)
-template <int NT>
+template <int NT, int EP = 0>
 __global__ __launch_bounds__(512, 4) void icg_hconv_kernel(HconvP p) {
   constexpr int BM = 128, BN = 32 * NT, BKC = 32;                   // BKC: channels (halfs) per K-tile = 64 bytes per row
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, SLOT = A_BYTES + B_BYTES, NBUF = 3;
@@ -184,13 +195,38 @@ __global__ __launch_bounds__(512, 4) void icg_hconv_kernel(HconvP p) {
       const int mx = mm % Wph, tq = mm / Wph, my = tq % Hph, b = tq / Hph;
       orow = ((size_t)b * (unsigned)p.Ho + (unsigned)(2 * my + al)) * (unsigned)p.Wo + (unsigned)(2 * mx + be);
     }
+    int eb = 0;
+    float nz = 0.f;
+    if (EP) {                                                        // sample and pixel of this row; its noise term, rounded as the fp16 tensor is
+      const int hw = p.Ho * p.Wo, mm = m < Mph ? m : 0;
+      eb = mm / hw;
+      if (p.ep_noise) nz = (float)(_Float16)(p.ep_noise[(long)eb * p.ep_nbs + (mm - eb * hw)] * *p.ep_strength);
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + 16 * NT * wn + 16 * j + 4 * kk;
       if (m < Mph && n < p.N) {
         const hc_f32x4 v = acc[i][j];
         hc_h4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        *reinterpret_cast<hc_h4*>(p.C + orow * (unsigned)p.N + n) = o;
+        if (!EP || p.C) *reinterpret_cast<hc_h4*>(p.C + orow * (unsigned)p.N + n) = o;
+        if (EP) {
+          hc_f32x4 dv = {1.f, 1.f, 1.f, 1.f}, bv = {0.f, 0.f, 0.f, 0.f};
+          if (p.ep_d) dv = *reinterpret_cast<const hc_f32x4*>(p.ep_d + (size_t)eb * (unsigned)p.N + n);
+          if (p.ep_bias) bv = *reinterpret_cast<const hc_f32x4*>(p.ep_bias + n);
+          hc_h4 y;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float z = (float)o[k];
+            if (p.ep_d) z = (float)(_Float16)__builtin_fmaf(z, (float)(_Float16)dv[k], nz);
+            else if (p.ep_noise) z = (float)(_Float16)(z + nz);
+            z += (float)(_Float16)bv[k];
+            z = (p.ep_act == 3 && z < 0.f) ? z * p.ep_alpha : z;
+            z *= p.ep_gain;
+            if (p.ep_clamp >= 0.f) z = fminf(fmaxf(z, -p.ep_clamp), p.ep_clamp);
+            y[k] = (_Float16)z;
+          }
+          *reinterpret_cast<hc_h4*>(p.Y + orow * (unsigned)p.N + n) = y;
+        }
       }
     }
   }
@@ -204,21 +240,23 @@ extern "C" int icg_conv2d_g_fprop_f16_applies(int Cin, int Cout, int R, int stri
   return 1;
 }
 
-extern "C" int icg_conv2d_g_fprop_f16(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Hout, int Wout,
-                                      int Cout, int R, int stride, int pad, int zins, void* stream) {
-  ICG_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0 && Hout > 0 && Wout > 0 && pad >= 0);
+static int hconv_launch(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Hout, int Wout, int Cout, int R, int stride,
+                        int pad, int zins, const HconvP* ep, void* stream) {
+  ICG_REQUIRE(x && w && B > 0 && H > 0 && W > 0 && Hout > 0 && Wout > 0 && pad >= 0 && (y || ep));
   ICG_REQUIRE(icg_conv2d_g_fprop_f16_applies(Cin, Cout, R, stride, zins));
   ICG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 8) == 0);
   const long M = (long)B * Hout * Wout;
   ICG_REQUIRE(M < 0x7fffffffL && (long)B * H * W < 0x7fffffffL && (long)Cout * R * R * Cin < 0x3fffffffL);
   const int nt = (Cout % 128 == 0) ? 4 : ((Cout % 96 == 0) ? 3 : 2);
   HconvP p{};
+  if (ep) p = *ep;
   p.A = (const _Float16*)x; p.Bw = (const _Float16*)w; p.C = (_Float16*)y;
   p.M = (int)M; p.N = Cout; p.K = R * R * Cin;
   p.Ho = Hout; p.Wo = Wout; p.Hs = H; p.Ws = W; p.Cin = Cin; p.R = R; p.stride = stride; p.pad = pad; p.zs = (zins == 2) ? 1 : 0;
   p.tiles_n = Cout / (32 * nt);
   long total = icg_cdiv(M, 128) * p.tiles_n;
   if (p.zs) {                                                       // four phases, each with its own pixel grid
+    ICG_REQUIRE(!ep);
     total = 0;
     for (int ph = 0; ph < 4; ++ph) {
       const long hp = (Hout - (ph >> 1) + 1) / 2, wp = (Wout - (ph & 1) + 1) / 2;
@@ -233,8 +271,32 @@ extern "C" int icg_conv2d_g_fprop_f16(const void* x, const void* w, void* y, int
   p.swz = (total >= 16 && !no_swz) ? 1 : 0;
   const dim3 grid((unsigned)total), block(512);
   hipStream_t st = (hipStream_t)stream;
-  if (nt == 4) hipLaunchKernelGGL((icg_hconv_kernel<4>), grid, block, 0, st, p);
-  else if (nt == 3) hipLaunchKernelGGL((icg_hconv_kernel<3>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((icg_hconv_kernel<2>), grid, block, 0, st, p);
+  if (ep) {
+    if (nt == 4) hipLaunchKernelGGL((icg_hconv_kernel<4, 1>), grid, block, 0, st, p);
+    else if (nt == 3) hipLaunchKernelGGL((icg_hconv_kernel<3, 1>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((icg_hconv_kernel<2, 1>), grid, block, 0, st, p);
+  } else {
+    if (nt == 4) hipLaunchKernelGGL((icg_hconv_kernel<4, 0>), grid, block, 0, st, p);
+    else if (nt == 3) hipLaunchKernelGGL((icg_hconv_kernel<3, 0>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((icg_hconv_kernel<2, 0>), grid, block, 0, st, p);
+  }
   return icg_check_launch();
+}
+
+extern "C" int icg_conv2d_g_fprop_f16(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Hout, int Wout,
+                                      int Cout, int R, int stride, int pad, int zins, void* stream) {
+  ICG_REQUIRE(y);
+  return hconv_launch(x, w, y, B, H, W, Cin, Hout, Wout, Cout, R, stride, pad, zins, nullptr, stream);
+}
+
+// the same convolution (zero_insert = 0) with the StyleGAN2 layer epilogue on the accumulators (see HconvP): c (may be null) and y
+extern "C" int icg_conv2d_g_fprop_f16_act(const void* x, const void* w, void* c, void* y, const float* d, const float* noise, int64_t noise_bstride,
+                                          const float* strength, const float* bias, int act, float alpha, float gain, float clamp, int B, int H,
+                                          int W, int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, void* stream) {
+  ICG_REQUIRE(y && (act == 1 || act == 3) && (!noise || strength) && ((uintptr_t)y % 8) == 0);
+  ICG_REQUIRE(((uintptr_t)d % 16) == 0 && ((uintptr_t)bias % 16) == 0);
+  HconvP ep{};
+  ep.ep_d = d; ep.ep_noise = noise; ep.ep_strength = strength; ep.ep_bias = bias; ep.Y = (_Float16*)y; ep.ep_nbs = (long)noise_bstride;
+  ep.ep_act = act; ep.ep_alpha = alpha; ep.ep_gain = gain; ep.ep_clamp = clamp;
+  return hconv_launch(x, w, c, B, H, W, Cin, Hout, Wout, Cout, R, stride, pad, 0, &ep, stream);
 }

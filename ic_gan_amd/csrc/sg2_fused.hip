@@ -204,13 +204,18 @@ __global__ __launch_bounds__(256) void sg2_style_prep_kernel(const float* __rest
   __syncthreads();
   if (!wsq) return;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int k = 0; k < 16; ++k) {
-    const int o = blockIdx.y * 64 + wv * 16 + k;
+  for (int k = 0; k < 4; ++k) {
+    const int o = blockIdx.y * 16 + wv * 4 + k;
     if (o >= O) break;
     const float* row = wsq + (size_t)o * I;
-    float q = 0.f;
-    for (int i = lane; i < I; i += 64) { const float sv = sh_s[i]; q += sv * sv * row[i]; }
-    q = wave_sum(q);
+    float q0 = 0.f, q1 = 0.f;
+    int i = lane;
+    for (; i + 64 < I; i += 128) {
+      const float s0 = sh_s[i], s1 = sh_s[i + 64];
+      q0 += s0 * s0 * row[i]; q1 += s1 * s1 * row[i + 64];
+    }
+    if (i < I) { const float s0 = sh_s[i]; q0 += s0 * s0 * row[i]; }
+    const float q = wave_sum(q0 + q1);
     if (lane == 0) d_out[(size_t)n * O + o] = rsqrtf(q + 1e-8f);
   }
 }
@@ -346,28 +351,36 @@ __global__ __launch_bounds__(256) void sg2_rows_kernel(const T* __restrict__ a /
   }
 }
 
-// part [N * chunks][ctot]  ->  per [N][ctot] (sum over the chunks of a sample) and tot [ctot] (sum over everything); fixed order
-__global__ __launch_bounds__(256) void sg2_rows_final_kernel(const float* __restrict__ part, int N, int chunks, int ctot, float* __restrict__ per,
-                                                             float* __restrict__ tot) {
-  __shared__ float red[256];
+// part [N * chunks][ctot]  ->  per [N][ctot] (sum over the chunks of a sample) and tot [ctot] (sum over everything); fixed order.
+// Block: 64 columns x 16 sample groups (one (sample, column) chain of <= 64 loads per thread at N = 16)
+__global__ __launch_bounds__(1024) void sg2_rows_final_kernel(const float* __restrict__ part, int N, int chunks, int ctot, float* __restrict__ per,
+                                                              float* __restrict__ tot) {
+  __shared__ float red[1024];
   const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int ch = blockIdx.x * 64 + cl;
   float t = 0.f;
   if (ch < ctot) {
-    for (int n = grp; n < N; n += 4) {
+    for (int n = grp; n < N; n += 16) {
       const float* p = part + (size_t)n * chunks * ctot + ch;
-      float s0 = 0.f, s1 = 0.f;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       int k = 0;
-      for (; k + 1 < chunks; k += 2) { s0 += p[(size_t)k * ctot]; s1 += p[(size_t)(k + 1) * ctot]; }
-      if (k < chunks) s0 += p[(size_t)k * ctot];
-      const float s = s0 + s1;
+      for (; k + 3 < chunks; k += 4) {
+        s0 += p[(size_t)k * ctot]; s1 += p[(size_t)(k + 1) * ctot]; s2 += p[(size_t)(k + 2) * ctot]; s3 += p[(size_t)(k + 3) * ctot];
+      }
+      for (; k < chunks; ++k) s0 += p[(size_t)k * ctot];
+      const float s = (s0 + s1) + (s2 + s3);
       if (per) per[(size_t)n * ctot + ch] = s;
       t += s;
     }
   }
   red[threadIdx.x] = t;
   __syncthreads();
-  if (grp == 0 && ch < ctot && tot) tot[ch] = red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl];
+  if (grp == 0 && ch < ctot && tot) {
+    float a = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) a += red[g * 64 + cl];
+    tot[ch] = a;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -469,13 +482,13 @@ __global__ __launch_bounds__(256) void sg2_fc_bwd_dw_kernel(const float* __restr
       if (i0 + j < I) dW[(size_t)(i0 + j) * K + k] = acc[j] * wgain;
   }
 }
-// block: 64 columns k of dx, rows n0 .. n0 + 15 (blockIdx.y); 4 groups split the i range
+// block: 32 columns k of dx, rows n0 .. n0 + 15 (blockIdx.y); 8 groups split the i range
 __global__ __launch_bounds__(256) void sg2_fc_bwd_dx_kernel(const float* __restrict__ g, SgNorm nm, const float* __restrict__ W, int N, int I, int K,
                                                             float wgain, float* __restrict__ dx) {
-  __shared__ float dl[16][256];
-  __shared__ float red[4][16][64];
-  const int kl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + kl, n0 = blockIdx.y * 16;
+  __shared__ float dl[16][257];
+  __shared__ float red[8][16][32];
+  const int kl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + kl, n0 = blockIdx.y * 16;
   float acc[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -488,7 +501,13 @@ __global__ __launch_bounds__(256) void sg2_fc_bwd_dx_kernel(const float* __restr
     __syncthreads();
     if (k < K) {
       const int iend = min(256, I - i0);
-      for (int il = grp; il < iend; il += 4) {
+      int il = grp;
+      for (; il + 8 < iend; il += 16) {
+        const float w0 = W[(size_t)(i0 + il) * K + k], w1 = W[(size_t)(i0 + il + 8) * K + k];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] += dl[q][il] * w0 + dl[q][il + 8] * w1;
+      }
+      for (; il < iend; il += 8) {
         const float wv = W[(size_t)(i0 + il) * K + k];
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] += dl[q][il] * wv;
@@ -499,8 +518,13 @@ __global__ __launch_bounds__(256) void sg2_fc_bwd_dx_kernel(const float* __restr
   for (int q = 0; q < 16; ++q) red[grp][q][kl] = acc[q];
   __syncthreads();
   if (k < K) {
-    for (int q = grp; q < 16; q += 4)
-      if (n0 + q < N) dx[(size_t)(n0 + q) * K + k] = (red[0][q][kl] + red[1][q][kl] + red[2][q][kl] + red[3][q][kl]) * wgain;
+    for (int q = grp; q < 16; q += 8)
+      if (n0 + q < N) {
+        float a = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < 8; ++gq) a += red[gq][q][kl];
+        dx[(size_t)(n0 + q) * K + k] = a * wgain;
+      }
   }
 }
 
@@ -723,6 +747,88 @@ __global__ __launch_bounds__(256) void sg2_torgb_bwd_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// FIR pass (up = down = 1: the blur after a transposed convolution, conv2d_resample.py:163-186) with the layer epilogue on the filtered
+// values: c = fir(x) (stored for the demodulation gradient), y = clamp(gain * act(c * d + noise + bias)).  A thread owns one 16-byte
+// channel vector of a vertical strip of TY outputs, as the stand-alone upfirdn2d kernel does (csrc/stylegan_ops_typed.hip).
+// ------------------------------------------------------------------------------------------------------------------------------
+template <typename T, int TY>
+__global__ __launch_bounds__(256) void sg2_fir_act_kernel(const T* __restrict__ x, const float* __restrict__ f, T* __restrict__ cout_,
+                                                          T* __restrict__ y, const float* __restrict__ d, const float* __restrict__ noise,
+                                                          long noise_bstride, const float* __restrict__ strength, const float* __restrict__ bias,
+                                                          int N, int H, int W, int CV, int fh, int fw, int padx0, int pady0, float fgain,
+                                                          int outH, int outW, int act, float alpha, float gain, float clamp) {
+  constexpr int VEC = Sg<T>::VEC;
+  __shared__ float fs[64];
+  for (int i = threadIdx.x; i < fh * fw; i += blockDim.x) {
+    const int ty = i / fw, tx = i - ty * fw;
+    fs[i] = f[(fh - 1 - ty) * fw + (fw - 1 - tx)] * fgain;            // flip_filter = False: correlation with the flipped filter
+  }
+  __syncthreads();
+  const float st = (noise && strength) ? *strength : 1.f;
+  const int strips = (outH + TY - 1) / TY;
+  const long total = (long)N * strips * outW * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long t = i / CV;
+    const int ox = (int)(t % outW);
+    t /= outW;
+    const int ys = (int)(t % strips), n = (int)(t / strips);
+    const int oy0 = ys * TY;
+    const int bx = ox - padx0, by0 = oy0 - pady0;
+    const int ix0 = max(bx, 0), ix1 = min(bx + fw, W);
+    const int iy0 = max(by0, 0), iy1 = min(min(oy0 + TY, outH) - 1 - pady0 + fh, H);
+    float acc[TY][VEC];
+#pragma unroll
+    for (int j = 0; j < TY; ++j)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[j][e] = 0.f;
+    const T* xp = x + ((long)n * H * W * CV + cv) * VEC;
+    for (int iy = iy0; iy < iy1; ++iy) {
+      const int zy = iy - by0;
+      for (int ix = ix0; ix < ix1; ++ix) {
+        const int tx = ix - bx;
+        float v[VEC];
+        Sg<T>::ld(xp + ((long)iy * W + ix) * CV * VEC, v);
+#pragma unroll
+        for (int j = 0; j < TY; ++j) {
+          const int ty = zy - j;
+          if (ty >= 0 && ty < fh) {
+            const float w = fs[ty * fw + tx];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[j][e] += v[e] * w;
+          }
+        }
+      }
+    }
+    float dv[VEC], bv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      dv[e] = d ? Sg<T>::rnd(d[((long)n * CV + cv) * VEC + e]) : 1.f;
+      bv[e] = bias ? Sg<T>::rnd(bias[cv * VEC + e]) : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TY; ++j) {
+      if (oy0 + j >= outH) break;
+      const long o = ((((long)n * outH + oy0 + j) * outW + ox) * CV + cv) * VEC;
+      const float nz = noise ? Sg<T>::rnd(noise[n * noise_bstride + (long)(oy0 + j) * outW + ox] * st) : 0.f;
+      float cv_[VEC], yv[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        cv_[e] = Sg<T>::rnd(acc[j][e]);
+        float z = cv_[e];
+        if (d) z = Sg<T>::rnd(__fmaf_rn(z, dv[e], nz));
+        else if (noise) z = Sg<T>::rnd(z + nz);
+        float o2 = sg2_act(act, z + bv[e], alpha) * gain;
+        if (clamp >= 0.f) o2 = fminf(fmaxf(o2, -clamp), clamp);
+        yv[e] = o2;
+      }
+      if (cout_) Sg<T>::st(cout_ + o, cv_);
+      Sg<T>::st(y + o, yv);
+    }
+  }
+}
+
 int rows_geometry(long HW, int V, int* rpb, int* chunks) {
   const int nrl = 256 / V;
   long r = icg_cdiv(HW, 64);
@@ -772,7 +878,7 @@ extern "C" int icg_sg2_weight_prep_multi(const icg_sg2_weight* layers, int n, vo
 extern "C" int icg_sg2_style_prep(const float* lin, const float* bias, float bias_gain, float post_gain, const float* wsq, int N, int I, int O,
                                   int prenorm, float* s, float* smax, int* sarg, float* d, void* stream) {
   ICG_REQUIRE(lin && s && N > 0 && I > 0 && I <= 8192 && (!wsq || (d && O > 0)) && (!prenorm || (smax && sarg)));
-  const dim3 grid(N, wsq ? (unsigned)icg_cdiv(O, 64) : 1);
+  const dim3 grid(N, wsq ? (unsigned)icg_cdiv(O, 16) : 1);
   hipLaunchKernelGGL(sg2_style_prep_kernel, grid, dim3(256), (size_t)I * sizeof(float), (hipStream_t)stream, lin, bias, bias_gain, post_gain, wsq, I,
                      O, prenorm, s, smax, sarg, d);
   return icg_check_launch();
@@ -810,6 +916,26 @@ extern "C" int icg_sg2_act_fwd(const void* c, const float* d, const float* noise
   return icg_check_launch();
 }
 
+extern "C" int icg_sg2_fir_act_fwd(const void* x, const float* f, void* c, void* y, const float* d, const float* noise, int64_t noise_bstride,
+                                   const float* strength, const float* bias, int N, int C, int H, int W, int fh, int fw, int padx0, int padx1,
+                                   int pady0, int pady1, float fgain, int outH, int outW, int act, float alpha, float gain, float clamp, int dtype,
+                                   void* stream) {
+  ICG_REQUIRE(x && f && y && N > 0 && H > 0 && W > 0 && fh >= 1 && fw >= 1 && fh * fw <= 64 && (act == 1 || act == 3));
+  ICG_REQUIRE(icg_sg2_rows_applies(C, dtype) && al16(x) && al16(y) && al16(c));
+  ICG_REQUIRE(outW == W + padx0 + padx1 - fw + 1 && outH == H + pady0 + pady1 - fh + 1 && outW >= 1 && outH >= 1);
+  constexpr int TY = 4;
+  const int CV = C / (dtype == 1 ? 8 : 4);
+  const long total = (long)N * ((outH + TY - 1) / TY) * outW * CV;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 1)
+    hipLaunchKernelGGL((sg2_fir_act_kernel<__half, TY>), dim3(ew_grid(total)), dim3(256), 0, st, (const __half*)x, f, (__half*)c, (__half*)y, d, noise,
+                       (long)noise_bstride, strength, bias, N, H, W, CV, fh, fw, padx0, pady0, fgain, outH, outW, act, alpha, gain, clamp);
+  else
+    hipLaunchKernelGGL((sg2_fir_act_kernel<float, TY>), dim3(ew_grid(total)), dim3(256), 0, st, (const float*)x, f, (float*)c, (float*)y, d, noise,
+                       (long)noise_bstride, strength, bias, N, H, W, CV, fh, fw, padx0, pady0, fgain, outH, outW, act, alpha, gain, clamp);
+  return icg_check_launch();
+}
+
 extern "C" size_t icg_sg2_rows_workspace_bytes(int N, int64_t HW, int C, int ncols, int dtype) {
   if (!icg_sg2_rows_applies(C, dtype) || N <= 0 || HW <= 0) return 0;
   int rpb, chunks;
@@ -837,7 +963,7 @@ extern "C" int icg_sg2_act_bwd(const void* dy, const void* y, const void* c, con
   else
     hipLaunchKernelGGL((sg2_rows_kernel<float, 0>), dim3(N * chunks), dim3(256), 0, st, (const float*)dy, (const float*)y, (const float*)c, d, noise,
                        (long)noise_bstride, (float*)dc, part, ctot, (long)HW, V, rpb, chunks, act, alpha, gain, clamp);
-  hipLaunchKernelGGL(sg2_rows_final_kernel, dim3((unsigned)icg_cdiv(ctot, 64)), dim3(256), 0, st, part, N, chunks, ctot, sums, tot);
+  hipLaunchKernelGGL(sg2_rows_final_kernel, dim3((unsigned)icg_cdiv(ctot, 64)), dim3(1024), 0, st, part, N, chunks, ctot, sums, tot);
   return icg_check_launch();
 }
 
@@ -856,7 +982,7 @@ extern "C" int icg_sg2_modulate_bwd(const void* dxs, const void* x, const float*
   else
     hipLaunchKernelGGL((sg2_rows_kernel<float, 1>), dim3(N * chunks), dim3(256), 0, st, (const float*)dxs, (const float*)x, (const float*)nullptr, s,
                        (const float*)nullptr, 0L, (float*)dx, part, C, (long)HW, V, rpb, chunks, 1, 0.f, 1.f, -1.f);
-  hipLaunchKernelGGL(sg2_rows_final_kernel, dim3((unsigned)icg_cdiv(C, 64)), dim3(256), 0, st, part, N, chunks, C, ds, (float*)nullptr);
+  hipLaunchKernelGGL(sg2_rows_final_kernel, dim3((unsigned)icg_cdiv(C, 64)), dim3(1024), 0, st, part, N, chunks, C, ds, (float*)nullptr);
   return icg_check_launch();
 }
 
@@ -878,7 +1004,7 @@ extern "C" int icg_sg2_fc_bwd(const float* g, const float* smax, const int* sarg
   if (dW || db)
     hipLaunchKernelGGL(sg2_fc_bwd_dw_kernel, dim3((unsigned)icg_cdiv(I, 8)), dim3(256), 0, st, g, nm, x, N, I, K, wgain, bias_gain, dW, db);
   if (dx)
-    hipLaunchKernelGGL(sg2_fc_bwd_dx_kernel, dim3((unsigned)icg_cdiv(K, 64), (unsigned)icg_cdiv(N, 16)), dim3(256), 0, st, g, nm, W, N, I, K, wgain, dx);
+    hipLaunchKernelGGL(sg2_fc_bwd_dx_kernel, dim3((unsigned)icg_cdiv(K, 32), (unsigned)icg_cdiv(N, 16)), dim3(256), 0, st, g, nm, W, N, I, K, wgain, dx);
   return icg_check_launch();
 }
 
@@ -951,7 +1077,7 @@ static int torgb_bwd_launch(const float* dimg, const void* y, const void* x, con
   else ICG_TORGB_B(4);
 #undef ICG_TORGB_B
   const int ctot = 4 * C + 3;
-  hipLaunchKernelGGL(sg2_rows_final_kernel, dim3((unsigned)icg_cdiv(ctot, 64)), dim3(256), 0, st, part, N, chunks, ctot, sums, tot);
+  hipLaunchKernelGGL(sg2_rows_final_kernel, dim3((unsigned)icg_cdiv(ctot, 64)), dim3(1024), 0, st, part, N, chunks, ctot, sums, tot);
   return icg_check_launch();
 }
 // sums [N][4 C + 3]: ds = sums[:, 0 .. C);  tot [4 C + 3]: dw[o][c] = tot[(1 + o) C + c], db[o] = tot[4 C + o]

@@ -23,6 +23,7 @@ and keep the composed operators (stylegan_ops/modconv.py, conv2d_resample.py, bi
 serve.  Without autograd (`torch.no_grad()`: sampling, the generator pass of Dmain) the fused forward is used as well.
 Same arithmetic as the composed path, including the places where fp16 tensors round (csrc/sg2_fused.hip)."""
 import contextlib
+import os
 import weakref
 from dataclasses import dataclass
 from typing import Optional
@@ -38,7 +39,7 @@ from . import bias_act as _bias_act
 from . import conv2d_gradfix as G
 from . import upfirdn2d as U
 
-ENABLED = True          # False: every layer keeps the composed operators (measurement / parity switch)
+ENABLED = os.environ.get("ICG_SG2_FUSED", "1") != "0"          # False: every layer keeps the composed operators (measurement / parity switch)
 _FIRST_ORDER = 0
 
 
@@ -125,6 +126,27 @@ def plan(H, W, R, up, down, padding, fw, flip_weight):
 def _fir(x, f2, spec):
     up, down, pad, gain = spec
     return U._run(x, f2, (up, up), (down, down), pad, False, gain)
+
+
+def _fir_act(x, f2, spec, d, noise, nbs, strength, bias, act, act_gain, clamp, keep_c):
+    """the FIR pass `spec` (up = down = 1) with the layer epilogue on its results in one launch -> (c or None, y)"""
+    up, down, (px0, px1, py0, py1), gain = spec
+    assert up == 1 and down == 1
+    x = _cl(x)
+    N, C, H, W = (int(v) for v in x.shape)
+    fh, fw = (int(v) for v in f2.shape)
+    oh, ow = H + py0 + py1 - fh + 1, W + px0 + px1 - fw + 1
+    y = torch.empty((N, C, oh, ow), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    c = torch.empty_like(y) if keep_c else None
+    L.call("icg_sg2_fir_act_fwd", x, f2, c, y, d, noise, nbs, strength, bias, N, C, H, W, fh, fw, px0, px1, py0, py1, float(gain), oh, ow, act,
+           0.2, act_gain, clamp, _dt(x))
+    return c, y
+
+
+def _hconv_epilogue(x, I, O, pl):
+    """does the fp16 convolution kernel take this layer with the epilogue on its accumulators (no FIR pass behind it)?"""
+    return (x.dtype == torch.float16 and pl.post is None and pl.geo.zins == 0 and G.FP16_MFMA
+            and bool(L.query("icg_conv2d_g_fprop_f16_applies", I, O, pl.geo.R, pl.geo.stride, 0)))
 
 
 def _fir_adjoint(dy, f2, spec, in_hw):
@@ -255,13 +277,23 @@ class _ModConvFn(Function):
         L.call("icg_sg2_style_prep", lin, ab, cfg.affine_bgain, 1.0, p.wsq, N, I, O, int(half), s, smax, sarg, d)
         xs = torch.empty_like(x)
         L.call("icg_sg2_modulate", x, s, xs, N, H * W, I, dt)
-        c = G.gather_conv(xs, p.w_fwd, pl.geo, p.cache)
-        if pl.post is not None:
-            c = _fir(c, f2, pl.post)
-        Ho, Wo = int(c.shape[2]), int(c.shape[3])
-        y = torch.empty_like(c)
-        L.call("icg_sg2_act_fwd", c, d, noise, cfg.noise_bstride, strength if noise is not None else None, bias, y, N, Ho * Wo, O, 3, 0.2,
-               cfg.act_gain, cfg.clamp, dt)
+        st = strength if noise is not None else None
+        if _hconv_epilogue(x, I, O, pl):
+            # demodulation, noise, bias, lrelu and clamp on the convolution's accumulators (csrc/hconv.hip, EP = 1)
+            Ho, Wo = pl.geo.out
+            c = torch.empty((N, O, Ho, Wo), device=dev, dtype=x.dtype, memory_format=torch.channels_last)
+            y = torch.empty_like(c)
+            L.call("icg_conv2d_g_fprop_f16_act", xs, p.w_fwd, c, y, d, noise, cfg.noise_bstride, st, bias, 3, 0.2, cfg.act_gain, cfg.clamp,
+                   N, H, W, I, Ho, Wo, O, R, pl.geo.stride, pl.geo.pad)
+        else:
+            c = G.gather_conv(xs, p.w_fwd, pl.geo, p.cache)
+            if pl.post is not None:      # up-sampling layer: the same epilogue on the blur's results
+                c, y = _fir_act(c, f2, pl.post, d, noise, cfg.noise_bstride, st, bias, 3, cfg.act_gain, cfg.clamp, True)
+            else:
+                y = torch.empty_like(c)
+                L.call("icg_sg2_act_fwd", c, d, noise, cfg.noise_bstride, st, bias, y, N, int(c.shape[2]) * int(c.shape[3]), O, 3, 0.2,
+                       cfg.act_gain, cfg.clamp, dt)
+            Ho, Wo = int(c.shape[2]), int(c.shape[3])
         ctx.cfg, ctx.p, ctx.dims = cfg, p, (N, I, H, W, O, R, Ho, Wo)
         ctx.save_for_backward(x, xs, c, y, s, d, smax, sarg, wl, aw, weight, noise, f2)
         return y
@@ -425,14 +457,20 @@ class _ConvFn(Function):
         plain = cfg.act == 1 and not cfg.has_bias and cfg.clamp < 0
         p = _prep(owner, weight, x.dtype, False, cfg.weight_gain * (cfg.act_gain if plain else 1.0), pl.flip, False)
         xin = _fir(x, f2, pl.pre) if pl.pre is not None else x
-        c = G.gather_conv(xin, p.w_fwd, pl.geo, p.cache)
-        if pl.post is not None:
-            c = _fir(c, f2, pl.post)
-        y = c
-        if not plain:
-            y = torch.empty_like(c)
-            L.call("icg_sg2_act_fwd", c, None, None, 0, None, bias, y, N, int(c.shape[2]) * int(c.shape[3]), O, cfg.act, 0.2, cfg.act_gain,
-                   cfg.clamp, dt)
+        if not plain and _hconv_epilogue(xin, I, O, pl):
+            Ho, Wo = pl.geo.out
+            y = torch.empty((N, O, Ho, Wo), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+            L.call("icg_conv2d_g_fprop_f16_act", xin, p.w_fwd, None, y, None, None, 0, None, bias, cfg.act, 0.2, cfg.act_gain, cfg.clamp,
+                   N, int(xin.shape[2]), int(xin.shape[3]), I, Ho, Wo, O, R, pl.geo.stride, pl.geo.pad)
+        else:
+            c = G.gather_conv(xin, p.w_fwd, pl.geo, p.cache)
+            if pl.post is not None:
+                c = _fir(c, f2, pl.post)
+            y = c
+            if not plain:
+                y = torch.empty_like(c)
+                L.call("icg_sg2_act_fwd", c, None, None, 0, None, bias, y, N, int(c.shape[2]) * int(c.shape[3]), O, cfg.act, 0.2, cfg.act_gain,
+                       cfg.clamp, dt)
         ctx.cfg, ctx.p, ctx.plain, ctx.in_hw = cfg, p, plain, (int(x.shape[2]), int(x.shape[3]))
         ctx.save_for_backward(xin, None if plain else y, weight, f2)
         return y

@@ -176,6 +176,15 @@ int icg_conv2d_g_wgrad_f16(const void* x, const void* dy, float* dw, int B, int 
 int icg_conv2d_g_fprop_f16_applies(int Cin, int Cout, int R, int stride, int zero_insert);
 int icg_conv2d_g_fprop_f16(const void* x, const void* w, void* out, int B, int Hin, int Win, int Cin, int Hout, int Wout,
                            int Cout, int R, int stride, int pad, int zero_insert, void* stream);
+/* The same convolution (zero_insert = 0) with the StyleGAN2 layer epilogue applied to the accumulators before they leave the registers:
+ *   c = fp16(acc)                                             stored when c != NULL (the demodulation gradient reads it)
+ *   y = clamp(gain * act(c * d[b][n] + noise[b * noise_bstride + p] * strength[0] + bias[n]))     act 1 linear / 3 lrelu(alpha)
+ * with the fp16 rounding points of the reference's separate operations (networks.py:86-94 fma, 432-442 bias_act) -- the results of
+ * icg_conv2d_g_fprop_f16 followed by icg_sg2_act_fwd, in one pass.  d [B][Cout], bias [Cout] fp32 (16-byte aligned), noise fp32; each
+ * may be NULL. */
+int icg_conv2d_g_fprop_f16_act(const void* x, const void* w, void* c, void* y, const float* d, const float* noise, int64_t noise_bstride,
+                               const float* strength, const float* bias, int act, float alpha, float gain, float clamp, int B, int Hin,
+                               int Win, int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, void* stream);
 /*   dw[r][s][ci][co] = sum_{b,oy,ox} x[b, oy*stride + r - pad, ox*stride + s - pad, ci] * dy[b,oy,ox,co]
  * (weight gradient of either direction: for the transposed convolution swap the roles of x and dy). */
 size_t icg_conv2d_g_wgrad_workspace_bytes(int B, int Hout, int Wout, int Cin, int Cout, int R);
@@ -629,6 +638,13 @@ int icg_sg2_modulate(const void* x, const float* s, void* xs, int N, int64_t HW,
  * (networks.py:86-94 fma / add, 432-442 bias_act).  d, noise, bias may be NULL; clamp < 0: none. */
 int icg_sg2_act_fwd(const void* c, const float* d, const float* noise, int64_t noise_bstride, const float* strength, const float* bias,
                     void* y, int N, int64_t HW, int O, int act, float alpha, float gain, float clamp, int dtype, void* stream);
+/* FIR pass with up = down = 1 (upfirdn2d's blur after the transposed convolution of an up-sampling layer, conv2d_resample.py:163-186;
+ * filter f [fh][fw] fp32 applied as upfirdn2d(flip_filter=False) does, times fgain) fused with icg_sg2_act_fwd on its result:
+ * c = fir(x) (may be NULL), y = clamp(gain * act(c * d + noise * strength + bias)); x [N][H][W][C], c / y [N][outH][outW][C]. */
+int icg_sg2_fir_act_fwd(const void* x, const float* f, void* c, void* y, const float* d, const float* noise, int64_t noise_bstride,
+                        const float* strength, const float* bias, int N, int C, int H, int W, int fh, int fw, int padx0, int padx1,
+                        int pady0, int pady1, float fgain, int outH, int outW, int act, float alpha, float gain, float clamp, int dtype,
+                        void* stream);
 size_t icg_sg2_rows_workspace_bytes(int N, int64_t HW, int C, int ncols, int dtype);
 /* gradient of icg_sg2_act_fwd: dz = dy * gain * act'(y) [|y| < clamp] (bias_act.cu's grad = 1 pass);  dc = dz * d (may be NULL);
  * sums [N][2 O + 1] per sample and tot [2 O + 1] over the batch of (dz | dz * c | dz * noise):  d bias = tot[0 .. O),

@@ -1171,6 +1171,29 @@ def icg_sg2_act_fwd(c, d, noise, noise_bstride, strength, bias, y, N, HW, O, act
     mem(y)[: N * HW * O].copy_(o.reshape(-1).to(y.dtype))
 
 
+def icg_sg2_fir_act_fwd(x, f, c, y, d, noise, noise_bstride, strength, bias, N, C, H, W, fh, fw, padx0, padx1, pady0, pady1, fgain, outH,
+                        outW, act, alpha, gain, clamp, dtype):
+    """icg_upfirdn2d_typed (up = down = 1, channels-last) followed by icg_sg2_act_fwd"""
+    tmp = torch.empty(N * outH * outW * C, dtype=x.dtype)
+    if dtype == 1:
+        icg_upfirdn2d_typed(x, f, tmp, N, C, H, W, fh, fw, 1, 1, 1, 1, padx0, padx1, pady0, pady1, 0, fgain, outH, outW, 1, 1)
+    else:
+        icg_upfirdn2d_nhwc(x, f, tmp, N, C, H, W, fh, fw, 1, 1, 1, 1, padx0, padx1, pady0, pady1, 0, fgain, outH, outW)
+    if c is not None:
+        mem(c)[: tmp.numel()].copy_(tmp)
+    icg_sg2_act_fwd(tmp, d, noise, noise_bstride, strength, bias, y, N, outH * outW, C, act, alpha, gain, clamp, dtype)
+
+
+def icg_conv2d_g_fprop_f16_act(x, w, c, y, d, noise, noise_bstride, strength, bias, act, alpha, gain, clamp, B, Hin, Win, Cin, Hout, Wout, Cout,
+                               R, stride, pad):
+    """icg_conv2d_g_fprop_f16 followed by icg_sg2_act_fwd"""
+    tmp = torch.empty(B * Hout * Wout * Cout, dtype=torch.float16)
+    icg_conv2d_g_fprop_f16(x, w, tmp, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, 0)
+    if c is not None:
+        mem(c)[: tmp.numel()].copy_(tmp)
+    icg_sg2_act_fwd(tmp, d, noise, noise_bstride, strength, bias, y, B, Hout * Wout, Cout, act, alpha, gain, clamp, 1)
+
+
 def _rows_geometry(HW, V):
     nrl = 256 // V
     r = max(-(-HW // 64), nrl)

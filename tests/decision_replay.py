@@ -12,6 +12,13 @@ rounding-noise distribution of its tensor (what the dense four-part rule of test
                               the kernel that reads it is launched (the backward kernels recompute their masks from the same saved
                               tensor), so that sign(x*scale+shift) and the window winners equal the fp64 pattern.
 
+Fixture format (v2, tests/golden/decisions_<case>.npz): a decision can only differ between an fp32 and the fp64 forward where the
+ReLU input lies within rounding distance of zero, so per ReLU input only the elements with |a| < BAND x rms(a) are stored (flat
+NCHW index + sign, ~2e-4 of the elements) together with two digests of the FULL fp64 sign pattern (number of positive elements and
+the sum of their flat indices): the replay imposes the stored signs and then proves with the digests that every other element agrees
+too.  (v1 stored every sign bit: 4 MB per toy case, ~300 MB at the headline configuration.)  Max-pool winners (attention only, small)
+are stored in full.
+
 The nudge moves an element by <= 4e-6 of its own magnitude (it was within rounding distance of the decision boundary to begin
 with), so the two runs differ by the flipped paths and nothing else.  tests/test_decision_replay_gpu.py holds the HIP gradients of
 the replayed step to the fp64 reference two orders of magnitude tighter than GRAD_RTOL; tools/mask_attribution.py prints the
@@ -31,6 +38,19 @@ MASK_DIR = os.path.join(ROOT, "tools", "_masks")      # scratch (git-ignored); c
 def decisions_path(case):
     p = os.path.join(GOLDEN_DIR, "decisions_%s.npz" % case)
     return p if os.path.exists(p) else os.path.join(MASK_DIR, case + ".npz")
+
+
+BAND = 2e-4          # |a| < BAND * rms(a): the elements whose sign an fp32 forward may take differently (measured deviations: ~1e-5)
+
+
+def _sparse_decisions(a):
+    """(shape, flat indices of the near-zero elements, their signs, #positive, sum of the flat indices of the positive elements)"""
+    flat = a.reshape(-1)
+    pos = flat > 0
+    rms = float(flat.double().square().mean().sqrt())
+    idx = torch.nonzero(flat.abs() < BAND * rms).reshape(-1)
+    allpos = torch.nonzero(pos).reshape(-1)
+    return (tuple(a.shape), idx.numpy().astype(np.int64), pos[idx].numpy(), int(allpos.numel()), int(allpos.sum()))
 
 
 def make_masks(case, out_path=None):
@@ -59,7 +79,7 @@ def make_masks(case, out_path=None):
         @staticmethod
         def relu(x, *a, **k):
             if x.dim() == 4:
-                masks.append((x.detach() > 0).numpy())
+                masks.append(_sparse_decisions(x.detach()))
             return torch.nn.functional.relu(x, *a, **k)
 
         @staticmethod
@@ -97,12 +117,14 @@ def make_masks(case, out_path=None):
     assert worst == 0.0, "the oracle's fp64 step is not the reference's fp64 step"
     out_path = out_path or os.path.join(MASK_DIR, case + ".npz")
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
-    np.savez_compressed(out_path, n=len(masks), npool=len(pools),
-                        shapes=json.dumps([m.shape for m in masks]),
-                        **{"m%d" % i: np.packbits(m.reshape(-1)) for i, m in enumerate(masks)},
+    np.savez_compressed(out_path, version=2, band=BAND, n=len(masks), npool=len(pools),
+                        shapes=json.dumps([m[0] for m in masks]),
+                        digests=np.array([[m[3], m[4]] for m in masks], dtype=np.int64),
+                        **{"i%d" % i: (m[1].astype(np.uint32) if int(np.prod(m[0])) < 2 ** 32 else m[1]) for i, m in enumerate(masks)},
+                        **{"s%d" % i: np.packbits(m[2]) for i, m in enumerate(masks)},
                         **{"p%d" % i: q for i, q in enumerate(pools)})
-    print(case, len(masks), "ReLU inputs,", sum(m.size for m in masks), "elements;", len(pools), "max-pool inputs,",
-          sum(q.size for q in pools), "windows")
+    print(case, len(masks), "ReLU inputs,", sum(int(np.prod(m[0])) for m in masks), "elements,", sum(m[1].size for m in masks),
+          "of them inside the band;", len(pools), "max-pool inputs,", sum(q.size for q in pools), "windows")
 
 
 # -------------------------------------------------------------------------------------------------------------------- run (GPU)
@@ -119,21 +141,30 @@ ENTRIES = {
 class Nudger:
     def __init__(self, case, L):
         z = np.load(decisions_path(case))
-        self.z, self.shapes, self.n = z, json.loads(str(z["shapes"])), int(z["n"])
+        assert int(z["version"]) == 2, "decision fixture of the old dense format: regenerate (tools/mask_attribution.py masks --golden)"
+        self.z, self.shapes, self.n, self.digests = z, json.loads(str(z["shapes"])), int(z["n"]), z["digests"]
         self.i, self.ip, self.npool, self.L, self.orig = 0, 0, int(z["npool"]), L, L.call
         self.census = []                # (entry, shape, flips, residual mismatches)
         self.pool_census = []           # (shape, windows whose winner differs, left after the nudge)
 
-    def mask(self, shape):
+    def decisions(self, shape):
+        """-> (flat NCHW indices inside the band, the fp64 signs there, (#positive, index sum) of the full fp64 pattern)"""
         assert self.i < self.n, "more ReLU prologues in the HIP step than ReLUs in the oracle step"
         want = tuple(self.shapes[self.i])
         assert want == tuple(shape), ("ReLU #%d" % self.i, want, tuple(shape))
-        bits = np.unpackbits(self.z["m%d" % self.i])[: int(np.prod(want))].astype(bool).reshape(want)
+        idx = torch.from_numpy(self.z["i%d" % self.i].astype(np.int64)).cuda()
+        sign = torch.from_numpy(np.unpackbits(self.z["s%d" % self.i])[: idx.numel()].astype(bool)).cuda()
+        dig = self.digests[self.i]
         self.i += 1
-        return torch.from_numpy(bits).cuda()
+        return idx, sign, (int(dig[0]), int(dig[1]))
+
+    @staticmethod
+    def _digest(a):
+        pos = torch.nonzero(a.reshape(-1) > 0).reshape(-1)
+        return int(pos.numel()), int(pos.sum())
 
     def nudge(self, name, x, scale, shift, ssb):
-        want = self.mask(x.shape)
+        idx, sign, digest = self.decisions(x.shape)
         B, C = x.shape[:2]
         xd = x.data
         if scale is not None:
@@ -144,15 +175,25 @@ class Nudger:
         else:
             sc = sh = None
             a = xd
-        bad = (a > 0) != want
-        flips = int(bad.sum())
+        mism = (a.reshape(-1)[idx] > 0) != sign
+        flips = int(mism.sum())
         if flips:
+            bad = torch.zeros(a.numel(), dtype=torch.bool, device=a.device)
+            bad[idx[mism]] = True
+            bad = bad.view(a.shape)
+            want = torch.zeros(a.numel(), dtype=torch.bool, device=a.device)
+            want[idx] = sign
+            want = want.view(a.shape)
             mag = (xd * sc).abs() + sh.abs() if sc is not None else xd.abs()
             target = torch.where(want, 1.0, -1.0) * (4e-6 * mag + 1e-30)
             xn = (target - sh) / torch.where(sc == 0, torch.ones_like(sc), sc) if sc is not None else target
             xd.copy_(torch.where(bad, xn, xd))
             a = xd * sc + sh if sc is not None else xd
-        self.census.append((name, tuple(x.shape), flips, int(((a > 0) != want).sum())))
+        # residual: stored signs still unmatched, plus the full pattern's digests (elements outside the band)
+        left = int(((a.reshape(-1)[idx] > 0) != sign).sum())
+        if self._digest(a) != digest:
+            left += 1
+        self.census.append((name, tuple(x.shape), flips, left))
 
     def nudge_pool(self, x):
         """2 x 2 max-pool input: where the window's winner differs from the fp64 forward's, lift the fp64 winner just above the

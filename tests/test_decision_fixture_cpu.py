@@ -19,4 +19,8 @@ def test_decision_fixture_is_the_fp64_oracles(tmp_path):
     for k in old.files:
         assert np.array_equal(new[k], old[k]), k
     shapes = json.loads(str(old["shapes"]))
-    assert all(old["m%d" % i].size == -(-int(np.prod(s)) // 8) for i, s in enumerate(shapes))
+    assert int(old["version"]) == 2 and old["digests"].shape == (38, 2)
+    # sparse: only the elements inside the band are stored, with the digests of the full pattern beside them
+    total, kept = sum(int(np.prod(s)) for s in shapes), sum(old["i%d" % i].size for i in range(38))
+    assert 0 < kept < 1e-3 * total
+    assert all(0 <= int(old["digests"][i][0]) <= int(np.prod(s)) for i, s in enumerate(shapes))

@@ -297,3 +297,46 @@ def test_fully_connected_fused_equals_composed_hip():
         layer = N.FullyConnectedLayer(fin, fout, activation=act, lr_multiplier=0.01 if act == "lrelu" else 1).cuda()
         _init(layer, 6)
         _check(lambda x: layer(x), layer, [rnd(16, fin, seed=5).cuda()], False)
+
+
+# ------------------------------------------------------------------------------------------------ epilogues fused into the producers
+@pytest.mark.parametrize("B,H,W,Cin,Cout,Rk,stride,pad", [(2, 16, 16, 64, 64, 3, 1, 1), (2, 20, 12, 32, 128, 3, 1, 1), (3, 17, 17, 64, 96, 3, 2, 0),
+                                                           (2, 32, 32, 512, 512, 3, 1, 1), (2, 8, 8, 128, 64, 1, 1, 0)])
+@pytest.mark.parametrize("variant", ["full", "per_sample_noise", "bias_act_only"])
+def test_hconv_with_layer_epilogue(B, H, W, Cin, Cout, Rk, stride, pad, variant):
+    Ho, Wo = (H + 2 * pad - Rk) // stride + 1, (W + 2 * pad - Rk) // stride + 1
+    x = rnd(B, H, W, Cin, seed=1).half()
+    w = rnd(Cout, Rk, Rk, Cin, seed=2, scale=1 / np.sqrt(Cin * Rk * Rk)).half()
+    d = rnd(B, Cout, seed=3).abs() + 0.5 if variant != "bias_act_only" else None
+    noise, nbs = (rnd(Ho * Wo, seed=4), 0) if variant == "full" else ((rnd(B, Ho * Wo, seed=4), Ho * Wo) if variant == "per_sample_noise" else (None, 0))
+    strength = torch.tensor([0.3]) if noise is not None else None
+    bias = rnd(Cout, seed=5)
+    c, y = torch.empty(B, Ho, Wo, Cout, dtype=torch.float16), torch.empty(B, Ho, Wo, Cout, dtype=torch.float16)
+    args = [x, w, c if d is not None else None, y, d, noise, nbs, strength, bias, 3, 0.2, float(np.sqrt(2)), 1.5, B, H, W, Cin, Ho, Wo, Cout, Rk, stride, pad]
+    outs = run_pair("icg_conv2d_g_fprop_f16_act", args, [3] + ([2] if d is not None else []))
+    close(outs[0][0].float(), outs[0][1].float(), 3e-3, "y")           # (one fp16 ulp of c moves y by one ulp: fp32 vs fp64 accumulation)
+    if d is not None:
+        close(outs[1][0].float(), outs[1][1].float(), 2e-3, "c")
+    # and bit-for-bit what the two separate kernels give on the GPU
+    L = _L()
+    xg, wg = x.cuda(), w.cuda()
+    c2, y2 = torch.empty_like(c, device="cuda"), torch.empty_like(y, device="cuda")
+    L.call("icg_conv2d_g_fprop_f16", xg, wg, c2, B, H, W, Cin, Ho, Wo, Cout, Rk, stride, pad, 0)
+    dv = lambda t: None if t is None else t.cuda()
+    L.call("icg_sg2_act_fwd", c2, dv(d), dv(noise), nbs, dv(strength), dv(bias), y2, B, Ho * Wo, Cout, 3, 0.2, float(np.sqrt(2)), 1.5, 1)
+    assert torch.equal(y2, outs[0][0]), "fused epilogue differs from conv + act_fwd: %d elements" % int((y2 != outs[0][0]).sum())
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 17, 17, 64), (3, 9, 13, 16), (2, 65, 65, 128), (2, 33, 33, 512)])
+@pytest.mark.parametrize("half", [False, True])
+def test_fir_with_layer_epilogue(N, H, W, C, half):
+    from ic_gan_amd.stylegan_ops import upfirdn2d as U
+    f = U.setup_filter([1, 3, 3, 1])
+    oh, ow = H + 2 - 4 + 1, W + 2 - 4 + 1
+    x = act(N, H * W, C, half, 1).reshape(N, H, W, C)
+    d, noise, strength, bias = rnd(N, C, seed=2).abs() + 0.5, rnd(N, oh * ow, seed=3), torch.tensor([0.3]), rnd(C, seed=4)
+    c, y = torch.empty(N, oh, ow, C, dtype=x.dtype), torch.empty(N, oh, ow, C, dtype=x.dtype)
+    args = [x, f, c, y, d, noise, oh * ow, strength, bias, N, C, H, W, 4, 4, 1, 1, 1, 1, 4.0, oh, ow, 3, 0.2, float(np.sqrt(2)), 2.0, 1 if half else 0]
+    (gc, rc), (gy, ry) = run_pair("icg_sg2_fir_act_fwd", args, [2, 3])
+    close(gc.float(), rc.float(), 2e-3 if half else 1e-5, "c")
+    close(gy.float(), ry.float(), 3e-3 if half else 1e-5, "y")

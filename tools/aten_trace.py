@@ -109,7 +109,7 @@ def main_sg2(case="ic_r32_fp16"):
     from tests import stylegan_cases as SC
     kernel_ref.install(Patch())
     tr = Trace()
-    for mod, names in ((L, ("call", "query")), (ops, ("adam_multi", "ema_multi"))):
+    for mod, names in ((L, ("call", "query")), (ops, ("adam_multi", "ema_multi", "nan_to_num_multi", "sg2_weight_prep_multi"))):
         for n in names:
             f = getattr(mod, n)
 
