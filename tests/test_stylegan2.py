@@ -233,3 +233,59 @@ def test_style_mixing_select_equals_the_slice_assignment():
             want[:, cutoff:] = b[:, cutoff:]
             assert torch.equal(ws, want), (seed, prob, int(cutoff))
     assert calls[:2] == [False, True]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ic_r32_fp16", "cfg4_r256_fp16"])
+def test_fp16_mfma_route_equals_the_fp32_kernel_route_hip(name, monkeypatch):
+    """ADVICE r03 / VERDICT r04: the loose fp16 tolerances above are rounding-point differences against the reference's CPU run.  Between
+    the two ROUTES of this engine the rounding points are identical -- the fp16-input MFMA kernels (exact fp16 products, fp32
+    accumulation, one rounding) and `FP16_MFMA = False` (the same operands cast to fp32, exact-fp32 MFMA kernels, one rounding) differ
+    only in the summation order inside a convolution -- so whole networks must agree to a few fp16 ulps of a handful of elements:
+    forward images and logits, and the first-order gradients of the Gmain / Dmain phases (fused layers on both routes)."""
+    from ic_gan_amd.stylegan2.loss import StyleGAN2Loss
+    from ic_gan_amd.stylegan_ops import conv2d_gradfix
+    dev = "cuda:0"
+    cfg, G, D = _build(name, dev, monkeypatch)
+    b = cfg["batch"]
+    z, gc, gh, img, rc, rh = (t.to(dev) for t in sg2_inputs(cfg, 7, 4))
+
+    def run():
+        out = {}
+        with torch.no_grad():
+            fake = G(z[:b], gc[:b], gh[:b], noise_mode="const")
+            out["img"], out["logits"] = fake.float(), D(fake, gc[:b], gh[:b]).float()
+        for pi, phase in enumerate(["Gmain", "Dmain"]):
+            L = StyleGAN2Loss(device=dev, G_mapping=G.mapping, G_synthesis=G.synthesis, D=D, **SG2_LOSS)
+            mod = G if phase[0] == "G" else D
+            mod.requires_grad_(True)
+            for p in mod.parameters():
+                p.grad = None
+            torch.manual_seed(100 + pi)
+            L.accumulate_gradients(phase=phase, real_img=img, real_c=rc, real_h=rh, gen_z=z[:b], gen_c=gc[:b], gen_h=gh[:b], sync=True,
+                                   gain=cfg.get("phase_gain", 1))
+            mod.requires_grad_(False)
+            for n, p in mod.named_parameters():
+                if p.grad is not None:
+                    out[phase + "/" + n] = p.grad.float().clone()
+                p.grad = None
+        return out
+
+    a = run()
+    monkeypatch.setattr(conv2d_gradfix, "FP16_MFMA", False)
+    bb = run()
+    assert set(a) == set(bb) and len(a) > 20
+    worst = ("", 0.0)
+    for k in a:
+        scale = float(bb[k].double().square().mean().sqrt()) + 1e-30
+        err = float((a[k] - bb[k]).abs().max()) / scale
+        if err > worst[1]:
+            worst = (k, err)
+    # forward: <= 2 fp16 ulps of the largest activation (1e-3 of the rms); gradients: a few 1e-3 of the tensor rms, against the
+    # 8e-2 ... 3e-1 the comparison with the reference's CPU run needs
+    fwd = max(float((a[k] - bb[k]).abs().max()) / (float(bb[k].abs().max()) + 1e-30) for k in ("img", "logits"))
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/sg2_route_check.txt", "a") as fh:
+            fh.write("%s: forward max err / max %.3e; worst gradient max err / rms %.3e (%s)\n" % (name, fwd, worst[1], worst[0]))
+    assert fwd <= 2e-3
+    assert worst[1] <= 2e-2, worst
