@@ -46,6 +46,9 @@ struct HconvP {
   long ep_nbs;
   int ep_act;
   float ep_alpha, ep_gain, ep_clamp;
+  // MOD = 1: style modulation of the A operand (networks.py:78 `x * styles`): fragment (pixel of sample b, channels c .. c + 7) is
+  // multiplied by fp16(sty[b][c .. c + 7]) after its LDS read, one rounding per element -- the tensor x * s is never materialised
+  const float* sty;       // [B][Cin] fp32
 };
 
 __device__ __attribute__((aligned(64))) _Float16 g_hc_zero_page[32];      // zero-initialised: DMA source of the padding taps
@@ -79,12 +82,13 @@ __device__ __forceinline__ void hc_dma16_ptr(const void* lane_src, unsigned lds_
 }
 
 // NT: 16-column MFMA tiles per wave (workgroup tile 128 x 32 NT; 8 waves as 4 x 2, wave tile 32 x 16 NT)
-template <int NT, int EP = 0>
+constexpr int HC_MOD_MAXC = 1024;                                   // MOD: the styles of the (at most two) samples a tile meets sit in LDS
+template <int NT, int EP = 0, int MOD = 0>
 __global__ __launch_bounds__(512, 4) void icg_hconv_kernel(HconvP p) {
   constexpr int BM = 128, BN = 32 * NT, BKC = 32;                   // BKC: channels (halfs) per K-tile = 64 bytes per row
   constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, SLOT = A_BYTES + B_BYTES, NBUF = 3;
   constexpr int BROWS = BN / 8;                                     // B rows per wave and K-tile: 16 / 12 / 8
-  __shared__ __attribute__((aligned(1024))) char lds[NBUF * SLOT];
+  __shared__ __attribute__((aligned(1024))) char lds[NBUF * SLOT + (MOD ? 2 * HC_MOD_MAXC * 2 : 0)];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,6 +162,28 @@ __global__ __launch_bounds__(512, 4) void icg_hconv_kernel(HconvP p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = hc_f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // MOD: styles of the tile's first sample and the next one as fp16 [2][Cin] behind the ring (a 128-row tile spans at most two
+  // samples: the host admits pixel grids of >= 127 per sample only); filled with ordinary loads BEFORE the first DMA is issued, so
+  // the hand-counted vmcnt below sees DMAs only
+  const char* sfp[2] = {nullptr, nullptr};
+  if (MOD) {
+    _Float16* stab = reinterpret_cast<_Float16*>(lds + NBUF * SLOT);
+    const int hwph = Hph * Wph, nb = p.M / (p.Ho * p.Wo), bt0 = m0 / hwph;
+    for (int e = tid; e < 2 * p.Cin; e += 512) {
+      const int sel = e >= p.Cin ? 1 : 0, c = e - sel * p.Cin;
+      stab[sel * HC_MOD_MAXC + c] = (_Float16)p.sty[(size_t)min(bt0 + sel, nb - 1) * (unsigned)p.Cin + c];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int mrow = min(m0 + 32 * wm + 16 * i + r, Mph - 1);
+      sfp[i] = reinterpret_cast<const char*>(stab) + ((mrow / hwph - bt0) * HC_MOD_MAXC + 8 * kk) * 2;
+    }
+    __syncthreads();
+  }
+  int cc0 = 0, ctap = 0;                                            // consume cursor: channel slice of K-tile kt, tap count inside it
+  const int ntaps = ntr * nts;
+  hc_h8 sf[2];
+
   if (nk > 0) {                                                     // (a phase without taps -- 1x1, odd parity -- stores zeros)
     issue_next(0u);
     issue_next((unsigned)SLOT);
@@ -176,6 +202,15 @@ __global__ __launch_bounds__(512, 4) void icg_hconv_kernel(HconvP p) {
     for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const hc_h8*>(fa + cur + i * 1024);
 #pragma unroll
     for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const hc_h8*>(fb + cur + j * 1024);
+    if (MOD) {
+      if (ctap == 0) {                                              // (wave-uniform) a new channel slice: its style fragments
+        sf[0] = *reinterpret_cast<const hc_h8*>(sfp[0] + cc0 * 2);
+        sf[1] = *reinterpret_cast<const hc_h8*>(sfp[1] + cc0 * 2);
+      }
+      a[0] *= sf[0];                                                // v_pk_mul_f16: x * s rounded to fp16, as the reference's tensor is
+      a[1] *= sf[1];
+      if (++ctap == ntaps) { ctap = 0; cc0 += BKC; }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -240,8 +275,12 @@ extern "C" int icg_conv2d_g_fprop_f16_applies(int Cin, int Cout, int R, int stri
   return 1;
 }
 
+static long hconv_min_phase_pixels(int Hout, int Wout, int zins) {
+  return zins == 2 ? (long)(Hout / 2) * (Wout / 2) : (long)Hout * Wout;
+}
+
 static int hconv_launch(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Hout, int Wout, int Cout, int R, int stride,
-                        int pad, int zins, const HconvP* ep, void* stream) {
+                        int pad, int zins, const HconvP* ep, const float* style, void* stream) {
   ICG_REQUIRE(x && w && B > 0 && H > 0 && W > 0 && Hout > 0 && Wout > 0 && pad >= 0 && (y || ep));
   ICG_REQUIRE(icg_conv2d_g_fprop_f16_applies(Cin, Cout, R, stride, zins));
   ICG_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 8) == 0);
@@ -250,6 +289,8 @@ static int hconv_launch(const void* x, const void* w, void* y, int B, int H, int
   const int nt = (Cout % 128 == 0) ? 4 : ((Cout % 96 == 0) ? 3 : 2);
   HconvP p{};
   if (ep) p = *ep;
+  if (style) ICG_REQUIRE(Cin <= HC_MOD_MAXC && hconv_min_phase_pixels(Hout, Wout, zins) >= 127);
+  p.sty = style;
   p.A = (const _Float16*)x; p.Bw = (const _Float16*)w; p.C = (_Float16*)y;
   p.M = (int)M; p.N = Cout; p.K = R * R * Cin;
   p.Ho = Hout; p.Wo = Wout; p.Hs = H; p.Ws = W; p.Cin = Cin; p.R = R; p.stride = stride; p.pad = pad; p.zs = (zins == 2) ? 1 : 0;
@@ -271,32 +312,51 @@ static int hconv_launch(const void* x, const void* w, void* y, int B, int H, int
   p.swz = (total >= 16 && !no_swz) ? 1 : 0;
   const dim3 grid((unsigned)total), block(512);
   hipStream_t st = (hipStream_t)stream;
-  if (ep) {
-    if (nt == 4) hipLaunchKernelGGL((icg_hconv_kernel<4, 1>), grid, block, 0, st, p);
-    else if (nt == 3) hipLaunchKernelGGL((icg_hconv_kernel<3, 1>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((icg_hconv_kernel<2, 1>), grid, block, 0, st, p);
-  } else {
-    if (nt == 4) hipLaunchKernelGGL((icg_hconv_kernel<4, 0>), grid, block, 0, st, p);
-    else if (nt == 3) hipLaunchKernelGGL((icg_hconv_kernel<3, 0>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((icg_hconv_kernel<2, 0>), grid, block, 0, st, p);
-  }
+#define ICG_HC_LAUNCH(EPV, MODV)                                                                     \
+  do {                                                                                               \
+    if (nt == 4) hipLaunchKernelGGL((icg_hconv_kernel<4, EPV, MODV>), grid, block, 0, st, p);        \
+    else if (nt == 3) hipLaunchKernelGGL((icg_hconv_kernel<3, EPV, MODV>), grid, block, 0, st, p);   \
+    else hipLaunchKernelGGL((icg_hconv_kernel<2, EPV, MODV>), grid, block, 0, st, p);                \
+  } while (0)
+  if (ep && style) ICG_HC_LAUNCH(1, 1);
+  else if (ep) ICG_HC_LAUNCH(1, 0);
+  else if (style) ICG_HC_LAUNCH(0, 1);
+  else ICG_HC_LAUNCH(0, 0);
+#undef ICG_HC_LAUNCH
   return icg_check_launch();
 }
 
 extern "C" int icg_conv2d_g_fprop_f16(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int Hout, int Wout,
                                       int Cout, int R, int stride, int pad, int zins, void* stream) {
   ICG_REQUIRE(y);
-  return hconv_launch(x, w, y, B, H, W, Cin, Hout, Wout, Cout, R, stride, pad, zins, nullptr, stream);
+  return hconv_launch(x, w, y, B, H, W, Cin, Hout, Wout, Cout, R, stride, pad, zins, nullptr, nullptr, stream);
 }
 
 // the same convolution (zero_insert = 0) with the StyleGAN2 layer epilogue on the accumulators (see HconvP): c (may be null) and y
 extern "C" int icg_conv2d_g_fprop_f16_act(const void* x, const void* w, void* c, void* y, const float* d, const float* noise, int64_t noise_bstride,
                                           const float* strength, const float* bias, int act, float alpha, float gain, float clamp, int B, int H,
                                           int W, int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, void* stream) {
-  ICG_REQUIRE(y && (act == 1 || act == 3) && (!noise || strength) && ((uintptr_t)y % 8) == 0);
+  return icg_modconv2d_f16(x, nullptr, w, c, y, d, noise, noise_bstride, strength, bias, act, alpha, gain, clamp, B, H, W, Cin, Hout, Wout, Cout, R,
+                           stride, pad, 0, stream);
+}
+
+extern "C" int icg_modconv2d_f16_applies(int Cin, int Cout, int R, int stride, int zins, int Hout, int Wout) {
+  return icg_conv2d_g_fprop_f16_applies(Cin, Cout, R, stride, zins) && Cin <= HC_MOD_MAXC && hconv_min_phase_pixels(Hout, Wout, zins) >= 127;
+}
+
+// modulated convolution of a StyleGAN2 layer in ONE launch: style scale on the A fragments (style != null), the contraction, and
+// (y != null; zero_insert = 0) demodulation + noise + bias + activation + clamp on the accumulators
+extern "C" int icg_modconv2d_f16(const void* x, const float* style, const void* w, void* c, void* y, const float* d, const float* noise,
+                                 int64_t noise_bstride, const float* strength, const float* bias, int act, float alpha, float gain, float clamp,
+                                 int B, int H, int W, int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, int zins, void* stream) {
+  if (!y) {
+    ICG_REQUIRE(c);
+    return hconv_launch(x, w, c, B, H, W, Cin, Hout, Wout, Cout, R, stride, pad, zins, nullptr, style, stream);
+  }
+  ICG_REQUIRE(zins == 0 && (act == 1 || act == 3) && (!noise || strength) && ((uintptr_t)y % 8) == 0);
   ICG_REQUIRE(((uintptr_t)d % 16) == 0 && ((uintptr_t)bias % 16) == 0);
   HconvP ep{};
   ep.ep_d = d; ep.ep_noise = noise; ep.ep_strength = strength; ep.ep_bias = bias; ep.Y = (_Float16*)y; ep.ep_nbs = (long)noise_bstride;
   ep.ep_act = act; ep.ep_alpha = alpha; ep.ep_gain = gain; ep.ep_clamp = clamp;
-  return hconv_launch(x, w, c, B, H, W, Cin, Hout, Wout, Cout, R, stride, pad, 0, &ep, stream);
+  return hconv_launch(x, w, c, B, H, W, Cin, Hout, Wout, Cout, R, stride, pad, 0, &ep, style, stream);
 }

@@ -275,25 +275,35 @@ class _ModConvFn(Function):
         smax = torch.empty(N, device=dev, dtype=torch.float32) if half else None
         sarg = torch.empty(N, device=dev, dtype=torch.int32) if half else None
         L.call("icg_sg2_style_prep", lin, ab, cfg.affine_bgain, 1.0, p.wsq, N, I, O, int(half), s, smax, sarg, d)
-        xs = torch.empty_like(x)
-        L.call("icg_sg2_modulate", x, s, xs, N, H * W, I, dt)
         st = strength if noise is not None else None
-        if _hconv_epilogue(x, I, O, pl):
-            # demodulation, noise, bias, lrelu and clamp on the convolution's accumulators (csrc/hconv.hip, EP = 1)
-            Ho, Wo = pl.geo.out
-            c = torch.empty((N, O, Ho, Wo), device=dev, dtype=x.dtype, memory_format=torch.channels_last)
-            y = torch.empty_like(c)
-            L.call("icg_conv2d_g_fprop_f16_act", xs, p.w_fwd, c, y, d, noise, cfg.noise_bstride, st, bias, 3, 0.2, cfg.act_gain, cfg.clamp,
-                   N, H, W, I, Ho, Wo, O, R, pl.geo.stride, pl.geo.pad)
-        else:
-            c = G.gather_conv(xs, p.w_fwd, pl.geo, p.cache)
+        geo = pl.geo
+        xs = None
+        if half and G.FP16_MFMA and L.query("icg_modconv2d_f16_applies", I, O, R, geo.stride, geo.zins, geo.out[0], geo.out[1]):
+            # ONE launch: x * s on the convolution's A fragments, the contraction, and -- without a blur behind it -- demodulation,
+            # noise, bias, lrelu and clamp on its accumulators (csrc/hconv.hip, MOD / EP); x * s is never written
+            c = torch.empty((N, O, geo.out[0], geo.out[1]), device=dev, dtype=x.dtype, memory_format=torch.channels_last)
+            y = torch.empty_like(c) if pl.post is None else None
+            L.call("icg_modconv2d_f16", x, s, p.w_fwd, c, y, d, noise, cfg.noise_bstride, st, bias, 3, 0.2, cfg.act_gain, cfg.clamp,
+                   N, H, W, I, geo.out[0], geo.out[1], O, R, geo.stride, geo.pad, geo.zins)
             if pl.post is not None:      # up-sampling layer: the same epilogue on the blur's results
                 c, y = _fir_act(c, f2, pl.post, d, noise, cfg.noise_bstride, st, bias, 3, cfg.act_gain, cfg.clamp, True)
-            else:
+        else:
+            xs = torch.empty_like(x)
+            L.call("icg_sg2_modulate", x, s, xs, N, H * W, I, dt)
+            if _hconv_epilogue(x, I, O, pl):
+                c = torch.empty((N, O, geo.out[0], geo.out[1]), device=dev, dtype=x.dtype, memory_format=torch.channels_last)
                 y = torch.empty_like(c)
-                L.call("icg_sg2_act_fwd", c, d, noise, cfg.noise_bstride, st, bias, y, N, int(c.shape[2]) * int(c.shape[3]), O, 3, 0.2,
-                       cfg.act_gain, cfg.clamp, dt)
-            Ho, Wo = int(c.shape[2]), int(c.shape[3])
+                L.call("icg_conv2d_g_fprop_f16_act", xs, p.w_fwd, c, y, d, noise, cfg.noise_bstride, st, bias, 3, 0.2, cfg.act_gain,
+                       cfg.clamp, N, H, W, I, geo.out[0], geo.out[1], O, R, geo.stride, geo.pad)
+            else:
+                c = G.gather_conv(xs, p.w_fwd, geo, p.cache)
+                if pl.post is not None:
+                    c, y = _fir_act(c, f2, pl.post, d, noise, cfg.noise_bstride, st, bias, 3, cfg.act_gain, cfg.clamp, True)
+                else:
+                    y = torch.empty_like(c)
+                    L.call("icg_sg2_act_fwd", c, d, noise, cfg.noise_bstride, st, bias, y, N, int(c.shape[2]) * int(c.shape[3]), O, 3,
+                           0.2, cfg.act_gain, cfg.clamp, dt)
+        Ho, Wo = int(c.shape[2]), int(c.shape[3])
         ctx.cfg, ctx.p, ctx.dims = cfg, p, (N, I, H, W, O, R, Ho, Wo)
         ctx.save_for_backward(x, xs, c, y, s, d, smax, sarg, wl, aw, weight, noise, f2)
         return y
@@ -340,6 +350,9 @@ class _ModConvFn(Function):
                 L.call("icg_sg2_fc_bwd", g, smax, sarg, pdot if smax is not None else None, nblk, 1.0, wl, aw, N, I, K, cfg.affine_wgain,
                        cfg.affine_bgain, daw, dab, dwl)
         if need_w and not G.weight_gradients_disabled:
+            if xs is None:      # the forward modulated inside the convolution: the weight gradient's operand is rebuilt here
+                xs = torch.empty_like(x)
+                L.call("icg_sg2_modulate", x, s, xs, N, H * W, I, dt)
             tw, layout = G.gather_wgrad_raw(xs, dc, pl.geo)
             dweight = torch.empty_like(weight)
             nbw = L.query("icg_sg2_weight_bwd_workspace_bytes", O, I) if p.prenorm else 0

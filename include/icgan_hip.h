@@ -185,6 +185,16 @@ int icg_conv2d_g_fprop_f16(const void* x, const void* w, void* out, int B, int H
 int icg_conv2d_g_fprop_f16_act(const void* x, const void* w, void* c, void* y, const float* d, const float* noise, int64_t noise_bstride,
                                const float* strength, const float* bias, int act, float alpha, float gain, float clamp, int B, int Hin,
                                int Win, int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, void* stream);
+/* modulated_conv2d (networks.py:37-117, the training form) in ONE launch: the style scale x * s (style [B][Cin] fp32, may be NULL) is
+ * applied to the A fragments after their LDS read -- fp16(x * fp16(s)), the rounding of the reference's tensor, which is never
+ * materialised -- then the contraction, then (y != NULL; zero_insert = 0 only) the epilogue of icg_conv2d_g_fprop_f16_act.  y == NULL:
+ * the plain (modulated) convolution into c, zero_insert 0 or 2.  `_applies`: the fp16 kernel takes the shape, Cin <= 1024, and every
+ * phase has >= 127 pixels per sample (a 128-pixel tile then meets at most two samples' styles, which it keeps in LDS). */
+int icg_modconv2d_f16_applies(int Cin, int Cout, int R, int stride, int zero_insert, int Hout, int Wout);
+int icg_modconv2d_f16(const void* x, const float* style, const void* w, void* c, void* y, const float* d, const float* noise,
+                      int64_t noise_bstride, const float* strength, const float* bias, int act, float alpha, float gain, float clamp,
+                      int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int R, int stride, int pad, int zero_insert,
+                      void* stream);
 /*   dw[r][s][ci][co] = sum_{b,oy,ox} x[b, oy*stride + r - pad, ox*stride + s - pad, ci] * dy[b,oy,ox,co]
  * (weight gradient of either direction: for the transposed convolution swap the roles of x and dy). */
 size_t icg_conv2d_g_wgrad_workspace_bytes(int B, int Hout, int Wout, int Cin, int Cout, int R);

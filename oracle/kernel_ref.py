@@ -1194,6 +1194,26 @@ def icg_conv2d_g_fprop_f16_act(x, w, c, y, d, noise, noise_bstride, strength, bi
     icg_sg2_act_fwd(tmp, d, noise, noise_bstride, strength, bias, y, B, Hout * Wout, Cout, act, alpha, gain, clamp, 1)
 
 
+def icg_modconv2d_f16_applies(Cin, Cout, R, stride, zero_insert, Hout, Wout):
+    px = (Hout // 2) * (Wout // 2) if zero_insert == 2 else Hout * Wout
+    return int(bool(icg_conv2d_g_fprop_f16_applies(Cin, Cout, R, stride, zero_insert)) and Cin <= 1024 and px >= 127)
+
+
+def icg_modconv2d_f16(x, style, w, c, y, d, noise, noise_bstride, strength, bias, act, alpha, gain, clamp, B, Hin, Win, Cin, Hout, Wout, Cout,
+                      R, stride, pad, zero_insert):
+    """icg_sg2_modulate, icg_conv2d_g_fprop_f16 and (y given) icg_sg2_act_fwd"""
+    xs = x
+    if style is not None:
+        xs = torch.empty(B * Hin * Win * Cin, dtype=torch.float16)
+        icg_sg2_modulate(x, style, xs, B, Hin * Win, Cin, 1)
+    tmp = torch.empty(B * Hout * Wout * Cout, dtype=torch.float16)
+    icg_conv2d_g_fprop_f16(xs, w, tmp, B, Hin, Win, Cin, Hout, Wout, Cout, R, stride, pad, zero_insert)
+    if c is not None:
+        mem(c)[: tmp.numel()].copy_(tmp)
+    if y is not None:
+        icg_sg2_act_fwd(tmp, d, noise, noise_bstride, strength, bias, y, B, Hout * Wout, Cout, act, alpha, gain, clamp, 1)
+
+
 def _rows_geometry(HW, V):
     nrl = 256 // V
     r = max(-(-HW // 64), nrl)

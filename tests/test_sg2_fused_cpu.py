@@ -84,6 +84,8 @@ SYN = [  # Cin, Cout, res(out), up, half, noise_mode, clamp, gain, N
     (32, 32, 16, 2, True, "random", 256, 1.0, 2),
     (64, 32, 8, 2, True, "none", 2.0, float(np.sqrt(0.5)), 2),       # clamp active, resnet gain
     (8, 8, 4, 1, False, "random", 0.5, 1.0, 4),
+    (64, 64, 16, 1, True, "const", 256, 1.0, 2),          # widths the fp16 MFMA kernel takes: modulation + epilogue inside the convolution
+    (64, 64, 32, 2, True, "random", 256, 1.0, 2),         # ... up-sampling: modulation inside the transposed convolution, epilogue on the blur
 ]
 
 

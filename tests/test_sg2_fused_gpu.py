@@ -342,3 +342,38 @@ def test_fir_with_layer_epilogue(N, H, W, C, half):
     (gc, rc), (gy, ry) = run_pair("icg_sg2_fir_act_fwd", args, [2, 3])
     close(gc.float(), rc.float(), 2e-3 if half else 1e-5, "c")
     close(gy.float(), ry.float(), 3e-3 if half else 1e-5, "y")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,Rk,stride,pad,zins", [(2, 16, 16, 64, 64, 3, 1, 1, 0), (3, 12, 11, 32, 128, 3, 1, 1, 0), (2, 32, 32, 512, 512, 3, 1, 1, 0),
+                                                                (3, 16, 16, 64, 128, 3, 1, 2, 2), (2, 32, 32, 256, 64, 3, 1, 2, 2), (2, 12, 12, 128, 64, 1, 1, 0, 0)])
+@pytest.mark.parametrize("epilogue", [False, True])
+def test_modulated_convolution_in_one_launch(B, H, W, Cin, Cout, Rk, stride, pad, zins, epilogue):
+    """icg_modconv2d_f16: style scale on the A fragments (+ the layer epilogue) = bit for bit the separate kernels' result"""
+    L = _L()
+    if zins:
+        Ho, Wo = (H - 1) * 2 + Rk - 2 * (Rk - 1 - pad), (W - 1) * 2 + Rk - 2 * (Rk - 1 - pad)
+        Ho, Wo = 2 * H + 1, 2 * W + 1
+        epilogue = False
+    else:
+        Ho, Wo = (H + 2 * pad - Rk) // stride + 1, (W + 2 * pad - Rk) // stride + 1
+    assert L.query("icg_modconv2d_f16_applies", Cin, Cout, Rk, stride, zins, Ho, Wo) == R.icg_modconv2d_f16_applies(Cin, Cout, Rk, stride, zins, Ho, Wo) == 1
+    x = rnd(B, H, W, Cin, seed=1).half().cuda()
+    w = rnd(Cout, Rk, Rk, Cin, seed=2, scale=1 / np.sqrt(Cin * Rk * Rk)).half().cuda()
+    s = rnd(B, Cin, seed=3).cuda()
+    d, noise, strength, bias = (rnd(B, Cout, seed=4).abs() + 0.5).cuda(), rnd(B, Ho * Wo, seed=5).cuda(), torch.tensor([0.3]).cuda(), rnd(Cout, seed=6).cuda()
+    c1, y1 = torch.empty(B, Ho, Wo, Cout, dtype=torch.float16, device="cuda"), torch.empty(B, Ho, Wo, Cout, dtype=torch.float16, device="cuda")
+    L.call("icg_modconv2d_f16", x, s, w, c1, y1 if epilogue else None, d, noise, Ho * Wo, strength, bias, 3, 0.2, 1.4, 2.0, B, H, W, Cin, Ho, Wo, Cout,
+           Rk, stride, pad, zins)
+    xs, c2, y2 = torch.empty_like(x), torch.empty_like(c1), torch.empty_like(y1)
+    L.call("icg_sg2_modulate", x, s, xs, B, H * W, Cin, 1)
+    L.call("icg_conv2d_g_fprop_f16", xs, w, c2, B, H, W, Cin, Ho, Wo, Cout, Rk, stride, pad, zins)
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2), "modulated convolution differs from modulate + conv: %d elements" % int((c1 != c2).sum())
+    if epilogue and L.query("icg_sg2_rows_applies", Cout, 1):
+        L.call("icg_sg2_act_fwd", c2, d, noise, Ho * Wo, strength, bias, y2, B, Ho * Wo, Cout, 3, 0.2, 1.4, 2.0, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y2)
+    # and the CPU restatement
+    cr = torch.empty(B, Ho, Wo, Cout, dtype=torch.float16)
+    R.icg_modconv2d_f16(x.cpu(), s.cpu(), w.cpu(), cr, None, None, None, 0, None, None, 3, 0.2, 1.4, 2.0, B, H, W, Cin, Ho, Wo, Cout, Rk, stride, pad, zins)
+    close(c1.float(), cr.float(), 2e-3, "c vs kernel_ref")
