@@ -765,6 +765,27 @@ def self_launch(n):
         raise SystemExit(rc)
 
 
+def rank_host_resources(local_rank, local_world):
+    """One rank per GPU shares the node's cores with its siblings: give each an equal, disjoint slice of the cores this process may
+    run on (affinity) and as many intra-op threads -- under torchrun every rank otherwise inherits OMP_NUM_THREADS=1 (its default)
+    or, unset, all cores (N ranks x all cores oversubscribe the host-side conditioning sampler).  `self_launch` sets the thread count
+    in the environment for the ranks it starts; this covers the driver's torchrun form as well.  ICG_NO_AFFINITY=1: leave both alone."""
+    if os.environ.get("ICG_NO_AFFINITY") == "1" or local_world <= 1:
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    per = max(1, len(cores) // local_world)
+    mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        mine = cores
+    torch.set_num_threads(max(1, min(len(mine), 16)))
+    return {"cores": len(mine), "first_core": mine[0], "intra_op_threads": torch.get_num_threads()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -825,6 +846,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_ddp = world > 1 or os.environ.get("ICG_FORCE_DDP") == "1"   # (the override exercises the RCCL/DDP wiring on 1 GPU)
+    host = rank_host_resources(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else None
     if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -971,7 +993,20 @@ def main():
         base = uninstr if uninstr is not None else elapsed
         comm_report = {**per_step, "ms_per_step_without_collectives": round(t_nosync / args.steps * 1e3, 3),
                        "exposed_ms_per_step": round((base - t_nosync) / args.steps * 1e3, 3),
+                       "comm_savings": bool(train_fns.COMM_SAVINGS),
                        "hook": "counting comm hook (default averaging all-reduce); train_fns.COMM_SAVINGS=%s" % train_fns.COMM_SAVINGS}
+        if not args.sync_bn and world > 1:
+            # the same steps with cross-replica BN statistics (north_star: "SyncBatchNorm stats overlapped with backward"): the layers
+            # read their `sync_bn` attribute per call, so the leg toggles it on the built networks -- one extra figure in the same run
+            bns = [m for net in (G, G_ema) for m in net.modules() if hasattr(m, "sync_bn")]
+            for m in bns:
+                m.sync_bn = True
+            one_step()
+            t_sync = timed_region(args.steps)
+            for m in bns:
+                m.sync_bn = False
+            comm_report["sync_bn_leg"] = {"ms_per_step": round(t_sync / args.steps * 1e3, 3),
+                                          "images_per_sec": round(batch * acc * world * args.steps / t_sync, 3), "bn_layers": len(bns)}
 
     if rank == 0:
         roof = None if args.no_kernel_timer else assemble_roofline(timer, args.steps, elapsed,
@@ -994,7 +1029,7 @@ def main():
                        "timer_period": (None if args.no_kernel_timer else timer.period),   # HIP-event brackets on every P-th launch per (entry point, shape)
                        "uninstrumented_ms_per_step": (round(uninstr / args.steps * 1e3, 3) if uninstr is not None else None),
                        "uninstrumented_images_per_sec": (round(batch * acc * world * args.steps / uninstr, 3) if uninstr is not None else None),
-                       "comm": comm_report,
+                       "comm": comm_report, "rank_host_resources": host,
                        "rccl_world_size": (dist.get_world_size() if use_ddp else 1), "init": init, "sync_bn": bool(args.sync_bn), "winograd": not args.no_winograd, "wgrad_side_stream": bool(args.wgrad_stream),
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "losses_last_step": metrics},
             "roofline": roof,

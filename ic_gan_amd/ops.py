@@ -299,8 +299,16 @@ def resample_winograd_applies(cin, cout, h, w, batch):
 
 
 def resample_winograd_directions(cin, cout, upsample):
+    """(fprop, dgrad, wgrad) in the 25-plane domain?  The pool-fused forward / data gradient go there from 96 channels only because the
+    fused narrow-layer kernel (csrc/fwino.hip) takes them; below 192 channels the three-kernel composite it would otherwise fall to is
+    slower than the 4x4-stride-2 form, so that range is admitted only for widths the fused kernel serves (Cin % 32 == 0 and a column
+    count of 96 k) -- a batch-independent proxy of icg_fwino_applies, which keeps the prefetched spectral-norm layouts stable
+    (ADVICE r04)."""
     c = min(cin, cout)
-    return tuple(c >= m for m in RS_WINOGRAD_MIN_CHANNELS[bool(upsample)])
+    th = RS_WINOGRAD_MIN_CHANNELS[bool(upsample)]
+    if not upsample and c < 192 and not (cin % 32 == 0 and cout % 96 == 0 and cin % 96 == 0):
+        th = tuple(max(t, 192) for t in th)
+    return tuple(c >= m for m in th)
 
 
 WINOGRAD4_WGRAD_MIN_CHANNELS = 96       # weight gradient: F(4x4,3x3) domain from here (2.25x transform volume instead of 4x)

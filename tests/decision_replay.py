@@ -53,6 +53,17 @@ def _sparse_decisions(a):
     return (tuple(a.shape), idx.numpy().astype(np.int64), pos[idx].numpy(), int(allpos.numel()), int(allpos.sum()))
 
 
+def _sparse_pool_decisions(win):
+    """win [B, C, H/2, W/2, 4] -> (shape, flat indices of the windows whose two largest entries lie within BAND x rms of each other,
+    their winners, digests of ALL winners: sum of the winners and sum of window index x winner)"""
+    top2 = win.topk(2, dim=-1).values
+    rms = float(win.double().square().mean().sqrt())
+    winner = win.argmax(-1).reshape(-1)
+    idx = torch.nonzero((top2[..., 0] - top2[..., 1]).reshape(-1) < BAND * rms).reshape(-1)
+    ar = torch.arange(winner.numel(), dtype=torch.int64)
+    return (tuple(win.shape[:4]), idx.numpy().astype(np.int64), winner[idx].to(torch.uint8).numpy(), int(winner.sum()), int((ar * winner).sum()))
+
+
 def make_masks(case, out_path=None):
     import tests.helpers as H
     from oracle import biggan_oracle as O
@@ -87,7 +98,7 @@ def make_masks(case, out_path=None):
             assert list(k) == [2, 2] and not a and not kw
             B, C, H, W = x.shape
             win = x.detach().reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, H // 2, W // 2, 4)
-            pools.append(win.argmax(-1).to(torch.uint8).numpy())          # winner of every 2 x 2 window: 2 dy + dx
+            pools.append(_sparse_pool_decisions(win))                    # winner of a 2 x 2 window: 2 dy + dx
             return torch.nn.functional.max_pool2d(x, k)
 
     saved_F, O.F = O.F, FProxy()
@@ -122,9 +133,13 @@ def make_masks(case, out_path=None):
                         digests=np.array([[m[3], m[4]] for m in masks], dtype=np.int64),
                         **{"i%d" % i: (m[1].astype(np.uint32) if int(np.prod(m[0])) < 2 ** 32 else m[1]) for i, m in enumerate(masks)},
                         **{"s%d" % i: np.packbits(m[2]) for i, m in enumerate(masks)},
-                        **{"p%d" % i: q for i, q in enumerate(pools)})
+                        pshapes=json.dumps([q[0] for q in pools]),
+                        pdigests=np.array([[q[3], q[4]] for q in pools], dtype=np.int64).reshape(-1, 2),
+                        **{"pi%d" % i: q[1].astype(np.uint32) for i, q in enumerate(pools)},
+                        **{"pw%d" % i: q[2] for i, q in enumerate(pools)})
     print(case, len(masks), "ReLU inputs,", sum(int(np.prod(m[0])) for m in masks), "elements,", sum(m[1].size for m in masks),
-          "of them inside the band;", len(pools), "max-pool inputs,", sum(q.size for q in pools), "windows")
+          "of them inside the band;", len(pools), "max-pool inputs,", sum(int(np.prod(q[0])) for q in pools), "windows,",
+          sum(q[1].size for q in pools), "inside the band")
 
 
 # -------------------------------------------------------------------------------------------------------------------- run (GPU)
@@ -199,13 +214,19 @@ class Nudger:
         """2 x 2 max-pool input: where the window's winner differs from the fp64 forward's, lift the fp64 winner just above the
         window maximum (it was within rounding distance of it)."""
         assert self.ip < self.npool
-        want = torch.from_numpy(self.z["p%d" % self.ip].astype(np.int64)).cuda()
+        idx = torch.from_numpy(self.z["pi%d" % self.ip].astype(np.int64)).cuda()
+        wsel = torch.from_numpy(self.z["pw%d" % self.ip].astype(np.int64)).cuda()
+        digest = tuple(int(v) for v in self.z["pdigests"][self.ip])
+        pshape = tuple(json.loads(str(self.z["pshapes"]))[self.ip])
         self.ip += 1
         B, C, H, W = x.shape
-        assert tuple(want.shape) == (B, C, H // 2, W // 2), (tuple(want.shape), tuple(x.shape))
+        assert pshape == (B, C, H // 2, W // 2), (pshape, tuple(x.shape))
         win = x.data.unfold(2, 2, 2).unfold(3, 2, 2)                       # view [B, C, H/2, W/2, 2, 2] of the storage
         flat = win.reshape(B, C, H // 2, W // 2, 4)                         # (copy)
         mx, have = flat.max(-1)
+        want = have.clone().reshape(-1)
+        want[idx] = wsel                                                   # outside the band the fp32 winner is the fp64 one (digest below)
+        want = want.view_as(have)
         bad = have != want
         n = int(bad.sum())
         if n:
@@ -213,7 +234,11 @@ class Nudger:
             sel = torch.nn.functional.one_hot(want, 4).bool().reshape(B, C, H // 2, W // 2, 2, 2) & bad[..., None, None]
             win[sel] = lifted[..., None, None].expand_as(win)[sel]
             have = x.data.unfold(2, 2, 2).unfold(3, 2, 2).reshape(B, C, H // 2, W // 2, 4).argmax(-1)
-        self.pool_census.append((tuple(x.shape), n, int((have != want).sum())))
+        left = int((have != want).sum())
+        hv = have.reshape(-1)
+        if (int(hv.sum()), int((torch.arange(hv.numel(), device=hv.device) * hv).sum())) != digest:
+            left += 1
+        self.pool_census.append((tuple(x.shape), n, left))
 
     def call(self, name, *args):
         if name in ENTRIES:

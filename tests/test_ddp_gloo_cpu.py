@@ -100,13 +100,22 @@ def _worker_step(rank, world, port, out, savings=True, accumulations=1):
     bufs = lambda: torch.cat([b.detach().reshape(-1).float() for b in list(G.buffers()) + list(D.buffers())])
     bg = [torch.empty_like(bufs()) for _ in range(world)]
     dist.all_gather(bg, bufs())
-    utils.sync_buffers(Gd); utils.sync_buffers(Dd)                  # the explicit rank-0 broadcast (train_fns docstring)
+    # a checkpoint written from ANY rank carries rank 0's buffers: utils.save_weights aligns DistributedDataParallel-wrapped modules
+    # itself (utils.sync_buffers, the explicit rank-0 broadcast of the train_fns docstring) before it writes
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        utils.save_weights(Gd, Dd, {"itr": 1}, tmp, "exp", "rank%d" % rank, None, embedded_optimizers=False, G_optim=opt_g, D_optim=opt_d)
+        saved = torch.load("%s/exp/G_rank%d.pth" % (tmp, rank))
+    ckpt = torch.cat([saved["module." + k].reshape(-1).float() for k, _ in G.named_buffers()])
+    cg = [torch.empty_like(ckpt) for _ in range(world)]
+    dist.all_gather(cg, ckpt)
     bs = [torch.empty_like(bufs()) for _ in range(world)]
     dist.all_gather(bs, bufs())
     if rank == 0:
         out["buffers_identical_after_step"] = all(bool(torch.equal(bg[0], g)) for g in bg[1:])
         out["buffers_identical_after_sync"] = all(bool(torch.equal(bs[0], g)) for g in bs[1:])
         out["buffers_rank0_unchanged_by_sync"] = bool(torch.equal(bs[0], bg[0]))
+        out["checkpoints_carry_rank0_buffers"] = all(bool(torch.equal(cg[0], g)) for g in cg[1:])
         out["identical"] = all(bool(torch.equal(gathered[0], g)) for g in gathered[1:])
         out["finite"] = bool(torch.isfinite(flat).all())
         out["loss"] = m
@@ -203,7 +212,7 @@ def test_ddp_buffers_after_accumulation():
     differ although every parameter is bit-identical; utils.sync_buffers re-aligns them on rank 0's values."""
     out = _spawn(_worker_step, True, 2)
     assert out["identical"] and out["finite"]
-    assert out["buffers_identical_after_sync"] and out["buffers_rank0_unchanged_by_sync"]
+    assert out["buffers_identical_after_sync"] and out["buffers_rank0_unchanged_by_sync"] and out["checkpoints_carry_rank0_buffers"]
     ref = _spawn(_worker_step, False, 2)           # the reference pattern: every forward synchronises
     assert ref["identical"] and ref["buffers_identical_after_sync"]
 

@@ -104,6 +104,13 @@ def test_bench_script_two_ranks_sharing_one_gpu(extra):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
     assert d["config"]["rccl_world_size"] == 2 and d["config"]["sync_bn"] == bool(extra)
+    comm = d["config"]["comm"]
+    assert comm["comm_savings"] is True and "exposed_ms_per_step" in comm and comm["G"]["buckets_per_step"] > 0
+    assert ("sync_bn_leg" in comm) == (not extra)                        # the plain run reports a cross-replica-BN leg beside it
+    if not extra:
+        assert comm["sync_bn_leg"]["ms_per_step"] > 0 and comm["sync_bn_leg"]["bn_layers"] > 10
+    host = d["config"]["rank_host_resources"]
+    assert host is None or (host["cores"] >= 1 and host["intra_op_threads"] >= 1)
     assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-2 * d["value"]
     assert all(v == v for v in d["config"]["losses_last_step"].values())          # finite losses
     assert "cpu_baseline" not in d
