@@ -829,6 +829,98 @@ __global__ __launch_bounds__(256) void sg2_fir_act_kernel(const T* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// fromRGB (networks.py:831-836, Conv2dLayer 1x1 over the 3-channel image + bias + lrelu + clamp): y[n][p][o] written once from the
+// planar image -- the generic path runs an fp32 [pixels x 3] GEMM, a cast and the activation pass (three tensors of the size of y)
+// ------------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sg2_fromrgb_fwd_kernel(const T* __restrict__ x /*[N][3][HW]*/, const T* __restrict__ w /*[O][3]*/,
+                                                              const float* __restrict__ bias, T* __restrict__ y, long nvec, long HW, int V, int act,
+                                                              float alpha, float gain, float clamp) {
+  constexpr int VEC = Sg<T>::VEC;
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < nvec; g += (long)gridDim.x * 256) {
+    const int v = (int)(g % V);
+    const long row = g / V, n = row / HW, p = row - n * HW;
+    const float x0 = Sg<T>::ld1(x + (n * 3 + 0) * HW + p), x1 = Sg<T>::ld1(x + (n * 3 + 1) * HW + p), x2 = Sg<T>::ld1(x + (n * 3 + 2) * HW + p);
+    float o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const T* wp = w + (size_t)(v * VEC + j) * 3;
+      float a = Sg<T>::rnd(x0 * Sg<T>::ld1(wp) + x1 * Sg<T>::ld1(wp + 1) + x2 * Sg<T>::ld1(wp + 2));
+      a = sg2_act(act, a + (bias ? Sg<T>::rnd(bias[v * VEC + j]) : 0.f), alpha) * gain;
+      if (clamp >= 0.f) a = fminf(fmaxf(a, -clamp), clamp);
+      o[j] = a;
+    }
+    Sg<T>::st(y + g * VEC, o);
+  }
+}
+
+// dz = dy * gain * act'(y) [|y| < clamp];  sums per channel o: dz x0 | dz x1 | dz x2 | dz  (columns 4 o + k);  dimg[n][c][p] = sum_o dz w[o][c]
+template <typename T>
+__global__ __launch_bounds__(256) void sg2_fromrgb_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+                                                              const T* __restrict__ w, T* __restrict__ dimg, float* __restrict__ part, long HW, int V,
+                                                              int rpb, int chunks, int act, float alpha, float gain, float clamp) {
+  constexpr int VEC = Sg<T>::VEC;
+  __shared__ float red[256 * VEC];
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
+  const int v = threadIdx.x % V, rl = threadIdx.x / V, nrl = 256 / V;
+  const long r0 = (long)chunk * rpb, r1 = min(r0 + rpb, HW);
+  const int C = V * VEC, ctot = 4 * C;
+  float acc[4][VEC], wv[3][VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k][j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wv[k][j] = dimg ? Sg<T>::ld1(w + (size_t)(v * VEC + j) * 3 + k) : 0.f;
+  }
+  for (long rb = r0; rb < r1; rb += nrl) {                    // (all lanes stay in the loop: shuffles below)
+    const long r = rb + rl;
+    const bool ok = r < r1;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (ok) {
+      const long g = ((long)n * HW + r) * V + v;
+      float gv[VEC], yv[VEC];
+      Sg<T>::ld(dy + g * VEC, gv);
+      Sg<T>::ld(y + g * VEC, yv);
+      const float x0 = Sg<T>::ld1(x + ((long)n * 3 + 0) * HW + r), x1 = Sg<T>::ld1(x + ((long)n * 3 + 1) * HW + r),
+                  x2 = Sg<T>::ld1(x + ((long)n * 3 + 2) * HW + r);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float dz = gv[j] * (gain * ((act == 3 && !(yv[j] > 0.f)) ? alpha : 1.f));
+        if (clamp >= 0.f && !(yv[j] > -clamp && yv[j] < clamp)) dz = 0.f;
+        dz = Sg<T>::rnd(dz);
+        acc[0][j] += dz * x0; acc[1][j] += dz * x1; acc[2][j] += dz * x2; acc[3][j] += dz;
+        d0 += dz * wv[0][j]; d1 += dz * wv[1][j]; d2 += dz * wv[2][j];
+      }
+    }
+    if (dimg) {
+      for (int off = V >> 1; off > 0; off >>= 1) {
+        d0 += __shfl_xor(d0, off, 64); d1 += __shfl_xor(d1, off, 64); d2 += __shfl_xor(d2, off, 64);
+      }
+      if (ok && v == 0) {
+        Sg<T>::st1(dimg + ((long)n * 3 + 0) * HW + r, d0);
+        Sg<T>::st1(dimg + ((long)n * 3 + 1) * HW + r, d1);
+        Sg<T>::st1(dimg + ((long)n * 3 + 2) * HW + r, d2);
+      }
+    }
+  }
+  float* prow = part + (size_t)blockIdx.x * ctot;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = acc[k][j];
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+      const int v2 = ch / VEC, j = ch % VEC;
+      float s = 0.f;
+      for (int q = 0; q < nrl; ++q) s += red[(q * V + v2) * VEC + j];
+      prow[4 * ch + k] = s;
+    }
+  }
+}
+
 int rows_geometry(long HW, int V, int* rpb, int* chunks) {
   const int nrl = 256 / V;
   long r = icg_cdiv(HW, 64);
@@ -1022,6 +1114,48 @@ extern "C" int icg_sg2_weight_bwd(const float* dw_conv, int layout, const float*
   if (prenorm)
     hipLaunchKernelGGL(sg2_weight_bwd_fix_kernel, dim3((unsigned)icg_cdiv(O, 256)), dim3(256), 0, st, (const float*)workspace, p.tiles_i, w, wscale, warg,
                        c0, O, I * p.RR, dw);
+  return icg_check_launch();
+}
+
+// y [N][HW][O] = clamp(gain * act(x . w + bias)) from the planar image x [N][3][HW] (same storage type), w [O][3] (prepared: gain folded, storage type)
+extern "C" int icg_sg2_fromrgb_applies(int O, int dtype) {
+  const int vec = dtype == 1 ? 8 : 4;
+  if (!icg_sg2_rows_applies(O, dtype)) return 0;
+  return (O / vec) <= 64 ? 1 : 0;               // a pixel's channel vectors sit in one wavefront (the image gradient is reduced by shuffles)
+}
+extern "C" int icg_sg2_fromrgb_fwd(const void* x, const void* w, const float* bias, void* y, int N, int64_t HW, int O, int act, float alpha,
+                                   float gain, float clamp, int dtype, void* stream) {
+  ICG_REQUIRE(x && w && y && N > 0 && HW > 0 && icg_sg2_fromrgb_applies(O, dtype) && (act == 1 || act == 3) && al16(y));
+  const int V = O / (dtype == 1 ? 8 : 4);
+  const long nvec = (long)N * HW * V;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 1)
+    hipLaunchKernelGGL(sg2_fromrgb_fwd_kernel<__half>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const __half*)x, (const __half*)w, bias, (__half*)y, nvec,
+                       (long)HW, V, act, alpha, gain, clamp);
+  else
+    hipLaunchKernelGGL(sg2_fromrgb_fwd_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, (const float*)w, bias, (float*)y, nvec,
+                       (long)HW, V, act, alpha, gain, clamp);
+  return icg_check_launch();
+}
+// tot [4 O]: (d w[o][0..2], d bias[o]) at 4 o + k, with respect to the PREPARED weight;  dimg [N][3][HW] (may be NULL).
+// workspace: icg_sg2_rows_workspace_bytes(N, HW, O, 4 O, dtype)
+extern "C" int icg_sg2_fromrgb_bwd(const void* dy, const void* y, const void* x, const void* w, void* dimg, float* tot, int N, int64_t HW, int O,
+                                   int act, float alpha, float gain, float clamp, int dtype, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  ICG_REQUIRE(dy && y && x && w && tot && N > 0 && HW > 0 && icg_sg2_fromrgb_applies(O, dtype) && (act == 1 || act == 3) && workspace);
+  ICG_REQUIRE(al16(dy) && al16(y) && workspace_bytes >= icg_sg2_rows_workspace_bytes(N, HW, O, 4 * O, dtype));
+  const int V = O / (dtype == 1 ? 8 : 4);
+  int rpb, chunks;
+  rows_geometry((long)HW, V, &rpb, &chunks);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  if (dtype == 1)
+    hipLaunchKernelGGL(sg2_fromrgb_bwd_kernel<__half>, dim3(N * chunks), dim3(256), 0, st, (const __half*)dy, (const __half*)y, (const __half*)x,
+                       (const __half*)w, (__half*)dimg, part, (long)HW, V, rpb, chunks, act, alpha, gain, clamp);
+  else
+    hipLaunchKernelGGL(sg2_fromrgb_bwd_kernel<float>, dim3(N * chunks), dim3(256), 0, st, (const float*)dy, (const float*)y, (const float*)x,
+                       (const float*)w, (float*)dimg, part, (long)HW, V, rpb, chunks, act, alpha, gain, clamp);
+  hipLaunchKernelGGL(sg2_rows_final_kernel, dim3((unsigned)icg_cdiv(4 * O, 64)), dim3(1024), 0, st, part, N, chunks, 4 * O, (float*)nullptr, tot);
   return icg_check_launch();
 }
 

@@ -14,6 +14,10 @@ import numpy as np
 import torch
 
 from ..stylegan_ops import conv2d_gradfix, fused_layers
+from . import networks
+
+
+MERGE_D_PASSES = True      # Dmain: D(generated) and D(real) as one pass over the concatenated batch (False: two passes, as the reference runs them)
 
 
 def _randn_like(t):
@@ -95,6 +99,20 @@ class StyleGAN2Loss:
             (gen_img[:, 0, 0, 0] * 0 + loss_Gpl).mean().mul(gain).backward()
 
         loss_Dgen = 0
+        if do_Dmain and not do_Dr1 and MERGE_D_PASSES and gen_z.shape[0] == real_img.shape[0]:
+            # Dmain alone (every iteration): the generated and the real batch go through D in ONE pass of 2 B images and one backward
+            # -- the same gradients as the reference's two passes (loss.py:148-178: every layer of D acts per sample; the minibatch-
+            # standard-deviation layer is told to keep the two halves apart), half the launches and one all-reduce under DDP
+            with fused_layers.first_order():
+                gen_img, _ = self.run_G(gen_z, gen_c, gen_h, sync=False)
+                b = gen_img.shape[0]
+                with networks.separate_batches(2):
+                    logits = self.run_D(torch.cat([gen_img.detach(), real_img.detach().to(gen_img.dtype)]), torch.cat([gen_c, real_c]),
+                                        torch.cat([gen_h, real_h]), sync=sync)
+                loss_Dgen, loss_Dreal = softplus(logits[:b]), softplus(-logits[b:])
+                self.stats["Loss/D/loss"] = (loss_Dgen + loss_Dreal).detach()
+                (loss_Dgen.mean() + loss_Dreal.mean()).mul(gain).backward()
+            return
         if do_Dmain:
             with fused_layers.first_order():
                 gen_img, _ = self.run_G(gen_z, gen_c, gen_h, sync=False)

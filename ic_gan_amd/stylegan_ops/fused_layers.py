@@ -462,10 +462,23 @@ class ConvCfg:
 class _ConvFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, f2, cfg, owner):
-        x = _cl(x)
         N = int(x.shape[0])
         O, I, R = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
         dt, pl = _dt(x), cfg.plan
+        ctx.from_rgb = False
+        if (I == 3 and R == 1 and pl.pre is None and pl.post is None and pl.geo.stride == 1 and pl.geo.pad == 0
+                and (cfg.has_bias or cfg.act != 1 or cfg.clamp >= 0) and L.query("icg_sg2_fromrgb_applies", O, dt)):
+            # fromRGB: y written once from the planar image (csrc/sg2_fused.hip) instead of an fp32 [pixels x 3] GEMM, a cast and the
+            # activation pass
+            xin = x.contiguous()
+            H, W = int(x.shape[2]), int(x.shape[3])
+            p = _prep(owner, weight, x.dtype, False, cfg.weight_gain, pl.flip, False)
+            y = torch.empty((N, O, H, W), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+            L.call("icg_sg2_fromrgb_fwd", xin, p.w_fwd, bias, y, N, H * W, O, cfg.act, 0.2, cfg.act_gain, cfg.clamp, dt)
+            ctx.cfg, ctx.p, ctx.plain, ctx.in_hw, ctx.from_rgb = cfg, p, False, (H, W), True
+            ctx.save_for_backward(xin, y, weight, f2)
+            return y
+        x = _cl(x)
         # a pure gain (no bias, linear, no clamp: the resnet skip) rides in the prepared weight
         plain = cfg.act == 1 and not cfg.has_bias and cfg.clamp < 0
         p = _prep(owner, weight, x.dtype, False, cfg.weight_gain * (cfg.act_gain if plain else 1.0), pl.flip, False)
@@ -497,6 +510,15 @@ class _ConvFn(Function):
         O, I, R = int(weight.shape[0]), int(weight.shape[1]), int(weight.shape[2])
         dt, dev = _dt(xin), xin.device
         dz = _cl(dy.to(xin.dtype))
+        if ctx.from_rgb:
+            HW = ctx.in_hw[0] * ctx.in_hw[1]
+            tot = torch.empty(O, 4, device=dev, dtype=torch.float32)
+            dimg = torch.empty_like(xin) if ctx.needs_input_grad[0] else None
+            ws, nb = _rows_ws(N, HW, O, 4 * O, dt, dev)
+            L.call("icg_sg2_fromrgb_bwd", dz, y, xin, p.w_fwd, dimg, tot, N, HW, O, cfg.act, 0.2, cfg.act_gain, cfg.clamp, dt, ws, nb)
+            dweight = (tot[:, :3] * p.gain).reshape(weight.shape) if (ctx.needs_input_grad[1] and not G.weight_gradients_disabled) else None
+            dbias = tot[:, 3].contiguous() if (cfg.has_bias and ctx.needs_input_grad[2]) else None
+            return dimg, dweight, dbias, None, None, None
         dbias = None
         if not ctx.plain:
             HWo = int(dz.shape[2]) * int(dz.shape[3])

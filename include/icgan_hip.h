@@ -683,6 +683,15 @@ size_t icg_sg2_weight_bwd_workspace_bytes(int O, int I);
 int icg_sg2_weight_bwd(const float* dw_conv, int layout, const float* t, const float* s, int N, const float* w, const float* wscale,
                        const int* warg, int prenorm, float c0, int round_f16, float* dw, int O, int I, int R, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* fromRGB (networks.py:831-836: Conv2dLayer 1x1 over the 3-channel image, bias, activation, clamp) as one pass: x [N][3][HW] planar and
+ * w [O][3] (the prepared weight: gain folded in) in the storage type, y [N][HW][O] = clamp(gain * act(x . w + bias)); and its gradient:
+ * tot [4 O] = (d w[o][0..2], d bias[o]) at 4 o + k with respect to the prepared weight, dimg [N][3][HW] (may be NULL).
+ * workspace: icg_sg2_rows_workspace_bytes(N, HW, O, 4 O, dtype). */
+int icg_sg2_fromrgb_applies(int O, int dtype);
+int icg_sg2_fromrgb_fwd(const void* x, const void* w, const float* bias, void* y, int N, int64_t HW, int O, int act, float alpha,
+                        float gain, float clamp, int dtype, void* stream);
+int icg_sg2_fromrgb_bwd(const void* dy, const void* y, const void* x, const void* w, void* dimg, float* tot, int N, int64_t HW, int O,
+                        int act, float alpha, float gain, float clamp, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* ToRGB (networks.py:450-486) as one pass over x: y[n][p][o] = clamp(sum_c (x * s)[n][p][c] w[o][c] + bias[o]), o < 3, stored in the
  * activation type (kept for the backward) and accumulated into the fp32 NCHW image: img_out = img_in + y (img_in may be NULL). */
 int icg_sg2_torgb_applies(int C, int dtype);

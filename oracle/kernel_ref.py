@@ -1332,6 +1332,40 @@ def icg_sg2_weight_bwd(dw_conv, layout, t, s, N, w, wscale, warg, prenorm, c0, r
     mem(dw)[: O * I * RR].copy_(out.reshape(-1))
 
 
+def icg_sg2_fromrgb_applies(O, dtype):
+    return int(bool(icg_sg2_rows_applies(O, dtype)) and O // (8 if dtype == 1 else 4) <= 64)
+
+
+def icg_sg2_fromrgb_fwd(x, w, bias, y, N, HW, O, act, alpha, gain, clamp, dtype):
+    xv = mem(x)[: N * 3 * HW].view(N, 3, HW).float()
+    wv = mem(w)[: O * 3].view(O, 3).float()
+    a = _rt(torch.einsum("ncp,oc->npo", xv, wv), dtype)
+    if bias is not None:
+        a = a + _rt(mem(bias)[:O], dtype)
+    o = _sg2_act(a, act, alpha) * gain
+    if clamp >= 0:
+        o = o.clamp(-clamp, clamp)
+    mem(y)[: N * HW * O].copy_(o.reshape(-1).to(y.dtype))
+
+
+def icg_sg2_fromrgb_bwd(dy, y, x, w, dimg, tot, N, HW, O, act, alpha, gain, clamp, dtype, workspace, workspace_bytes):
+    g = mem(dy)[: N * HW * O].view(N, HW, O).float()
+    yv = mem(y)[: N * HW * O].view(N, HW, O).float()
+    slope = torch.where(yv > 0, torch.ones_like(yv), torch.full_like(yv, alpha)) if act == 3 else torch.ones_like(yv)
+    dz = g * (gain * slope)
+    if clamp >= 0:
+        dz = torch.where((yv > -clamp) & (yv < clamp), dz, torch.zeros_like(dz))
+    dz = _rt(dz, dtype).double()
+    xv = mem(x)[: N * 3 * HW].view(N, 3, HW).double()
+    out = torch.zeros(O, 4, dtype=torch.float64)
+    out[:, :3] = torch.einsum("npo,ncp->oc", dz, xv)
+    out[:, 3] = dz.sum(dim=[0, 1])
+    mem(tot)[: 4 * O].copy_(out.float().reshape(-1))
+    if dimg is not None:
+        di = torch.einsum("npo,oc->ncp", dz, mem(w)[: O * 3].view(O, 3).double())
+        mem(dimg)[: N * 3 * HW].copy_(di.float().reshape(-1).to(dimg.dtype))
+
+
 def icg_sg2_torgb_applies(C, dtype):
     vec = 8 if dtype == 1 else 4
     if dtype not in (0, 1) or C < vec or C % vec:

@@ -64,8 +64,12 @@ def _fail(cond, msg, ratio):
 
 
 DENSE_EXCEED_SHARE = 1.0 / 64     # dense groups: share of a tensor's samples that may exceed the per-element tolerance ...
-DENSE_MAX_MULT = 3.25             # ... by at most this factor (round 4: 4.0 -> 3.25; measured worst 2.95, profiles/r04_parity_report.txt),
-DENSE_RMS_FRAC = 0.3              # ... while the rms of the differences stays below this fraction of the tolerance (0.5 -> 0.3; worst 0.22)
+# round 5: GRAD_RTOL 1.5e-2 -> 1e-2 (below); the two dense OUTLIER bounds keep their absolute size (x 1.5 in units of the new tolerance):
+# they bound isolated decision flips -- what an fp32 ReLU / max-pool network does to itself (profiles/r03_reference_sensitivity.txt) -- and the
+# arithmetic behind them is pinned two orders of magnitude tighter with the fp64 forward's decisions imposed, at cfg1, cfg2 AND the
+# headline cfg3 (tests/test_decision_replay_gpu.py: rms <= 1e-4 / 2e-4, max <= 2e-3 of the tensor rms)
+DENSE_MAX_MULT = 4.875            # ... by at most this factor (= 3.25 x 1.5e-2 / 1e-2; measured worst: profiles/r05_parity_report.txt),
+DENSE_RMS_FRAC = 0.45             # ... while the rms of the differences stays below this fraction of the tolerance (= 0.3 x 1.5)
 
 
 def check_group(gold, prefix, tensors, rtol, atol, what="", noise_floor=2e-3, extra_atol=None):
@@ -135,7 +139,7 @@ def check_group(gold, prefix, tensors, rtol, atol, what="", noise_floor=2e-3, ex
     return worst
 
 
-GRAD_RTOL = 1.5e-2     # of the tensor rms; the goldens' own fp32-vs-fp64 conditioning is <= 3.5e-3 (B = 4 cases)
+GRAD_RTOL = 1e-2       # of the tensor rms (round 5: 1.5e-2 -> 1e-2); the goldens' own fp32-vs-fp64 conditioning is <= 3.5e-3 (B = 4 cases)
 STATE_RTOL = 5e-3
 COND_K = 4.0           # real-width cases: + COND_K x |fp32 reference - fp64 reference| per tensor (see conditioning_slack)
 

@@ -377,3 +377,24 @@ def test_modulated_convolution_in_one_launch(B, H, W, Cin, Cout, Rk, stride, pad
     cr = torch.empty(B, Ho, Wo, Cout, dtype=torch.float16)
     R.icg_modconv2d_f16(x.cpu(), s.cpu(), w.cpu(), cr, None, None, None, 0, None, None, 3, 0.2, 1.4, 2.0, B, H, W, Cin, Ho, Wo, Cout, Rk, stride, pad, zins)
     close(c1.float(), cr.float(), 2e-3, "c vs kernel_ref")
+
+
+@pytest.mark.parametrize("N,HW,O", [(2, 64, 16), (3, 100, 32), (2, 4096, 64), (2, 777, 128), (2, 256, 512)])
+@pytest.mark.parametrize("half", [False, True])
+def test_fromrgb_forward_and_backward(N, HW, O, half):
+    dt = 1 if half else 0
+    if not R.icg_sg2_fromrgb_applies(O, dt):
+        assert not _L().query("icg_sg2_fromrgb_applies", O, dt)
+        pytest.skip("shape not served")
+    cast = (lambda t: t.half()) if half else (lambda t: t)
+    x, w, bias = cast(rnd(N, 3, HW, seed=1)), cast(rnd(O, 3, seed=2, scale=0.5)), rnd(O, seed=3)
+    y = torch.empty(N, HW, O, dtype=x.dtype)
+    ((gy, ry),) = run_pair("icg_sg2_fromrgb_fwd", [x, w, bias, y, N, HW, O, 3, 0.2, float(np.sqrt(2)), 1.2, dt], [3])
+    close(gy.float(), ry.float(), 2e-3 if half else 2e-6, "fromrgb y")
+    dy = act(N, HW, O, half, 5)
+    dimg, tot = torch.empty_like(x), torch.empty(4 * O)
+    nb = R.icg_sg2_rows_workspace_bytes(N, HW, O, 4 * O, dt)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8)
+    (gd, rd), (gt, rt) = run_pair("icg_sg2_fromrgb_bwd", [dy, ry, x, w, dimg, tot, N, HW, O, 3, 0.2, float(np.sqrt(2)), 1.2, dt, ws, nb], [4, 5])
+    close(gd.float(), rd.float(), 3e-3 if half else 1e-5, "fromrgb dimg")
+    close(gt, rt, 5e-5, "fromrgb sums")

@@ -298,5 +298,7 @@ def test_fp16_mfma_route_equals_the_fp32_kernel_route_hip(name, monkeypatch):
             fh.write("%s: forward max err / max %.3e; gradient rel L2: median %.3e, worst %.3e (%s), %d tensors\n" % (
                 name, fwd, med, worst[1], worst[0], len(rel)))
     # forward: <= 2 fp16 ulps of the largest activation; gradients: the reference comparison above needs 8e-2 ... 3e-1 of the rms per ELEMENT
+    # measured on MI355X (round 5): ic_r32_fp16 forward 7e-6, gradients median 3.8e-5 / worst 1.8e-4; cfg4_r256_fp16 forward 1.2e-3
+    # (one fp16 ulp of the largest activation), gradients median 3.8e-3 / worst 1.4e-2 (Dmain b8.conv1.bias)
     assert fwd <= 2.5e-3
-    assert med <= 1e-2 and worst[1] <= 1e-1, (med, worst)
+    assert med <= 8e-3 and worst[1] <= 3e-2, (med, worst)
