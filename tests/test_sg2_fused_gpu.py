@@ -246,7 +246,8 @@ def _check(fn, mod, inputs, half):
     for n, a, b in zip(names, gp1, gp0):
         assert (a is None) == (b is None), n
         if a is not None:
-            close(a, b, 6e-3 if half else 5e-5, "grad " + n)
+            # (a scalar noise strength is one sum of ~1e5 ... 1e6 signed fp16 products: the composed path rounds partial results to fp16)
+            close(a, b, (3e-2 if a.numel() == 1 else 6e-3) if half else 5e-5, "grad " + n)
 
 
 @pytest.mark.parametrize("cin,cout,res,up,half,noise_mode,n", [(512, 512, 16, 1, False, "random", 4), (512, 512, 16, 2, False, "const", 4),
