@@ -73,7 +73,13 @@ class KernelTimer:
             # StyleGAN2 (cfg4): general-geometry convolutions and the two HBM-bound plugins
             "icg_conv2d_g_fprop": (4, "gconv"), "icg_conv2d_g_fprop_ws": (4, "gconv"), "icg_conv2d_tr2_fprop": (4, "tr2"),
             "icg_conv2d_g_wgrad": (3, "gconv"), "icg_conv2d_g_fprop_f16": (3, "hconv"), "icg_conv2d_g_wgrad_f16": (3, "hwgrad"), "icg_bias_act": (6, "bias_act"), "icg_bias_act_typed": (6, "bias_act"),
-            "icg_upfirdn2d": (3, "upfirdn2d"), "icg_upfirdn2d_nhwc": (3, "upfirdn2d"), "icg_upfirdn2d_typed": (3, "upfirdn2d")}
+            "icg_upfirdn2d": (3, "upfirdn2d"), "icg_upfirdn2d_nhwc": (3, "upfirdn2d"), "icg_upfirdn2d_typed": (3, "upfirdn2d"),
+            # fused StyleGAN2 layers (round 5): the fp16 convolution with the layer epilogue on its accumulators / the style scale on its
+            # A fragments, and the HBM-bound row kernels of csrc/sg2_fused.hip (algorithmic bytes = one pass over each activation operand)
+            "icg_conv2d_g_fprop_f16_act": (13, "hconv"), "icg_modconv2d_f16": (14, "hconv"),
+            "icg_sg2_act_fwd": (7, "sg2_rows"), "icg_sg2_modulate": (3, "sg2_rows"), "icg_sg2_act_bwd": (9, "sg2_rows"),
+            "icg_sg2_modulate_bwd": (5, "sg2_rows"), "icg_sg2_torgb_fwd": (8, "sg2_rows"), "icg_sg2_torgb_bwd": (10, "sg2_rows"),
+            "icg_sg2_fromrgb_fwd": (4, "sg2_rows"), "icg_sg2_fromrgb_bwd": (6, "sg2_rows"), "icg_sg2_fir_act_fwd": (9, "sg2_fir")}
 
     def __init__(self, period=4):
         # Stratified sampling: every launch is COUNTED per (entry point, shape); every `period`-th launch of such a key is bracketed
@@ -117,8 +123,17 @@ class KernelTimer:
             if not timer.enabled or name not in timer.SPEC:
                 return raw(name, *args)
             sl, mode = timer.SPEC[name]
-            if mode in ("bias_act", "upfirdn2d"):          # HBM-bound plugins: algorithmic bytes / HIP-event time
-                if mode == "bias_act":
+            if mode in ("bias_act", "upfirdn2d", "sg2_rows", "sg2_fir"):          # HBM-bound plugins: algorithmic bytes / HIP-event time
+                if mode == "sg2_rows":       # N, HW, C at args[sl:sl + 3]; storage type = the activation tensors'; one pass per activation operand
+                    N, HW, C = args[sl:sl + 3]
+                    acts = [a for a in args[:sl] if isinstance(a, torch.Tensor) and a.numel() >= N * HW * min(C, 3)]
+                    byt = float(sum(a.numel() * a.element_size() for a in acts))
+                elif mode == "sg2_fir":
+                    N, C, H, W = args[sl:sl + 4]
+                    oh, ow = args[sl + 11], args[sl + 12]
+                    esz = 2 if args[-1] == 1 else 4
+                    byt = float(N) * C * (H * W + (2 if args[2] is not None else 1) * oh * ow) * esz
+                elif mode == "bias_act":
                     n = args[sl]
                     esz = {1: 2, 2: 8}.get(args[-1], 4) if name.endswith("typed") else 4
                     byt = float(n) * esz * (2 + sum(1 for a in args[2:5] if a is not None))     # x, y (+ xref / yref / dy)
@@ -140,8 +155,10 @@ class KernelTimer:
                 return
             if mode == "hconv":      # the same gather on fp16 operands (csrc/hconv.hip); zero-inserted sources run as four tap phases
                 B, Hin, Win, Cin, Hout, Wout, Cout, R = args[sl:sl + 8]
-                alg = exe = 2.0 * B * Hout * Wout * Cout * Cin * R * R / (4.0 if args[sl + 10] == 2 else 1.0)   # phased: R R / 4 taps per output
-                byt = 2.0 * (B * (Hin * Win * Cin + Hout * Wout * Cout) + Cout * Cin * R * R)
+                zins = args[sl + 10] if len(args) > sl + 10 else 0
+                alg = exe = 2.0 * B * Hout * Wout * Cout * Cin * R * R / (4.0 if zins == 2 else 1.0)   # phased: R R / 4 taps per output
+                outs = 1 if name == "icg_conv2d_g_fprop_f16" else sum(1 for a in (args[3 if name == "icg_modconv2d_f16" else 2], args[4 if name == "icg_modconv2d_f16" else 3]) if a is not None)
+                byt = 2.0 * (B * (Hin * Win * Cin + outs * Hout * Wout * Cout) + Cout * Cin * R * R)
             elif mode == "hwgrad":   # fp16 weight gradient (csrc/hwgrad.hip): executed on 128 x 128 tiles of the [R R Cin][Cout] result
                 B, Hin, Win, Cin, Hout, Wout, Cout, R = args[sl:sl + 8]
                 alg = 2.0 * B * Hout * Wout * Cout * Cin * R * R
@@ -216,7 +233,9 @@ class KernelTimer:
                 kname = "icg_hwgrad_kernel(HwgradP)"
             elif mode == "hconv":
                 cout = args[sl + 6]
-                kname = "void icg_hconv_kernel<%d>(HconvP)" % (4 if cout % 128 == 0 else (3 if cout % 96 == 0 else 2))
+                ep = 0 if name == "icg_conv2d_g_fprop_f16" else (1 if name == "icg_conv2d_g_fprop_f16_act" else int(args[4] is not None))
+                mod = int(name == "icg_modconv2d_f16" and args[1] is not None)
+                kname = "void icg_hconv_kernel<%d, %d, %d>(HconvP)" % (4 if cout % 128 == 0 else (3 if cout % 96 == 0 else 2), ep, mod)
             elif mode == "from_v":
                 kname = "composite: weight gradient from the saved V planes (wino4_dy_kernel + %d batched split-K %s GEMMs + reduce + wino4_dw_kernel)" % (args[sl + 5], wg_gemm())
             elif mode in ("rs_up", "rs_down"):
@@ -334,7 +353,7 @@ def csrc_sha256():
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ic_gan_amd", "csrc")
     # the traffic file is taken on the cfg3 step: sources none of whose kernels that step launches (StyleGAN2's fp16 convolutions and
     # plugins, the kNN build) do not invalidate it
-    other = {"hconv.hip", "hwgrad.hip", "stylegan_ops.hip", "stylegan_ops_typed.hip", "knn.hip"}
+    other = {"hconv.hip", "hwgrad.hip", "stylegan_ops.hip", "stylegan_ops_typed.hip", "knn.hip", "sg2_fused.hip"}
     for path in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
         if os.path.basename(path) in other:
             continue
