@@ -17,8 +17,11 @@ reference does (networks.py:505-515, 581-600, 793-870) -- fp16 storage through b
 fp16 weights, and convolutions on the fp16-input MFMA kernels (csrc/hconv.hip, csrc/hwgrad.hip: exact fp16 products, fp32
 accumulation, one rounding per convolution output -- the reference's cuDNN arithmetic there); layers those kernels do not serve
 (3-channel toRGB / fromRGB) run on the exact-fp32 kernels between two casts.
-Not fused (SURVEY 8(f) N1 asks for it, VERDICT r03 missing 2): style modulation, demodulation, noise and the per-pass weight
-preparation are PyTorch elementwise ops around the convolution (stylegan_ops/modconv.py).
+Fused: in the phases that differentiate once (Gmain, Dmain -- every iteration) and without autograd every
+SynthesisLayer / ToRGBLayer / Conv2dLayer / FullyConnectedLayer is ONE autograd node (stylegan_ops/fused_layers.py): weights prepared
+once per optimiser step, the style scale applied to the convolution's A fragments, demodulation x noise + bias + lrelu + clamp on its
+accumulators (csrc/hconv.hip MOD / EP, csrc/sg2_fused.hip).  The lazy regularisers (R1, path length) differentiate twice and run the
+composed operators below (stylegan_ops/modconv.py), to which every fused layer is held equal in tests/test_sg2_fused_{cpu,gpu}.py.
 """
 import contextlib
 
@@ -26,6 +29,7 @@ import numpy as np
 import torch
 
 from ..stylegan_ops import bias_act, conv2d_gradfix, conv2d_resample, fused_layers, modulated_conv2d, upfirdn2d
+from ..stylegan_ops import modconv as _modconv
 
 _DEF_GAIN = {name: spec[2] for name, spec in bias_act.activation_funcs.items()}
 
@@ -163,8 +167,10 @@ class SynthesisLayer(torch.nn.Module):
     def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1):
         assert noise_mode in ["random", "const", "none"]
         assert x.shape[1] == self.weight.shape[1] and x.shape[2] == self.resolution // self.up
-        pl = fused_layers.modconv_applies(x, self.weight, w, self.affine.weight, self.up, self.padding,
-                                          int(self.resample_filter.shape[-1]), self.up == 1)
+        pl = None
+        if not (fused_modconv and _modconv.GROUPED_FUSED_MODCONV):      # (the literal grouped route is a request for that op graph)
+            pl = fused_layers.modconv_applies(x, self.weight, w, self.affine.weight, self.up, self.padding,
+                                              int(self.resample_filter.shape[-1]), self.up == 1)
         if pl is not None:      # one autograd node for the whole layer (stylegan_ops/fused_layers.py)
             base, bstride = None, 0
             if self.use_noise and noise_mode == "random":

@@ -7,7 +7,12 @@ computed through the same branch by default: x*s -> conv(w) -> *d equals conv(w*
 rounding here, and needs no per-sample weight tensor [N, O, I, k, k] in HBM.  `GROUPED_FUSED_MODCONV = True` switches a
 `fused_modconv=True` call to the reference's literal formulation (networks.py:64-73,100-117: per-sample weights, one group per
 sample through `conv2d_resample(groups=N)`) — N convolutions of batch 1 instead of one of batch N, there for parity checks
-against the reference's fused goldens and for callers who ask for exactly that op graph."""
+against the reference's fused goldens and for callers who ask for exactly that op graph.
+
+Role since round 5: this composed form -- closed under differentiation -- serves the phases that differentiate TWICE (path-length and R1
+regularisation) and every shape the fused layers do not take; the first-order phases and inference run a SynthesisLayer / ToRGBLayer
+as one autograd node with modulation and demodulation inside the convolution kernel (fused_layers.py), which the tests hold equal to
+this function (outputs and all first-order gradients, fp32 and fp16)."""
 import numpy as np
 import torch
 
