@@ -130,7 +130,7 @@ class KernelTimer:
                     byt = float(sum(a.numel() * a.element_size() for a in acts))
                 elif mode == "sg2_fir":
                     N, C, H, W = args[sl:sl + 4]
-                    oh, ow = args[sl + 11], args[sl + 12]
+                    oh, ow = args[sl + 12], args[sl + 13]
                     esz = 2 if args[-1] == 1 else 4
                     byt = float(N) * C * (H * W + (2 if args[2] is not None else 1) * oh * ow) * esz
                 elif mode == "bias_act":

@@ -224,15 +224,17 @@ __global__ __launch_bounds__(256) void sg2_style_prep_kernel(const float* __rest
 // elementwise: modulate, demodulate + noise + bias + activation + clamp
 // ------------------------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void sg2_modulate_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ xs, long nvec,
-                                                           long HW, int V) {
+__global__ __launch_bounds__(256) void sg2_modulate_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ xs, unsigned nrows,
+                                                           unsigned HW, int V) {
   constexpr int VEC = Sg<T>::VEC;
-  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < nvec; g += (long)gridDim.x * 256) {
-    const int v = (int)(g % V);
-    const long n = (g / V) / HW;
+  const unsigned t0 = blockIdx.x * 256u + threadIdx.x;
+  const unsigned v = t0 % (unsigned)V, rstep = gridDim.x * 256u / (unsigned)V;
+  for (unsigned row = t0 / (unsigned)V; row < nrows; row += rstep) {
+    const unsigned n = row / HW;
+    const size_t g = (size_t)row * V + v;
     float xv[VEC];
     Sg<T>::ld(x + g * VEC, xv);
-    const float* sp = s + (n * V + v) * VEC;
+    const float* sp = s + ((size_t)n * V + v) * VEC;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) xv[j] = xv[j] * Sg<T>::rnd(sp[j]);
     Sg<T>::st(xs + g * VEC, xv);
@@ -242,24 +244,31 @@ __global__ __launch_bounds__(256) void sg2_modulate_kernel(const T* __restrict__
 __device__ __forceinline__ float sg2_act(int act, float v, float alpha) { return (act == 3 && v < 0.f) ? v * alpha : v; }
 
 // y = clamp(gain * act(c * d[n][o] + noise[n][p] * strength + bias[o]))   (act 1 = linear, 3 = lrelu)
+// The grid stride is a multiple of V (a power of two <= 256), so a thread keeps its channel vector: bias in registers, 32-bit index math
 template <typename T>
 __global__ __launch_bounds__(256) void sg2_act_fwd_kernel(const T* __restrict__ c, const float* __restrict__ d, const float* __restrict__ noise,
                                                           long noise_bstride, const float* __restrict__ strength, const float* __restrict__ bias,
-                                                          T* __restrict__ y, long nvec, long HW, int V, int act, float alpha, float gain, float clamp) {
+                                                          T* __restrict__ y, unsigned nrows, unsigned HW, int V, int act, float alpha, float gain,
+                                                          float clamp) {
   constexpr int VEC = Sg<T>::VEC;
   const float st = (noise && strength) ? *strength : 1.f;
-  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < nvec; g += (long)gridDim.x * 256) {
-    const int v = (int)(g % V);
-    const long row = g / V, n = row / HW, p = row - n * HW;
-    float cv[VEC], bv[VEC];
+  const unsigned t0 = blockIdx.x * 256u + threadIdx.x;
+  const unsigned v = t0 % (unsigned)V, rstep = gridDim.x * 256u / (unsigned)V;
+  float bv[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) bv[j] = bias ? Sg<T>::rnd(bias[v * VEC + j]) : 0.f;
+  for (unsigned row = t0 / (unsigned)V; row < nrows; row += rstep) {
+    const unsigned n = row / HW, p = row - n * HW;
+    const size_t g = (size_t)row * V + v;
+    float cv[VEC];
     Sg<T>::ld(c + g * VEC, cv);
-    const float nz = noise ? Sg<T>::rnd(noise[n * noise_bstride + p] * st) : 0.f;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) bv[j] = bias ? Sg<T>::rnd(bias[v * VEC + j]) : 0.f;
+    const float nz = noise ? Sg<T>::rnd(noise[(size_t)n * noise_bstride + p] * st) : 0.f;
     if (d) {
-      const float* dp = d + (n * V + v) * VEC;
+      float dv[VEC];
+      Sg<float>::ld(d + ((size_t)n * V + v) * VEC, dv);
+      if (VEC == 8) Sg<float>::ld(d + ((size_t)n * V + v) * VEC + 4, dv + 4);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) cv[j] = Sg<T>::rnd(__fmaf_rn(cv[j], Sg<T>::rnd(dp[j]), nz));      // fma.fma = addcmul: one rounding
+      for (int j = 0; j < VEC; ++j) cv[j] = Sg<T>::rnd(__fmaf_rn(cv[j], Sg<T>::rnd(dv[j]), nz));      // fma.fma = addcmul: one rounding
     } else if (noise) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) cv[j] = Sg<T>::rnd(cv[j] + nz);
@@ -752,79 +761,118 @@ __global__ __launch_bounds__(256) void sg2_torgb_bwd_kernel(const float* __restr
 // values: c = fir(x) (stored for the demodulation gradient), y = clamp(gain * act(c * d + noise + bias)).  A thread owns one 16-byte
 // channel vector of a vertical strip of TY outputs, as the stand-alone upfirdn2d kernel does (csrc/stylegan_ops_typed.hip).
 // ------------------------------------------------------------------------------------------------------------------------------
-template <typename T, int TY>
+// TX output columns x TY output rows per thread: the (TY + fh - 1) x (TX + fw - 1) window is loaded once for TX TY outputs (TX = 2, TY = 4
+// with the 4 x 4 filter of the networks: 35 loads per 8 outputs; the stand-alone upfirdn2d kernel does 28 per 4 and is bound by L1 traffic).
+// FS > 0: filter size known at compile time (fully unrolled tap selection); FS = 0: any fh x fw <= 64 taps.
+template <typename T, int TY, int TX, int FS>
 __global__ __launch_bounds__(256) void sg2_fir_act_kernel(const T* __restrict__ x, const float* __restrict__ f, T* __restrict__ cout_,
                                                           T* __restrict__ y, const float* __restrict__ d, const float* __restrict__ noise,
                                                           long noise_bstride, const float* __restrict__ strength, const float* __restrict__ bias,
-                                                          int N, int H, int W, int CV, int fh, int fw, int padx0, int pady0, float fgain,
+                                                          int N, int H, int W, int CV, int fh_, int fw_, int padx0, int pady0, int flip, float fgain,
                                                           int outH, int outW, int act, float alpha, float gain, float clamp) {
   constexpr int VEC = Sg<T>::VEC;
+  const int fh = FS ? FS : fh_, fw = FS ? FS : fw_;
   __shared__ float fs[64];
   for (int i = threadIdx.x; i < fh * fw; i += blockDim.x) {
     const int ty = i / fw, tx = i - ty * fw;
-    fs[i] = f[(fh - 1 - ty) * fw + (fw - 1 - tx)] * fgain;            // flip_filter = False: correlation with the flipped filter
+    fs[i] = f[(flip ? ty : fh - 1 - ty) * fw + (flip ? tx : fw - 1 - tx)] * fgain;      // upfirdn2d: correlation with the flipped filter unless flip_filter
   }
   __syncthreads();
   const float st = (noise && strength) ? *strength : 1.f;
-  const int strips = (outH + TY - 1) / TY;
-  const long total = (long)N * strips * outW * CV;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % CV);
-    long t = i / CV;
-    const int ox = (int)(t % outW);
-    t /= outW;
+  const unsigned strips = (unsigned)((outH + TY - 1) / TY), cols = (unsigned)((outW + TX - 1) / TX);
+  const unsigned total = (unsigned)N * strips * cols * (unsigned)CV;
+  const unsigned t0 = blockIdx.x * 256u + threadIdx.x;
+  const unsigned cv = t0 % (unsigned)CV;                            // (grid stride is a multiple of CV: the thread keeps its channel vector)
+  float bv[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) bv[e] = bias ? Sg<T>::rnd(bias[cv * VEC + e]) : 0.f;
+  for (unsigned i = t0; i < total; i += gridDim.x * 256u) {
+    unsigned t = i / (unsigned)CV;
+    const int ox0 = (int)(t % cols) * TX;
+    t /= cols;
     const int ys = (int)(t % strips), n = (int)(t / strips);
     const int oy0 = ys * TY;
-    const int bx = ox - padx0, by0 = oy0 - pady0;
-    const int ix0 = max(bx, 0), ix1 = min(bx + fw, W);
-    const int iy0 = max(by0, 0), iy1 = min(min(oy0 + TY, outH) - 1 - pady0 + fh, H);
-    float acc[TY][VEC];
+    const int bx = ox0 - padx0, by0 = oy0 - pady0;
+    float acc[TY][TX][VEC];
 #pragma unroll
     for (int j = 0; j < TY; ++j)
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) acc[j][e] = 0.f;
-    const T* xp = x + ((long)n * H * W * CV + cv) * VEC;
-    for (int iy = iy0; iy < iy1; ++iy) {
-      const int zy = iy - by0;
-      for (int ix = ix0; ix < ix1; ++ix) {
-        const int tx = ix - bx;
-        float v[VEC];
-        Sg<T>::ld(xp + ((long)iy * W + ix) * CV * VEC, v);
+      for (int q = 0; q < TX; ++q)
 #pragma unroll
-        for (int j = 0; j < TY; ++j) {
-          const int ty = zy - j;
-          if (ty >= 0 && ty < fh) {
-            const float w = fs[ty * fw + tx];
+        for (int e = 0; e < VEC; ++e) acc[j][q][e] = 0.f;
+    const T* xp = x + ((size_t)n * H * W * CV + cv) * VEC;
+    if (FS) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[j][e] += v[e] * w;
+      for (int r = 0; r < TY + FS - 1; ++r) {
+        const int iy = by0 + r;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int cc = 0; cc < TX + FS - 1; ++cc) {
+          const int ix = bx + cc;
+          if (ix < 0 || ix >= W) continue;
+          float v[VEC];
+          Sg<T>::ld(xp + ((size_t)iy * W + ix) * CV * VEC, v);
+#pragma unroll
+          for (int j = 0; j < TY; ++j) {
+            if (r - j < 0 || r - j >= FS) continue;                 // (compile-time after unrolling)
+#pragma unroll
+            for (int q = 0; q < TX; ++q) {
+              if (cc - q < 0 || cc - q >= FS) continue;
+              const float w = fs[(r - j) * FS + (cc - q)];
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) acc[j][q][e] += v[e] * w;
+            }
+          }
+        }
+      }
+    } else {
+      const int ix0 = max(bx, 0), ix1 = min(bx + TX - 1 + fw, W);
+      const int iy0 = max(by0, 0), iy1 = min(by0 + TY - 1 + fh, H);
+      for (int iy = iy0; iy < iy1; ++iy) {
+        for (int ix = ix0; ix < ix1; ++ix) {
+          float v[VEC];
+          Sg<T>::ld(xp + ((size_t)iy * W + ix) * CV * VEC, v);
+#pragma unroll
+          for (int j = 0; j < TY; ++j) {
+            const int ty = iy - by0 - j;
+            if (ty < 0 || ty >= fh) continue;
+#pragma unroll
+            for (int q = 0; q < TX; ++q) {
+              const int tx = ix - bx - q;
+              if (tx < 0 || tx >= fw) continue;
+              const float w = fs[ty * fw + tx];
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) acc[j][q][e] += v[e] * w;
+            }
           }
         }
       }
     }
-    float dv[VEC], bv[VEC];
+    float dv[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      dv[e] = d ? Sg<T>::rnd(d[((long)n * CV + cv) * VEC + e]) : 1.f;
-      bv[e] = bias ? Sg<T>::rnd(bias[cv * VEC + e]) : 0.f;
-    }
+    for (int e = 0; e < VEC; ++e) dv[e] = d ? Sg<T>::rnd(d[((size_t)n * CV + cv) * VEC + e]) : 1.f;
 #pragma unroll
     for (int j = 0; j < TY; ++j) {
       if (oy0 + j >= outH) break;
-      const long o = ((((long)n * outH + oy0 + j) * outW + ox) * CV + cv) * VEC;
-      const float nz = noise ? Sg<T>::rnd(noise[n * noise_bstride + (long)(oy0 + j) * outW + ox] * st) : 0.f;
-      float cv_[VEC], yv[VEC];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        cv_[e] = Sg<T>::rnd(acc[j][e]);
-        float z = cv_[e];
-        if (d) z = Sg<T>::rnd(__fmaf_rn(z, dv[e], nz));
-        else if (noise) z = Sg<T>::rnd(z + nz);
-        float o2 = sg2_act(act, z + bv[e], alpha) * gain;
-        if (clamp >= 0.f) o2 = fminf(fmaxf(o2, -clamp), clamp);
-        yv[e] = o2;
+      for (int q = 0; q < TX; ++q) {
+        if (ox0 + q >= outW) break;
+        const size_t o = ((((size_t)n * outH + oy0 + j) * outW + ox0 + q) * CV + cv) * VEC;
+        const float nz = noise ? Sg<T>::rnd(noise[n * noise_bstride + (long)(oy0 + j) * outW + ox0 + q] * st) : 0.f;
+        float cv_[VEC], yv[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          cv_[e] = Sg<T>::rnd(acc[j][q][e]);
+          float z = cv_[e];
+          if (d) z = Sg<T>::rnd(__fmaf_rn(z, dv[e], nz));
+          else if (noise) z = Sg<T>::rnd(z + nz);
+          float o2 = sg2_act(act, z + bv[e], alpha) * gain;
+          if (clamp >= 0.f) o2 = fminf(fmaxf(o2, -clamp), clamp);
+          yv[e] = o2;
+        }
+        if (cout_) Sg<T>::st(cout_ + o, cv_);
+        Sg<T>::st(y + o, yv);
       }
-      if (cout_) Sg<T>::st(cout_ + o, cv_);
-      Sg<T>::st(y + o, yv);
     }
   }
 }
@@ -835,23 +883,31 @@ __global__ __launch_bounds__(256) void sg2_fir_act_kernel(const T* __restrict__ 
 // ------------------------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void sg2_fromrgb_fwd_kernel(const T* __restrict__ x /*[N][3][HW]*/, const T* __restrict__ w /*[O][3]*/,
-                                                              const float* __restrict__ bias, T* __restrict__ y, long nvec, long HW, int V, int act,
-                                                              float alpha, float gain, float clamp) {
+                                                              const float* __restrict__ bias, T* __restrict__ y, unsigned nrows, unsigned HW, int V,
+                                                              int act, float alpha, float gain, float clamp) {
   constexpr int VEC = Sg<T>::VEC;
-  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < nvec; g += (long)gridDim.x * 256) {
-    const int v = (int)(g % V);
-    const long row = g / V, n = row / HW, p = row - n * HW;
-    const float x0 = Sg<T>::ld1(x + (n * 3 + 0) * HW + p), x1 = Sg<T>::ld1(x + (n * 3 + 1) * HW + p), x2 = Sg<T>::ld1(x + (n * 3 + 2) * HW + p);
+  const unsigned t0 = blockIdx.x * 256u + threadIdx.x;
+  const unsigned v = t0 % (unsigned)V, rstep = gridDim.x * 256u / (unsigned)V;      // (the grid stride is a multiple of V: the thread keeps its channels)
+  float wv[VEC][3], bv[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const T* wp = w + (size_t)(v * VEC + j) * 3;
+    wv[j][0] = Sg<T>::ld1(wp); wv[j][1] = Sg<T>::ld1(wp + 1); wv[j][2] = Sg<T>::ld1(wp + 2);
+    bv[j] = bias ? Sg<T>::rnd(bias[v * VEC + j]) : 0.f;
+  }
+  for (unsigned row = t0 / (unsigned)V; row < nrows; row += rstep) {
+    const unsigned n = row / HW, p = row - n * HW;
+    const T* xp = x + (size_t)n * 3 * HW + p;
+    const float x0 = Sg<T>::ld1(xp), x1 = Sg<T>::ld1(xp + HW), x2 = Sg<T>::ld1(xp + 2 * (size_t)HW);
     float o[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const T* wp = w + (size_t)(v * VEC + j) * 3;
-      float a = Sg<T>::rnd(x0 * Sg<T>::ld1(wp) + x1 * Sg<T>::ld1(wp + 1) + x2 * Sg<T>::ld1(wp + 2));
-      a = sg2_act(act, a + (bias ? Sg<T>::rnd(bias[v * VEC + j]) : 0.f), alpha) * gain;
+      float a = Sg<T>::rnd(x0 * wv[j][0] + x1 * wv[j][1] + x2 * wv[j][2]);
+      a = sg2_act(act, a + bv[j], alpha) * gain;
       if (clamp >= 0.f) a = fminf(fmaxf(a, -clamp), clamp);
       o[j] = a;
     }
-    Sg<T>::st(y + g * VEC, o);
+    Sg<T>::st(y + ((size_t)row * V + v) * VEC, o);
   }
 }
 
@@ -988,44 +1044,58 @@ extern "C" int icg_sg2_modulate(const void* x, const float* s, void* xs, int N, 
   const int V = C / (dtype == 1 ? 8 : 4);
   const long nvec = (long)N * HW * V;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 1) hipLaunchKernelGGL(sg2_modulate_kernel<__half>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const __half*)x, s, (__half*)xs, nvec, (long)HW, V);
-  else hipLaunchKernelGGL(sg2_modulate_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, s, (float*)xs, nvec, (long)HW, V);
+  ICG_REQUIRE((long)N * HW < 0x7fffffffL);
+  if (dtype == 1)
+    hipLaunchKernelGGL(sg2_modulate_kernel<__half>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const __half*)x, s, (__half*)xs, (unsigned)((long)N * HW), (unsigned)HW, V);
+  else
+    hipLaunchKernelGGL(sg2_modulate_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, s, (float*)xs, (unsigned)((long)N * HW), (unsigned)HW, V);
   return icg_check_launch();
 }
 
 extern "C" int icg_sg2_act_fwd(const void* c, const float* d, const float* noise, int64_t noise_bstride, const float* strength, const float* bias,
                                void* y, int N, int64_t HW, int O, int act, float alpha, float gain, float clamp, int dtype, void* stream) {
-  ICG_REQUIRE(c && y && N > 0 && HW > 0 && icg_sg2_rows_applies(O, dtype) && (act == 1 || act == 3) && al16(c) && al16(y));
+  ICG_REQUIRE(c && y && N > 0 && HW > 0 && icg_sg2_rows_applies(O, dtype) && (act == 1 || act == 3) && al16(c) && al16(y) && al16(d));
+  ICG_REQUIRE((long)N * HW < 0x7fffffffL);
   const int V = O / (dtype == 1 ? 8 : 4);
   const long nvec = (long)N * HW * V;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 1)
     hipLaunchKernelGGL(sg2_act_fwd_kernel<__half>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const __half*)c, d, noise, (long)noise_bstride, strength, bias,
-                       (__half*)y, nvec, (long)HW, V, act, alpha, gain, clamp);
+                       (__half*)y, (unsigned)((long)N * HW), (unsigned)HW, V, act, alpha, gain, clamp);
   else
     hipLaunchKernelGGL(sg2_act_fwd_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)c, d, noise, (long)noise_bstride, strength, bias,
-                       (float*)y, nvec, (long)HW, V, act, alpha, gain, clamp);
+                       (float*)y, (unsigned)((long)N * HW), (unsigned)HW, V, act, alpha, gain, clamp);
   return icg_check_launch();
 }
 
+template <typename T>
+static int fir_act_launch(const void* x, const float* f, void* c, void* y, const float* d, const float* noise, long noise_bstride, const float* strength,
+                          const float* bias, int N, int C, int H, int W, int fh, int fw, int padx0, int pady0, int flip, float fgain, int outH, int outW,
+                          int act, float alpha, float gain, float clamp, hipStream_t st) {
+  constexpr int TY = 4, TX = 2;
+  const int CV = C / Sg<T>::VEC;
+  const long total = (long)N * ((outH + TY - 1) / TY) * ((outW + TX - 1) / TX) * CV;
+  ICG_REQUIRE(total < 0x7fffffffL);
+  if (fh == 4 && fw == 4)
+    hipLaunchKernelGGL((sg2_fir_act_kernel<T, TY, TX, 4>), dim3(ew_grid(total)), dim3(256), 0, st, (const T*)x, f, (T*)c, (T*)y, d, noise, noise_bstride,
+                       strength, bias, N, H, W, CV, fh, fw, padx0, pady0, flip, fgain, outH, outW, act, alpha, gain, clamp);
+  else
+    hipLaunchKernelGGL((sg2_fir_act_kernel<T, TY, TX, 0>), dim3(ew_grid(total)), dim3(256), 0, st, (const T*)x, f, (T*)c, (T*)y, d, noise, noise_bstride,
+                       strength, bias, N, H, W, CV, fh, fw, padx0, pady0, flip, fgain, outH, outW, act, alpha, gain, clamp);
+  return icg_check_launch();
+}
 extern "C" int icg_sg2_fir_act_fwd(const void* x, const float* f, void* c, void* y, const float* d, const float* noise, int64_t noise_bstride,
                                    const float* strength, const float* bias, int N, int C, int H, int W, int fh, int fw, int padx0, int padx1,
-                                   int pady0, int pady1, float fgain, int outH, int outW, int act, float alpha, float gain, float clamp, int dtype,
-                                   void* stream) {
+                                   int pady0, int pady1, int flip, float fgain, int outH, int outW, int act, float alpha, float gain, float clamp,
+                                   int dtype, void* stream) {
   ICG_REQUIRE(x && f && y && N > 0 && H > 0 && W > 0 && fh >= 1 && fw >= 1 && fh * fw <= 64 && (act == 1 || act == 3));
   ICG_REQUIRE(icg_sg2_rows_applies(C, dtype) && al16(x) && al16(y) && al16(c));
   ICG_REQUIRE(outW == W + padx0 + padx1 - fw + 1 && outH == H + pady0 + pady1 - fh + 1 && outW >= 1 && outH >= 1);
-  constexpr int TY = 4;
-  const int CV = C / (dtype == 1 ? 8 : 4);
-  const long total = (long)N * ((outH + TY - 1) / TY) * outW * CV;
-  hipStream_t st = (hipStream_t)stream;
   if (dtype == 1)
-    hipLaunchKernelGGL((sg2_fir_act_kernel<__half, TY>), dim3(ew_grid(total)), dim3(256), 0, st, (const __half*)x, f, (__half*)c, (__half*)y, d, noise,
-                       (long)noise_bstride, strength, bias, N, H, W, CV, fh, fw, padx0, pady0, fgain, outH, outW, act, alpha, gain, clamp);
-  else
-    hipLaunchKernelGGL((sg2_fir_act_kernel<float, TY>), dim3(ew_grid(total)), dim3(256), 0, st, (const float*)x, f, (float*)c, (float*)y, d, noise,
-                       (long)noise_bstride, strength, bias, N, H, W, CV, fh, fw, padx0, pady0, fgain, outH, outW, act, alpha, gain, clamp);
-  return icg_check_launch();
+    return fir_act_launch<__half>(x, f, c, y, d, noise, (long)noise_bstride, strength, bias, N, C, H, W, fh, fw, padx0, pady0, flip, fgain, outH, outW,
+                                  act, alpha, gain, clamp, (hipStream_t)stream);
+  return fir_act_launch<float>(x, f, c, y, d, noise, (long)noise_bstride, strength, bias, N, C, H, W, fh, fw, padx0, pady0, flip, fgain, outH, outW, act,
+                               alpha, gain, clamp, (hipStream_t)stream);
 }
 
 extern "C" size_t icg_sg2_rows_workspace_bytes(int N, int64_t HW, int C, int ncols, int dtype) {
@@ -1125,16 +1195,16 @@ extern "C" int icg_sg2_fromrgb_applies(int O, int dtype) {
 }
 extern "C" int icg_sg2_fromrgb_fwd(const void* x, const void* w, const float* bias, void* y, int N, int64_t HW, int O, int act, float alpha,
                                    float gain, float clamp, int dtype, void* stream) {
-  ICG_REQUIRE(x && w && y && N > 0 && HW > 0 && icg_sg2_fromrgb_applies(O, dtype) && (act == 1 || act == 3) && al16(y));
+  ICG_REQUIRE(x && w && y && N > 0 && HW > 0 && icg_sg2_fromrgb_applies(O, dtype) && (act == 1 || act == 3) && al16(y) && (long)N * HW < 0x7fffffffL);
   const int V = O / (dtype == 1 ? 8 : 4);
   const long nvec = (long)N * HW * V;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 1)
-    hipLaunchKernelGGL(sg2_fromrgb_fwd_kernel<__half>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const __half*)x, (const __half*)w, bias, (__half*)y, nvec,
-                       (long)HW, V, act, alpha, gain, clamp);
+    hipLaunchKernelGGL(sg2_fromrgb_fwd_kernel<__half>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const __half*)x, (const __half*)w, bias, (__half*)y,
+                       (unsigned)((long)N * HW), (unsigned)HW, V, act, alpha, gain, clamp);
   else
-    hipLaunchKernelGGL(sg2_fromrgb_fwd_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, (const float*)w, bias, (float*)y, nvec,
-                       (long)HW, V, act, alpha, gain, clamp);
+    hipLaunchKernelGGL(sg2_fromrgb_fwd_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, (const float*)w, bias, (float*)y,
+                       (unsigned)((long)N * HW), (unsigned)HW, V, act, alpha, gain, clamp);
   return icg_check_launch();
 }
 // tot [4 O]: (d w[o][0..2], d bias[o]) at 4 o + k, with respect to the PREPARED weight;  dimg [N][3][HW] (may be NULL).

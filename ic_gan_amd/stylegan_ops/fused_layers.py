@@ -123,8 +123,27 @@ def plan(H, W, R, up, down, padding, fw, flip_weight):
     return None
 
 
+def _blur(x, f2, pad, flip, gain):
+    """up = down = 1 FIR pass on the 2 x 4-strip kernel of csrc/sg2_fused.hip (icg_sg2_fir_act_fwd without an epilogue) where it takes
+    the tensor, else the general upfirdn2d kernel"""
+    if x.dim() == 4 and x.dtype in (torch.float16, torch.float32) and L.query("icg_sg2_rows_applies", int(x.shape[1]), _dt(x)):
+        x = _cl(x)
+        N, C, H, W = (int(v) for v in x.shape)
+        fh, fw = (int(v) for v in f2.shape)
+        px0, px1, py0, py1 = pad
+        oh, ow = H + py0 + py1 - fh + 1, W + px0 + px1 - fw + 1
+        if oh >= 1 and ow >= 1 and fh * fw <= 64:
+            y = torch.empty((N, C, oh, ow), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+            L.call("icg_sg2_fir_act_fwd", x, f2, None, y, None, None, 0, None, None, N, C, H, W, fh, fw, px0, px1, py0, py1, int(flip), float(gain),
+                   oh, ow, 1, 0.2, 1.0, -1.0, _dt(x))
+            return y
+    return U._run(x, f2, (1, 1), (1, 1), pad, bool(flip), gain)
+
+
 def _fir(x, f2, spec):
     up, down, pad, gain = spec
+    if up == 1 and down == 1:
+        return _blur(x, f2, pad, False, gain)
     return U._run(x, f2, (up, up), (down, down), pad, False, gain)
 
 
@@ -138,7 +157,7 @@ def _fir_act(x, f2, spec, d, noise, nbs, strength, bias, act, act_gain, clamp, k
     oh, ow = H + py0 + py1 - fh + 1, W + px0 + px1 - fw + 1
     y = torch.empty((N, C, oh, ow), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
     c = torch.empty_like(y) if keep_c else None
-    L.call("icg_sg2_fir_act_fwd", x, f2, c, y, d, noise, nbs, strength, bias, N, C, H, W, fh, fw, px0, px1, py0, py1, float(gain), oh, ow, act,
+    L.call("icg_sg2_fir_act_fwd", x, f2, c, y, d, noise, nbs, strength, bias, N, C, H, W, fh, fw, px0, px1, py0, py1, 0, float(gain), oh, ow, act,
            0.2, act_gain, clamp, _dt(x))
     return c, y
 
@@ -156,6 +175,8 @@ def _fir_adjoint(dy, f2, spec, in_hw):
     oh, ow = int(dy.shape[2]), int(dy.shape[3])
     fh, fw = f2.shape
     p = (fw - px0 - 1, iw * up - ow * down + px0 - up + 1, fh - py0 - 1, ih * up - oh * down + py0 - up + 1)
+    if up == 1 and down == 1:
+        return _blur(dy, f2, p, True, gain)
     return U._run(dy, f2, (down, down), (up, up), p, True, gain)
 
 

@@ -648,13 +648,15 @@ int icg_sg2_modulate(const void* x, const float* s, void* xs, int N, int64_t HW,
  * (networks.py:86-94 fma / add, 432-442 bias_act).  d, noise, bias may be NULL; clamp < 0: none. */
 int icg_sg2_act_fwd(const void* c, const float* d, const float* noise, int64_t noise_bstride, const float* strength, const float* bias,
                     void* y, int N, int64_t HW, int O, int act, float alpha, float gain, float clamp, int dtype, void* stream);
-/* FIR pass with up = down = 1 (upfirdn2d's blur after the transposed convolution of an up-sampling layer, conv2d_resample.py:163-186;
- * filter f [fh][fw] fp32 applied as upfirdn2d(flip_filter=False) does, times fgain) fused with icg_sg2_act_fwd on its result:
- * c = fir(x) (may be NULL), y = clamp(gain * act(c * d + noise * strength + bias)); x [N][H][W][C], c / y [N][outH][outW][C]. */
+/* FIR pass with up = down = 1 (upfirdn2d's blur after the transposed convolution of an up-sampling layer / before a strided one,
+ * conv2d_resample.py:152-186, and their adjoints; filter f [fh][fw] fp32 applied as upfirdn2d(flip_filter=flip) does, times fgain) fused with
+ * icg_sg2_act_fwd on its result: c = fir(x) (may be NULL), y = clamp(gain * act(c * d + noise * strength + bias)); x [N][H][W][C],
+ * c / y [N][outH][outW][C].  With act = 1, gain = 1, no d / noise / bias / clamp it is the plain blur (2 columns x 4 rows per thread: 35 window
+ * loads per 8 outputs where the general upfirdn2d kernel does 28 per 4). */
 int icg_sg2_fir_act_fwd(const void* x, const float* f, void* c, void* y, const float* d, const float* noise, int64_t noise_bstride,
                         const float* strength, const float* bias, int N, int C, int H, int W, int fh, int fw, int padx0, int padx1,
-                        int pady0, int pady1, float fgain, int outH, int outW, int act, float alpha, float gain, float clamp, int dtype,
-                        void* stream);
+                        int pady0, int pady1, int flip, float fgain, int outH, int outW, int act, float alpha, float gain, float clamp,
+                        int dtype, void* stream);
 size_t icg_sg2_rows_workspace_bytes(int N, int64_t HW, int C, int ncols, int dtype);
 /* gradient of icg_sg2_act_fwd: dz = dy * gain * act'(y) [|y| < clamp] (bias_act.cu's grad = 1 pass);  dc = dz * d (may be NULL);
  * sums [N][2 O + 1] per sample and tot [2 O + 1] over the batch of (dz | dz * c | dz * noise):  d bias = tot[0 .. O),

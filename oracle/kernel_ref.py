@@ -1171,14 +1171,14 @@ def icg_sg2_act_fwd(c, d, noise, noise_bstride, strength, bias, y, N, HW, O, act
     mem(y)[: N * HW * O].copy_(o.reshape(-1).to(y.dtype))
 
 
-def icg_sg2_fir_act_fwd(x, f, c, y, d, noise, noise_bstride, strength, bias, N, C, H, W, fh, fw, padx0, padx1, pady0, pady1, fgain, outH,
+def icg_sg2_fir_act_fwd(x, f, c, y, d, noise, noise_bstride, strength, bias, N, C, H, W, fh, fw, padx0, padx1, pady0, pady1, flip, fgain, outH,
                         outW, act, alpha, gain, clamp, dtype):
     """icg_upfirdn2d_typed (up = down = 1, channels-last) followed by icg_sg2_act_fwd"""
     tmp = torch.empty(N * outH * outW * C, dtype=x.dtype)
     if dtype == 1:
-        icg_upfirdn2d_typed(x, f, tmp, N, C, H, W, fh, fw, 1, 1, 1, 1, padx0, padx1, pady0, pady1, 0, fgain, outH, outW, 1, 1)
+        icg_upfirdn2d_typed(x, f, tmp, N, C, H, W, fh, fw, 1, 1, 1, 1, padx0, padx1, pady0, pady1, flip, fgain, outH, outW, 1, 1)
     else:
-        icg_upfirdn2d_nhwc(x, f, tmp, N, C, H, W, fh, fw, 1, 1, 1, 1, padx0, padx1, pady0, pady1, 0, fgain, outH, outW)
+        icg_upfirdn2d_nhwc(x, f, tmp, N, C, H, W, fh, fw, 1, 1, 1, 1, padx0, padx1, pady0, pady1, flip, fgain, outH, outW)
     if c is not None:
         mem(c)[: tmp.numel()].copy_(tmp)
     icg_sg2_act_fwd(tmp, d, noise, noise_bstride, strength, bias, y, N, outH * outW, C, act, alpha, gain, clamp, dtype)

@@ -339,10 +339,21 @@ def test_fir_with_layer_epilogue(N, H, W, C, half):
     x = act(N, H * W, C, half, 1).reshape(N, H, W, C)
     d, noise, strength, bias = rnd(N, C, seed=2).abs() + 0.5, rnd(N, oh * ow, seed=3), torch.tensor([0.3]), rnd(C, seed=4)
     c, y = torch.empty(N, oh, ow, C, dtype=x.dtype), torch.empty(N, oh, ow, C, dtype=x.dtype)
-    args = [x, f, c, y, d, noise, oh * ow, strength, bias, N, C, H, W, 4, 4, 1, 1, 1, 1, 4.0, oh, ow, 3, 0.2, float(np.sqrt(2)), 2.0, 1 if half else 0]
+    args = [x, f, c, y, d, noise, oh * ow, strength, bias, N, C, H, W, 4, 4, 1, 1, 1, 1, 0, 4.0, oh, ow, 3, 0.2, float(np.sqrt(2)), 2.0, 1 if half else 0]
     (gc, rc), (gy, ry) = run_pair("icg_sg2_fir_act_fwd", args, [2, 3])
     close(gc.float(), rc.float(), 2e-3 if half else 1e-5, "c")
     close(gy.float(), ry.float(), 3e-3 if half else 1e-5, "y")
+    # the plain blur form (no epilogue) with a flipped asymmetric filter and asymmetric / negative padding, 4 x 4 and 3 x 5 taps
+    for taps, pad in (([1, 2, 3, 4], (2, 1, 0, 3)), ([1, 3, 3, 1], (-1, 2, 1, -1))):
+        f4 = U.setup_filter(taps)
+        for ff in (f4, f4[:3, :].contiguous() if f4.dim() == 2 else f4):
+            fh, fw = ff.shape
+            o2h, o2w = H + pad[2] + pad[3] - fh + 1, W + pad[0] + pad[1] - fw + 1
+            y2 = torch.empty(N, o2h, o2w, C, dtype=x.dtype)
+            a2 = [x, ff, None, y2, None, None, 0, None, None, N, C, H, W, fh, fw, pad[0], pad[1], pad[2], pad[3], 1, 0.7, o2h, o2w, 1, 0.2, 1.0, -1.0,
+                  1 if half else 0]
+            ((g2, r2),) = run_pair("icg_sg2_fir_act_fwd", a2, [3])
+            close(g2.float(), r2.float(), 2e-3 if half else 1e-5, "blur %dx%d" % (fh, fw))
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,Rk,stride,pad,zins", [(2, 16, 16, 64, 64, 3, 1, 1, 0), (3, 12, 11, 32, 128, 3, 1, 1, 0), (2, 32, 32, 512, 512, 3, 1, 1, 0),

@@ -152,6 +152,62 @@ def main():
     xs = cl(16, 64, 257, 257).half()
     report("upfirdn2d_nhwc fp16 blur after up-conv [16,64,257,257]->256", 2 * (xs.numel() + 16 * 64 * 256 * 256),
            ev(lambda: UF.upfirdn2d(xs, f, padding=[1, 1, 1, 1], gain=4)))
+    # ---- fused StyleGAN2 layer kernels (csrc/sg2_fused.hip, round 5) at cfg4's largest fp16 layer [16, 64, 256, 256] and a wide one [16, 512, 32, 32]
+    for (N, C, R) in ((16, 64, 256), (16, 512, 32)):
+        HW = R * R
+        x = cl(N, C, R, R).half(); y = torch.empty_like(x); y2 = torch.empty_like(x)
+        n = x.numel()
+        s = torch.rand(N, C, device=dev) + 0.5; d = torch.rand(N, C, device=dev) + 0.5
+        noise = torch.randn(N, HW, device=dev); strength = torch.full((1,), 0.1, device=dev); bias = torch.randn(C, device=dev)
+        tag = "[%d,%d,%d,%d] fp16" % (N, C, R, R)
+        report("sg2_modulate " + tag, 4 * n, ev(lambda: L.call("icg_sg2_modulate", x, s, y, N, HW, C, 1)))
+        report("sg2_act_fwd (demod + noise + bias + lrelu + clamp) " + tag, 4 * n,
+               ev(lambda: L.call("icg_sg2_act_fwd", x, d, noise, HW, strength, bias, y, N, HW, C, 3, 0.2, 1.414, 256.0, 1)))
+        sums, tot = torch.empty(N, 2 * C + 1, device=dev), torch.empty(2 * C + 1, device=dev)
+        nb = L.query("icg_sg2_rows_workspace_bytes", N, HW, C, 2 * C + 1, 1); ws = ops._bytes(nb, dev)
+        report("sg2_act_bwd (dy, y, c -> dc + bias / demod / noise sums) " + tag, 8 * n,
+               ev(lambda: L.call("icg_sg2_act_bwd", x, y, y, d, noise, HW, y2, sums, tot, N, HW, C, 3, 0.2, 1.414, 256.0, 1, ws, nb)))
+        ds = torch.empty(N, C, device=dev)
+        nb2 = L.query("icg_sg2_rows_workspace_bytes", N, HW, C, C, 1); ws2 = ops._bytes(nb2, dev)
+        report("sg2_modulate_bwd (dxs, x -> dx + style sums) " + tag, 6 * n,
+               ev(lambda: L.call("icg_sg2_modulate_bwd", x, y, s, y2, ds, N, HW, C, 1, ws2, nb2)))
+        w3 = torch.randn(3, C, device=dev) * 0.1; b3 = torch.randn(3, device=dev)
+        img = torch.empty(N, 3, HW, device=dev); y3 = torch.empty(N, HW, 3, device=dev, dtype=torch.float16)
+        report("sg2_torgb_fwd (x -> image) " + tag, 2 * n + 22 * N * HW,
+               ev(lambda: L.call("icg_sg2_torgb_fwd", x, s, w3, b3, 256.0, None, img, y3, N, HW, C, 1)))
+        sums4, tot4 = torch.empty(N, 4 * C + 3, device=dev), torch.empty(4 * C + 3, device=dev)
+        nb3 = L.query("icg_sg2_torgb_bwd_workspace_bytes", N, HW, C, 1); ws3 = ops._bytes(nb3, dev)
+        report("sg2_torgb_bwd (x -> dx + style / weight sums) " + tag, 4 * n + 18 * N * HW,
+               ev(lambda: L.call("icg_sg2_torgb_bwd", img, y3, x, s, w3, 256.0, 1, y2, sums4, tot4, N, HW, C, 1, ws3, nb3)))
+        if C <= 128:
+            xi = torch.randn(N, 3, HW, device=dev).half(); wf = (torch.randn(C, 3, device=dev) * 0.5).half()
+            report("sg2_fromrgb_fwd (image -> y) " + tag, 2 * n + 6 * N * HW,
+                   ev(lambda: L.call("icg_sg2_fromrgb_fwd", xi, wf, bias, y, N, HW, C, 3, 0.2, 1.414, 256.0, 1)))
+            tot5 = torch.empty(4 * C, device=dev); di = torch.empty_like(xi)
+            nb5 = L.query("icg_sg2_rows_workspace_bytes", N, HW, C, 4 * C, 1); ws5 = ops._bytes(nb5, dev)
+            report("sg2_fromrgb_bwd (dy, y -> weight sums + dimg) " + tag, 4 * n + 12 * N * HW,
+                   ev(lambda: L.call("icg_sg2_fromrgb_bwd", x, y, xi, wf, di, tot5, N, HW, C, 3, 0.2, 1.414, 256.0, 1, ws5, nb5)))
+        xin = cl(N, C, R + 1, R + 1).half()
+        report("sg2_fir_act_fwd (blur 4x4 + epilogue; writes c and y) [%d,%d,%d,%d]->%d fp16" % (N, C, R + 1, R + 1, R), 2 * xin.numel() + 4 * n,
+               ev(lambda: L.call("icg_sg2_fir_act_fwd", xin, f, y, y2, d, noise, HW, strength, bias, N, C, R + 1, R + 1, 4, 4, 1, 1, 1, 1, 0, 4.0, R, R, 3,
+                                 0.2, 1.414, 256.0, 1)))
+        report("sg2 blur (fir without epilogue) [%d,%d,%d,%d]->%d fp16" % (N, C, R + 1, R + 1, R), 2 * xin.numel() + 2 * n,
+               ev(lambda: L.call("icg_sg2_fir_act_fwd", xin, f, None, y2, None, None, 0, None, None, N, C, R + 1, R + 1, 4, 4, 1, 1, 1, 1, 0, 4.0, R, R, 1,
+                                 0.2, 1.0, -1.0, 1)))
+        del x, y, y2, xin
+    # weight preparation of cfg4's generator (13 modulated 3x3 layers, 512 ... 64 channels) in one call: reads W, writes 2 fp16 layouts + wsq
+    from ic_gan_amd.stylegan_ops import fused_layers as FL
+    chans = [(512, 512)] * 7 + [(256, 512), (256, 256), (128, 256), (128, 128), (64, 128), (64, 64)]
+    items, nbytes = [], 0
+    for (O, I) in chans:
+        w = torch.randn(O, I, 3, 3, device=dev)
+        items.append(dict(w=w, w_fwd=torch.empty(O, 3, 3, I, device=dev, dtype=torch.float16), w_adj=torch.empty(I, 3, 3, O, device=dev, dtype=torch.float16),
+                          wsq=torch.empty(O, I, device=dev), wscale=torch.empty(O, device=dev), warg=torch.empty(O, device=dev, dtype=torch.int32),
+                          prenorm=True, gain=0.02, flip=False))
+        nbytes += w.numel() * (4 + 4 + 2 + 2) + O * I * 4          # (the rows kernel and the layout kernel each read W once)
+    report("sg2_weight_prep_multi, 13 layers of cfg4's G (two launches)", nbytes, ev(lambda: ops.sg2_weight_prep_multi(items)))
+    del items
+
     # bias gradient out of the Winograd dy transform (replaces the colsum pass): the pass itself, with and without the sums
     B, C, H = 64, 96, 256
     dy = cl(B, C, H, H)
