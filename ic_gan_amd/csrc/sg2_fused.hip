@@ -1087,10 +1087,10 @@ static int fir_act_launch(const void* x, const float* f, void* c, void* y, const
   const long total = (long)N * ((outH + TY - 1) / TY) * ((outW + TX - 1) / TX) * CV;
   ICG_REQUIRE(total < 0x7fffffffL);
   if (fh == 4 && fw == 4)
-    hipLaunchKernelGGL((sg2_fir_act_kernel<T, TY, TX, 4>), dim3(ew_grid_capped(total)), dim3(256), 0, st, (const T*)x, f, (T*)c, (T*)y, d, noise, noise_bstride,
+    hipLaunchKernelGGL((sg2_fir_act_kernel<T, TY, TX, 4>), dim3(ew_grid(total)), dim3(256), 0, st, (const T*)x, f, (T*)c, (T*)y, d, noise, noise_bstride,
                        strength, bias, N, H, W, CV, fh, fw, padx0, pady0, flip, fgain, outH, outW, act, alpha, gain, clamp);
   else
-    hipLaunchKernelGGL((sg2_fir_act_kernel<T, TY, TX, 0>), dim3(ew_grid_capped(total)), dim3(256), 0, st, (const T*)x, f, (T*)c, (T*)y, d, noise, noise_bstride,
+    hipLaunchKernelGGL((sg2_fir_act_kernel<T, TY, TX, 0>), dim3(ew_grid(total)), dim3(256), 0, st, (const T*)x, f, (T*)c, (T*)y, d, noise, noise_bstride,
                        strength, bias, N, H, W, CV, fh, fw, padx0, pady0, flip, fgain, outH, outW, act, alpha, gain, clamp);
   return icg_check_launch();
 }
