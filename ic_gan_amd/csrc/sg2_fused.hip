@@ -360,6 +360,84 @@ __global__ __launch_bounds__(256) void sg2_rows_kernel(const T* __restrict__ a /
   }
 }
 
+// u = x * a[n][c] + g * b[n][c]   (second-order passes: the cotangent of a modulated tensor; g / b may be null)
+template <typename T>
+__global__ __launch_bounds__(256) void sg2_mod2_kernel(const T* __restrict__ x, const float* __restrict__ a, const T* __restrict__ g,
+                                                       const float* __restrict__ b, T* __restrict__ u, unsigned nrows, unsigned HW, int V) {
+  constexpr int VEC = Sg<T>::VEC;
+  const unsigned t0 = blockIdx.x * 256u + threadIdx.x;
+  const unsigned v = t0 % (unsigned)V, rstep = gridDim.x * 256u / (unsigned)V;
+  for (unsigned row = t0 / (unsigned)V; row < nrows; row += rstep) {
+    const unsigned n = row / HW;
+    const size_t i = (size_t)row * V + v;
+    float xv[VEC], o[VEC];
+    Sg<T>::ld(x + i * VEC, xv);
+    const float* ap = a + ((size_t)n * V + v) * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = xv[j] * ap[j];
+    if (g) {
+      float gv[VEC];
+      Sg<T>::ld(g + i * VEC, gv);
+      const float* bp = b + ((size_t)n * V + v) * VEC;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = __fmaf_rn(gv[j], bp[j], o[j]);
+    }
+    Sg<T>::st(u + i * VEC, o);
+  }
+}
+
+// second-order pass through the activation / demodulation step of a layer's backward (dz = dy m, dc = dz d, dd = sum_p dz c):
+//   cdy = (cdc * d + cdd[n][o] * c) * m        cc = cdd[n][o] * dz        sums[n][o] = sum_p cdc * dz
+template <typename T>
+__global__ __launch_bounds__(256) void sg2_act_bwd2_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ c,
+                                                           const T* __restrict__ cdc, const float* __restrict__ d, const float* __restrict__ cdd,
+                                                           T* __restrict__ cdy, T* __restrict__ cc, float* __restrict__ part, long HW, int V, int rpb,
+                                                           int chunks, int act, float alpha, float gain, float clamp) {
+  constexpr int VEC = Sg<T>::VEC;
+  __shared__ float red[256 * VEC];
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
+  const int v = threadIdx.x % V, rl = threadIdx.x / V, nrl = 256 / V;
+  const long r0 = (long)chunk * rpb, r1 = min(r0 + rpb, HW);
+  const int C = V * VEC;
+  float acc[VEC], dv[VEC], ev[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    acc[j] = 0.f;
+    dv[j] = d ? Sg<T>::rnd(d[((long)n * V + v) * VEC + j]) : 1.f;
+    ev[j] = cdd ? cdd[((long)n * V + v) * VEC + j] : 0.f;
+  }
+  for (long r = r0 + rl; r < r1; r += nrl) {
+    const long g = ((long)n * HW + r) * V + v;
+    float gy[VEC], yv[VEC], cv[VEC], kv[VEC], o1[VEC], o2[VEC];
+    Sg<T>::ld(dy + g * VEC, gy);
+    Sg<T>::ld(y + g * VEC, yv);
+    Sg<T>::ld(cdc + g * VEC, kv);
+    if (c) Sg<T>::ld(c + g * VEC, cv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float m = gain * ((act == 3 && !(yv[j] > 0.f)) ? alpha : 1.f);
+      if (clamp >= 0.f && !(yv[j] > -clamp && yv[j] < clamp)) m = 0.f;
+      const float dz = Sg<T>::rnd(gy[j] * m);
+      acc[j] += kv[j] * dz;
+      o1[j] = (kv[j] * dv[j] + (c ? ev[j] * cv[j] : 0.f)) * m;
+      o2[j] = ev[j] * dz;
+    }
+    Sg<T>::st(cdy + g * VEC, o1);
+    if (cc) Sg<T>::st(cc + g * VEC, o2);
+  }
+  float* prow = part + (size_t)blockIdx.x * C;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = acc[j];
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < C; ch += 256) {
+    const int v2 = ch / VEC, j = ch % VEC;
+    float s = 0.f;
+    for (int q = 0; q < nrl; ++q) s += red[(q * V + v2) * VEC + j];
+    prow[ch] = s;
+  }
+}
+
 // part [N * chunks][ctot]  ->  per [N][ctot] (sum over the chunks of a sample) and tot [ctot] (sum over everything); fixed order.
 // Block: 64 columns x 16 sample groups (one (sample, column) chain of <= 64 loads per thread at N = 16)
 __global__ __launch_bounds__(1024) void sg2_rows_final_kernel(const float* __restrict__ part, int N, int chunks, int ctot, float* __restrict__ per,
@@ -542,6 +620,7 @@ __global__ __launch_bounds__(256) void sg2_fc_bwd_dx_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------------------------------------
 struct SgWb {
   const float* dwc;       // layout 0: [RR][I][O]; 1: [RR][O][I]
+  const float* Q;         // [O][I] or null: g += w scale Q[o][i]  (second-order passes: a general cotangent of the demodulation table)
   const float* t;         // [N][O] or null
   const float* s;         // [N][I]
   const float* w;         // [O][I][RR]
@@ -601,6 +680,7 @@ __global__ __launch_bounds__(256) void sg2_weight_bwd_kernel(SgWb p) {
         for (int n = 0; n < p.N; ++n) q += tt[n * 32 + ol] * ss[n * 32 + il];
         g += wv * sc * q;
       }
+      if (p.Q) g += wv * sc * p.Q[(size_t)o * p.I + i];
       dot += g * wv;
       p.dw[idx] = g * sc;
     }
@@ -981,6 +1061,96 @@ __global__ __launch_bounds__(256) void sg2_fromrgb_bwd_kernel(const T* __restric
   }
 }
 
+// second-order pass through ToRGB's backward (dz = dimg m, dxs = dz . w, dx = dxs s, ds = sum_p dxs x, dw = sum dz xs): with
+// u = x a[n][c] + cdx s (the cotangent of dxs):  cdimg[n][o][p] = m sum_c u_c w[o][c] (+ cim),  cx = dxs a,
+// sums[n]: cot s[c] = sum_p cdx dxs | cot w[o][c] = sum_p dz_o u_c   (columns C | 3 C)
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void sg2_torgb_bwd2_kernel(const float* __restrict__ dimg, const T* __restrict__ y, const T* __restrict__ x,
+                                                             const float* __restrict__ s, const float* __restrict__ w, const float* __restrict__ a,
+                                                             const T* __restrict__ cdx, const float* __restrict__ cim, float clamp, int mask_clamp,
+                                                             float* __restrict__ cdimg, T* __restrict__ cx, float* __restrict__ part, long HW, int C,
+                                                             int L, int rpb, int chunks) {
+  constexpr int VEC = Sg<T>::VEC;
+  __shared__ float red[256 * VEC];
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
+  const int l = threadIdx.x % L, rl = threadIdx.x / L, nrl = 256 / L;
+  const long r0 = (long)chunk * rpb, r1 = min(r0 + rpb, HW);
+  const int ctot = 4 * C;
+  float sv[NV][VEC], av[NV][VEC], wv[3][NV][VEC], acc[4][NV][VEC];
+#pragma unroll
+  for (int q = 0; q < NV; ++q)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int ch = (q * L + l) * VEC + j;
+      sv[q][j] = Sg<T>::rnd(s[(size_t)n * C + ch]);
+      av[q][j] = a[(size_t)n * C + ch];
+#pragma unroll
+      for (int o = 0; o < 3; ++o) wv[o][q][j] = Sg<T>::rnd(w[o * C + ch]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k][q][j] = 0.f;
+    }
+  for (long rb = r0; rb < r1; rb += nrl) {                  // (all lanes stay in the loop: shuffles below)
+    const long r = rb + rl;
+    const bool ok = r < r1;
+    float dz[3] = {0.f, 0.f, 0.f}, mk[3] = {0.f, 0.f, 0.f}, t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    if (ok) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        mk[k] = 1.f;
+        if (mask_clamp && clamp >= 0.f) {
+          const float yv = Sg<T>::ld1(y + ((long)n * HW + r) * 3 + k);
+          if (!(yv > -clamp && yv < clamp)) mk[k] = 0.f;
+        }
+        dz[k] = Sg<T>::rnd(dimg[((size_t)n * 3 + k) * HW + r]) * mk[k];
+      }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const long g = (((long)n * HW + r) * (NV * L) + q * L + l) * VEC;
+        float xv[VEC], gv[VEC], o[VEC];
+        Sg<T>::ld(x + g, xv);
+        if (cdx) Sg<T>::ld(cdx + g, gv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float dxs = Sg<T>::rnd(dz[0] * wv[0][q][j] + dz[1] * wv[1][q][j] + dz[2] * wv[2][q][j]);
+          const float u = xv[j] * av[q][j] + (cdx ? gv[j] * sv[q][j] : 0.f);
+          if (cdx) acc[0][q][j] += gv[j] * dxs;
+          acc[1][q][j] += dz[0] * u; acc[2][q][j] += dz[1] * u; acc[3][q][j] += dz[2] * u;
+          t0 += u * wv[0][q][j]; t1 += u * wv[1][q][j]; t2 += u * wv[2][q][j];
+          o[j] = dxs * av[q][j];
+        }
+        if (cx) Sg<T>::st(cx + g, o);
+      }
+    }
+    for (int off = L >> 1; off > 0; off >>= 1) {
+      t0 += __shfl_xor(t0, off, 64); t1 += __shfl_xor(t1, off, 64); t2 += __shfl_xor(t2, off, 64);
+    }
+    if (ok && l == 0) {
+      const float tt[3] = {t0, t1, t2};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const size_t ip = ((size_t)n * 3 + k) * HW + r;
+        cdimg[ip] = tt[k] * mk[k] + (cim ? cim[ip] : 0.f);
+      }
+    }
+  }
+  float* prow = part + (size_t)blockIdx.x * ctot;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = acc[k][q][j];
+      __syncthreads();
+      for (int e = threadIdx.x; e < L * VEC; e += 256) {
+        const int l2 = e / VEC, j = e % VEC;
+        float sum = 0.f;
+        for (int t = 0; t < nrl; ++t) sum += red[(t * L + l2) * VEC + j];
+        prow[k * C + (q * L + l2) * VEC + j] = sum;
+      }
+    }
+}
+
 int rows_geometry(long HW, int V, int* rpb, int* chunks) {
   const int nrl = 256 / V;
   long r = icg_cdiv(HW, 64);
@@ -1158,6 +1328,42 @@ extern "C" int icg_sg2_modulate_bwd(const void* dxs, const void* x, const float*
   return icg_check_launch();
 }
 
+extern "C" int icg_sg2_mod2(const void* x, const float* a, const void* g, const float* b, void* u, int N, int64_t HW, int C, int dtype, void* stream) {
+  ICG_REQUIRE(x && a && u && (!g || b) && N > 0 && HW > 0 && icg_sg2_rows_applies(C, dtype) && al16(x) && al16(g) && al16(u) && (long)N * HW < 0x7fffffffL);
+  const int V = C / (dtype == 1 ? 8 : 4);
+  const long nvec = (long)N * HW * V;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 1)
+    hipLaunchKernelGGL(sg2_mod2_kernel<__half>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const __half*)x, a, (const __half*)g, b, (__half*)u,
+                       (unsigned)((long)N * HW), (unsigned)HW, V);
+  else
+    hipLaunchKernelGGL(sg2_mod2_kernel<float>, dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, a, (const float*)g, b, (float*)u,
+                       (unsigned)((long)N * HW), (unsigned)HW, V);
+  return icg_check_launch();
+}
+
+// sums [N][O] = sum_p cdc * dz;  workspace: icg_sg2_rows_workspace_bytes(N, HW, O, O, dtype)
+extern "C" int icg_sg2_act_bwd2(const void* dy, const void* y, const void* c, const void* cdc, const float* d, const float* cdd, void* cdy, void* cc,
+                                float* sums, int N, int64_t HW, int O, int act, float alpha, float gain, float clamp, int dtype, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(dy && y && cdc && cdy && sums && N > 0 && HW > 0 && icg_sg2_rows_applies(O, dtype) && (act == 1 || act == 3) && workspace);
+  ICG_REQUIRE((!cdd || c) && al16(dy) && al16(y) && al16(c) && al16(cdc) && al16(cdy) && al16(cc));
+  ICG_REQUIRE(workspace_bytes >= icg_sg2_rows_workspace_bytes(N, HW, O, O, dtype));
+  const int V = O / (dtype == 1 ? 8 : 4);
+  int rpb, chunks;
+  rows_geometry((long)HW, V, &rpb, &chunks);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  if (dtype == 1)
+    hipLaunchKernelGGL(sg2_act_bwd2_kernel<__half>, dim3(N * chunks), dim3(256), 0, st, (const __half*)dy, (const __half*)y, (const __half*)c,
+                       (const __half*)cdc, d, cdd, (__half*)cdy, (__half*)cc, part, (long)HW, V, rpb, chunks, act, alpha, gain, clamp);
+  else
+    hipLaunchKernelGGL(sg2_act_bwd2_kernel<float>, dim3(N * chunks), dim3(256), 0, st, (const float*)dy, (const float*)y, (const float*)c,
+                       (const float*)cdc, d, cdd, (float*)cdy, (float*)cc, part, (long)HW, V, rpb, chunks, act, alpha, gain, clamp);
+  hipLaunchKernelGGL(sg2_rows_final_kernel, dim3((unsigned)icg_cdiv(O, 64)), dim3(1024), 0, st, part, N, chunks, O, sums, (float*)nullptr);
+  return icg_check_launch();
+}
+
 extern "C" int icg_sg2_style_bwd(const float* ds_mod, int64_t ds_stride, const float* dd, int64_t dd_stride, const float* d, const float* s,
                                  const float* wsq, int N, int I, int O, float* g, float* pdot, float* t, void* stream) {
   ICG_REQUIRE(ds_mod && s && g && pdot && N > 0 && I > 0 && (!dd || (d && wsq && t && O > 0 && O <= 8192)));
@@ -1185,9 +1391,15 @@ extern "C" size_t icg_sg2_weight_bwd_workspace_bytes(int O, int I) { return (siz
 extern "C" int icg_sg2_weight_bwd(const float* dw_conv, int layout, const float* t, const float* s, int N, const float* w, const float* wscale,
                                   const int* warg, int prenorm, float c0, int round_f16, float* dw, int O, int I, int R, void* workspace,
                                   size_t workspace_bytes, void* stream) {
+  return icg_sg2_weight_bwd_q(dw_conv, layout, t, s, N, nullptr, w, wscale, warg, prenorm, c0, round_f16, dw, O, I, R, workspace, workspace_bytes, stream);
+}
+
+extern "C" int icg_sg2_weight_bwd_q(const float* dw_conv, int layout, const float* t, const float* s, int N, const float* Q, const float* w,
+                                    const float* wscale, const int* warg, int prenorm, float c0, int round_f16, float* dw, int O, int I, int R,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
   ICG_REQUIRE(dw_conv && w && wscale && dw && O > 0 && I > 0 && R >= 1 && R <= 3 && (layout == 0 || layout == 1) && (!t || (s && N > 0 && N <= 64)));
   ICG_REQUIRE(!prenorm || (warg && workspace && workspace_bytes >= icg_sg2_weight_bwd_workspace_bytes(O, I)));
-  SgWb p{dw_conv, t, s, w, wscale, dw, prenorm ? (float*)workspace : nullptr, layout, t ? N : 0, O, I, R * R, round_f16, (int)icg_cdiv(I, 32)};
+  SgWb p{dw_conv, Q, t, s, w, wscale, dw, prenorm ? (float*)workspace : nullptr, layout, t ? N : 0, O, I, R * R, round_f16, (int)icg_cdiv(I, 32)};
   const size_t lds = ((size_t)32 * (32 * p.RR + 1) + (size_t)p.N * 64) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(sg2_weight_bwd_kernel, dim3((unsigned)(icg_cdiv(O, 32) * p.tiles_i)), dim3(256), lds, st, p);
@@ -1294,6 +1506,38 @@ static int torgb_bwd_launch(const float* dimg, const void* y, const void* x, con
   hipLaunchKernelGGL(sg2_rows_final_kernel, dim3((unsigned)icg_cdiv(ctot, 64)), dim3(1024), 0, st, part, N, chunks, ctot, sums, tot);
   return icg_check_launch();
 }
+template <typename T>
+static int torgb_bwd2_launch(const float* dimg, const void* y, const void* x, const float* s, const float* w, const float* a, const void* cdx,
+                             const float* cim, float clamp, int mask_clamp, float* cdimg, void* cx, float* sums, float* tot, int N, long HW, int C,
+                             float* part, hipStream_t st) {
+  const int V = C / Sg<T>::VEC, L = V < 64 ? V : 64, NV = V / L;
+  int rpb, chunks;
+  rows_geometry(HW, L, &rpb, &chunks);
+  const dim3 grid(N * chunks), block(256);
+#define ICG_TORGB_B2(NVV)                                                                                                                            \
+  hipLaunchKernelGGL((sg2_torgb_bwd2_kernel<T, NVV>), grid, block, 0, st, dimg, (const T*)y, (const T*)x, s, w, a, (const T*)cdx, cim, clamp, mask_clamp, \
+                     cdimg, (T*)cx, part, HW, C, L, rpb, chunks)
+  if (NV == 1) ICG_TORGB_B2(1);
+  else if (NV == 2) ICG_TORGB_B2(2);
+  else ICG_TORGB_B2(4);
+#undef ICG_TORGB_B2
+  hipLaunchKernelGGL(sg2_rows_final_kernel, dim3((unsigned)icg_cdiv(4 * C, 64)), dim3(1024), 0, st, part, N, chunks, 4 * C, sums, tot);
+  return icg_check_launch();
+}
+// sums [N][4 C] (cot s = sums[:, 0 .. C)), tot [4 C] (cot w[o][c] = tot[(1 + o) C + c]); workspace: icg_sg2_torgb_bwd_workspace_bytes
+extern "C" int icg_sg2_torgb_bwd2(const float* dimg, const void* y, const void* x, const float* s, const float* w, const float* a, const void* cdx,
+                                  const float* cim, float clamp, int mask_clamp, float* cdimg, void* cx, float* sums, float* tot, int N, int64_t HW,
+                                  int C, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  ICG_REQUIRE(dimg && y && x && s && w && a && cdimg && sums && tot && N > 0 && HW > 0 && icg_sg2_torgb_applies(C, dtype) && al16(x) && al16(cdx) &&
+              al16(cx) && workspace);
+  ICG_REQUIRE(workspace_bytes >= icg_sg2_torgb_bwd_workspace_bytes(N, HW, C, dtype));
+  if (dtype == 1)
+    return torgb_bwd2_launch<__half>(dimg, y, x, s, w, a, cdx, cim, clamp, mask_clamp, cdimg, cx, sums, tot, N, (long)HW, C, (float*)workspace,
+                                     (hipStream_t)stream);
+  return torgb_bwd2_launch<float>(dimg, y, x, s, w, a, cdx, cim, clamp, mask_clamp, cdimg, cx, sums, tot, N, (long)HW, C, (float*)workspace,
+                                  (hipStream_t)stream);
+}
+
 // sums [N][4 C + 3]: ds = sums[:, 0 .. C);  tot [4 C + 3]: dw[o][c] = tot[(1 + o) C + c], db[o] = tot[4 C + o]
 extern "C" int icg_sg2_torgb_bwd(const float* dimg, const void* y, const void* x, const float* s, const float* w, float clamp, int mask_clamp, void* dx,
                                  float* sums, float* tot, int N, int64_t HW, int C, int dtype, void* workspace, size_t workspace_bytes, void* stream) {

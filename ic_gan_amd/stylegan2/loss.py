@@ -84,19 +84,22 @@ class StyleGAN2Loss:
                 loss_Gmain.mean().mul(gain).backward()
 
         if do_Gpl:
-            n = gen_z.shape[0] // self.pl_batch_shrink
-            gen_img, gen_ws = self.run_G(gen_z[:n], gen_c[:n], gen_h[:n], sync=sync)
-            pl_noise = _randn_like(gen_img) / np.sqrt(gen_img.shape[2] * gen_img.shape[3])
-            with conv2d_gradfix.no_weight_gradients():
-                (pl_grads,) = torch.autograd.grad(outputs=[(gen_img * pl_noise).sum()], inputs=[gen_ws],
-                                                  create_graph=True, only_inputs=True)
-            pl_lengths = pl_grads.square().sum(2).mean(1).sqrt()
-            pl_mean = self.pl_mean.lerp(pl_lengths.mean(), self.pl_decay)
-            self.pl_mean.copy_(pl_mean.detach())
-            pl_penalty = (pl_lengths - pl_mean).square()
-            loss_Gpl = pl_penalty * self.pl_weight
-            self.stats["Loss/pl_penalty"] = pl_penalty.detach()
-            (gen_img[:, 0, 0, 0] * 0 + loss_Gpl).mean().mul(gain).backward()
+            # the path-length penalty differentiates the synthesis network's backward: its modulated-convolution and toRGB layers run as
+            # nodes whose backward is a node with a hand-written adjoint (stylegan_ops/fused_layers.py: second_order)
+            with fused_layers.second_order():
+                n = gen_z.shape[0] // self.pl_batch_shrink
+                gen_img, gen_ws = self.run_G(gen_z[:n], gen_c[:n], gen_h[:n], sync=sync)
+                pl_noise = _randn_like(gen_img) / np.sqrt(gen_img.shape[2] * gen_img.shape[3])
+                with conv2d_gradfix.no_weight_gradients():
+                    (pl_grads,) = torch.autograd.grad(outputs=[(gen_img * pl_noise).sum()], inputs=[gen_ws],
+                                                      create_graph=True, only_inputs=True)
+                pl_lengths = pl_grads.square().sum(2).mean(1).sqrt()
+                pl_mean = self.pl_mean.lerp(pl_lengths.mean(), self.pl_decay)
+                self.pl_mean.copy_(pl_mean.detach())
+                pl_penalty = (pl_lengths - pl_mean).square()
+                loss_Gpl = pl_penalty * self.pl_weight
+                self.stats["Loss/pl_penalty"] = pl_penalty.detach()
+                (gen_img[:, 0, 0, 0] * 0 + loss_Gpl).mean().mul(gain).backward()
 
         loss_Dgen = 0
         if do_Dmain and not do_Dr1 and MERGE_D_PASSES and gen_z.shape[0] == real_img.shape[0]:

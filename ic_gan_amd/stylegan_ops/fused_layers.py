@@ -54,7 +54,36 @@ def first_order():
         _FIRST_ORDER -= 1
 
 
+_SECOND_ORDER = 0
+
+
+@contextlib.contextmanager
+def second_order():
+    """inside: the modulated-convolution and toRGB layers are nodes whose backward is itself a node with a hand-written adjoint (the
+    path-length regulariser differentiates the synthesis network's backward once more, loss.py:112-146); every other layer keeps its
+    composed, arbitrarily differentiable operators"""
+    global _SECOND_ORDER
+    _SECOND_ORDER += 1
+    try:
+        yield
+    finally:
+        _SECOND_ORDER -= 1
+
+
+SECOND_ORDER_ENABLED = os.environ.get("ICG_SG2_FUSED2", "1") != "0"      # False: the regulariser phases keep the composed operators
+
+
+def twice():
+    return _SECOND_ORDER > 0 and SECOND_ORDER_ENABLED
+
+
 def active():
+    """modulated-convolution / toRGB layers: fused in first-order phases, in second-order phases (twice-differentiable nodes), without autograd"""
+    return ENABLED and (_FIRST_ORDER > 0 or twice() or not torch.is_grad_enabled())
+
+
+def active1():
+    """Conv2dLayer / FullyConnectedLayer: fused (once-differentiable) nodes in first-order phases and without autograd only"""
     return ENABLED and (_FIRST_ORDER > 0 or not torch.is_grad_enabled())
 
 
@@ -272,6 +301,7 @@ _EMULATED = False       # set by the CPU host-logic tests (kernels emulated by o
 class _ModConvFn(Function):
     @staticmethod
     def forward(ctx, x, wl, aw, ab, weight, strength, bias, noise, f2, cfg, owner):
+        x_in, wl_in = x, wl          # (the node's own inputs: the second-order form hands THEM to its backward node, not the re-laid-out copies)
         x = _cl(x)
         N, I, H, W = (int(v) for v in x.shape)
         O, R = int(weight.shape[0]), int(weight.shape[2])
@@ -315,68 +345,217 @@ class _ModConvFn(Function):
                            0.2, cfg.act_gain, cfg.clamp, dt)
         Ho, Wo = int(c.shape[2]), int(c.shape[3])
         ctx.cfg, ctx.p, ctx.dims = cfg, p, (N, I, H, W, O, R, Ho, Wo)
-        ctx.save_for_backward(x, xs, c, y, s, d, smax, sarg, wl, aw, weight, noise, f2)
+        ctx.save_for_backward(x, xs, c, y, s, d, smax, sarg, wl, aw, weight, noise, f2, ab, x_in, wl_in)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, xs, c, y, s, d, smax, sarg, wl, aw, weight, noise, f2 = ctx.saved_tensors
-        cfg, p, (N, I, H, W, O, R, Ho, Wo) = ctx.cfg, ctx.p, ctx.dims
+        return _modconv_backward(ctx.saved_tensors[:13], ctx.cfg, ctx.p, ctx.dims, ctx.needs_input_grad, dy, None) + (None, None, None, None)
+
+
+def _modconv_backward(saved, cfg, p, dims, needs, dy, keep):
+    """first-order gradients of a modulated-convolution layer as kernel calls -> (dx, dwl, daw, dab, dweight, dstrength, dbias);
+    `keep` (a dict or None) receives the intermediates the second-order pass needs"""
+    x, xs, c, y, s, d, smax, sarg, wl, aw, weight, noise, f2 = saved
+    N, I, H, W, O, R, Ho, Wo = dims
+    pl, dt, dev = cfg.plan, _dt(x), x.device
+    dy = _cl(dy.to(y.dtype))
+    dc = torch.empty_like(dy)
+    sums = torch.empty(N, 2 * O + 1, device=dev, dtype=torch.float32)
+    tot = torch.empty(2 * O + 1, device=dev, dtype=torch.float32)
+    ws, nb = _rows_ws(N, Ho * Wo, O, 2 * O + 1, dt, dev)
+    L.call("icg_sg2_act_bwd", dy, y, c, d, noise, cfg.noise_bstride, dc, sums, tot, N, Ho * Wo, O, 3, 0.2, cfg.act_gain, cfg.clamp, dt,
+           ws, nb)
+    if pl.post is not None:
+        dc = _fir_adjoint(dc, f2, pl.post, pl.geo.out)
+    need_w = needs[4]
+    need_s = any(needs[1:4])
+    dx = dwl = daw = dab = dweight = None
+    t = dxs = g = pdot = None
+    if needs[0] or need_s:
+        dxs = G.gather_conv(dc, p.w_adj, pl.geo.adjoint(), p.cache)
+        dxo = torch.empty_like(x) if needs[0] else None
+        ds = torch.empty(N, I, device=dev, dtype=torch.float32)
+        ws, nb = _rows_ws(N, H * W, I, I, dt, dev)
+        L.call("icg_sg2_modulate_bwd", dxs, x, s, dxo, ds, N, H * W, I, dt, ws, nb)
+        dx = dxo
+    if need_s or need_w:
+        nblk = (I + 63) // 64
+        g = torch.empty(N, I, device=dev, dtype=torch.float32)
+        pdot = torch.empty(N, nblk, device=dev, dtype=torch.float32)
+        t = torch.empty(N, O, device=dev, dtype=torch.float32)
+        if not (needs[0] or need_s):
+            ds = torch.zeros(N, I, device=dev, dtype=torch.float32)
+        L.call("icg_sg2_style_bwd", ds, I, sums[:, O:], 2 * O + 1, d, s, p.wsq, N, I, O, g, pdot, t)
+        if need_s:
+            K = int(wl.shape[1])
+            daw = torch.empty_like(aw) if needs[2] else None
+            dab = torch.empty(I, device=dev, dtype=torch.float32) if needs[3] else None
+            dwl = torch.empty_like(wl) if needs[1] else None
+            L.call("icg_sg2_fc_bwd", g, smax, sarg, pdot if smax is not None else None, nblk, 1.0, wl, aw, N, I, K, cfg.affine_wgain,
+                   cfg.affine_bgain, daw, dab, dwl)
+    if need_w and not G.weight_gradients_disabled:
+        if xs is None:      # the forward modulated inside the convolution: the weight gradient's operand is rebuilt here
+            xs = torch.empty_like(x)
+            L.call("icg_sg2_modulate", x, s, xs, N, H * W, I, dt)
+        tw, layout = G.gather_wgrad_raw(xs, dc, pl.geo)
+        dweight = torch.empty_like(weight)
+        nbw = L.query("icg_sg2_weight_bwd_workspace_bytes", O, I) if p.prenorm else 0
+        L.call("icg_sg2_weight_bwd", tw, layout, t, s, N, weight, p.wscale, p.warg, int(p.prenorm), p.gain, dt, dweight, O, I, R,
+               _ops._bytes(nbw, dev) if nbw else None, nbw)
+    dstrength = tot[2 * O].reshape(()) if (noise is not None and needs[5]) else None
+    dbias = tot[:O] if needs[6] else None
+    if keep is not None:
+        keep.update(dy=dy, dc_conv=dc, dxs=dxs, g=g, pdot=pdot, t=t, dd=sums[:, O:2 * O].contiguous(), xs=xs)
+    return dx, dwl, daw, dab, dweight, dstrength, dbias
+
+
+def _mm(a, b, ta=False, tb=False, alpha=1.0):
+    """alpha op(a) op(b) on the HIP GEMM (fp32, small matrices of the style / affine algebra): no vendor library in the step"""
+    a, b = a.contiguous(), b.contiguous()
+    m = a.shape[1] if ta else a.shape[0]
+    k = a.shape[0] if ta else a.shape[1]
+    n = b.shape[0] if tb else b.shape[1]
+    c = torch.empty(m, n, device=a.device, dtype=torch.float32)
+    L.call("icg_gemm_batched", a, b, c, int(m), int(n), int(k), int(ta), int(tb), 0, 0, 0, 1, float(alpha))
+    return c
+
+
+class _ModConv2Fn(Function):
+    """the same layer for phases that differentiate TWICE: its backward is the node _ModConvBwdFn, whose adjoint is written out below"""
+
+    @staticmethod
+    def forward(ctx, x, wl, aw, ab, weight, strength, bias, noise, f2, cfg, owner):
+        return _ModConvFn.forward(ctx, x, wl, aw, ab, weight, strength, bias, noise, f2, cfg, owner)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xs, c, y, s, d, smax, sarg, wl, aw, weight, noise, f2, ab, x_in, wl_in = ctx.saved_tensors
+        st = dict(saved=(x.detach(), xs, c, y, s, d, smax, sarg, wl.detach(), aw.detach(), weight.detach(), noise, f2), cfg=ctx.cfg, p=ctx.p,
+                  dims=ctx.dims, needs=ctx.needs_input_grad)
+        out = _ModConvBwdFn.apply(dy, x_in, wl_in, aw, ab, weight, st)
+        return tuple(out) + (None, None, None, None)
+
+
+class _ModConvBwdFn(Function):
+    """B(dy; x, wl, A, ab, W) -> (dx, dwl, dA, dab, dW, dstrength, dbias): the first-order gradients as a node.  Its backward -- the adjoint of B
+    with respect to (dy, x, wl, A, W) for cotangents of dx and dwl, what the path-length penalty sends back -- follows B's own steps in reverse and
+    then the layer's forward dependencies (c = K(x s, W~), d = (s^2 wsq + eps)^-1/2, s = N(lin), lin = wg wl A^T + ab):
+        affine / pre-normalisation  ->  style algebra on [N x I], [N x O] matrices (ATen, no autograd)  ->  u = x cot(ds) + cot(dx) s
+        -> K(u), wgrad(u, dc)  ->  icg_sg2_act_bwd2  ->  K^T(cot c), wgrad(x s, cot c)  ->  icg_sg2_modulate_bwd  ->  the same algebra backwards"""
+
+    @staticmethod
+    def forward(ctx, dy, x, wl, aw, ab, weight, st):
+        keep = {}
+        outs = _modconv_backward(st["saved"], st["cfg"], st["p"], st["dims"], st["needs"], dy, keep)
+        ctx.st, ctx.keep = st, keep
+        ctx.mark_non_differentiable(*[o for o in outs[2:] if o is not None])
+        return outs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, cdx, cdwl, *rest):
+        st, kp = ctx.st, ctx.keep
+        x, xs, c, y, s, d, smax, sarg, wl, aw, weight, noise, f2 = st["saved"]
+        cfg, p, (N, I, H, W, O, R, Ho, Wo) = st["cfg"], st["p"], st["dims"]
         pl, dt, dev = cfg.plan, _dt(x), x.device
-        dy = _cl(dy.to(y.dtype))
-        dc = torch.empty_like(dy)
-        sums = torch.empty(N, 2 * O + 1, device=dev, dtype=torch.float32)
-        tot = torch.empty(2 * O + 1, device=dev, dtype=torch.float32)
-        ws, nb = _rows_ws(N, Ho * Wo, O, 2 * O + 1, dt, dev)
-        L.call("icg_sg2_act_bwd", dy, y, c, d, noise, cfg.noise_bstride, dc, sums, tot, N, Ho * Wo, O, 3, 0.2, cfg.act_gain, cfg.clamp, dt,
-               ws, nb)
-        if pl.post is not None:
-            dc = _fir_adjoint(dc, f2, pl.post, pl.geo.out)
-        need_w = ctx.needs_input_grad[4]
-        need_s = any(ctx.needs_input_grad[1:4])
-        dx = dwl = daw = dab = dweight = None
-        t = None
-        if ctx.needs_input_grad[0] or need_s:
-            dxs = G.gather_conv(dc, p.w_adj, pl.geo.adjoint(), p.cache)
-            dxo = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-            ds = torch.empty(N, I, device=dev, dtype=torch.float32)
+        half = smax is not None
+        wg, bg = cfg.affine_wgain, cfg.affine_bgain
+        dy, dc_conv, dxs, g, t, dd = kp["dy"], kp["dc_conv"], kp["dxs"], kp["g"], kp["t"], kp["dd"]
+        wsq = p.wsq
+        ar = torch.arange(N, device=dev)
+        f32 = dict(device=dev, dtype=torch.float32)
+        # ---- affine layer and pre-normalisation of B:  dwl = wg dlin A,  dlin = J^T g
+        cl = _mm(cdwl.float(), aw, False, True, wg) if cdwl is not None else torch.zeros(N, I, **f32)          # cot(dlin) = wg cdwl A^T
+        if half:
+            m, sg, e = smax.abs(), torch.sign(smax), sarg.long()
+            P = (g * s).sum(1)
+            dlin = g / m[:, None]
+            dlin[ar, e] -= sg * P / m
+            cle = cl[ar, e]
+            cg = cl / m[:, None] - s * (sg * cle / m)[:, None]
+            cot_m = -(cl * g).sum(1) / (m * m) + cle * sg * P / (m * m)
+            cs = -(cle * sg / m)[:, None] * g
+        else:
+            dlin, cg, cs, cot_m = g, cl, torch.zeros(N, I, **f32), None
+        c_aw = _mm(dlin, cdwl.float(), True, False, wg) if cdwl is not None else torch.zeros_like(aw)          # cot(A) = wg dlin^T cdwl
+        # ---- g = ds_mod + s (t wsq),  t = -dd d^3
+        tw_ = _mm(t, wsq)
+        cs = cs + cg * tw_
+        cgs = cg * s
+        cot_t = _mm(cgs, wsq, False, True)
+        cwsq = _mm(t, cgs, True, False)
+        d3 = d * d * d
+        cdd = -cot_t * d3
+        cd = -3.0 * cot_t * dd * d * d
+        # ---- ds_mod = sum_p dxs x,  dx = dxs s:  u = cot(dxs)
+        s_r = s.half().float() if dt == 1 else s
+        u = torch.empty_like(x)
+        L.call("icg_sg2_mod2", x, cg, cdx if cdx is None else _cl(cdx.to(x.dtype)), s_r if cdx is not None else None, u, N, H * W, I, dt)
+        cx1 = torch.empty_like(x)
+        if cdx is not None:
+            sums1 = torch.empty(N, I, **f32)
             ws, nb = _rows_ws(N, H * W, I, I, dt, dev)
-            L.call("icg_sg2_modulate_bwd", dxs, x, s, dxo, ds, N, H * W, I, dt, ws, nb)
-            dx = dxo
-        if need_s or need_w:
-            nblk = (I + 63) // 64
-            g = torch.empty(N, I, device=dev, dtype=torch.float32)
-            pdot = torch.empty(N, nblk, device=dev, dtype=torch.float32)
-            t = torch.empty(N, O, device=dev, dtype=torch.float32)
-            if not (ctx.needs_input_grad[0] or need_s):
-                ds = torch.zeros(N, I, device=dev, dtype=torch.float32)
-            L.call("icg_sg2_style_bwd", ds, I, sums[:, O:], 2 * O + 1, d, s, p.wsq, N, I, O, g, pdot, t)
-            if need_s:
-                K = int(wl.shape[1])
-                daw = torch.empty_like(aw) if ctx.needs_input_grad[2] else None
-                dab = torch.empty(I, device=dev, dtype=torch.float32) if ctx.needs_input_grad[3] else None
-                dwl = torch.empty_like(wl) if ctx.needs_input_grad[1] else None
-                L.call("icg_sg2_fc_bwd", g, smax, sarg, pdot if smax is not None else None, nblk, 1.0, wl, aw, N, I, K, cfg.affine_wgain,
-                       cfg.affine_bgain, daw, dab, dwl)
-        if need_w and not G.weight_gradients_disabled:
-            if xs is None:      # the forward modulated inside the convolution: the weight gradient's operand is rebuilt here
-                xs = torch.empty_like(x)
-                L.call("icg_sg2_modulate", x, s, xs, N, H * W, I, dt)
-            tw, layout = G.gather_wgrad_raw(xs, dc, pl.geo)
-            dweight = torch.empty_like(weight)
-            nbw = L.query("icg_sg2_weight_bwd_workspace_bytes", O, I) if p.prenorm else 0
-            L.call("icg_sg2_weight_bwd", tw, layout, t, s, N, weight, p.wscale, p.warg, int(p.prenorm), p.gain, dt, dweight, O, I, R,
-                   _ops._bytes(nbw, dev) if nbw else None, nbw)
-        dstrength = tot[2 * O].reshape(()) if (noise is not None and ctx.needs_input_grad[5]) else None
-        dbias = tot[:O] if ctx.needs_input_grad[6] else None
-        return dx, dwl, daw, dab, dweight, dstrength, dbias, None, None, None, None
+            L.call("icg_sg2_modulate_bwd", dxs, _cl(cdx.to(x.dtype)), cg, cx1, sums1, N, H * W, I, dt, ws, nb)        # dxs cot(ds), sum_p dxs cdx
+            cs = cs + sums1
+        else:
+            L.call("icg_sg2_modulate", dxs, cg, cx1, N, H * W, I, dt)
+        # ---- dxs = K^T(dc, W~):  cot(dc) = K(u),  cot(W~) += wgrad(u, dc)
+        cdc = G.gather_conv(u, p.w_fwd, pl.geo, p.cache)
+        if pl.post is not None:
+            cdc = _fir(cdc, f2, pl.post)
+        tw1, layout = G.gather_wgrad_raw(u, dc_conv, pl.geo)
+        # ---- dc = dz d, dd = sum_p dz c, dz = dy m
+        cdy = torch.empty_like(dy)
+        cc = torch.empty_like(dy)
+        sums2 = torch.empty(N, O, **f32)
+        ws, nb = _rows_ws(N, Ho * Wo, O, O, dt, dev)
+        L.call("icg_sg2_act_bwd2", dy, y, c, cdc, d, cdd.contiguous(), cdy, cc, sums2, N, Ho * Wo, O, 3, 0.2, cfg.act_gain, cfg.clamp, dt, ws, nb)
+        cd = cd + sums2
+        # ---- the layer's forward dependencies: c = K(xs, W~), xs = x s
+        cc_conv = _fir_adjoint(cc, f2, pl.post, pl.geo.out) if pl.post is not None else cc
+        cxs = G.gather_conv(cc_conv, p.w_adj, pl.geo.adjoint(), p.cache)
+        if xs is None:
+            xs = kp.get("xs")
+        if xs is None:
+            xs = torch.empty_like(x)
+            L.call("icg_sg2_modulate", x, s, xs, N, H * W, I, dt)
+        tw2, layout2 = G.gather_wgrad_raw(xs, cc_conv, pl.geo)
+        assert layout2 == layout
+        cx2 = torch.empty_like(x)
+        sums3 = torch.empty(N, I, **f32)
+        ws, nb = _rows_ws(N, H * W, I, I, dt, dev)
+        L.call("icg_sg2_modulate_bwd", cxs, x, s, cx2, sums3, N, H * W, I, dt, ws, nb)
+        cs = cs + sums3
+        cx = cx1 + cx2
+        # ---- d = (q + eps)^-1/2, q = s^2 wsq^T
+        cq = -0.5 * d3 * cd
+        cs = cs + 2.0 * s * _mm(cq, wsq)
+        cwsq = cwsq + _mm(cq, s * s, True, False)
+        # ---- s = N(lin), lin = wg wl A^T + bg ab
+        if half:
+            clin = cs / m[:, None]
+            clin[ar, e] -= sg * (cs * s).sum(1) / m
+            clin[ar, e] += sg * cot_m
+        else:
+            clin = cs
+        c_wl = _mm(clin, aw, False, False, wg)
+        c_aw = c_aw + _mm(clin, wl, True, False, wg)
+        c_ab = clin.sum(0) * bg
+        # ---- W~ = W scale(W), wsq = sum_k W~^2
+        cweight = torch.empty_like(weight)
+        nbw = L.query("icg_sg2_weight_bwd_workspace_bytes", O, I) if p.prenorm else 0
+        L.call("icg_sg2_weight_bwd_q", tw1 + tw2, layout, None, None, 0, (2.0 * cwsq).contiguous(), weight, p.wscale, p.warg, int(p.prenorm), p.gain, 0,
+               cweight, O, I, R, _ops._bytes(nbw, dev) if nbw else None, nbw)
+        return cdy, cx, c_wl, c_aw, c_ab, cweight, None
 
 
 def modconv_layer(owner, x, w_latent, affine, weight, strength, bias, noise, noise_bstride, f2, pl, act_gain, clamp):
     cfg = ModConvCfg(pl, float(act_gain), float(clamp if clamp is not None else -1), float(affine.weight_gain), float(affine.bias_gain),
                      int(noise_bstride))
-    return _ModConvFn.apply(x, w_latent, affine.weight, affine.bias, weight, strength, bias, noise, f2, cfg, owner)
+    fn = _ModConv2Fn if (twice() and torch.is_grad_enabled()) else _ModConvFn
+    return fn.apply(x, w_latent, affine.weight, affine.bias, weight, strength, bias, noise, f2, cfg, owner)
 
 
 # ------------------------------------------------------------------------------------------------------------------ ToRGBLayer
@@ -390,6 +569,7 @@ def torgb_applies(x, weight, w_latent):
 class _ToRGBFn(Function):
     @staticmethod
     def forward(ctx, x, wl, aw, ab, weight, bias, img, wgain, awgain, abgain, clamp):
+        x_in, wl_in = x, wl
         x = _cl(x)
         N, C, H, W = (int(v) for v in x.shape)
         dt, dev = _dt(x), x.device
@@ -404,44 +584,109 @@ class _ToRGBFn(Function):
         out = torch.empty(N, 3, H, W, device=dev, dtype=torch.float32)
         L.call("icg_sg2_torgb_fwd", x, s, weight.detach().contiguous(), bias, clamp, img, out, y, N, H * W, C, dt)
         ctx.k = (wgain, awgain, abgain, clamp, N, C, H, W, img is not None)
-        ctx.save_for_backward(x, y, s, wl, aw, weight)
+        ctx.save_for_backward(x, y, s, wl, aw, weight, ab, x_in, wl_in)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dimg):
-        x, y, s, wl, aw, weight = ctx.saved_tensors
-        wgain, awgain, abgain, clamp, N, C, H, W, has_img = ctx.k
+        return _torgb_backward(ctx.saved_tensors[:6], ctx.k, ctx.needs_input_grad, dimg, None) + (None, None, None, None)
+
+
+def _torgb_backward(saved, k, needs, dimg, keep):
+    x, y, s, wl, aw, weight = saved
+    wgain, awgain, abgain, clamp, N, C, H, W, has_img = k
+    dt, dev = _dt(x), x.device
+    dimg = dimg.contiguous()
+    need_s = any(needs[1:4])
+    dx = torch.empty_like(x) if needs[0] else None
+    ctot = 4 * C + 3
+    sums = torch.empty(N, ctot, device=dev, dtype=torch.float32)
+    tot = torch.empty(ctot, device=dev, dtype=torch.float32)
+    nb = L.query("icg_sg2_torgb_bwd_workspace_bytes", N, H * W, C, dt)
+    L.call("icg_sg2_torgb_bwd", dimg, y, x, s, weight.detach().contiguous(), clamp, int(not _bias_act.REFERENCE_CLAMP_GRAD), dx, sums,
+           tot, N, H * W, C, dt, _ops._bytes(nb, dev), nb)
+    dwl = daw = dab = None
+    if need_s:
+        nblk = (C + 63) // 64
+        g = torch.empty(N, C, device=dev, dtype=torch.float32)
+        pdot = torch.empty(N, nblk, device=dev, dtype=torch.float32)
+        L.call("icg_sg2_style_bwd", sums, ctot, None, 0, None, s, None, N, C, 0, g, pdot, None)
+        K = int(wl.shape[1])
+        daw = torch.empty_like(aw) if needs[2] else None
+        dab = torch.empty(C, device=dev, dtype=torch.float32) if needs[3] else None
+        dwl = torch.empty_like(wl) if needs[1] else None
+        L.call("icg_sg2_fc_bwd", g, None, None, None, 0, wgain, wl, aw, N, C, K, awgain, abgain, daw, dab, dwl)
+    dweight = tot[C:4 * C].reshape(weight.shape) if needs[4] else None
+    dbias = tot[4 * C:] if needs[5] else None
+    if keep is not None:
+        keep.update(dimg=dimg, ds=sums[:, :C].contiguous())
+    return dx, dwl, daw, dab, dweight, dbias, (dimg if has_img and needs[6] else None)
+
+
+class _ToRGB2Fn(Function):
+    """ToRGB for phases that differentiate twice: its backward is the node _ToRGBBwdFn"""
+
+    @staticmethod
+    def forward(ctx, x, wl, aw, ab, weight, bias, img, wgain, awgain, abgain, clamp):
+        return _ToRGBFn.forward(ctx, x, wl, aw, ab, weight, bias, img, wgain, awgain, abgain, clamp)
+
+    @staticmethod
+    def backward(ctx, dimg):
+        x, y, s, wl, aw, weight, ab, x_in, wl_in = ctx.saved_tensors
+        st = dict(saved=(x.detach(), y, s, wl.detach(), aw.detach(), weight.detach()), k=ctx.k, needs=ctx.needs_input_grad)
+        out = _ToRGBBwdFn.apply(dimg, x_in, wl_in, aw, ab, weight, st)
+        return tuple(out) + (None, None, None, None)
+
+
+class _ToRGBBwdFn(Function):
+    """B(dimg; x, wl, A, ab, W) -> (dx, dwl, dA, dab, dW, dbias, dimg_in); adjoint for cotangents of dx, dwl and dimg_in (icg_sg2_torgb_bwd2)"""
+
+    @staticmethod
+    def forward(ctx, dimg, x, wl, aw, ab, weight, st):
+        keep = {}
+        outs = _torgb_backward(st["saved"], st["k"], st["needs"], dimg, keep)
+        ctx.st, ctx.keep = st, keep
+        ctx.mark_non_differentiable(*[o for o in outs[2:6] if o is not None])
+        if outs[6] is not None:           # (the image gradient passes through: a view of the incoming tensor would alias an input of this node)
+            outs = outs[:6] + (outs[6].clone(),)
+        return outs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, cdx, cdwl, c2, c3, c4, c5, cim):
+        st, kp = ctx.st, ctx.keep
+        x, y, s, wl, aw, weight = st["saved"]
+        wgain, awgain, abgain, clamp, N, C, H, W, has_img = st["k"]
         dt, dev = _dt(x), x.device
-        dimg = dimg.contiguous()
-        need_s = any(ctx.needs_input_grad[1:4])
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        ctot = 4 * C + 3
-        sums = torch.empty(N, ctot, device=dev, dtype=torch.float32)
-        tot = torch.empty(ctot, device=dev, dtype=torch.float32)
+        ds = kp["ds"]
+        dlin = ds * wgain
+        if cdwl is not None:
+            cl = _mm(cdwl.float(), aw, False, True, awgain)
+            c_aw = _mm(dlin, cdwl.float(), True, False, awgain)
+        else:
+            cl, c_aw = torch.zeros(N, C, device=dev), torch.zeros_like(aw)
+        a = (cl * wgain).contiguous()
+        cdimg = torch.empty(N, 3, H, W, device=dev, dtype=torch.float32)
+        cx = torch.empty_like(x)
+        sums = torch.empty(N, 4 * C, device=dev, dtype=torch.float32)
+        tot = torch.empty(4 * C, device=dev, dtype=torch.float32)
         nb = L.query("icg_sg2_torgb_bwd_workspace_bytes", N, H * W, C, dt)
-        L.call("icg_sg2_torgb_bwd", dimg, y, x, s, weight.detach().contiguous(), clamp, int(not _bias_act.REFERENCE_CLAMP_GRAD), dx, sums,
-               tot, N, H * W, C, dt, _ops._bytes(nb, dev), nb)
-        dwl = daw = dab = None
-        if need_s:
-            nblk = (C + 63) // 64
-            g = torch.empty(N, C, device=dev, dtype=torch.float32)
-            pdot = torch.empty(N, nblk, device=dev, dtype=torch.float32)
-            L.call("icg_sg2_style_bwd", sums, ctot, None, 0, None, s, None, N, C, 0, g, pdot, None)
-            K = int(wl.shape[1])
-            daw = torch.empty_like(aw) if ctx.needs_input_grad[2] else None
-            dab = torch.empty(C, device=dev, dtype=torch.float32) if ctx.needs_input_grad[3] else None
-            dwl = torch.empty_like(wl) if ctx.needs_input_grad[1] else None
-            L.call("icg_sg2_fc_bwd", g, None, None, None, 0, wgain, wl, aw, N, C, K, awgain, abgain, daw, dab, dwl)
-        dweight = tot[C:4 * C].reshape(weight.shape) if ctx.needs_input_grad[4] else None
-        dbias = tot[4 * C:] if ctx.needs_input_grad[5] else None
-        return dx, dwl, daw, dab, dweight, dbias, (dimg if has_img and ctx.needs_input_grad[6] else None), None, None, None, None
+        L.call("icg_sg2_torgb_bwd2", kp["dimg"], y, x, s, weight.contiguous(), a, None if cdx is None else _cl(cdx.to(x.dtype)),
+               None if cim is None else cim.contiguous(), clamp, int(not _bias_act.REFERENCE_CLAMP_GRAD), cdimg, cx, sums, tot, N, H * W, C, dt,
+               _ops._bytes(nb, dev), nb)
+        clin = sums[:, :C] * wgain
+        c_wl = _mm(clin, aw, False, False, awgain)
+        c_aw = c_aw + _mm(clin, wl, True, False, awgain)
+        c_ab = clin.sum(0) * abgain
+        return cdimg, cx, c_wl, c_aw, c_ab, tot[C:4 * C].reshape(weight.shape).clone(), None
 
 
 def torgb_layer(x, w_latent, affine, weight, bias, img, weight_gain, clamp):
     """-> img + torgb(x)   (img may be None), fp32 NCHW"""
-    return _ToRGBFn.apply(x, w_latent, affine.weight, affine.bias, weight, bias, img, float(weight_gain), float(affine.weight_gain),
-                          float(affine.bias_gain), float(clamp if clamp is not None else -1))
+    fn = _ToRGB2Fn if (twice() and torch.is_grad_enabled()) else _ToRGBFn
+    return fn.apply(x, w_latent, affine.weight, affine.bias, weight, bias, img, float(weight_gain), float(affine.weight_gain),
+                    float(affine.bias_gain), float(clamp if clamp is not None else -1))
 
 
 # ------------------------------------------------------------------------------------------------------------------ Conv2dLayer
@@ -449,7 +694,7 @@ _ACT_IDS = {"linear": 1, "lrelu": 3}
 
 
 def conv_applies(x, weight, activation, up, down, padding, fw, flip_weight):
-    if not (active() and (x.is_cuda or _EMULATED)) or x.dtype not in (torch.float32, torch.float16) or x.dim() != 4:
+    if not (active1() and (x.is_cuda or _EMULATED)) or x.dtype not in (torch.float32, torch.float16) or x.dim() != 4:
         return None
     O, I, R, R2 = (int(v) for v in weight.shape)
     if R != R2 or R not in (1, 3) or activation not in _ACT_IDS or weight.dtype != torch.float32 or (I % 4 and I >= 8):
@@ -560,7 +805,7 @@ def conv_layer(owner, x, weight, bias, f2, pl, activation, weight_gain, act_gain
 
 # ------------------------------------------------------------------------------------------------------------------ FullyConnectedLayer
 def fc_applies(x, weight, activation):
-    return bool(active() and (x.is_cuda or _EMULATED) and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
+    return bool(active1() and (x.is_cuda or _EMULATED) and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
                 and int(x.shape[0]) <= 64 and activation in _ACT_IDS)
 
 

@@ -694,6 +694,26 @@ int icg_sg2_fromrgb_fwd(const void* x, const void* w, const float* bias, void* y
                         float gain, float clamp, int dtype, void* stream);
 int icg_sg2_fromrgb_bwd(const void* dy, const void* y, const void* x, const void* w, void* dimg, float* tot, int N, int64_t HW, int O,
                         int act, float alpha, float gain, float clamp, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* ---- second-order passes (path-length regularisation differentiates a synthesis layer's backward, loss.py:112-146): the adjoints of the first-order
+ * kernels above, used by fused_layers' twice-differentiable layer nodes ---- */
+/* u = x * a[n][c] + g * b[n][c]  (g / b may be NULL) */
+int icg_sg2_mod2(const void* x, const float* a, const void* g, const float* b, void* u, int N, int64_t HW, int C, int dtype, void* stream);
+/* adjoint of icg_sg2_act_bwd with respect to (dy, c, d): given cdc = cot(dc) and cdd = cot(dd) [N][O]:
+ *   cdy = (cdc * d + cdd * c) * act'(y)-mask,  cc = cot(c) = cdd * dz (may be NULL),  sums [N][O] = sum_p cdc * dz  (+= cot(d));  dz = dy * mask
+ * workspace: icg_sg2_rows_workspace_bytes(N, HW, O, O, dtype) */
+int icg_sg2_act_bwd2(const void* dy, const void* y, const void* c, const void* cdc, const float* d, const float* cdd, void* cdy, void* cc,
+                     float* sums, int N, int64_t HW, int O, int act, float alpha, float gain, float clamp, int dtype, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* icg_sg2_weight_bwd with a general demodulation-table cotangent: g += w scale Q[o][i]  (Q [O][I], may be NULL) */
+int icg_sg2_weight_bwd_q(const float* dw_conv, int layout, const float* t, const float* s, int N, const float* Q, const float* w,
+                         const float* wscale, const int* warg, int prenorm, float c0, int round_f16, float* dw, int O, int I, int R,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* adjoint of icg_sg2_torgb_bwd: a [N][C] = cot(ds), cdx = cot(dx) (may be NULL), cim = cot(d img_in) (may be NULL) ->
+ *   cdimg [N][3][HW] = mask * sum_c (x a + cdx s)_c w[o][c] + cim,  cx = cot(x) = dxs * a (may be NULL),
+ *   sums [N][4 C] (cot s = sums[:, 0 .. C)), tot [4 C] (cot w[o][c] = tot[(1 + o) C + c]);  workspace as icg_sg2_torgb_bwd */
+int icg_sg2_torgb_bwd2(const float* dimg, const void* y, const void* x, const float* s, const float* w, const float* a, const void* cdx,
+                       const float* cim, float clamp, int mask_clamp, float* cdimg, void* cx, float* sums, float* tot, int N, int64_t HW,
+                       int C, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* ToRGB (networks.py:450-486) as one pass over x: y[n][p][o] = clamp(sum_c (x * s)[n][p][c] w[o][c] + bias[o]), o < 3, stored in the
  * activation type (kept for the backward) and accumulated into the fp32 NCHW image: img_out = img_in + y (img_in may be NULL). */
 int icg_sg2_torgb_applies(int C, int dtype);

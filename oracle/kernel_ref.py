@@ -1268,6 +1268,88 @@ def _raw(t):
     return t.as_strided((n,), (1,))
 
 
+def icg_sg2_mod2(x, a, g, b, u, N, HW, C, dtype):
+    o = mem(x)[: N * HW * C].view(N, HW, C).float() * mem(a)[: N * C].view(N, 1, C)
+    if g is not None:
+        o = o + mem(g)[: N * HW * C].view(N, HW, C).float() * mem(b)[: N * C].view(N, 1, C)
+    mem(u)[: N * HW * C].copy_(o.reshape(-1).to(u.dtype))
+
+
+def icg_sg2_act_bwd2(dy, y, c, cdc, d, cdd, cdy, cc, sums, N, HW, O, act, alpha, gain, clamp, dtype, workspace, workspace_bytes):
+    g = mem(dy)[: N * HW * O].view(N, HW, O).float()
+    yv = mem(y)[: N * HW * O].view(N, HW, O).float()
+    m = gain * (torch.where(yv > 0, torch.ones_like(yv), torch.full_like(yv, alpha)) if act == 3 else torch.ones_like(yv))
+    if clamp >= 0:
+        m = torch.where((yv > -clamp) & (yv < clamp), m, torch.zeros_like(m))
+    dz = _rt(g * m, dtype)
+    kv = mem(cdc)[: N * HW * O].view(N, HW, O).float()
+    dv = _rt(mem(d)[: N * O].view(N, 1, O), dtype) if d is not None else 1.0
+    o1 = kv * dv
+    if cdd is not None:
+        ev = mem(cdd)[: N * O].view(N, 1, O)
+        o1 = o1 + ev * mem(c)[: N * HW * O].view(N, HW, O).float()
+        if cc is not None:
+            mem(cc)[: N * HW * O].copy_((ev * dz).reshape(-1).to(cc.dtype))
+    elif cc is not None:
+        mem(cc)[: N * HW * O].zero_()
+    mem(cdy)[: N * HW * O].copy_((o1 * m).reshape(-1).to(cdy.dtype))
+    mem(sums)[: N * O].copy_((kv.double() * dz.double()).sum(1).float().reshape(-1))
+
+
+def icg_sg2_weight_bwd_q(dw_conv, layout, t, s, N, Q, w, wscale, warg, prenorm, c0, round_f16, dw, O, I, R, workspace, workspace_bytes):
+    RR = R * R
+    dc = mem(dw_conv)[: RR * I * O]
+    dc = dc.view(RR, I, O).permute(2, 1, 0) if layout == 0 else dc.view(RR, O, I).permute(1, 2, 0)      # -> [O][I][RR]
+    if round_f16:
+        dc = dc.half().float()
+    wv = mem(w)[: O * I * RR].view(O, I, RR)
+    sc = mem(wscale)[:O].view(O, 1, 1)
+    g = dc
+    if t is not None:
+        q = mem(t)[: N * O].view(N, O).t() @ mem(s)[: N * I].view(N, I).square()                 # [O][I]
+        g = g + wv * sc * q[:, :, None]
+    if Q is not None:
+        g = g + wv * sc * mem(Q)[: O * I].view(O, I)[:, :, None]
+    out = g * sc
+    if prenorm:
+        D = (g * wv).sum(dim=[1, 2])
+        arg = mem(warg)[:O].long()
+        flat = out.reshape(O, -1).clone()
+        wa = wv.reshape(O, -1)[torch.arange(O), arg]
+        flat[torch.arange(O), arg] -= torch.sign(wa) * D * sc.view(O) * sc.view(O) / c0
+        out = flat
+    mem(dw)[: O * I * RR].copy_(out.reshape(-1))
+
+
+def icg_sg2_torgb_bwd2(dimg, y, x, s, w, a, cdx, cim, clamp, mask_clamp, cdimg, cx, sums, tot, N, HW, C, dtype, workspace, workspace_bytes):
+    mk = torch.ones(N, HW, 3)
+    if mask_clamp and clamp >= 0:
+        yv = mem(y)[: N * HW * 3].view(N, HW, 3).float()
+        mk = ((yv > -clamp) & (yv < clamp)).float()
+    dz = _rt(mem(dimg)[: N * 3 * HW].view(N, 3, HW).permute(0, 2, 1), dtype) * mk                 # [N][HW][3]
+    xv = mem(x)[: N * HW * C].view(N, HW, C).float()
+    sv = _rt(mem(s)[: N * C].view(N, 1, C), dtype)
+    wv = _rt(mem(w)[: 3 * C].view(3, C), dtype)
+    av = mem(a)[: N * C].view(N, 1, C)
+    dxs = _rt(dz @ wv, dtype)
+    u = xv * av
+    per = torch.zeros(N, 4 * C, dtype=torch.float64)
+    if cdx is not None:
+        gv = mem(cdx)[: N * HW * C].view(N, HW, C).float()
+        u = u + gv * sv
+        per[:, :C] = (gv.double() * dxs.double()).sum(1)
+    per[:, C:] = torch.einsum("npo,npc->noc", dz.double(), u.double()).reshape(N, 3 * C)
+    out = (u @ wv.t()) * mk                                                                           # [N][HW][3]
+    out = out.permute(0, 2, 1)
+    if cim is not None:
+        out = out + mem(cim)[: N * 3 * HW].view(N, 3, HW)
+    mem(cdimg)[: N * 3 * HW].copy_(out.reshape(-1))
+    if cx is not None:
+        mem(cx)[: N * HW * C].copy_((dxs * av).reshape(-1).to(cx.dtype))
+    mem(sums)[: N * 4 * C].copy_(per.float().reshape(-1))
+    mem(tot)[: 4 * C].copy_(per.sum(0).float())
+
+
 def icg_sg2_style_bwd(ds_mod, ds_stride, dd, dd_stride, d, s, wsq, N, I, O, g, pdot, t):
     dsm = torch.stack([_raw(ds_mod)[n * ds_stride: n * ds_stride + I] for n in range(N)])
     sv = mem(s)[: N * I].view(N, I)
@@ -1310,26 +1392,7 @@ def icg_sg2_weight_bwd_workspace_bytes(O, I):
 
 
 def icg_sg2_weight_bwd(dw_conv, layout, t, s, N, w, wscale, warg, prenorm, c0, round_f16, dw, O, I, R, workspace, workspace_bytes):
-    RR = R * R
-    dc = mem(dw_conv)[: RR * I * O]
-    dc = dc.view(RR, I, O).permute(2, 1, 0) if layout == 0 else dc.view(RR, O, I).permute(1, 2, 0)      # -> [O][I][RR]
-    if round_f16:
-        dc = dc.half().float()
-    wv = mem(w)[: O * I * RR].view(O, I, RR)
-    sc = mem(wscale)[:O].view(O, 1, 1)
-    g = dc
-    if t is not None:
-        q = mem(t)[: N * O].view(N, O).t() @ mem(s)[: N * I].view(N, I).square()                 # [O][I]
-        g = dc + wv * sc * q[:, :, None]
-    out = g * sc
-    if prenorm:
-        D = (g * wv).sum(dim=[1, 2])
-        arg = mem(warg)[:O].long()
-        flat = out.reshape(O, -1).clone()
-        wa = wv.reshape(O, -1)[torch.arange(O), arg]
-        flat[torch.arange(O), arg] -= torch.sign(wa) * D * sc.view(O) * sc.view(O) / c0
-        out = flat
-    mem(dw)[: O * I * RR].copy_(out.reshape(-1))
+    icg_sg2_weight_bwd_q(dw_conv, layout, t, s, N, None, w, wscale, warg, prenorm, c0, round_f16, dw, O, I, R, workspace, workspace_bytes)
 
 
 def icg_sg2_fromrgb_applies(O, dtype):

@@ -192,3 +192,106 @@ def test_prepared_weights_follow_the_parameter(emu):
             assert float((y2 - ref).abs().max()) < 1e-4
     finally:
         ops.sg2_weight_prep_multi = orig
+
+
+# ---------------------------------------------------------------------------------------------- second order (path-length regulariser)
+def _second_order(fn, params, inputs, fused):
+    """the path-length pattern of loss.py:112-146 on one layer: g = d <y, r> / d w with create_graph, then the gradient of |g|^2 + <g, q>"""
+    from ic_gan_amd.stylegan_ops import conv2d_gradfix, fused_layers as FL
+    import contextlib
+    for p in params:
+        p.grad = None
+    ins = [t.detach().clone().requires_grad_(True) for t in inputs]
+    with (FL.second_order() if fused else contextlib.nullcontext()):
+        y = fn(*ins)
+        # the incoming gradient dy = r * rs carries history (in a network it is the next layer's dx): its cotangent is checked through rs
+        rs = _rnd(tuple(y.shape), 95).requires_grad_(True)
+        ins.append(rs)
+        r = _rnd(tuple(y.shape), 99)
+        with conv2d_gradfix.no_weight_gradients():
+            # (both the style gradient -- the path-length vector -- and the gradient that travels on to the previous layer)
+            g, gx = torch.autograd.grad([(y.float() * (r * rs)).sum()], [ins[1], ins[0]], create_graph=True, only_inputs=True)
+        q, qx, qy = _rnd(tuple(g.shape), 98), _rnd(tuple(gx.shape), 97), _rnd(tuple(y.shape), 96)
+        # ... and a cotangent on the layer's OUTPUT in the final pass, as the next layer's second-order node sends one
+        (g.square().sum() * 0.5 + (g * q).sum() + (gx.float() * qx).sum() + (y.float() * qy).sum() * 0.1).backward()
+    return g.detach().float(), [t.grad.float() for t in ins], [p.grad.float() if p.grad is not None else None for p in params]
+
+
+def _check2(fn, mod, inputs, half, monkeypatch):
+    from ic_gan_amd import _lib as L
+    params, names = list(mod.parameters()), [n for n, _ in mod.named_parameters()]
+    seen = []
+    orig = L.call
+    monkeypatch.setattr(L, "call", lambda name, *a: (seen.append(name), orig(name, *a))[1])
+    g0, gi0, gp0 = _second_order(fn, params, inputs, fused=False)
+    assert not any(n.startswith("icg_sg2_") for n in seen)
+    del seen[:]
+    g1, gi1, gp1 = _second_order(fn, params, inputs, fused=True)
+    assert any(n in ("icg_sg2_act_bwd2", "icg_sg2_torgb_bwd2") for n in seen), "second-order fused path not taken: %s" % sorted(set(seen))
+    tol = 1.5e-2 if half else 1e-4
+    _cmp(g1, g0, 4e-3 if half else 2e-5, "first-order gradient (the path-length vector)")
+    for i, (a, b) in enumerate(zip(gi1, gi0)):
+        _cmp(a, b, tol, "second-order grad input %d" % i)
+    for n, a, b in zip(names, gp1, gp0):
+        if n.endswith("noise_strength") or (n.endswith("bias") and "affine" not in n):
+            continue          # (their second-order gradients are identically zero: masks only)
+        _cmp(a, b, tol, "second-order grad " + n)
+
+
+@pytest.mark.parametrize("case", SYN)
+def test_synthesis_layer_second_order_fused_equals_composed(case, emu, monkeypatch):
+    from ic_gan_amd.stylegan2 import networks as N
+    cin, cout, res, up, half, noise_mode, clamp, gain, n = case
+    layer = N.SynthesisLayer(cin, cout, w_dim=24, resolution=res, up=up, conv_clamp=clamp)
+    _init(layer, 3)
+    draws = _rnd((n, 1, res, res), 77)
+    monkeypatch.setattr(N, "_randn", lambda shape, device: draws.clone())
+    x = _rnd((n, cin, res // up, res // up), 5).contiguous(memory_format=torch.channels_last)
+    w = _rnd((n, 24), 6)
+    if half:
+        x = x.half()
+    _check2(lambda x, w: layer(x, w, noise_mode=noise_mode, fused_modconv=False, gain=gain), layer, [x, w], half, monkeypatch)
+
+
+@pytest.mark.parametrize("half,clamp,with_img,cin", [(False, None, False, 16), (True, 256, True, 32), (True, 0.7, True, 64), (False, 0.5, True, 512)])
+def test_torgb_layer_second_order_fused_equals_composed(half, clamp, with_img, cin, emu, monkeypatch):
+    from ic_gan_amd.stylegan2 import networks as N
+    layer = N.ToRGBLayer(cin, 3, w_dim=24, conv_clamp=clamp)
+    _init(layer, 4)
+    n, res = 2, 8
+    x = _rnd((n, cin, res, res), 5).contiguous(memory_format=torch.channels_last)
+    w = _rnd((n, 24), 6)
+    img = _rnd((n, 3, res, res), 8)
+    if half:
+        x = x.half()
+    if with_img:
+        _check2(lambda x, w, img: layer(x, w, fused_modconv=False, img=img), layer, [x, w, img], half, monkeypatch)
+    else:
+        _check2(lambda x, w: layer(x, w, fused_modconv=False), layer, [x, w], half, monkeypatch)
+
+
+def test_second_order_chain_of_layers_with_relaid_inputs(emu):
+    """two layers in a row fed the way the networks feed them -- x in NCHW order (re-laid-out inside the node), w an unbound slice of ws (made
+    contiguous inside the node): the backward nodes must receive the layers' OWN inputs, or the cotangents of x and ws are dropped on the way"""
+    import contextlib
+    from ic_gan_amd.stylegan2 import networks as N
+    from ic_gan_amd.stylegan_ops import conv2d_gradfix, fused_layers as FL
+    l1 = N.SynthesisLayer(16, 16, w_dim=24, resolution=8, conv_clamp=256)
+    l2 = N.SynthesisLayer(16, 16, w_dim=24, resolution=8, up=1, conv_clamp=256)
+    _init(l1, 3); _init(l2, 4)
+    x0, ws0, r = _rnd((2, 16, 8, 8), 1), _rnd((2, 2, 24), 2), _rnd((2, 16, 8, 8), 3)
+
+    def run(fused):
+        for p in list(l1.parameters()) + list(l2.parameters()):
+            p.grad = None
+        x, ws = x0.clone().requires_grad_(True), ws0.clone().requires_grad_(True)
+        with (FL.second_order() if fused else contextlib.nullcontext()):
+            w1, w2 = ws.unbind(1)
+            y = l2(l1(x, w1, noise_mode="const", fused_modconv=False), w2, noise_mode="const", fused_modconv=False)
+            with conv2d_gradfix.no_weight_gradients():
+                (g,) = torch.autograd.grad([(y * r).sum()], [ws], create_graph=True, only_inputs=True)
+            (g.square().sum(2).mean(1).sqrt() - 0.5).square().sum().backward()
+        return [x.grad.clone(), ws.grad.clone(), l1.weight.grad.clone(), l2.affine.weight.grad.clone()]
+
+    for what, a, b in zip(("x", "ws", "l1.weight", "l2.affine.weight"), run(True), run(False)):
+        _cmp(a, b, 1e-4, what)

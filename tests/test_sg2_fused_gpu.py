@@ -410,3 +410,121 @@ def test_fromrgb_forward_and_backward(N, HW, O, half):
     (gd, rd), (gt, rt) = run_pair("icg_sg2_fromrgb_bwd", [dy, ry, x, w, dimg, tot, N, HW, O, 3, 0.2, float(np.sqrt(2)), 1.2, dt, ws, nb], [4, 5])
     close(gd.float(), rd.float(), 3e-3 if half else 1e-5, "fromrgb dimg")
     close(gt, rt, 5e-5, "fromrgb sums")
+
+
+# ------------------------------------------------------------------------------------------------ second-order kernels and layers
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("half", [False, True])
+def test_second_order_row_kernels(shape, half):
+    N, HW, C = shape
+    dt = 1 if half else 0
+    x, g = act(N, HW, C, half, 1), act(N, HW, C, half, 2)
+    a, b = rnd(N, C, seed=3), rnd(N, C, seed=4)
+    u = torch.empty_like(x)
+    for with_g in (True, False):
+        ((gu, ru),) = run_pair("icg_sg2_mod2", [x, a, g if with_g else None, b if with_g else None, u, N, HW, C, dt], [4])
+        close(gu.float(), ru.float(), 3e-3 if half else 2e-6, "mod2")
+    dy, y, c, cdc = act(N, HW, C, half, 5), act(N, HW, C, half, 6), act(N, HW, C, half, 7), act(N, HW, C, half, 8)
+    d, cdd = rnd(N, C, seed=9).abs() + 0.5, rnd(N, C, seed=10)
+    cdy, cc, sums = torch.empty_like(x), torch.empty_like(x), torch.empty(N, C)
+    nb = R.icg_sg2_rows_workspace_bytes(N, HW, C, C, dt)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8)
+    args = [dy, y, c, cdc, d, cdd, cdy, cc, sums, N, HW, C, 3, 0.2, float(np.sqrt(2)), 1.0, dt, ws, nb]
+    (g1, r1), (g2, r2), (g3, r3) = run_pair("icg_sg2_act_bwd2", args, [6, 7, 8])
+    close(g1.float(), r1.float(), 3e-3 if half else 2e-6, "act_bwd2 cdy")
+    close(g2.float(), r2.float(), 3e-3 if half else 2e-6, "act_bwd2 cc")
+    close(g3, r3, 5e-5, "act_bwd2 sums")
+
+
+def test_weight_backward_with_general_table_cotangent():
+    O, I, Rk, N = 40, 33, 3, 5
+    RR = Rk * Rk
+    dwc, Q, w = rnd(RR, I, O, seed=1), rnd(O, I, seed=2), rnd(O, I, Rk, Rk, seed=4)
+    c0 = float(np.float32(1 / np.sqrt(I * RR)))
+    m, arg = w.reshape(O, -1).abs().max(dim=1)
+    wscale, warg = (1.0 / m) * c0, arg.to(torch.int32)
+    dw = torch.empty(O, I, Rk, Rk)
+    nb = R.icg_sg2_weight_bwd_workspace_bytes(O, I)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8)
+    ((a, b),) = run_pair("icg_sg2_weight_bwd_q", [dwc, 0, None, None, 0, Q, w, wscale, warg, 1, c0, 0, dw, O, I, Rk, ws, nb], [12])
+    close(a, b, 3e-5, "weight_bwd_q")
+
+
+@pytest.mark.parametrize("N,HW,C", [(2, 64, 16), (3, 100, 32), (2, 4096, 64), (2, 1024, 512)])
+@pytest.mark.parametrize("half", [False, True])
+def test_torgb_second_order_kernel(N, HW, C, half):
+    dt = 1 if half else 0
+    x, cdx = act(N, HW, C, half, 1), act(N, HW, C, half, 7)
+    s, w, a = rnd(N, C, seed=2), rnd(3, C, seed=3, scale=0.1), rnd(N, C, seed=8)
+    dimg, cim = rnd(N, 3, HW, seed=6), rnd(N, 3, HW, seed=9)
+    y = (rnd(N, HW, 3, seed=5) * 0.6)
+    y = y.half() if half else y
+    for with_cdx in (True, False):
+        cdimg, cx, sums, tot = torch.empty(N, 3, HW), torch.empty_like(x), torch.empty(N, 4 * C), torch.empty(4 * C)
+        nb = _L().query("icg_sg2_torgb_bwd_workspace_bytes", N, HW, C, dt)
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8)
+        args = [dimg, y, x, s, w, a, cdx if with_cdx else None, cim if with_cdx else None, 0.8, 1, cdimg, cx, sums, tot, N, HW, C, dt, ws, nb]
+        (g1, r1), (g2, r2), (g3, r3), (g4, r4) = run_pair("icg_sg2_torgb_bwd2", args, [10, 11, 12, 13])
+        close(g1, r1, 3e-3 if half else 2e-5, "torgb_bwd2 cdimg")
+        close(g2.float(), r2.float(), 3e-3 if half else 2e-6, "torgb_bwd2 cx")
+        close(g3, r3, 5e-5, "torgb_bwd2 sums")
+        close(g4, r4, 5e-5, "torgb_bwd2 tot")
+
+
+def _second_order(fn, params, inputs, fused):
+    import contextlib
+    from ic_gan_amd.stylegan_ops import conv2d_gradfix, fused_layers as FL
+    for p in params:
+        p.grad = None
+    ins = [t.detach().clone().requires_grad_(True) for t in inputs]
+    with (FL.second_order() if fused else contextlib.nullcontext()):
+        y = fn(*ins)
+        rs = rnd(*y.shape, seed=95).to(y.device).requires_grad_(True)
+        ins.append(rs)
+        r = rnd(*y.shape, seed=99).to(y.device)
+        with conv2d_gradfix.no_weight_gradients():
+            g, gx = torch.autograd.grad([(y.float() * (r * rs)).sum()], [ins[1], ins[0]], create_graph=True, only_inputs=True)
+        q, qx, qy = rnd(*g.shape, seed=98).to(y.device), rnd(*gx.shape, seed=97).to(y.device), rnd(*y.shape, seed=96).to(y.device)
+        (g.square().sum() * 0.5 + (g * q).sum() + (gx.float() * qx).sum() + (y.float() * qy).sum() * 0.1).backward()
+    return g.detach().float(), [t.grad.float() for t in ins], [p.grad.float() if p.grad is not None else None for p in params]
+
+
+def _check2(fn, mod, inputs, half):
+    params, names = list(mod.parameters()), [n for n, _ in mod.named_parameters()]
+    g0, gi0, gp0 = _second_order(fn, params, inputs, False)
+    g1, gi1, gp1 = _second_order(fn, params, inputs, True)
+    close(g1, g0, 6e-3 if half else 5e-5, "path-length vector")
+    for i, (a, b) in enumerate(zip(gi1, gi0)):
+        close(a, b, 3e-2 if half else 2e-4, "second-order grad input %d" % i)
+    for n, a, b in zip(names, gp1, gp0):
+        if n.endswith("noise_strength") or (n.endswith("bias") and "affine" not in n) or a is None or b is None:
+            continue
+        close(a, b, 3e-2 if half else 2e-4, "second-order grad " + n)
+
+
+@pytest.mark.parametrize("cin,cout,res,up,half,noise_mode,n", [(512, 512, 16, 1, False, "random", 4), (512, 512, 16, 2, False, "const", 4),
+                                                                (512, 512, 32, 2, True, "random", 4), (128, 64, 64, 2, True, "random", 2),
+                                                                (64, 64, 64, 1, True, "const", 2)])
+def test_synthesis_layer_second_order_fused_equals_composed_hip(cin, cout, res, up, half, noise_mode, n, monkeypatch):
+    from ic_gan_amd.stylegan2 import networks as N
+    layer = N.SynthesisLayer(cin, cout, w_dim=512, resolution=res, up=up, conv_clamp=256).cuda()
+    _init(layer, 3)
+    draws = rnd(n, 1, res, res, seed=77).cuda()
+    monkeypatch.setattr(N, "_randn", lambda shape, device: draws.clone())
+    x = rnd(n, cin, res // up, res // up, seed=5).cuda()            # (NCHW order: re-laid-out inside the node)
+    w = rnd(n, 3, 512, seed=6).cuda()[:, 1]                         # (a non-contiguous slice, as ws.unbind gives)
+    if half:
+        x = x.half()
+    _check2(lambda x, w: layer(x, w, noise_mode=noise_mode, fused_modconv=False), layer, [x, w], half)
+
+
+@pytest.mark.parametrize("cin,res,half", [(512, 16, False), (64, 64, True)])
+def test_torgb_layer_second_order_fused_equals_composed_hip(cin, res, half):
+    from ic_gan_amd.stylegan2 import networks as N
+    layer = N.ToRGBLayer(cin, 3, w_dim=512, conv_clamp=256).cuda()
+    _init(layer, 4)
+    x = rnd(2, cin, res, res, seed=5).cuda()
+    if half:
+        x = x.half()
+    w, img = rnd(2, 512, seed=6).cuda(), rnd(2, 3, res, res, seed=8).cuda()
+    _check2(lambda x, w, img: layer(x, w, fused_modconv=False, img=img), layer, [x, w, img], half)
