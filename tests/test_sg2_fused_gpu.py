@@ -481,7 +481,8 @@ def _second_order(fn, params, inputs, fused):
         y = fn(*ins)
         rs = rnd(*y.shape, seed=95).to(y.device).requires_grad_(True)
         ins.append(rs)
-        r = rnd(*y.shape, seed=99).to(y.device)
+        # (small probes: at these widths the composed path's fp16 partial sums of the double backward overflow for O(1) cotangents)
+        r = rnd(*y.shape, seed=99, scale=0.02 if y.dtype == torch.float16 else 1.0).to(y.device)
         with conv2d_gradfix.no_weight_gradients():
             g, gx = torch.autograd.grad([(y.float() * (r * rs)).sum()], [ins[1], ins[0]], create_graph=True, only_inputs=True)
         q, qx, qy = rnd(*g.shape, seed=98).to(y.device), rnd(*gx.shape, seed=97).to(y.device), rnd(*y.shape, seed=96).to(y.device)
