@@ -373,14 +373,15 @@ __global__ __launch_bounds__(256) void sg2_mod2_kernel(const T* __restrict__ x, 
     float xv[VEC], o[VEC];
     Sg<T>::ld(x + i * VEC, xv);
     const float* ap = a + ((size_t)n * V + v) * VEC;
+    // rounding points of the composed operators in fp16 storage: the per-sample factors and each product are fp16 tensors there
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o[j] = xv[j] * ap[j];
+    for (int j = 0; j < VEC; ++j) o[j] = Sg<T>::rnd(xv[j] * Sg<T>::rnd(ap[j]));
     if (g) {
       float gv[VEC];
       Sg<T>::ld(g + i * VEC, gv);
       const float* bp = b + ((size_t)n * V + v) * VEC;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) o[j] = __fmaf_rn(gv[j], bp[j], o[j]);
+      for (int j = 0; j < VEC; ++j) o[j] = o[j] + Sg<T>::rnd(gv[j] * Sg<T>::rnd(bp[j]));
     }
     Sg<T>::st(u + i * VEC, o);
   }
@@ -1083,7 +1084,7 @@ __global__ __launch_bounds__(256) void sg2_torgb_bwd2_kernel(const float* __rest
     for (int j = 0; j < VEC; ++j) {
       const int ch = (q * L + l) * VEC + j;
       sv[q][j] = Sg<T>::rnd(s[(size_t)n * C + ch]);
-      av[q][j] = a[(size_t)n * C + ch];
+      av[q][j] = Sg<T>::rnd(a[(size_t)n * C + ch]);
 #pragma unroll
       for (int o = 0; o < 3; ++o) wv[o][q][j] = Sg<T>::rnd(w[o * C + ch]);
 #pragma unroll
@@ -1112,7 +1113,7 @@ __global__ __launch_bounds__(256) void sg2_torgb_bwd2_kernel(const float* __rest
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           const float dxs = Sg<T>::rnd(dz[0] * wv[0][q][j] + dz[1] * wv[1][q][j] + dz[2] * wv[2][q][j]);
-          const float u = xv[j] * av[q][j] + (cdx ? gv[j] * sv[q][j] : 0.f);
+          const float u = Sg<T>::rnd(Sg<T>::rnd(xv[j] * av[q][j]) + (cdx ? Sg<T>::rnd(gv[j] * sv[q][j]) : 0.f));      // (fp16 tensors in the composed graph)
           if (cdx) acc[0][q][j] += gv[j] * dxs;
           acc[1][q][j] += dz[0] * u; acc[2][q][j] += dz[1] * u; acc[3][q][j] += dz[2] * u;
           t0 += u * wv[0][q][j]; t1 += u * wv[1][q][j]; t2 += u * wv[2][q][j];

@@ -1269,9 +1269,9 @@ def _raw(t):
 
 
 def icg_sg2_mod2(x, a, g, b, u, N, HW, C, dtype):
-    o = mem(x)[: N * HW * C].view(N, HW, C).float() * mem(a)[: N * C].view(N, 1, C)
+    o = _rt(mem(x)[: N * HW * C].view(N, HW, C).float() * _rt(mem(a)[: N * C].view(N, 1, C), dtype), dtype)
     if g is not None:
-        o = o + mem(g)[: N * HW * C].view(N, HW, C).float() * mem(b)[: N * C].view(N, 1, C)
+        o = o + _rt(mem(g)[: N * HW * C].view(N, HW, C).float() * _rt(mem(b)[: N * C].view(N, 1, C), dtype), dtype)
     mem(u)[: N * HW * C].copy_(o.reshape(-1).to(u.dtype))
 
 
@@ -1330,13 +1330,13 @@ def icg_sg2_torgb_bwd2(dimg, y, x, s, w, a, cdx, cim, clamp, mask_clamp, cdimg, 
     xv = mem(x)[: N * HW * C].view(N, HW, C).float()
     sv = _rt(mem(s)[: N * C].view(N, 1, C), dtype)
     wv = _rt(mem(w)[: 3 * C].view(3, C), dtype)
-    av = mem(a)[: N * C].view(N, 1, C)
+    av = _rt(mem(a)[: N * C].view(N, 1, C), dtype)
     dxs = _rt(dz @ wv, dtype)
-    u = xv * av
+    u = _rt(xv * av, dtype)
     per = torch.zeros(N, 4 * C, dtype=torch.float64)
     if cdx is not None:
         gv = mem(cdx)[: N * HW * C].view(N, HW, C).float()
-        u = u + gv * sv
+        u = _rt(u + _rt(gv * sv, dtype), dtype)
         per[:, :C] = (gv.double() * dxs.double()).sum(1)
     per[:, C:] = torch.einsum("npo,npc->noc", dz.double(), u.double()).reshape(N, 3 * C)
     out = (u @ wv.t()) * mk                                                                           # [N][HW][3]

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import kernel_ref
-from tests.helpers import GOLDEN_DIR, check_group
+from tests.helpers import GOLDEN_DIR, check_group, fingerprint
 from tests.stylegan_cases import SG2_LOSS, SG2_NETS, SG2_OPT, SG2_REAL_NETS, sg2_inputs, sg2_state
 
 CASES = sorted(SG2_NETS)
@@ -64,6 +64,16 @@ def _tol(name):
         # (6.5 fp16 ulps) against the reference's CPU run, where the 32x32 toy net measures 3e-3
         return 45.0
     return 30.0 if name.endswith("_fp16") else 1.0
+
+
+def _median_sample_error(gold, prefix, tensors):
+    """Median over the tensors of a gradient group of  max |sample - golden sample| / rms(golden tensor)."""
+    names, out = json.loads(str(gold[prefix + "names"])), []
+    for i, n in enumerate(names):
+        gsamp = gold[prefix + "samp"][i]
+        rms = float(np.sqrt(gold[prefix + "sq"][i] / max(tensors[n].numel(), 1)))
+        out.append(float(np.abs(fingerprint(tensors[n], gsamp.shape[0])[2] - gsamp).max()) / max(rms, 1e-30))
+    return float(np.median(out))
 
 
 def _close(got, ref, rtol, what):
@@ -140,11 +150,19 @@ def _phase_grads(name, dev, monkeypatch):
                 # 0.06 - 0.13 (Dmain), 0.10 median / 0.84 worst (Greg) of the tensor rms over these 64 samples
                 # (tools/sg2_fp16_noise.py -> profiles/r03_sg2_fp16_noise.txt): a second fp16 implementation with other rounding
                 # points cannot be held closer to the fp16 goldens than that.  Measured here: up to 0.16 (Dmain, b16.conv1.weight) /
-                # 0.21 (Greg), moving by +-30 % when only the rounding of the fp32 dense layers changes
-                rtol = 3e-1 if phase.endswith("reg") else 2e-1
+                # 0.21 (Greg), moving by +-30 % when only the rounding of the fp32 dense layers changes.  Round 5: with the
+                # path-length double backward running through the fused layers' hand-written adjoint nodes, Greg measures 0.37
+                # (b256.torgb.affine.bias; the composed operators measure 0.33 on b64.conv1.affine.weight in the same run, the two
+                # implementations differ from EACH OTHER by 0.05 median / 0.24 worst, and sit at the same median distance from the
+                # goldens, 0.069 / 0.066: profiles/r05_cfg4_greg_second_order.txt) -- the same noise class, so the element bound is
+                # 0.45 and the median over tensors is held at 0.10 beside it.  The ALGEBRA of those adjoints is held by the fp32
+                # network (cfg4_r256, 1e-2 above) and by tests/test_sg2_fused_gpu.py
+                rtol = 4.5e-1 if phase.endswith("reg") else 2e-1
             top = max(float(v.abs().max()) for v in grads.values())
             extra = {n: 0.05 * top for n in grads if n.endswith("noise_strength")}
         check_group(g, f"grad/{phase}/", grads, rtol=rtol, atol=1e-7, what=phase + " ", extra_atol=extra)
+        if name == "cfg4_r256_fp16" and phase == "Greg":
+            assert _median_sample_error(g, f"grad/{phase}/", grads) <= 0.10
         assert abs(float(L.pl_mean) - float(g[f"grad/{phase}/pl_mean"])) <= 1e-3 * _tol(name) * max(abs(float(g[f"grad/{phase}/pl_mean"])), 1e-3)
         for p in mod.parameters():
             p.grad = None
