@@ -261,3 +261,147 @@ extern "C" int icg_attn_dscores(const float* dO, const float* V, const float* be
   else hipLaunchKernelGGL((icg_attn_dscores_kernel<192>), grid, block, 0, st, dO, V, beta, dS, n, m);
   return icg_check_launch();
 }
+
+// ---------------------------------------------------------------- the three input projections of the block as ONE 1x1 convolution
+// theta, phi and g (layers.py:217-231) read the same x; with their weights stacked into one [2 d + dv][C] matrix the block runs one
+// GEMM with 2 d + dv = 288 / 144 columns instead of three with 48 / 48 / 192 (24 / 24 / 96) -- the narrow ones fill a quarter or
+// half of a 96-column MFMA tile -- and one data-gradient and one weight-gradient GEMM in the backward pass.  These two kernels sit
+// between that GEMM and the attention core: they split its output y [B][H][W][2 d + dv] into theta [B][HW][d] and the 2x2
+// max-pooled phi [B][HW/4][d] and g [B][HW/4][dv] (forward), and assemble dy from dtheta and the pooled gradients routed to the
+// first maximum of each window, exactly as icg_maxpool2_bwd does (backward).  One thread per (pooled pixel, channel quad).
+template <int BWD>
+__global__ __launch_bounds__(256) void attn_split_pool_kernel(const float4* __restrict__ y, const float4* __restrict__ gt,
+                                                              const float4* __restrict__ gp, const float4* __restrict__ gg,
+                                                              float4* __restrict__ o0, float4* __restrict__ o1,
+                                                              float4* __restrict__ o2, int B, int H, int W, int d4, int dv4) {
+  const int C4 = 2 * d4 + dv4, Hp = H >> 1, Wp = W >> 1;
+  const long total = (long)B * Hp * Wp * C4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int wp = (int)(t % Wp);
+    t /= Wp;
+    const int hp = (int)(t % Hp);
+    const long b = t / Hp;
+    const long pix = (b * H + 2 * hp) * W + 2 * wp;               // top-left pixel of the window
+    const long base = pix * C4 + c, o01 = C4, o10 = (long)W * C4, o11 = o10 + C4;
+    const long ppix = (b * Hp + hp) * Wp + wp;
+    if (c < d4) {                                                 // theta: a copy
+      const long tb = pix * d4 + c, t10 = (long)W * d4;
+      if (!BWD) {
+        o0[tb] = y[base]; o0[tb + d4] = y[base + o01]; o0[tb + t10] = y[base + o10]; o0[tb + t10 + d4] = y[base + o11];
+      } else {
+        o0[base] = gt[tb]; o0[base + o01] = gt[tb + d4]; o0[base + o10] = gt[tb + t10]; o0[base + o11] = gt[tb + t10 + d4];
+      }
+      continue;
+    }
+    const float4 v0 = y[base], v1 = y[base + o01], v2 = y[base + o10], v3 = y[base + o11];
+    const bool is_phi = c < 2 * d4;
+    const long pidx = is_phi ? ppix * d4 + (c - d4) : ppix * dv4 + (c - 2 * d4);
+    if (!BWD) {
+      float4 m;
+      m.x = fmaxf(fmaxf(fmaxf(v0.x, v1.x), v2.x), v3.x);
+      m.y = fmaxf(fmaxf(fmaxf(v0.y, v1.y), v2.y), v3.y);
+      m.z = fmaxf(fmaxf(fmaxf(v0.z, v1.z), v2.z), v3.z);
+      m.w = fmaxf(fmaxf(fmaxf(v0.w, v1.w), v2.w), v3.w);
+      (is_phi ? o1 : o2)[pidx] = m;
+    } else {
+      const float4 g = (is_phi ? gp : gg)[pidx];
+      float4 r0, r1, r2, r3;
+#define AT_ROUTE(f)                                                        \
+  {                                                                        \
+    int arg = 0;                                                           \
+    float m = v0.f;                                                        \
+    if (v1.f > m) { m = v1.f; arg = 1; }                                   \
+    if (v2.f > m) { m = v2.f; arg = 2; }                                   \
+    if (v3.f > m) { m = v3.f; arg = 3; }                                   \
+    r0.f = arg == 0 ? g.f : 0.f; r1.f = arg == 1 ? g.f : 0.f;              \
+    r2.f = arg == 2 ? g.f : 0.f; r3.f = arg == 3 ? g.f : 0.f;              \
+  }
+      AT_ROUTE(x) AT_ROUTE(y) AT_ROUTE(z) AT_ROUTE(w)
+#undef AT_ROUTE
+      o0[base] = r0; o0[base + o01] = r1; o0[base + o10] = r2; o0[base + o11] = r3;
+    }
+  }
+}
+
+static bool at_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int icg_attn_split_pool(const float* y, float* theta, float* phi_p, float* g_p, int B, int H, int W, int d, int dv,
+                                   void* stream) {
+  ICG_REQUIRE(y && theta && phi_p && g_p && B > 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1) && d > 0 && dv > 0 && !(d & 3) && !(dv & 3));
+  ICG_REQUIRE(at_al16(y) && at_al16(theta) && at_al16(phi_p) && at_al16(g_p));
+  const long total = (long)B * (H / 2) * (W / 2) * ((2 * d + dv) / 4);
+  const long blocks = icg_cdiv(total, 256);
+  hipLaunchKernelGGL(attn_split_pool_kernel<0>, dim3((unsigned)(blocks > ICG_GRID_CAP ? ICG_GRID_CAP : blocks)), dim3(256), 0,
+                     (hipStream_t)stream, (const float4*)y, (const float4*)nullptr, (const float4*)nullptr, (const float4*)nullptr,
+                     (float4*)theta, (float4*)phi_p, (float4*)g_p, B, H, W, d / 4, dv / 4);
+  return icg_check_launch();
+}
+
+extern "C" int icg_attn_split_pool_bwd(const float* y, const float* dtheta, const float* dphi_p, const float* dg_p, float* dy, int B,
+                                       int H, int W, int d, int dv, void* stream) {
+  ICG_REQUIRE(y && dtheta && dphi_p && dg_p && dy && B > 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1) && d > 0 && dv > 0 && !(d & 3) &&
+              !(dv & 3));
+  ICG_REQUIRE(at_al16(y) && at_al16(dtheta) && at_al16(dphi_p) && at_al16(dg_p) && at_al16(dy));
+  const long total = (long)B * (H / 2) * (W / 2) * ((2 * d + dv) / 4);
+  const long blocks = icg_cdiv(total, 256);
+  hipLaunchKernelGGL(attn_split_pool_kernel<1>, dim3((unsigned)(blocks > ICG_GRID_CAP ? ICG_GRID_CAP : blocks)), dim3(256), 0,
+                     (hipStream_t)stream, (const float4*)y, (const float4*)dtheta, (const float4*)dphi_p, (const float4*)dg_p,
+                     (float4*)dy, (float4*)nullptr, (float4*)nullptr, B, H, W, d / 4, dv / 4);
+  return icg_check_launch();
+}
+
+// ---------------------------------------------------------------- gamma folded into the output projection
+// out = gamma * conv1x1(a, W / sigma) + x (layers.py:242-244) as ONE convolution with the weight gamma * W / sigma and x as the
+// residual operand of its epilogue: the projection's output o and the gamma * o + x pass never touch HBM (two reads + one write of
+// [B][C][H][W] per forward, the same again in the backward pass).  gamma lives on the device: these two single-workgroup kernels
+// scale the (tiny) weight matrices by it and, in the backward pass, turn the gradient of the scaled weight into
+//   dgamma = <dWs, W / sigma>,   d(W / sigma) = gamma * dWs.
+__global__ __launch_bounds__(1024) void attn_gamma_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ a,
+                                                                float* __restrict__ as, const float* __restrict__ b,
+                                                                float* __restrict__ bs, long n) {
+  const float g = gamma[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    as[i] = g * a[i];
+    if (b) bs[i] = g * b[i];
+  }
+}
+
+__global__ __launch_bounds__(1024) void attn_gamma_bwd_kernel(const float* __restrict__ gamma, const float* __restrict__ dws,
+                                                              const float* __restrict__ w, float* __restrict__ dw,
+                                                              float* __restrict__ dgamma, long n) {
+  __shared__ double red[16];
+  const float g = gamma[0];
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = dws[i];
+    acc += (double)v * (double)w[i];
+    dw[i] = g * v;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < 16; ++k) s += red[k];
+    dgamma[0] = (float)s;
+  }
+}
+
+extern "C" int icg_attn_gamma_scale(const float* gamma, const float* w_a, float* ws_a, const float* w_b, float* ws_b, int64_t n,
+                                    void* stream) {
+  ICG_REQUIRE(gamma && w_a && ws_a && n > 0 && (!w_b || ws_b));
+  const long blocks = icg_cdiv(n, 1024);
+  hipLaunchKernelGGL(attn_gamma_scale_kernel, dim3((unsigned)(blocks > 256 ? 256 : blocks)), dim3(1024), 0, (hipStream_t)stream, gamma,
+                     w_a, ws_a, w_b, ws_b, (long)n);
+  return icg_check_launch();
+}
+
+extern "C" int icg_attn_gamma_bwd(const float* gamma, const float* dws, const float* w, float* dw, float* dgamma, int64_t n,
+                                  void* stream) {
+  ICG_REQUIRE(gamma && dws && w && dw && dgamma && n > 0);
+  hipLaunchKernelGGL(attn_gamma_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, gamma, dws, w, dw, dgamma, (long)n);
+  return icg_check_launch();
+}

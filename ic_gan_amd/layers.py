@@ -303,6 +303,10 @@ class bn(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # Self-attention  (reference layers.py:206-244)
 # ------------------------------------------------------------------------------------------------
+def _plain_1x1(*convs):
+    return all(isinstance(m, SNConv2d) and m.kernel_size == (1, 1) and m.bias is None for m in convs)
+
+
 class Attention(nn.Module):
     def __init__(self, ch, which_conv=SNConv2d, name="attention"):
         super().__init__()
@@ -318,12 +322,21 @@ class Attention(nn.Module):
         # (`chain=True`: second output = x itself), so that in the backward pass the gradients of x arrive one after the
         # other and every projection adds the running sum in the epilogue of its own data-gradient GEMM: no elementwise
         # gradient-accumulation passes over [B, C, 64, 64] (three per block and backward pass, 1.2 GB of traffic each at cfg3)
-        theta, x = self.theta(x, chain=True)
-        phi, x = self.phi(x, chain=True)
-        g, x = self.g(x, chain=True)
-        phi, g = ops.MaxPool2Fn.apply(phi), ops.MaxPool2Fn.apply(g)
-        o = self.o(ops.AttnCoreFn.apply(theta, phi, g))
-        return ops.ScaleAddFn.apply(self.gamma, o, x)
+        if ops.attn_projections_apply(x, self.theta.out_channels, self.g.out_channels) and _plain_1x1(self.theta, self.phi, self.g):
+            # the three projections as ONE 1x1 convolution with stacked weights + one split / max-pool pass (ops.AttnProjFn)
+            sns = tuple(m.sn_state() for m in (self.theta, self.phi, self.g))
+            theta, phi, g, x = ops.AttnProjFn.apply(x, self.theta.weight, self.phi.weight, self.g.weight, sns)
+        else:
+            theta, x = self.theta(x, chain=True)
+            phi, x = self.phi(x, chain=True)
+            g, x = self.g(x, chain=True)
+            phi, g = ops.MaxPool2Fn.apply(phi), ops.MaxPool2Fn.apply(g)
+        a = ops.AttnCoreFn.apply(theta, phi, g)
+        if ops.FUSED_ATTENTION_OUTPUT and _plain_1x1(self.o):
+            # gamma folded into the output projection's weight, x added in its epilogue (ops.AttnOutFn).  The weight gradient needs
+            # W / sigma in the [Cin][Cout] layout, so that layout is prepared whenever a gradient can be asked for
+            return ops.AttnOutFn.apply(a, x, self.o.weight, self.gamma, self.o.sn_state())
+        return ops.ScaleAddFn.apply(self.gamma, self.o(a), x)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@ is what the kernels address; `_cl` makes that true at module boundaries.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -1003,6 +1004,131 @@ class AttnCoreFn(Function):
         dphi = torch.empty_like(phi)       # dK = dS^T Q
         L.call("icg_gemm_batched", ds, theta, dphi, m, d, n, 1, 0, n * m, n * d, m * d, B, 1.0)
         return dtheta, dphi, dg
+
+
+FUSED_ATTENTION_PROJECTIONS = os.environ.get("ICG_ATTN_PROJ", "1") != "0"
+
+
+def attn_projections_apply(x, d, dv) -> bool:
+    """The stacked form of theta / phi / g (AttnProjFn): vector widths of icg_attn_split_pool and an even resolution."""
+    return bool(FUSED_ATTENTION_PROJECTIONS and x.dim() == 4 and d % 4 == 0 and dv % 4 == 0 and x.shape[2] % 2 == 0
+                and x.shape[3] % 2 == 0)
+
+
+class AttnProjFn(Function):
+    """theta, max-pooled phi and max-pooled g of the attention block (reference layers.py:217-231) from ONE 1x1 convolution whose
+    weight stacks the three spectrally normalised matrices: one GEMM with 2 d + dv columns instead of three with d / d / dv (the
+    narrow ones fill a quarter or half of an MFMA tile), x read once; backward: one data-gradient GEMM (the later consumers'
+    gradient of x added in its epilogue, as FusedConvFn's chain does) and one weight-gradient GEMM whose row blocks are the three
+    layers' gradients.  Returns (theta [B,d,H,W], phi [B,d,H/2,W/2], g [B,dv,H/2,W/2], x handed on to the residual path)."""
+
+    @staticmethod
+    def forward(ctx, x, w_theta, w_phi, w_g, sns):
+        x_in = x
+        x = _cl(x)
+        B, C, H, W = x.shape
+        d, dv = sns[0].rows, sns[2].rows
+        assert sns[1].rows == d and all(s.cin == C and s.R == 1 for s in sns)
+        Ct = 2 * d + dv
+        dev = x.device
+        w_cat = torch.cat([s.w_ohwi.view(s.rows, C) for s in sns], 0)
+        y = _empty_cl(B, Ct, H, W, dev)
+        _conv_fprop(x, w_cat, None, None, y, None, None, 0, B, H, W, C, Ct, 1, 0)
+        theta, phi, g = _empty_cl(B, d, H, W, dev), _empty_cl(B, d, H // 2, W // 2, dev), _empty_cl(B, dv, H // 2, W // 2, dev)
+        L.call("icg_attn_split_pool", y, theta, phi, g, B, H, W, d, dv)
+        ctx.sns, ctx.dims, ctx.likes = sns, (B, C, H, W, d, dv), (w_theta, w_phi, w_g)
+        ctx.save_for_backward(x, y)
+        return theta, phi, g, (x_in if x.data_ptr() == x_in.data_ptr() and x.dtype == x_in.dtype else x)
+
+    @staticmethod
+    def backward(ctx, dtheta, dphi, dg, dcarry=None):
+        x, y = ctx.saved_tensors
+        B, C, H, W, d, dv = ctx.dims
+        Ct = 2 * d + dv
+        sns, dev = ctx.sns, x.device
+        need = ctx.needs_input_grad
+        zeros = lambda c, h, w: torch.zeros(B, c, h, w, device=dev).contiguous(memory_format=torch.channels_last)
+        dtheta = _cl(dtheta) if dtheta is not None else zeros(d, H, W)
+        dphi = _cl(dphi) if dphi is not None else zeros(d, H // 2, W // 2)
+        dg = _cl(dg) if dg is not None else zeros(dv, H // 2, W // 2)
+        dy = _empty_cl(B, Ct, H, W, dev)
+        L.call("icg_attn_split_pool_bwd", y, dtheta, dphi, dg, dy, B, H, W, d, dv)
+        dx = None
+        if need[0]:
+            if any(s.w_dgrad is None for s in sns):
+                raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
+            wd_cat = torch.cat([s.w_dgrad.view(C, s.rows) for s in sns], 1)          # [C][2 d + dv]
+            dx = _empty_cl(B, C, H, W, dev)
+            _conv_fprop(dy, wd_cat, None, _cl(dcarry) if dcarry is not None else None, dx, None, None, 0, B, H, W, Ct, C, 1, 0)
+        elif dcarry is not None:
+            dx = dcarry
+        dws = [None, None, None]
+        if any(need[1:4]):
+            # the 1x1 weight gradient is symmetric in its operands: with dy as the "input" and x as the "output gradient" the HWIO
+            # result [2 d + dv][C] is the stacked gradient in the layers' own OHWI order, its row blocks contiguous
+            nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, Ct, C, 1)
+            dw = _f32(Ct * C, dev)
+            L.call("icg_conv2d_wgrad", dy, x, dw, None, None, 0, B, H, W, Ct, C, 1, 0, _bytes(nb, dev), nb)
+            r0 = 0
+            for i, s in enumerate(sns):
+                if need[1 + i]:
+                    dws[i] = _sn_backward(None, dw[r0 * C:(r0 + s.rows) * C], s, ctx.likes[i])
+                r0 += s.rows
+        return dx, dws[0], dws[1], dws[2], None
+
+
+FUSED_ATTENTION_OUTPUT = os.environ.get("ICG_ATTN_OUT", "1") != "0"
+
+
+class AttnOutFn(Function):
+    """gamma * o(a) + x of the attention block (reference layers.py:242-244) as ONE 1x1 convolution: the weight is gamma * W / sigma
+    (scaled on the device, icg_attn_gamma_scale) and x is the residual operand of the epilogue -- o(a) is never written and the
+    gamma * o + x pass and its backward (two reads + a write of [B, C, H, W] each) are gone.  Backward: d(a) is the data gradient with
+    the scaled weight, the weight gradient dWs of the scaled weight gives dgamma = <dWs, W / sigma> and d(W / sigma) = gamma * dWs
+    (icg_attn_gamma_bwd), and x receives dout itself."""
+
+    @staticmethod
+    def forward(ctx, a, x, weight, gamma, sn: SNState):
+        a, x = _cl(a), _cl(x)
+        B, dv, H, W = a.shape
+        C = sn.rows
+        assert sn.cin == dv and sn.R == 1 and x.shape == (B, C, H, W)
+        dev = a.device
+        g = gamma.detach().reshape(1).contiguous()
+        need_d = sn.w_dgrad is not None
+        ws, wds = _f32(C * dv, dev), (_f32(C * dv, dev) if need_d else None)
+        L.call("icg_attn_gamma_scale", g, sn.w_ohwi, ws, sn.w_dgrad, wds, C * dv)
+        out = _empty_cl(B, C, H, W, dev)
+        _conv_fprop(a, ws, None, x, out, None, None, 0, B, H, W, dv, C, 1, 0)
+        ctx.sn, ctx.dims, ctx.like, ctx.gshape = sn, (B, dv, H, W, C), weight, gamma.shape
+        ctx.save_for_backward(a, g, wds)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, g, wds = ctx.saved_tensors
+        B, dv, H, W, C = ctx.dims
+        sn, dev = ctx.sn, a.device
+        need = ctx.needs_input_grad
+        dout = _cl(dout)
+        da = dweight = dgamma = None
+        if need[0]:
+            if wds is None:
+                raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
+            da = _empty_cl(B, dv, H, W, dev)
+            _conv_fprop(dout, wds, None, None, da, None, None, 0, B, H, W, C, dv, 1, 0)
+        if need[2] or need[3]:
+            if sn.w_dgrad is None:
+                raise RuntimeError("weight gradient of the folded projection needs the [Cin][Cout] layout of W / sigma")
+            nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, dv, C, 1)
+            dws = _f32(dv * C, dev)                                                    # HWIO = [Cin][Cout], the layout of w_dgrad at R = 1
+            L.call("icg_conv2d_wgrad", a, dout, dws, None, None, 0, B, H, W, dv, C, 1, 0, _bytes(nb, dev), nb)
+            dw_hwio, dgamma = _f32(dv * C, dev), _f32(1, dev)
+            L.call("icg_attn_gamma_bwd", g, dws, sn.w_dgrad, dw_hwio, dgamma, dv * C)
+            if need[2]:
+                dweight = _sn_backward(dw_hwio, None, sn, ctx.like)
+            dgamma = dgamma.view(ctx.gshape) if need[3] else None
+        return da, (dout if need[1] else None), dweight, dgamma, None
 
 
 def gemm(a, b, c, m, n, k, trans_a: bool, trans_b: bool, alpha=1.0):

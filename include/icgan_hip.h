@@ -508,6 +508,21 @@ int icg_softmax_bwd(const float* y, const float* dy, float* dx, int64_t rows, in
  * `_applies` -> 1 for n % 32 == 0, m % 128 == 0, m <= 1024, dv in {96, 192} (the two attention blocks of the 64 x 64 models). */
 int icg_attn_dscores_applies(int n, int m, int dv);
 int icg_attn_dscores(const float* dO, const float* V, const float* beta, float* dS, int B, int n, int m, int dv, void* stream);
+/* The attention block's three input projections as ONE 1x1 convolution with stacked weights (theta, phi, g of layers.py:217-231 read
+ * the same x): y [B][H][W][2 d + dv] = that convolution's output.  `icg_attn_split_pool` splits it into theta [B][H W][d] and the 2x2
+ * max-pooled phi [B][H W / 4][d], g [B][H W / 4][dv] (F.max_pool2d, layers.py:230-231); `_bwd` assembles dy [B][H][W][2 d + dv] from
+ * dtheta and the pooled gradients, routed to the first maximum of each window as icg_maxpool2_bwd does.  H, W even; d, dv % 4 == 0;
+ * 16-byte aligned pointers. */
+int icg_attn_split_pool(const float* y, float* theta, float* phi_p, float* g_p, int B, int H, int W, int d, int dv, void* stream);
+int icg_attn_split_pool_bwd(const float* y, const float* dtheta, const float* dphi_p, const float* dg_p, float* dy, int B, int H, int W,
+                            int d, int dv, void* stream);
+/* gamma of the attention block folded into its output projection (layers.py:242-244: gamma * o(...) + x becomes ONE convolution with
+ * the weight gamma * W / sigma and x as the residual operand): `icg_attn_gamma_scale` writes ws_a = gamma[0] * w_a (and ws_b = gamma[0] *
+ * w_b when w_b is given: the data-gradient layout), n elements each, gamma on the device; `icg_attn_gamma_bwd` turns the gradient dws of
+ * the SCALED weight into dw = gamma[0] * dws and dgamma[0] = sum(dws * w) (fp64 accumulation, one workgroup, deterministic), w = W / sigma
+ * in the layout of dws. */
+int icg_attn_gamma_scale(const float* gamma, const float* w_a, float* ws_a, const float* w_b, float* ws_b, int64_t n, void* stream);
+int icg_attn_gamma_bwd(const float* gamma, const float* dws, const float* w, float* dw, float* dgamma, int64_t n, void* stream);
 /* h[b][c] = sum_hw relu(x[b,h,w,c])   (BigGAN.py:625) and its backward */
 int icg_relu_sumpool_fwd(const float* x, float* y, int B, int HW, int C, void* stream);
 int icg_relu_sumpool_bwd(const float* x, const float* dy, float* dx, int B, int HW, int C, void* stream);

@@ -769,6 +769,42 @@ def icg_maxpool2_bwd(x, dy, dx, B, H, W, C):
     mem(dx)[: B * H * W * C].copy_(gx.permute(0, 2, 3, 1).reshape(-1))
 
 
+def icg_attn_split_pool(y, theta, phi_p, g_p, B, H, W, d, dv):
+    yy = _nhwc(y, B, H, W, 2 * d + dv)
+    mem(theta)[: B * H * W * d].copy_(yy[..., :d].reshape(-1))
+    for dst, sl, c in ((phi_p, slice(d, 2 * d), d), (g_p, slice(2 * d, 2 * d + dv), dv)):
+        p = F.max_pool2d(yy[..., sl].permute(0, 3, 1, 2), 2)
+        mem(dst)[: B * (H // 2) * (W // 2) * c].copy_(p.permute(0, 2, 3, 1).reshape(-1))
+
+
+def icg_attn_split_pool_bwd(y, dtheta, dphi_p, dg_p, dy, B, H, W, d, dv):
+    C = 2 * d + dv
+    yy = _nhwc(y, B, H, W, C)
+    out = torch.empty(B, H, W, C)
+    out[..., :d] = mem(dtheta)[: B * H * W * d].view(B, H, W, d)
+    for src, sl, c in ((dphi_p, slice(d, 2 * d), d), (dg_p, slice(2 * d, C), dv)):
+        with torch.enable_grad():
+            xn = yy[..., sl].permute(0, 3, 1, 2).detach().clone().requires_grad_(True)
+            o = F.max_pool2d(xn, 2)
+            g = mem(src)[: B * (H // 2) * (W // 2) * c].view(B, H // 2, W // 2, c).permute(0, 3, 1, 2)
+            (gx,) = torch.autograd.grad(o, xn, g)
+        out[..., sl] = gx.permute(0, 2, 3, 1)
+    mem(dy)[: B * H * W * C].copy_(out.reshape(-1))
+
+
+def icg_attn_gamma_scale(gamma, w_a, ws_a, w_b, ws_b, n):
+    g = mem(gamma)[0]
+    mem(ws_a)[:n].copy_(g * mem(w_a)[:n])
+    if w_b is not None:
+        mem(ws_b)[:n].copy_(g * mem(w_b)[:n])
+
+
+def icg_attn_gamma_bwd(gamma, dws, w, dw, dgamma, n):
+    g = mem(gamma)[0]
+    mem(dgamma)[0] = float((mem(dws)[:n].double() * mem(w)[:n].double()).sum())
+    mem(dw)[:n].copy_(g * mem(dws)[:n])
+
+
 def icg_softmax_fwd(x, y, rows, cols):
     mem(y)[: rows * cols].copy_(F.softmax(mem(x)[: rows * cols].view(rows, cols), -1).reshape(-1))
 

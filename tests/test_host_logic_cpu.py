@@ -57,6 +57,65 @@ def test_forward_host_logic(case, emu):
     check_group(g, "fwd/D_state/", D.state_dict(), rtol=1e-4, atol=1e-6, what="D buf ")
 
 
+def test_attention_stacked_projections_equal_the_three_convolutions(emu, monkeypatch):
+    """ops.AttnProjFn (theta / phi / g as one 1x1 convolution with stacked weights + icg_attn_split_pool) against the layer-by-layer
+    form (three SNConv2d + two max-pools, reference layers.py:217-231): same outputs, same gradients of x, of the four weights and
+    gamma, same power-iteration state -- on the emulated kernels, where both forms are exact up to fp32 summation order."""
+    import copy
+    import functools
+    from ic_gan_amd import layers, ops
+    torch.manual_seed(3)
+    conv = functools.partial(layers.SNConv2d, kernel_size=3, padding=1, num_svs=1, num_itrs=1, eps=1e-6)
+    a = layers.Attention(32, conv)
+    with torch.no_grad():
+        a.gamma.fill_(0.4)
+    b = copy.deepcopy(a)
+    x = torch.randn(2, 32, 8, 8)
+    dy = torch.randn(2, 32, 8, 8)
+    out = []
+    for m, on in ((a, True), (b, False)):
+        monkeypatch.setattr(ops, "FUSED_ATTENTION_PROJECTIONS", on)
+        monkeypatch.setattr(ops, "FUSED_ATTENTION_OUTPUT", on)       # gamma folded into the output projection (ops.AttnOutFn)
+        m.train()
+        xi = x.clone().requires_grad_(True)
+        h = xi * 1.5                       # a producer node, so that the chained gradient of x is summed inside the block
+        y = m(h)
+        y.backward(dy)
+        out.append((y.detach(), xi.grad, {n: p.grad for n, p in m.named_parameters()}, {n: v.clone() for n, v in m.named_buffers()}))
+    (ya, gxa, gpa, ba), (yb, gxb, gpb, bb) = out
+    torch.testing.assert_close(ya, yb, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gxa, gxb, rtol=1e-4, atol=1e-6)
+    assert set(gpa) == set(gpb) and all(g is not None for g in gpa.values())
+    for n in gpa:
+        torch.testing.assert_close(gpa[n], gpb[n], rtol=1e-4, atol=1e-6 + 1e-5 * float(gpb[n].abs().max()), msg=n)
+    for n in ba:
+        torch.testing.assert_close(ba[n], bb[n], rtol=1e-6, atol=1e-7, msg=n)
+    # no-grad forward (G's pass of the D step) takes the stacked form too and needs no dgrad layouts
+    with torch.no_grad():
+        monkeypatch.setattr(ops, "FUSED_ATTENTION_PROJECTIONS", True)
+        monkeypatch.setattr(ops, "FUSED_ATTENTION_OUTPUT", True)
+        ya = a(x)
+        monkeypatch.setattr(ops, "FUSED_ATTENTION_PROJECTIONS", False)
+        monkeypatch.setattr(ops, "FUSED_ATTENTION_OUTPUT", False)
+        torch.testing.assert_close(ya, b(x), rtol=1e-5, atol=1e-6)
+    # gamma = 0 (the initial value): the block is the identity, its parameters still receive gradients
+    for m, on in ((a, True), (b, False)):
+        monkeypatch.setattr(ops, "FUSED_ATTENTION_OUTPUT", on)
+        with torch.no_grad():
+            m.gamma.zero_()
+        for p in m.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = m(xi * 1.0)
+        torch.testing.assert_close(y.detach(), x, rtol=0, atol=0)
+        y.backward(dy)
+        out.append((xi.grad, m.gamma.grad.clone(), m.o.weight.grad.clone()))
+    (gx0, gg0, go0), (gx1, gg1, go1) = out[-2:]
+    torch.testing.assert_close(gx0, gx1, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gg0, gg1, rtol=1e-4, atol=1e-6)
+    assert float(gg1.abs()) > 0 and float(go0.abs().max()) == 0 and float(go1.abs().max()) == 0
+
+
 @pytest.mark.parametrize("wino", [0, 2, 4, 5])
 @pytest.mark.parametrize("case", ["cc_ic_r64", "ic_r64_acc2", "cc_r32_flat"])
 def test_train_step_host_logic(case, emu, wino, monkeypatch):

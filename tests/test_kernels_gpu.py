@@ -1218,6 +1218,43 @@ def test_attn_dscores(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 8, 8, 4, 16), (1, 64, 64, 48, 192), (3, 16, 32, 24, 96), (2, 6, 10, 8, 4)])
+def test_attn_split_pool(case):
+    """icg_attn_split_pool / _bwd (csrc/attn.hip) against slicing + F.max_pool2d and its autograd on the CPU: pure data movement and
+    comparisons, so bit for bit; windows with tied maxima route to the first one in both."""
+    B, H, W, d, dv = case
+    C = 2 * d + dv
+    y = rnd(B, H, W, C, seed=1)
+    y[0, :2, :2, d:d + 4] = 0.25                                   # a window of ties in phi
+    y[-1, 2:4, 2:4, 2 * d:2 * d + 4] = -1.0                        # ... and in g
+    th, ph, g = torch.zeros(B, H * W, d), torch.zeros(B, H * W // 4, d), torch.zeros(B, H * W // 4, dv)
+    pairs = run_pair("icg_attn_split_pool", [y, th, ph, g, B, H, W, d, dv], [1, 2, 3])
+    for got, ref in pairs:
+        assert torch.equal(got.cpu(), ref)
+    dth, dph, dg = rnd(B, H * W, d, seed=2), rnd(B, H * W // 4, d, seed=3), rnd(B, H * W // 4, dv, seed=4)
+    dy = torch.zeros(B, H, W, C)
+    (p,) = run_pair("icg_attn_split_pool_bwd", [y, dth, dph, dg, dy, B, H, W, d, dv], [4])
+    assert torch.equal(p[0].cpu(), p[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [7, 1024, 192 * 384, 300001])
+def test_attn_gamma_fold(n):
+    """icg_attn_gamma_scale / icg_attn_gamma_bwd (csrc/attn.hip: gamma of the attention block folded into its output projection)."""
+    gamma = torch.tensor([0.37])
+    wa, wb = rnd(n, seed=1), rnd(n, seed=2)
+    pairs = run_pair("icg_attn_gamma_scale", [gamma, wa, torch.zeros(n), wb, torch.zeros(n), n], [2, 4])
+    for got, ref in pairs:
+        assert torch.equal(got.cpu(), ref)
+    (p,) = run_pair("icg_attn_gamma_scale", [gamma, wa, torch.zeros(n), None, None, n], [2])
+    assert torch.equal(p[0].cpu(), p[1])
+    dws = rnd(n, seed=3)
+    pairs = run_pair("icg_attn_gamma_bwd", [gamma, dws, wa, torch.zeros(n), torch.zeros(1), n], [3, 4])
+    assert torch.equal(pairs[0][0].cpu(), pairs[0][1])
+    close(*pairs[1], rtol=1e-6, atol_rel=1e-6, what="dgamma")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rows,C", [(1000, 64), (37, 8), (5000, 512), (70000, 128), (300, 2048), (4 * 129 * 129, 256)])
 def test_colsum_f16(rows, C):
     """icg_colsum_f16 (bias gradient of bias_act in StyleGAN2's fp16 blocks): fp32 column sums of an fp16 [rows][C] tensor against fp64."""
