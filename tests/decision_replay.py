@@ -250,6 +250,11 @@ class Nudger:
             self.nudge(name, args[0], None, None, 0)
         elif name == "icg_maxpool2_fwd":
             self.nudge_pool(args[0])
+        elif name == "icg_attn_split_pool":
+            # the stacked projections of the attention block (ops.AttnProjFn): y [B, 2 d + dv, H, W], phi and g are pooled in that order
+            y, d, dv = args[0], int(args[7]), int(args[8])
+            self.nudge_pool(y[:, d:2 * d])
+            self.nudge_pool(y[:, 2 * d:2 * d + dv])
         return self.orig(name, *args)
 
 
