@@ -37,6 +37,12 @@ class SnLayer(ctypes.Structure):          # icg_sn_layer
                 ("reserved", ctypes.c_int)]
 
 
+class SnBwdItem(ctypes.Structure):        # icg_sn_bwd_item
+    _fields_ = [(n, ctypes.c_void_p) for n in ("dw_hwio", "dw_ohwi", "dw_up", "dw_down", "w_ohwi", "u", "v", "sigma", "dw", "scratch")] + \
+               [("scratch_bytes", ctypes.c_size_t), ("rows", ctypes.c_int), ("Cin", ctypes.c_int), ("R", ctypes.c_int),
+                ("accumulate", ctypes.c_int)]
+
+
 class WinoWeight(ctypes.Structure):        # icg_wino_weight
     _fields_ = [("w", ctypes.c_void_p), ("U", ctypes.c_void_p), ("N", ctypes.c_int), ("K", ctypes.c_int), ("planes", ctypes.c_int),
                 ("reserved", ctypes.c_int)]

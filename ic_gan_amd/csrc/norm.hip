@@ -159,6 +159,71 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   }
 }
 
+// icg_bn_reduce_partials + icg_bn_finalize of the training-mode forward in ONE launch (26 of each per cfg3 step otherwise): a block
+// owns 32 channels as both kernels do; its 32 slices of 32 lanes sum the partial rows in the order of bn_reduce_partials_kernel,
+// the 8 first slices then run bn_finalize_kernel's arithmetic on the block's own sums -- bit-identical to the two-kernel path.
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const float* __restrict__ partial, int nchunks, const float* kshift,
+                                                                  double count, float* running_mean, float* running_var,
+                                                                  float momentum, float eps, const float* __restrict__ gain,
+                                                                  const float* __restrict__ bias, int gb_rows, float gain_offset,
+                                                                  int C, float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                                  float* __restrict__ scale, float* __restrict__ shift) {
+  constexpr int SL = 32;
+  __shared__ double red[2][SL][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const bool live = c < C;
+  double a = 0.0, b = 0.0;
+  if (live) {
+    for (int k = sl; k < nchunks; k += SL) {
+      a += (double)partial[(long)k * 2 * C + c];
+      b += (double)partial[(long)k * 2 * C + C + c];
+    }
+  }
+  red[0][sl][cl] = a;
+  red[1][sl][cl] = b;
+  __syncthreads();
+  if (sl == 0) {
+    for (int k = 1; k < SL; ++k) {
+      a += red[0][k][cl];
+      b += red[1][k][cl];
+    }
+    red[0][0][cl] = a;
+    red[1][0][cl] = b;
+  }
+  __syncthreads();
+  const bool fin = sl < 8;                                  // the 8 x 32 threads bn_finalize_kernel runs
+  float mean = 0.f, invstd = 0.f;
+  double mu = 0.0, var = 0.0;
+  if (live && fin) {
+    const double k = kshift ? (double)kshift[c] : 0.0;      // read by every slice before the running mean is overwritten below
+    const double m1 = red[0][0][cl] / count;
+    var = red[1][0][cl] / count - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    mu = k + m1;
+    mean = (float)mu;
+    invstd = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();                                          // kshift may BE running_mean
+  if (live && sl == 0) {
+    if (running_mean) {
+      const double unb = (count > 1.0) ? var * count / (count - 1.0) : var;
+      running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mu);
+      running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+    }
+    mean_o[c] = mean;
+    invstd_o[c] = invstd;
+  }
+  if (!live || !fin) return;
+  for (int r = sl; r < gb_rows; r += 8) {
+    const float g = gain_offset + (gain ? gain[(long)r * C + c] : 0.f);
+    const float be = bias ? bias[(long)r * C + c] : 0.f;
+    const float sc = invstd * g;
+    scale[(long)r * C + c] = sc;
+    shift[(long)r * C + c] = be - mean * sc;
+  }
+}
+
 extern "C" size_t icg_bn_workspace_bytes(int64_t rows, int C) {
   if (rows <= 0 || C <= 0 || (C % 4) != 0) return 0;
   ColPlan pl = col_plan(rows, C, 1024);
@@ -193,6 +258,18 @@ extern "C" int icg_bn_finalize(const double* sums, const float* shift_k, double 
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)icg_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, sums,
                      shift_k, count, running_mean, running_var, momentum, eps, training, gain, bias, gb_rows,
                      gain_offset, C, mean, invstd, scale, shift);
+  return icg_check_launch();
+}
+
+extern "C" int icg_bn_reduce_finalize(const void* workspace, int64_t rows, int C, const float* shift_k, float* running_mean,
+                                      float* running_var, float momentum, float eps, const float* gain, const float* bias,
+                                      int gb_rows, float gain_offset, float* mean, float* invstd, float* scale, float* shift,
+                                      void* stream) {
+  ICG_REQUIRE(workspace && rows > 0 && C > 0 && (C % 4) == 0 && mean && invstd && scale && shift && gb_rows >= 1);
+  ColPlan pl = col_plan(rows, C, 1024);
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3((unsigned)icg_cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream,
+                     (const float*)workspace, pl.nchunks, shift_k, (double)rows, running_mean, running_var, momentum, eps, gain, bias,
+                     gb_rows, gain_offset, C, mean, invstd, scale, shift);
   return icg_check_launch();
 }
 

@@ -179,11 +179,13 @@ __global__ __launch_bounds__(1024) void sn_u_kernel(const float* __restrict__ s,
 // Both outputs are transposes of the parameter layout: a 32(co) x 32(ci) x R*R tile goes through LDS so that the read
 // (R*R*32 contiguous floats per co) and both writes (32 contiguous floats per (co, tap) / (ci, tap)) are coalesced; the
 // direct form wrote w_dgrad with a stride of R*R*rows floats between neighbouring lanes.
-__device__ __forceinline__ void sn_scale_body(int bx, int by, int gx, const float* __restrict__ w, const float* __restrict__ sigma,
-                                                       int rows, int Cin, int R, float* __restrict__ w_ohwi,
-                                                       float* __restrict__ w_dgrad) {
-  __shared__ float tile[32 * 9 * 33];
-  const int RR = R * R;                      // 1 or 9
+// (RRT: R * R as a compile-time constant for the 1x1 and 3x3 layers -- the index decompositions below are divisions by it, which made
+// this kernel ALU-bound with a run-time divisor: 1.2 TB/s; 0 = run-time R)
+template <int RRT>
+__device__ __forceinline__ void sn_scale_body_t(int bx, int gx, const float* __restrict__ w, const float* __restrict__ sigma,
+                                                int rows, int Cin, int R, float* __restrict__ w_ohwi, float* __restrict__ w_dgrad,
+                                                float* __restrict__ tile) {
+  const int RR = RRT ? RRT : R * R;
   const float sg = sigma[0];
   const int tco = (rows + 31) >> 5, tci = (Cin + 31) >> 5;
   const int per = 32 * 32 * RR;
@@ -213,6 +215,13 @@ __device__ __forceinline__ void sn_scale_body(int bx, int by, int gx, const floa
       }
     }
   }
+}
+__device__ __forceinline__ void sn_scale_body(int bx, int by, int gx, const float* __restrict__ w, const float* __restrict__ sigma,
+                                              int rows, int Cin, int R, float* __restrict__ w_ohwi, float* __restrict__ w_dgrad) {
+  __shared__ float tile[32 * 9 * 33];
+  if (R == 3) sn_scale_body_t<9>(bx, gx, w, sigma, rows, Cin, R, w_ohwi, w_dgrad, tile);
+  else if (R == 1) sn_scale_body_t<1>(bx, gx, w, sigma, rows, Cin, R, w_ohwi, w_dgrad, tile);
+  else sn_scale_body_t<0>(bx, gx, w, sigma, rows, Cin, R, w_ohwi, w_dgrad, tile);
 }
 __global__ __launch_bounds__(256) void sn_scale_kernel(const float* __restrict__ w, const float* __restrict__ sigma,
                                                        int rows, int Cin, int R, float* __restrict__ w_ohwi,
@@ -484,39 +493,49 @@ __device__ __forceinline__ float sn_gather_g(const float* __restrict__ dw_hwio, 
   return g;
 }
 
-__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ dw_hwio,
-                                                         const float* __restrict__ dw_ohwi,
-                                                         const float* __restrict__ dw_up,
-                                                         const float* __restrict__ dw_down,
-                                                         const float* __restrict__ w_ohwi, int rows, int Cin, int RR,
-                                                         double* __restrict__ part) {
+// (the three stages are written as bodies over (block index bx, blocks gx) so that the per-layer kernels and the many-layer kernels
+// of icg_sn_backward_multi run the same arithmetic in the same order)
+__device__ __forceinline__ void sn_bwd_dot_body(int bx, int gx, const float* __restrict__ dw_hwio,
+                                                const float* __restrict__ dw_ohwi, const float* __restrict__ dw_up,
+                                                const float* __restrict__ dw_down, const float* __restrict__ w_ohwi, int rows,
+                                                int Cin, int RR, double* __restrict__ part) {
   __shared__ double red[4];
   const long total = (long)rows * Cin * RR;
-  const long stride = (long)gridDim.x * blockDim.x;
+  const long stride = (long)gx * blockDim.x;
   double acc = 0.0;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-    // idx enumerates OHWI
-    const int ci = (int)(idx % Cin);
-    long t = idx / Cin;
-    const int tap = (int)(t % RR);
-    const int co = (int)(t / RR);
+  // idx enumerates OHWI; (row q = co * RR + tap, ci) advance with the loop (no 64-bit divisions per element)
+  long idx = (long)bx * blockDim.x + threadIdx.x;
+  long q = idx / Cin;
+  int ci = (int)(idx - q * Cin);
+  const long qs = stride / Cin;
+  const int rs = (int)(stride - qs * Cin);
+  for (; idx < total; idx += stride) {
+    const int qi = (int)q;
+    const int co = RR == 9 ? qi / 9 : (RR == 1 ? qi : qi / RR), tap = qi - co * RR;
     const float g = sn_gather_g(dw_hwio, dw_ohwi, dw_up, dw_down, co, ci, tap, rows, Cin, RR);
     acc += (double)g * (double)w_ohwi[idx];
+    q += qs;
+    ci += rs;
+    if (ci >= Cin) { ci -= Cin; ++q; }
   }
   acc = wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) part[bx] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ dw_hwio, const float* __restrict__ dw_ohwi,
+                                                         const float* __restrict__ dw_up, const float* __restrict__ dw_down,
+                                                         const float* __restrict__ w_ohwi, int rows, int Cin, int RR,
+                                                         double* __restrict__ part) {
+  sn_bwd_dot_body(blockIdx.x, gridDim.x, dw_hwio, dw_ohwi, dw_up, dw_down, w_ohwi, rows, Cin, RR, part);
 }
 
-__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dw_hwio,
-                                                           const float* __restrict__ dw_ohwi,
-                                                           const float* __restrict__ dw_up,
-                                                           const float* __restrict__ dw_down,
-                                                           const float* __restrict__ u, const float* __restrict__ v,
-                                                           const float* __restrict__ sigma,
-                                                           const double* __restrict__ part, int nparts, int rows,
-                                                           int Cin, int RR, float* __restrict__ dw, int accumulate) {
+__device__ __forceinline__ void sn_bwd_apply_body(int bx, int gx, const float* __restrict__ dw_hwio,
+                                                  const float* __restrict__ dw_ohwi, const float* __restrict__ dw_up,
+                                                  const float* __restrict__ dw_down, const float* __restrict__ u,
+                                                  const float* __restrict__ v, const float* __restrict__ sigma,
+                                                  const double* __restrict__ part, int nparts, int rows, int Cin, int RR,
+                                                  float* __restrict__ dw, int accumulate) {
   __shared__ double s_red[4];
   {   // every block re-reduces the per-block partial dots: all lanes, fixed order (deterministic)
     double d = 0.0;
@@ -528,35 +547,47 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
   const float dot = (float)((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
   const float inv_sigma = 1.0f / sigma[0];
   const long total = (long)rows * Cin * RR;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-    // idx enumerates the parameter layout [co][ci][tap] (coalesced stores); column j = ci*RR + tap
-    const int j = (int)(idx % ((long)Cin * RR));
-    const int co = (int)(idx / ((long)Cin * RR));
-    const int ci = j / RR, tap = j - ci * RR;
+  const long stride = (long)gx * blockDim.x;
+  // idx enumerates the parameter layout [co][ci][tap] (coalesced stores); column j = ci*RR + tap.  (co, j) advance with the loop
+  // instead of being divided out of a 64-bit index per element -- the divisions were this kernel's whole run time
+  const long CR = (long)Cin * RR;
+  long idx = (long)bx * blockDim.x + threadIdx.x;
+  int co = (int)(idx / CR), j = (int)(idx - (long)co * CR);
+  const int qs = (int)(stride / CR), rs = (int)(stride - (long)qs * CR);
+  for (; idx < total; idx += stride) {
+    const int ci = RR == 9 ? j / 9 : (RR == 1 ? j : j / RR), tap = j - ci * RR;
     const float g = sn_gather_g(dw_hwio, dw_ohwi, dw_up, dw_down, co, ci, tap, rows, Cin, RR);
     const float corr = (u != nullptr && v != nullptr) ? dot * u[co] * v[j] : 0.f;
     const float val = (g - corr) * inv_sigma;
     dw[idx] = accumulate ? dw[idx] + val : val;
+    co += qs;
+    j += rs;
+    if (j >= (int)CR) { j -= (int)CR; ++co; }
   }
+}
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dw_hwio, const float* __restrict__ dw_ohwi,
+                                                           const float* __restrict__ dw_up, const float* __restrict__ dw_down,
+                                                           const float* __restrict__ u, const float* __restrict__ v,
+                                                           const float* __restrict__ sigma, const double* __restrict__ part,
+                                                           int nparts, int rows, int Cin, int RR, float* __restrict__ dw,
+                                                           int accumulate) {
+  sn_bwd_apply_body(blockIdx.x, gridDim.x, dw_hwio, dw_ohwi, dw_up, dw_down, u, v, sigma, part, nparts, rows, Cin, RR, dw, accumulate);
 }
 
 // Coalesced form of the gather + dot: the HWIO-ordered sources (dw_hwio and the phase / pooled gradients, all with co as
 // the fastest index) are read 32x32 tiles at a time with co across lanes, transposed through LDS and written to
 // g[co][tap][ci] (OHWI, the order of w_ohwi and dw_ohwi) with (tap, ci) across lanes; <g, w_ohwi> is accumulated on the way.
-__global__ __launch_bounds__(256) void sn_bwd_gather_kernel(const float* __restrict__ dw_hwio,
-                                                            const float* __restrict__ dw_ohwi,
-                                                            const float* __restrict__ dw_up,
-                                                            const float* __restrict__ dw_down,
-                                                            const float* __restrict__ w_ohwi, int rows, int Cin, int RR,
-                                                            float* __restrict__ g_out, double* __restrict__ part) {
+__device__ __forceinline__ void sn_bwd_gather_body(int bx, int gx, const float* __restrict__ dw_hwio,
+                                                   const float* __restrict__ dw_ohwi, const float* __restrict__ dw_up,
+                                                   const float* __restrict__ dw_down, const float* __restrict__ w_ohwi, int rows,
+                                                   int Cin, int RR, float* __restrict__ g_out, double* __restrict__ part) {
   __shared__ float tile[32][33];
   __shared__ double red[4];
   const int K = Cin * RR;
   const int tk = (K + 31) / 32, tc = (rows + 31) / 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   double acc = 0.0;
-  for (int tno = blockIdx.x; tno < tk * tc; tno += gridDim.x) {
+  for (int tno = bx; tno < tk * tc; tno += gx) {
     const int k0 = (tno % tk) * 32, c0 = (tno / tk) * 32;
     __syncthreads();
 #pragma unroll
@@ -585,7 +616,13 @@ __global__ __launch_bounds__(256) void sn_bwd_gather_kernel(const float* __restr
   acc = wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) part[bx] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void sn_bwd_gather_kernel(const float* __restrict__ dw_hwio, const float* __restrict__ dw_ohwi,
+                                                            const float* __restrict__ dw_up, const float* __restrict__ dw_down,
+                                                            const float* __restrict__ w_ohwi, int rows, int Cin, int RR,
+                                                            float* __restrict__ g_out, double* __restrict__ part) {
+  sn_bwd_gather_body(blockIdx.x, gridDim.x, dw_hwio, dw_ohwi, dw_up, dw_down, w_ohwi, rows, Cin, RR, g_out, part);
 }
 
 #define SN_BWD_PARTS 2048     // blocks of the gather / dot pass (8 per CU: the pass is a latency-bound transpose at 1 per CU)
@@ -623,5 +660,73 @@ extern "C" int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dw_hwio, dw_ohwi, dw_up, dw_down, u_saved,
                      v_saved, sigma, (const double*)scratch, nparts, rows, Cin, RR, dw, accumulate);
+  return icg_check_launch();
+}
+
+// ---------------------------------------------------------------- backward of many layers in two launches
+// icg_sn_backward per layer is two launches of a few microseconds each, 150 per training step, issued from inside the autograd
+// nodes of the layers.  The autograd graph of ic_gan_amd.ops routes the raw weight gradients of a GROUP of layers through one node
+// (ops.SNGroupFn), whose backward calls this: stage 1 (transpose-gather + <g, W/sigma> partial sums, or the dot alone for gradients
+// that arrive in OHWI order) and stage 2 (the rank-one correction in parameter order) for up to ICG_SN_PACK layers per launch pair;
+// blockIdx.z selects the layer, blocks past a layer's own geometry exit at once.  Same bodies, same per-layer geometry: bit-identical
+// to icg_sn_backward per layer.
+struct SnBwdPack {
+  icg_sn_bwd_item l[ICG_SN_PACK];
+  int nparts[ICG_SN_PACK], blocks2[ICG_SN_PACK], gather[ICG_SN_PACK];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void sn_bwd_stage1_multi_kernel(SnBwdPack p) {
+  const int z = blockIdx.z;
+  if ((int)blockIdx.x >= p.nparts[z]) return;
+  const icg_sn_bwd_item& L = p.l[z];
+  const int RR = L.R * L.R;
+  double* part = reinterpret_cast<double*>(L.scratch);
+  if (p.gather[z])
+    sn_bwd_gather_body(blockIdx.x, p.nparts[z], L.dw_hwio, L.dw_ohwi, L.dw_up, L.dw_down, L.w_ohwi, L.rows, L.Cin, RR,
+                       reinterpret_cast<float*>(part + SN_BWD_PARTS), part);
+  else
+    sn_bwd_dot_body(blockIdx.x, p.nparts[z], L.dw_hwio, L.dw_ohwi, L.dw_up, L.dw_down, L.w_ohwi, L.rows, L.Cin, RR, part);
+}
+__global__ __launch_bounds__(256) void sn_bwd_stage2_multi_kernel(SnBwdPack p) {
+  const int z = blockIdx.z;
+  if ((int)blockIdx.x >= p.blocks2[z]) return;
+  const icg_sn_bwd_item& L = p.l[z];
+  const int RR = L.R * L.R;
+  const double* part = reinterpret_cast<const double*>(L.scratch);
+  if (p.gather[z])
+    sn_bwd_apply_body(blockIdx.x, p.blocks2[z], nullptr, reinterpret_cast<const float*>(part + SN_BWD_PARTS), nullptr, nullptr, L.u, L.v,
+                      L.sigma, part, p.nparts[z], L.rows, L.Cin, RR, L.dw, L.accumulate);
+  else
+    sn_bwd_apply_body(blockIdx.x, p.blocks2[z], L.dw_hwio, L.dw_ohwi, L.dw_up, L.dw_down, L.u, L.v, L.sigma, part, p.nparts[z], L.rows,
+                      L.Cin, RR, L.dw, L.accumulate);
+}
+
+extern "C" int icg_sn_backward_multi(const icg_sn_bwd_item* items, int n, void* stream) {
+  ICG_REQUIRE(items && n > 0);
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < n; base += ICG_SN_PACK) {
+    SnBwdPack p{};
+    p.n = (n - base < ICG_SN_PACK) ? n - base : ICG_SN_PACK;
+    unsigned g1 = 1, g2 = 1;
+    for (int i = 0; i < p.n; ++i) {
+      const icg_sn_bwd_item& L = items[base + i];
+      ICG_REQUIRE((L.dw_hwio || L.dw_ohwi || L.dw_up || L.dw_down) && L.w_ohwi && L.sigma && L.dw && L.scratch);
+      if (L.dw_up || L.dw_down) ICG_REQUIRE(L.R == 3);
+      ICG_REQUIRE(L.rows > 0 && L.Cin > 0 && L.R >= 1);
+      if (L.scratch_bytes < SN_BWD_PARTS * sizeof(double)) return ICG_ERR_WORKSPACE;
+      const long total = (long)L.rows * L.Cin * L.R * L.R;
+      p.l[i] = L;
+      p.nparts[i] = (int)(icg_cdiv(total, 1024) > SN_BWD_PARTS ? SN_BWD_PARTS : icg_cdiv(total, 1024));
+      p.gather[i] = ((L.dw_hwio || L.dw_up || L.dw_down) && L.scratch_bytes >= icg_sn_backward_scratch_bytes(L.rows, L.Cin, L.R)) ? 1 : 0;
+      long b2 = icg_cdiv(total, 256);
+      if (b2 > 2048) b2 = 2048;
+      p.blocks2[i] = (int)b2;
+      g1 = max(g1, (unsigned)p.nparts[i]);
+      g2 = max(g2, (unsigned)b2);
+    }
+    hipLaunchKernelGGL(sn_bwd_stage1_multi_kernel, dim3(g1, 1, (unsigned)p.n), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(sn_bwd_stage2_multi_kernel, dim3(g2, 1, (unsigned)p.n), dim3(256), 0, st, p);
+  }
   return icg_check_launch();
 }

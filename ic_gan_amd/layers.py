@@ -148,7 +148,9 @@ def sn_prefetch(modules):
             groups.setdefault((float(m.eps), bool(m.training)), []).append(m)
     for (eps, training), ms in groups.items():
         items = [(m.weight, m.u0, m.sv0) + m._sn_flags[mode] for m in ms]
-        for m, st in zip(ms, ops.sn_prepare_many(items, eps, training)):
+        states = ops.sn_prepare_many(items, eps, training)
+        ops.sn_group(states, [m.weight for m in ms])          # under autograd: one spectral-norm backward per group of layers
+        for m, st in zip(ms, states):
             m._sn_ready = (m._sn_flags[mode], st)
             key = m._sn_eval_key(m._sn_flags[mode])
             if key is not None:
@@ -225,7 +227,8 @@ class SNEmbedding(nn.Embedding, SN):
         self._sn_init(num_svs, num_itrs, num_embeddings, eps=eps)
 
     def forward(self, x):
-        return ops.SNEmbeddingFn.apply(x, self.weight, self.sn_state(False))
+        st = self.sn_state(False)
+        return ops.SNEmbeddingFn.apply(x, self.weight if st.handle is None else st.handle, st)
 
 
 class identity(nn.Module):
@@ -325,7 +328,8 @@ class Attention(nn.Module):
         if ops.attn_projections_apply(x, self.theta.out_channels, self.g.out_channels) and _plain_1x1(self.theta, self.phi, self.g):
             # the three projections as ONE 1x1 convolution with stacked weights + one split / max-pool pass (ops.AttnProjFn)
             sns = tuple(m.sn_state() for m in (self.theta, self.phi, self.g))
-            theta, phi, g, x = ops.AttnProjFn.apply(x, self.theta.weight, self.phi.weight, self.g.weight, sns)
+            ws = [m.weight if st.handle is None else st.handle for m, st in zip((self.theta, self.phi, self.g), sns)]
+            theta, phi, g, x = ops.AttnProjFn.apply(x, ws[0], ws[1], ws[2], sns)
         else:
             theta, x = self.theta(x, chain=True)
             phi, x = self.phi(x, chain=True)
@@ -335,7 +339,8 @@ class Attention(nn.Module):
         if ops.FUSED_ATTENTION_OUTPUT and _plain_1x1(self.o):
             # gamma folded into the output projection's weight, x added in its epilogue (ops.AttnOutFn).  The weight gradient needs
             # W / sigma in the [Cin][Cout] layout, so that layout is prepared whenever a gradient can be asked for
-            return ops.AttnOutFn.apply(a, x, self.o.weight, self.gamma, self.o.sn_state())
+            st = self.o.sn_state()
+            return ops.AttnOutFn.apply(a, x, self.o.weight if st.handle is None else st.handle, self.gamma, st)
         return ops.ScaleAddFn.apply(self.gamma, self.o(a), x)
 
 

@@ -67,6 +67,11 @@ class SNState:
     wino_m: int = 0                              # 2: F(2x2,3x3), 16 planes;  4: F(4x4,3x3), 36 planes;
     #                                              5: resample-fused layer in the 25-plane F(4x4,3x3) domain, per direction:
     rs: tuple = (False, False, False)            # (fprop, dgrad, wgrad) run in that domain (else phase / 4x4-stride-2 form)
+    raw_numel: int = 0                           # elements of the RAW weight gradient this layer's backward produces (HWIO / OHWI:
+    #                                              rows cin R R; phase form dw_up / pooled form dw_down: 16 rows cin)
+    handle: Optional[torch.Tensor] = None        # grouped spectral-norm backward (SNGroupFn): the tensor that stands for the weight
+    #                                              in the layer's autograd node; its gradient is the raw weight gradient
+    raw_form: int = -1                           # which argument of icg_sn_backward that gradient is (0 hwio, 1 ohwi, 2 up, 3 down)
 
 
 def _sn_alloc(weight, need_dgrad, upsample, downsample, winograd=False):
@@ -89,6 +94,7 @@ def _sn_alloc(weight, need_dgrad, upsample, downsample, winograd=False):
         rs = resample_winograd_directions(cin, rows, up)
     st = SNState(_f32(n, dev), _f32(n, dev) if (need_dgrad and ((not up and not down) or rs[1])) else None, _f32(rows, dev),
                  _f32(cin * R * R, dev), _f32(1, dev), rows, cin, R)
+    st.raw_numel = 16 * rows * cin if ((up or down) and not rs[2]) else n
     if any(rs):
         st.wino_m, st.rs = 5, rs
         st.w_wino = _f32(25 * rows * cin, dev) if rs[0] else None
@@ -179,13 +185,92 @@ def sn_prepare_many(items, eps: float, training: bool):
     return states
 
 
+SN_BACKWARD_GROUP = int(os.environ.get("ICG_SN_BWD_GROUP", "8"))   # layers per SNGroupFn node; 0: spectral-norm backward per layer
+
+
 def _sn_backward(dw_hwio, dw_ohwi, sn: SNState, like: torch.Tensor, dw_up=None, dw_down=None) -> torch.Tensor:
+    """Gradient of the PARAMETER from the raw gradient of W / sigma (autograd of SN.W_, reference layers.py:98-112).  When the layer's
+    autograd node was given the group handle in place of the weight (`like is sn.handle`), the raw gradient itself is returned: it
+    travels to SNGroupFn, which runs this for the whole group in two launches."""
+    if sn.handle is not None and like is sn.handle:
+        forms = (dw_hwio, dw_ohwi, dw_up, dw_down)
+        given = [i for i, t in enumerate(forms) if t is not None]
+        if len(given) != 1 or forms[given[0]].numel() != sn.raw_numel:
+            raise RuntimeError("grouped spectral-norm backward: expected one raw weight gradient of %d elements" % sn.raw_numel)
+        sn.raw_form = given[0]
+        return forms[given[0]].reshape(-1)
     dw = torch.empty_like(like, memory_format=torch.contiguous_format)
     nb = L.query("icg_sn_backward_scratch_bytes", sn.rows, sn.cin, sn.R)
     scratch = _bytes(nb, like.device)
     L.call("icg_sn_backward", dw_hwio, dw_ohwi, dw_up, dw_down, sn.w_ohwi, sn.u, sn.v, sn.sigma, sn.rows, sn.cin, sn.R, dw, 0,
            scratch, nb)
     return dw
+
+
+def sn_backward_many(items):
+    """`_sn_backward` of many layers in two launches per 16 (icg_sn_backward_multi): items = [(raw gradient, form, SNState, like)]
+    -> [dweight, ...]; bit-identical to the per-layer calls."""
+    import ctypes
+    arr = (L.SnBwdItem * len(items))()
+    out, keep = [], []
+    for i, (raw, form, sn, like) in enumerate(items):
+        raw = raw.contiguous()
+        dw = torch.empty_like(like, memory_format=torch.contiguous_format)
+        nb = L.query("icg_sn_backward_scratch_bytes", sn.rows, sn.cin, sn.R)
+        scratch = _bytes(nb, like.device)
+        d = arr[i]
+        for k, name in enumerate(("dw_hwio", "dw_ohwi", "dw_up", "dw_down")):
+            setattr(d, name, raw.data_ptr() if k == form else None)
+        d.w_ohwi, d.u, d.v, d.sigma = sn.w_ohwi.data_ptr(), sn.u.data_ptr(), sn.v.data_ptr(), sn.sigma.data_ptr()
+        d.dw, d.scratch, d.scratch_bytes = dw.data_ptr(), scratch.data_ptr(), nb
+        d.rows, d.Cin, d.R, d.accumulate = sn.rows, sn.cin, sn.R, 0
+        out.append(dw)
+        keep.append((raw, scratch))
+    L.call("icg_sn_backward_multi", ctypes.cast(arr, ctypes.c_void_p), len(items))
+    return out
+
+
+class SNGroupFn(Function):
+    """One autograd node in front of a GROUP of spectrally normalised layers: inputs = their weight parameters, outputs = one
+    HANDLE per layer (a storage-free tensor with the shape of that layer's raw weight gradient) which the layer's own node takes
+    in place of the weight.  The layers' backward passes return raw gradients of W / sigma; autograd delivers them here once the
+    whole group has run, and the spectral-norm backward (reference: autograd through SN.W_, layers.py:98-112) of all of them is two
+    launches instead of two per layer.  Groups are consecutive layers (SN_BACKWARD_GROUP), so under DDP the parameters of a group
+    become ready together and the bucketed all-reduce still overlaps the rest of the backward pass."""
+
+    @staticmethod
+    def forward(ctx, states, *weights):
+        ctx.states, ctx.likes = states, weights
+        ctx.set_materialize_grads(False)
+        return tuple(w.new_empty(1).expand(st.raw_numel) for st, w in zip(states, weights))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        items, where = [], []
+        for i, (st, g, like) in enumerate(zip(ctx.states, grads, ctx.likes)):
+            if g is not None and ctx.needs_input_grad[1 + i]:
+                if st.raw_form < 0:
+                    raise RuntimeError("grouped spectral-norm backward: a gradient arrived for a handle no layer consumed")
+                items.append((g, st.raw_form, st, like))
+                where.append(i)
+        out = [None] * len(grads)
+        if items:
+            for i, dw in zip(where, sn_backward_many(items)):
+                out[i] = dw
+        return (None,) + tuple(out)
+
+
+def sn_group(states, weights):
+    """Give consecutive groups of `states` (prepared for `weights`, one forward of a network under autograd) their SNGroupFn
+    handles.  No-op without autograd or when no weight requires a gradient."""
+    if SN_BACKWARD_GROUP <= 0 or not torch.is_grad_enabled():
+        return
+    for i in range(0, len(states), SN_BACKWARD_GROUP):
+        st, ws = states[i:i + SN_BACKWARD_GROUP], weights[i:i + SN_BACKWARD_GROUP]
+        if not any(w.requires_grad for w in ws):
+            continue
+        for s, h in zip(st, SNGroupFn.apply(tuple(st), *ws)):
+            s.handle = h if h.requires_grad else None
 
 
 def _conv_fprop(x, w, bias, res, out, scale, shift, ssb, B, H, W, Cin, Cout, R, flags):
@@ -695,6 +780,16 @@ def _bn_forward_stats(x, bn: BNOpt, gain, beta, stats: Optional[BNStats] = None)
     ssb = C if gb_rows > 1 else 0
     count = float(B * Hs * Ws)
     sums = shift_k = count_dev = None
+    if bn.training and stats is None and not _sync_enabled(bn):
+        # single replica: partial sums, then their reduction and the finalize step as ONE launch (icg_bn_reduce_finalize)
+        x = _cl(x)
+        rows = B * Hs * Ws
+        nb = L.query("icg_bn_workspace_bytes", rows, C)
+        ws = _bytes(nb, dev)
+        L.call("icg_bn_partial_stats", x, bn.running_mean, rows, C, ws, nb)
+        L.call("icg_bn_reduce_finalize", ws, rows, C, bn.running_mean, bn.running_mean, bn.running_var, float(bn.momentum),
+               float(bn.eps), gain, beta, gb_rows, float(bn.gain_offset), mean, invstd, scale, shift)
+        return gain, beta, gb_rows, ssb, count, count_dev, mean, invstd, scale, shift
     if bn.training:
         if stats is None:
             stats = bn_stats_begin(x, bn)
@@ -794,6 +889,8 @@ def fused_conv(x, weight, bias, sn: SNState, *, relu=False, upsample=False, resi
     downsample=True appends the 2x2 average pool (residual is then at the pooled resolution)."""
     opt = ConvOpt(sn=sn, relu=relu, upsample=upsample, res_up=res_up, bn=bn, downsample=downsample, bn_stats=bn_stats,
                   chain=bool(chain))
+    if sn.handle is not None:
+        weight = sn.handle                  # grouped spectral-norm backward: this node returns the raw gradient of W / sigma
     if bn is not None:
         g2 = gain if gain is None or gain.dim() == 2 else gain.view(1, -1)
         b2 = beta if beta is None or beta.dim() == 2 else beta.view(1, -1)

@@ -388,6 +388,11 @@ int icg_bn_finalize(const double* sums, const float* shift_k, double count, floa
                     float* running_var, float momentum, float eps, int training, const float* gain,
                     const float* bias, int gb_rows, float gain_offset, int C, float* mean,
                     float* invstd, float* scale, float* shift, void* stream);
+/* icg_bn_reduce_partials + icg_bn_finalize of the training-mode forward (single replica) in ONE launch; element count = rows.
+ * Bit-identical to the two calls (the fp64 channel sums are not written out: no caller of this form reads them). */
+int icg_bn_reduce_finalize(const void* workspace, int64_t rows, int C, const float* shift_k, float* running_mean,
+                           float* running_var, float momentum, float eps, const float* gain, const float* bias, int gb_rows,
+                           float gain_offset, float* mean, float* invstd, float* scale, float* shift, void* stream);
 
 /* stand-alone apply  y = relu?(x*scale[b][c] + shift[b][c])  (ccbn / bn used outside a fused block) */
 int icg_bn_apply(const float* x, const float* scale, const float* shift, int64_t ss_bstride, int B, int64_t HW,
@@ -474,6 +479,26 @@ int icg_sn_backward(const float* dw_hwio, const float* dw_ohwi, const float* dw_
                     const float* w_ohwi,
                     const float* u_saved, const float* v_saved, const float* sigma, int rows, int Cin,
                     int R, float* dw, int accumulate, void* scratch, size_t scratch_bytes, void* stream);
+
+/* icg_sn_backward for many layers in two launches per ICG_SN_PACK layers (the per-layer form is two launches of a few microseconds,
+ * 150 per training step): the fields are icg_sn_backward's arguments; `scratch` / `scratch_bytes` per layer as there.  Bit-identical
+ * to the per-layer calls.  Called from the backward of the autograd node that groups the layers of a network
+ * (ic_gan_amd/ops.py SNGroupFn; the reference differentiates SN.W_() per layer, layers.py:98-112). */
+typedef struct icg_sn_bwd_item {
+  const float* dw_hwio;
+  const float* dw_ohwi;
+  const float* dw_up;
+  const float* dw_down;
+  const float* w_ohwi;
+  const float* u;
+  const float* v;
+  const float* sigma;
+  float* dw;
+  void* scratch;
+  size_t scratch_bytes;
+  int rows, Cin, R, accumulate;
+} icg_sn_bwd_item;
+int icg_sn_backward_multi(const icg_sn_bwd_item* items, int n, void* stream);
 
 /* ---- pointwise / pooling / softmax ---------------------------------------------------- */
 int icg_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, void* stream);

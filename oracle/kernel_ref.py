@@ -511,6 +511,14 @@ def icg_bn_finalize(sums, shift_k, count, running_mean, running_var, momentum, e
     mem(shift)[: gb_rows * C].copy_((be - mean.view(1, C) * sc).reshape(-1))
 
 
+def icg_bn_reduce_finalize(workspace, rows, C, shift_k, running_mean, running_var, momentum, eps, gain, bias, gb_rows, gain_offset,
+                           mean, invstd, scale, shift):
+    sums = torch.empty(2 * C, dtype=torch.float64)
+    icg_bn_reduce_partials(workspace, rows, C, sums)
+    icg_bn_finalize(sums, shift_k, float(rows), running_mean, running_var, momentum, eps, 1, gain, bias, gb_rows, gain_offset, C, mean,
+                    invstd, scale, shift)
+
+
 def icg_bn_sync_pack(sums, shift_k, local_count, C, payload):
     k = mem(shift_k)[:C].double() if shift_k is not None else torch.zeros(C, dtype=torch.float64)
     s1, s2 = sums[:C], sums[C: 2 * C]
@@ -1541,5 +1549,16 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "sg2_weight_prep_multi", sg2_weight_prep_ref)
     import ic_gan_amd.stylegan_ops.fused_layers as FL
     monkeypatch.setattr(FL, "_EMULATED", True)
+    def sn_backward_many_ref(items):
+        out = []
+        for raw, form, sn, like in items:
+            forms = [None] * 4
+            forms[form] = raw.contiguous()
+            handle, sn.handle = sn.handle, None                 # the per-layer path
+            out.append(ops._sn_backward(forms[0], forms[1], sn, like, dw_up=forms[2], dw_down=forms[3]))
+            sn.handle = handle
+        return out
+
+    monkeypatch.setattr(ops, "sn_backward_many", sn_backward_many_ref)
     monkeypatch.setattr(ops, "sn_prepare_many", lambda items, eps, training: [
         ops.sn_prepare(w, u, sv, eps, training, nd, up, dn, *rest) for (w, u, sv, nd, up, dn, *rest) in items])

@@ -164,6 +164,56 @@ def test_train_step_host_logic(case, emu, wino, monkeypatch):
         check_group(g, f"step{s + 1}/EMA_state/", G_ema.state_dict(), STATE_RTOL, 2e-6, "EMA ", extra_atol=gx)
 
 
+def test_grouped_spectral_norm_backward_equals_the_per_layer_one(emu, monkeypatch):
+    """ops.SNGroupFn: from the second forward on (layouts known, batched prefetch) the layers' autograd nodes hand the RAW gradient of
+    W / sigma to one node per group of layers, whose backward runs the spectral-norm backward for the group -- same parameter
+    gradients as the per-layer path (SN_BACKWARD_GROUP = 0), through G and D (3x3 / 1x1 / upsample- and pool-fused convolutions,
+    linears, the class embedding, the attention block's stacked projections), and torch.autograd.grad works on the weights."""
+    import copy
+    from ic_gan_amd import layers, ops
+    g = load_golden("cc_ic_r64")
+    cfg = g["cfg"]
+    _, G, D = _build(g)
+    G.load_state_dict(synth.synth_state(g["gspec"], 11))
+    D.load_state_dict(synth.synth_state(g["dspec"], 22))
+    z, lab, fg = synth.CondSampler(cfg, G.dim_z, 2, seed=5)()
+    nets = {}
+    groups = []
+    real_many = ops.sn_backward_many
+    monkeypatch.setattr(ops, "sn_backward_many", lambda items: (groups.append(len(items)), real_many(items))[1])
+    for tag, size in (("grouped", 4), ("per_layer", 0)):
+        monkeypatch.setattr(ops, "SN_BACKWARD_GROUP", size)
+        Gn, Dn = copy.deepcopy(G), copy.deepcopy(D)
+        Gn.train(); Dn.train()
+        for it in range(2):                       # the first pass records the layouts; the second one is prefetched (and grouped)
+            for p in list(Gn.parameters()) + list(Dn.parameters()):
+                p.grad = None
+            n0 = len(groups)
+            out = Dn(Gn(z, lab, fg), lab, fg)
+            out.sum().backward()
+            if tag == "grouped":
+                assert (len(groups) > n0) == (it == 1)
+        nets[tag] = (Gn, Dn)
+    assert not any(isinstance(m, layers.SN) and m._sn_ready is not None for n in nets["grouped"] for m in n.modules())
+    n_sn = sum(1 for n in (G, D) for m in n.modules() if isinstance(m, layers.SN) and m.weight.requires_grad)
+    assert sum(groups) == n_sn and max(groups) <= 4
+    for a, b in zip(nets["grouped"], nets["per_layer"]):
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            assert (p.grad is None) == (q.grad is None), k
+            if p.grad is not None:
+                assert torch.equal(p.grad, q.grad), k
+        for (k, v), (_, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert torch.equal(v, v2), k
+    # the functional form: gradients of a few weights only (a third pass, grouped)
+    monkeypatch.setattr(ops, "SN_BACKWARD_GROUP", 4)
+    Gn, Dn = nets["grouped"]
+    ws = [Gn.blocks[0][0].conv1.weight, Dn.blocks[0][0].conv2.weight, Gn.linear.weight]
+    ref = [w.grad.clone() for w in ws]
+    got = torch.autograd.grad(Dn(Gn(z, lab, fg), lab, fg).sum(), ws)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+
+
 def test_sn_prefetch_bookkeeping(emu):
     """the batched spectral-norm pass is used from the second forward on, gives the same buffers as the per-layer path,
     and a forward that aborts midway leaves the module usable (prefetch is transactional)."""

@@ -599,6 +599,14 @@ def test_bn_forward_chain(rows, C):
         fn("icg_bn_finalize", sums, rmm, float(rows), rmm, rvv, 0.1, 1e-5, 1, to(gain), to(beta), B, 1.0, C, mean,
            invstd, scale, shift)
         outs[tag] = dict(sums=sums, mean=mean, invstd=invstd, scale=scale, shift=shift, rm=rmm, rv=rvv)
+        if tag == "gpu":
+            # the one-launch form of reduce + finalize: bit for bit the two-kernel path (same partials)
+            rm2, rv2 = to(rm), to(rv)
+            m2, i2, sc2, sh2 = (torch.empty_like(t) for t in (mean, invstd, scale, shift))
+            fn("icg_bn_reduce_finalize", ws, rows, C, rm2, rm2, rv2, 0.1, 1e-5, to(gain), to(beta), B, 1.0, m2, i2, sc2, sh2)
+            for a, b, what in ((m2, mean, "mean"), (i2, invstd, "invstd"), (sc2, scale, "scale"), (sh2, shift, "shift"), (rm2, rmm, "rm"),
+                               (rv2, rvv, "rv")):
+                assert torch.equal(a, b), what
     for k in outs["gpu"]:
         close(outs["gpu"][k], outs["ref"][k], rtol=3e-5, atol_rel=3e-5, what=f"bn fwd {k} {rows}x{C}")
     # against torch's own batch_norm statistics
@@ -883,6 +891,32 @@ def test_sn_forward_multi_bit_identical():
             assert (a is None) == (b is None), name
             if a is not None:
                 assert torch.equal(a, b), name
+
+
+def test_sn_backward_multi_equals_per_layer():
+    """icg_sn_backward_multi (the backward of ops.SNGroupFn: many layers in two launches per descriptor pack) == icg_sn_backward per
+    layer, bit for bit, over all four raw-gradient forms and more layers than one pack holds."""
+    from ic_gan_amd import ops
+    shapes = [(96, 192, 3), (3, 96, 3), (1536, 17, 1), (24, 8, 3), (768, 768, 1), (64, 128, 3), (1000, 128, 1), (48, 384, 1)] * 3
+    flags = [(True, False, False), (False, False, False), (True, False, False), (True, True, False), (True, False, False),
+             (True, False, True), (False, False, False), (True, False, False)] * 3
+    forms = [0, 0, 1, 2, 0, 3, 1, 1] * 3
+    items = []
+    for i, ((co, ci, r), fl) in enumerate(zip(shapes, flags)):
+        w = rnd(*((co, ci, r, r) if r > 1 else (co, ci)), seed=100 + i).cuda()
+        items.append((w, rnd(1, co, seed=200 + i).cuda(), torch.ones(1, device="cuda")) + fl)
+    states = ops.sn_prepare_many(items, 1e-6, True)
+    work = []
+    for i, (st, form, it) in enumerate(zip(states, forms, items)):
+        raw = rnd(st.raw_numel if form >= 2 else st.rows * st.cin * st.R * st.R, seed=300 + i).cuda()
+        assert form < 2 or st.raw_numel == 16 * st.rows * st.cin
+        work.append((raw, form, st, it[0]))
+    many = ops.sn_backward_many(work)
+    for (raw, form, st, like), got in zip(work, many):
+        f = [None] * 4
+        f[form] = raw
+        one = ops._sn_backward(f[0], f[1], st, like, dw_up=f[2], dw_down=f[3])
+        assert got.shape == like.shape and torch.equal(got, one), (st.rows, st.cin, st.R, form)
 
 
 @pytest.mark.parametrize("rows,Cin,taps", [(32, 32, 3), (3, 96, 3), (96, 3, 3), (1000, 64, 1), (130, 70, 3), (17, 5, 1)])
