@@ -43,6 +43,10 @@ class SnBwdItem(ctypes.Structure):        # icg_sn_bwd_item
                 ("accumulate", ctypes.c_int)]
 
 
+class LinearItem(ctypes.Structure):       # icg_linear_item
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "w", "dy", "out")] + [("N", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
 class WinoWeight(ctypes.Structure):        # icg_wino_weight
     _fields_ = [("w", ctypes.c_void_p), ("U", ctypes.c_void_p), ("N", ctypes.c_int), ("K", ctypes.c_int), ("planes", ctypes.c_int),
                 ("reserved", ctypes.c_int)]

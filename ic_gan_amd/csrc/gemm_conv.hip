@@ -1487,6 +1487,171 @@ static int smallm_nt_launch(const float* A, const float* B, const float* bias, f
   return icg_check_launch();
 }
 
+// ---- a GROUP of dense layers that read the same few rows: the four conditional-BN projections of a GBlock (bn1.gain, bn1.bias,
+// bn2.gain, bn2.bias of layers.py:367-374 applied to the same y, 64 rows x K = 657) as ONE launch per direction instead of four
+// launches of ~17 us of latency each.  blockIdx.z selects the item; the per-item arithmetic is smallm_nt_kernel's / skinny_wgrad_kernel's
+// (same order: bit-identical to the per-layer launches); the data gradient sums the items inside one accumulation chain.
+struct LinGroupPack {
+  icg_linear_item l[ICG_LINEAR_GROUP_MAX];
+  int n, M, K;
+};
+
+// mode 0: out_i[m][c] = sum_k x_i[m][k] w_i[c][k]        (wave: 16 rows x 4 columns, lanes stride over k)
+template <int VEC>
+__global__ __launch_bounds__(256) void lin_group_fprop_kernel(LinGroupPack p) {
+  const icg_linear_item& L = p.l[blockIdx.z];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n0 = ((int)blockIdx.x * 4 + wv) * 4, mbase = (int)blockIdx.y * 16;
+  const int M = p.M, K = p.K, N = L.N;
+  if (n0 >= N) return;
+  const float* __restrict__ A = L.x;
+  const float* __restrict__ B = L.w;
+  float acc[16][4];
+#pragma unroll
+  for (int m = 0; m < 16; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+  if constexpr (VEC == 4) {
+    const int K4 = K >> 2;
+    const float4* Bp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Bp[j] = reinterpret_cast<const float4*>(B + (long)min(n0 + j, N - 1) * K);
+    for (int k4 = lane; k4 < K4; k4 += 64) {
+      float4 b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bp[j][k4];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const float4 a = reinterpret_cast<const float4*>(A + (long)min(mbase + m, M - 1) * K)[k4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[m][j] = fmaf(a.w, b[j].w, fmaf(a.z, b[j].z, fmaf(a.y, b[j].y, fmaf(a.x, b[j].x, acc[m][j]))));
+      }
+    }
+  } else {
+    const float* Bp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Bp[j] = B + (long)min(n0 + j, N - 1) * K;
+    for (int k = lane; k < K; k += 64) {
+      float b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bp[j][k];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const float a = A[(long)min(mbase + m, M - 1) * K + k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = fmaf(a, b[j], acc[m][j]);
+      }
+    }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int m = 0; m < 16; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[m][j];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == m * 4 + j) mine = v;
+    }
+  const int m = mbase + (lane >> 2), n = n0 + (lane & 3);
+  if (m < M && n < N) L.out[(long)m * N + n] = mine;
+}
+
+// mode 1: dw_i[k][c .. c + 3] = sum_m x_i[m][k] dy_i[m][c .. c + 3]      (HWIO at R = 1; one thread per (k, column quad))
+__global__ __launch_bounds__(256) void lin_group_wgrad_kernel(LinGroupPack p) {
+  const icg_linear_item& L = p.l[blockIdx.z];
+  const int N4 = L.N >> 2, M = p.M, K = p.K;
+  const long total = (long)K * N4;
+  const long gstride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const int n4 = (int)(i % N4);
+    const int k = (int)(i / N4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* g = reinterpret_cast<const float4*>(L.dy) + n4;
+    for (int b = 0; b < M; ++b) {
+      const float xv = L.x[(long)b * K + k];
+      const float4 d = g[(long)b * N4];
+      acc.x = fmaf(xv, d.x, acc.x); acc.y = fmaf(xv, d.y, acc.y); acc.z = fmaf(xv, d.z, acc.z); acc.w = fmaf(xv, d.w, acc.w);
+    }
+    reinterpret_cast<float4*>(L.out)[i] = acc;
+  }
+}
+
+// mode 2: dx[m][k] = sum_i sum_c dy_i[m][c] wd_i[k][c]     (wd_i = W_i / sigma in the [K][N_i] layout; one chain over all items)
+__global__ __launch_bounds__(256) void lin_group_dgrad_kernel(LinGroupPack p) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k0 = ((int)blockIdx.x * 4 + wv) * 4, mbase = (int)blockIdx.y * 16;
+  const int M = p.M, K = p.K;
+  if (k0 >= K) return;
+  float acc[16][4];
+#pragma unroll
+  for (int m = 0; m < 16; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+  for (int it = 0; it < p.n; ++it) {
+    const icg_linear_item& L = p.l[it];
+    const int N4 = L.N >> 2;
+    const float4* Bp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Bp[j] = reinterpret_cast<const float4*>(L.w + (long)min(k0 + j, K - 1) * L.N);
+    for (int c4 = lane; c4 < N4; c4 += 64) {
+      float4 b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bp[j][c4];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const float4 a = reinterpret_cast<const float4*>(L.dy + (long)min(mbase + m, M - 1) * L.N)[c4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[m][j] = fmaf(a.w, b[j].w, fmaf(a.z, b[j].z, fmaf(a.y, b[j].y, fmaf(a.x, b[j].x, acc[m][j]))));
+      }
+    }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int m = 0; m < 16; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[m][j];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == m * 4 + j) mine = v;
+    }
+  const int m = mbase + (lane >> 2), k = k0 + (lane & 3);
+  if (m < M && k < K) p.l[0].out[(long)m * K + k] = mine;
+}
+
+extern "C" int icg_linear_group(const icg_linear_item* items, int n, int M, int K, int mode, void* stream) {
+  ICG_REQUIRE(items && n >= 1 && n <= ICG_LINEAR_GROUP_MAX && M >= 1 && K >= 1 && mode >= 0 && mode <= 2);
+  LinGroupPack p{};
+  p.n = n; p.M = M; p.K = K;
+  int nmax = 0;
+  bool vec = (K % 4 == 0);
+  for (int i = 0; i < n; ++i) {
+    const icg_linear_item& L = items[i];
+    ICG_REQUIRE(L.N >= 1 && (mode == 2 ? (L.dy && L.w) : (L.x && L.out && (mode == 0 ? L.w != nullptr : L.dy != nullptr))));
+    if (mode != 0) ICG_REQUIRE(L.N % 4 == 0 && aligned16(L.dy) && (mode == 1 ? aligned16(L.out) : aligned16(L.w)));
+    vec = vec && aligned16(L.x) && aligned16(L.w);
+    p.l[i] = L;
+    nmax = max(nmax, L.N);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) {
+    const dim3 grid((unsigned)icg_cdiv(nmax, 16), (unsigned)icg_cdiv(M, 16), (unsigned)n);
+    if (vec) hipLaunchKernelGGL((lin_group_fprop_kernel<4>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((lin_group_fprop_kernel<1>), grid, dim3(256), 0, st, p);
+  } else if (mode == 1) {
+    long nb = icg_cdiv((long)K * (nmax / 4), 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(lin_group_wgrad_kernel, dim3((unsigned)nb, 1, (unsigned)n), dim3(256), 0, st, p);
+  } else {
+    ICG_REQUIRE(items[0].out);
+    hipLaunchKernelGGL(lin_group_dgrad_kernel, dim3((unsigned)icg_cdiv(K, 16), (unsigned)icg_cdiv(M, 16)), dim3(256), 0, st, p);
+  }
+  return icg_check_launch();
+}
+
 static int conv2d_fprop_impl(const float* x, const float* w, const float* bias, const float* residual, float* out,
                              const float* scale, const float* shift, int64_t ss_bstride, int B, int H, int W, int Cin,
                              int Cout, int R, unsigned flags, float alpha, void* workspace, size_t workspace_bytes,

@@ -282,6 +282,18 @@ class ccbn(nn.Module):
         return f"out: {self.output_size}, in: {self.input_size}, sync_bn={self.sync_bn}"
 
 
+def ccbn_affine_pair(bn1, bn2, y):
+    """-> (gain1, bias1, gain2, bias2) of a block's two conditional BatchNorms for the same y: one grouped launch per direction
+    (ops.CcbnAffineFn) when the four projections are bias-free SNLinear layers, else the four layers one by one."""
+    mods = (bn1.gain, bn1.bias, bn2.gain, bn2.bias)
+    if ops.GROUPED_CCBN and y.dim() == 2 and all(isinstance(m, SNLinear) and m.bias is None and m.out_features % 4 == 0
+                                                 for m in mods):
+        sns = tuple(m.sn_state() for m in mods)
+        ws = [m.weight if st.handle is None else st.handle for m, st in zip(mods, sns)]
+        return ops.CcbnAffineFn.apply(y, sns, *ws)
+    return bn1.affine(y) + bn2.affine(y)
+
+
 class bn(nn.Module):
     """Plain affine BatchNorm (generator output layer)."""
 
@@ -373,8 +385,11 @@ class GBlock(nn.Module):
         o1, o2 = self.bn1.bn_opt(), self.bn2.bn_opt()
         if ops._sync_enabled(o1):
             return self._forward_sync(x, y, up, o1, o2)
-        g1, b1 = self.bn1.affine(y) if isinstance(self.bn1, ccbn) else (self.bn1.gain, self.bn1.bias)
-        g2, b2 = self.bn2.affine(y) if isinstance(self.bn2, ccbn) else (self.bn2.gain, self.bn2.bias)
+        if isinstance(self.bn1, ccbn) and isinstance(self.bn2, ccbn):
+            g1, b1, g2, b2 = ccbn_affine_pair(self.bn1, self.bn2, y)
+        else:
+            g1, b1 = self.bn1.affine(y) if isinstance(self.bn1, ccbn) else (self.bn1.gain, self.bn1.bias)
+            g2, b2 = self.bn2.affine(y) if isinstance(self.bn2, ccbn) else (self.bn2.gain, self.bn2.bias)
         # 1x1 shortcut commutes with nearest upsampling: run it at the input resolution.  x feeds the shortcut and the main path:
         # the shortcut hands x on (`chain=True`, see Attention.forward), so the main path's gradient of x is added in the
         # epilogue of the shortcut's data-gradient GEMM instead of by an elementwise pass
@@ -390,8 +405,11 @@ class GBlock(nn.Module):
         RCCL's stream) has independent kernels to hide behind -- bn1's behind the four conditioning projections, bn2's
         behind the 1x1 shortcut convolution."""
         st1 = ops.bn_stats_begin(x, o1)
-        g1, b1 = self.bn1.affine(y) if isinstance(self.bn1, ccbn) else (self.bn1.gain, self.bn1.bias)
-        g2, b2 = self.bn2.affine(y) if isinstance(self.bn2, ccbn) else (self.bn2.gain, self.bn2.bias)
+        if isinstance(self.bn1, ccbn) and isinstance(self.bn2, ccbn):
+            g1, b1, g2, b2 = ccbn_affine_pair(self.bn1, self.bn2, y)
+        else:
+            g1, b1 = self.bn1.affine(y) if isinstance(self.bn1, ccbn) else (self.bn1.gain, self.bn1.bias)
+            g2, b2 = self.bn2.affine(y) if isinstance(self.bn2, ccbn) else (self.bn2.gain, self.bn2.bias)
         h = self.conv1(x, relu=True, upsample=up, bn=o1, gain=g1, beta=b1, bn_stats=st1)
         st2 = ops.bn_stats_begin(h, o2)
         sc = self.conv_sc(x) if self.learnable_sc else x          # (launch order matters here: no gradient chain)

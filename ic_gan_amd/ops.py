@@ -907,6 +907,61 @@ def linear(x2d: torch.Tensor, weight, bias, sn: SNState):
 
 
 # ----------------------------------------------------------------------------------------------
+# the conditional-BN projections of a block as one launch per direction  (reference layers.py:367-374)
+# ----------------------------------------------------------------------------------------------
+GROUPED_CCBN = os.environ.get("ICG_CCBN_GROUP", "1") != "0"
+
+
+def _linear_group(mode, M, K, items):
+    """icg_linear_group: items = [(x, w, dy, out, N), ...] (tensors or None)."""
+    import ctypes
+    arr = (L.LinearItem * len(items))()
+    for d, (x, w, dy, out, n) in zip(arr, items):
+        d.x, d.w, d.dy, d.out = (t.data_ptr() if t is not None else None for t in (x, w, dy, out))
+        d.N = int(n)
+    L.call("icg_linear_group", ctypes.cast(arr, ctypes.c_void_p), len(items), int(M), int(K), int(mode))
+
+
+class CcbnAffineFn(Function):
+    """gain(y), bias(y) of bn1 and gain(y), bias(y) of bn2 of a GBlock -- four spectrally normalised linear layers without bias
+    applied to the same conditioning vector y [B, K] (reference layers.py:367-374, called from 542-552) -- as ONE launch forward, one
+    for the four weight gradients and one for the gradient of y (summed inside the kernel) instead of four launches each way plus
+    three elementwise adds.  Inputs: y, the SNStates, the weights (or their SNGroupFn handles)."""
+
+    @staticmethod
+    def forward(ctx, y, sns, *ws):
+        y = y.contiguous().float()
+        M, K = y.shape
+        _require_gpu(y)
+        outs = [torch.empty(M, sn.rows, device=y.device, dtype=torch.float32) for sn in sns]
+        _linear_group(0, M, K, [(y, sn.w_ohwi, None, o, sn.rows) for sn, o in zip(sns, outs)])
+        ctx.sns, ctx.likes = sns, ws
+        ctx.save_for_backward(y)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        (y,) = ctx.saved_tensors
+        M, K = y.shape
+        sns, need = ctx.sns, ctx.needs_input_grad
+        douts = [d.contiguous().float() for d in douts]
+        dy = None
+        if need[0]:
+            if any(sn.w_dgrad is None for sn in sns):
+                raise RuntimeError("data gradient requested but the layer was prepared without the dgrad layout")
+            dy = torch.empty_like(y)
+            _linear_group(2, M, K, [(None, sn.w_dgrad, d, dy if i == 0 else None, sn.rows) for i, (sn, d) in enumerate(zip(sns, douts))])
+        dws = [None] * len(sns)
+        todo = [i for i in range(len(sns)) if need[2 + i]]
+        if todo:
+            raws = {i: _f32(K * sns[i].rows, y.device) for i in todo}
+            _linear_group(1, M, K, [(y, None, douts[i], raws[i], sns[i].rows) for i in todo])
+            for i in todo:
+                dws[i] = _sn_backward(raws[i], None, sns[i], ctx.likes[i])
+        return (dy, None) + tuple(dws)
+
+
+# ----------------------------------------------------------------------------------------------
 # SN embedding  (reference layers.py:171-200)
 # ----------------------------------------------------------------------------------------------
 class SNEmbeddingFn(Function):

@@ -500,6 +500,24 @@ typedef struct icg_sn_bwd_item {
 } icg_sn_bwd_item;
 int icg_sn_backward_multi(const icg_sn_bwd_item* items, int n, void* stream);
 
+/* A group of dense layers over the same few rows in ONE launch per direction: the four conditional-BN projections of a GBlock
+ * (bn1.gain / bn1.bias / bn2.gain / bn2.bias applied to the same y, reference layers.py:367-374; 64 rows, K = 657) otherwise cost four
+ * latency-bound launches each way.  M rows and K inputs are common to the items; N = the item's output width.
+ *   mode 0 (forward):         out_i [M][N_i] = x_i [M][K] * w_i^T,   w_i = W / sigma as [N_i][K]
+ *   mode 1 (weight gradient): out_i [K][N_i] = x_i^T * dy_i          (HWIO at R = 1, what icg_sn_backward takes as dw_hwio); N_i % 4 == 0
+ *   mode 2 (data gradient):   items[0].out [M][K] = sum_i dy_i [M][N_i] * w_i^T,  w_i = W / sigma as [K][N_i] (the dgrad layout); N_i % 4 == 0
+ * Modes 0 / 1 are bit-identical to icg_conv2d_fprop / icg_conv2d_wgrad on the same operands; mode 2 sums the items in one chain. */
+#define ICG_LINEAR_GROUP_MAX 8
+typedef struct icg_linear_item {
+  const float* x;
+  const float* w;
+  const float* dy;
+  float* out;
+  int N;
+  int reserved;
+} icg_linear_item;
+int icg_linear_group(const icg_linear_item* items, int n, int M, int K, int mode, void* stream);
+
 /* ---- pointwise / pooling / softmax ---------------------------------------------------- */
 int icg_nchw_to_nhwc(const float* x, float* y, int B, int C, int H, int W, void* stream);
 int icg_nhwc_to_nchw(const float* x, float* y, int B, int C, int H, int W, void* stream);

@@ -1559,6 +1559,22 @@ def install(monkeypatch):
             sn.handle = handle
         return out
 
+    def linear_group_ref(mode, M, K, items):
+        """ops._linear_group (icg_linear_group): the per-item dense products it batches"""
+        if mode == 2:
+            acc = torch.zeros(M, K)
+            for _, w, dy, _, n in items:
+                acc += mem(dy)[: M * n].view(M, n) @ mem(w)[: K * n].view(K, n).t()
+            mem(items[0][3])[: M * K].copy_(acc.reshape(-1))
+            return
+        for x, w, dy, out, n in items:
+            xv = mem(x)[: M * K].view(M, K)
+            if mode == 0:
+                mem(out)[: M * n].copy_((xv @ mem(w)[: n * K].view(n, K).t()).reshape(-1))
+            else:
+                mem(out)[: K * n].copy_((xv.t() @ mem(dy)[: M * n].view(M, n)).reshape(-1))
+
+    monkeypatch.setattr(ops, "_linear_group", linear_group_ref)
     monkeypatch.setattr(ops, "sn_backward_many", sn_backward_many_ref)
     monkeypatch.setattr(ops, "sn_prepare_many", lambda items, eps, training: [
         ops.sn_prepare(w, u, sv, eps, training, nd, up, dn, *rest) for (w, u, sv, nd, up, dn, *rest) in items])

@@ -214,6 +214,47 @@ def test_grouped_spectral_norm_backward_equals_the_per_layer_one(emu, monkeypatc
         assert a.shape == b.shape and torch.isfinite(a).all()
 
 
+def test_grouped_conditional_bn_projections_equal_the_four_linears(emu, monkeypatch):
+    """ops.CcbnAffineFn (bn1.gain / bn1.bias / bn2.gain / bn2.bias of a GBlock on the same y as one grouped launch per direction,
+    reference layers.py:367-374) against the four SNLinear calls: same image, same gradients of every parameter and of the shared
+    embedding, same spectral-norm buffers."""
+    import copy
+    from ic_gan_amd import ops
+    g = load_golden("cc_ic_r64")
+    cfg = g["cfg"]
+    _, G, _ = _build(g)
+    G.load_state_dict(synth.synth_state(g["gspec"], 11))
+    z, lab, fg = synth.CondSampler(cfg, G.dim_z, 2, seed=5)()
+    calls = []
+    real = ops._linear_group
+    monkeypatch.setattr(ops, "_linear_group", lambda mode, M, K, items: (calls.append((mode, len(items))), real(mode, M, K, items))[1])
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(ops, "GROUPED_CCBN", on)
+        Gn = copy.deepcopy(G)
+        Gn.train()
+        for it in range(2):
+            for p in Gn.parameters():
+                p.grad = None
+            img = Gn(z, lab, fg)
+            (img * torch.linspace(-1, 1, img.numel()).view_as(img)).sum().backward()
+        res.append((img.detach(), Gn))
+    nblk = sum(1 for st in G.blocks for m in st if hasattr(m, "bn1"))
+    assert calls.count((0, 4)) == 2 * nblk and calls.count((1, 4)) == 2 * nblk and calls.count((2, 4)) == 2 * nblk
+    (ia, Ga), (ib, Gb) = res
+    torch.testing.assert_close(ia, ib, rtol=1e-4, atol=3e-5)        # (two different torch matmul routes on the emulated kernels)
+    # the two forms differ by fp32 summation order (here: two torch matmul routes), which this ReLU network amplifies to ~1e-4 of a
+    # gradient tensor's norm; gradients that are mathematically zero (a conv bias in front of a BatchNorm) are rounding noise in both
+    top = max(float(q.grad.norm()) for q in Gb.parameters() if q.grad is not None)
+    for (k, p), (_, q) in zip(Ga.named_parameters(), Gb.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), k
+        if p.grad is not None:
+            assert float((p.grad - q.grad).norm()) <= 1e-3 * float(q.grad.norm()) + 1e-6 * top, k
+    for (k, v), (_, v2) in zip(Ga.state_dict().items(), Gb.state_dict().items()):
+        if "weight" not in k:
+            torch.testing.assert_close(v, v2, rtol=1e-5, atol=1e-6, msg=k)
+
+
 def test_sn_prefetch_bookkeeping(emu):
     """the batched spectral-norm pass is used from the second forward on, gives the same buffers as the per-layer path,
     and a forward that aborts midway leaves the module usable (prefetch is transactional)."""

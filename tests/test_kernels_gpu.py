@@ -893,6 +893,39 @@ def test_sn_forward_multi_bit_identical():
                 assert torch.equal(a, b), name
 
 
+@pytest.mark.parametrize("M,K,Ns", [(64, 657, (1536, 1536, 768, 768)), (16, 148, (96, 96, 96, 96)), (7, 64, (12, 40)), (128, 657, (192,))])
+def test_linear_group(M, K, Ns):
+    """icg_linear_group (the conditional-BN projections of a block in one launch per direction): forward and weight gradient bit for
+    bit the per-layer kernels behind icg_conv2d_fprop / icg_conv2d_wgrad; the data gradient = the sum of the per-layer ones."""
+    from ic_gan_amd import ops
+    L = _L()
+    x = rnd(M, K, seed=1).cuda()
+    ws = [rnd(n, K, seed=10 + i, scale=K ** -0.5).cuda() for i, n in enumerate(Ns)]
+    dys = [rnd(M, n, seed=20 + i).cuda() for i, n in enumerate(Ns)]
+    outs = [torch.empty(M, n, device="cuda") for n in Ns]
+    ops._linear_group(0, M, K, [(x, w, None, o, n) for w, o, n in zip(ws, outs, Ns)])
+    raws = [torch.empty(K, n, device="cuda") for n in Ns]
+    ops._linear_group(1, M, K, [(x, None, d, r, n) for d, r, n in zip(dys, raws, Ns)])
+    wds = [w.t().contiguous() for w in ws]
+    dx = torch.empty(M, K, device="cuda")
+    ops._linear_group(2, M, K, [(None, wd, d, dx if i == 0 else None, n) for i, (wd, d, n) in enumerate(zip(wds, dys, Ns))])
+    ref_dx = torch.zeros(M, K, dtype=torch.float64)
+    for w, d, o, r, n in zip(ws, dys, outs, raws, Ns):
+        one = torch.empty(M, n, device="cuda")
+        L.call("icg_conv2d_fprop", x, w, None, None, one, None, None, 0, M, 1, 1, K, n, 1, 0, 1.0)
+        if M >= 16:                                                 # (below 16 rows the per-layer entry takes another kernel)
+            assert torch.equal(o, one)
+        close(o, one, rtol=2e-5, atol_rel=2e-5, what="group fprop vs icg_conv2d_fprop")
+        close(o, (x.cpu().double() @ w.cpu().double().t()).float(), rtol=2e-5, atol_rel=2e-5, what="group fprop")
+        nb = L.query("icg_conv2d_wgrad_workspace_bytes", M, 1, 1, K, n, 1)
+        dw = torch.empty(K, n, device="cuda")
+        L.call("icg_conv2d_wgrad", x, d, dw, None, None, 0, M, 1, 1, K, n, 1, 0, torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda"), nb)
+        close(r, dw, rtol=2e-5, atol_rel=2e-5, what="group wgrad vs icg_conv2d_wgrad")
+        close(r, (x.cpu().double().t() @ d.cpu().double()).float(), rtol=2e-5, atol_rel=2e-5, what="group wgrad")
+        ref_dx += d.cpu().double() @ w.cpu().double()
+    close(dx, ref_dx.float(), rtol=3e-5, atol_rel=3e-5, what="group dgrad")
+
+
 def test_sn_backward_multi_equals_per_layer():
     """icg_sn_backward_multi (the backward of ops.SNGroupFn: many layers in two launches per descriptor pack) == icg_sn_backward per
     layer, bit for bit, over all four raw-gradient forms and more layers than one pack holds."""

@@ -1,0 +1,7 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd $R && mkdir -p gpurun_out
+export PYTHONDONTWRITEBYTECODE=1
+for v in 0 32 0 32; do
+  ICG_PGEMM_L1_MINK=$v timeout 300 python bench.py --steps 10 --warmup 3 --init N02 --no-cpu-baseline --no-uninstrumented-leg 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); r=d['roofline']; print('L1_MINK=$v cfg3 ms_per_step', d['ms_per_step'], r['kernel'], 'frac', r['frac'], 'avg ms', r['avg_launch_ms'])"
+done
