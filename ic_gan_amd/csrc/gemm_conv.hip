@@ -1578,20 +1578,23 @@ __global__ __launch_bounds__(256) void lin_group_wgrad_kernel(LinGroupPack p) {
   }
 }
 
-// mode 2: dx[m][k] = sum_i sum_c dy_i[m][c] wd_i[k][c]     (wd_i = W_i / sigma in the [K][N_i] layout; one chain over all items)
+// mode 2: dx[m][k] = sum_i sum_c dy_i[m][c] wd_i[k][c]     (wd_i = W_i / sigma in the [K][N_i] layout).  Every item is reduced on
+// its own (lane chains + butterfly, the arithmetic of the per-layer data-gradient launch) and the items are added in order: the
+// result is what the four launches + three elementwise adds gave, up to the order of those adds.
 __global__ __launch_bounds__(256) void lin_group_dgrad_kernel(LinGroupPack p) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int k0 = ((int)blockIdx.x * 4 + wv) * 4, mbase = (int)blockIdx.y * 16;
   const int M = p.M, K = p.K;
   if (k0 >= K) return;
-  float acc[16][4];
-#pragma unroll
-  for (int m = 0; m < 16; ++m)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+  float total = 0.f;
   for (int it = 0; it < p.n; ++it) {
     const icg_linear_item& L = p.l[it];
     const int N4 = L.N >> 2;
+    float acc[16][4];
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
     const float4* Bp[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) Bp[j] = reinterpret_cast<const float4*>(L.w + (long)min(k0 + j, K - 1) * L.N);
@@ -1607,19 +1610,20 @@ __global__ __launch_bounds__(256) void lin_group_dgrad_kernel(LinGroupPack p) {
           acc[m][j] = fmaf(a.w, b[j].w, fmaf(a.z, b[j].z, fmaf(a.y, b[j].y, fmaf(a.x, b[j].x, acc[m][j]))));
       }
     }
+    float mine = 0.f;
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = acc[m][j];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == m * 4 + j) mine = v;
+      }
+    total = it == 0 ? mine : total + mine;
   }
-  float mine = 0.f;
-#pragma unroll
-  for (int m = 0; m < 16; ++m)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v = acc[m][j];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == m * 4 + j) mine = v;
-    }
   const int m = mbase + (lane >> 2), k = k0 + (lane & 3);
-  if (m < M && k < K) p.l[0].out[(long)m * K + k] = mine;
+  if (m < M && k < K) p.l[0].out[(long)m * K + k] = total;
 }
 
 extern "C" int icg_linear_group(const icg_linear_item* items, int n, int M, int K, int mode, void* stream) {

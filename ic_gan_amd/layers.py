@@ -286,8 +286,9 @@ def ccbn_affine_pair(bn1, bn2, y):
     """-> (gain1, bias1, gain2, bias2) of a block's two conditional BatchNorms for the same y: one grouped launch per direction
     (ops.CcbnAffineFn) when the four projections are bias-free SNLinear layers, else the four layers one by one."""
     mods = (bn1.gain, bn1.bias, bn2.gain, bn2.bias)
-    if ops.GROUPED_CCBN and y.dim() == 2 and all(isinstance(m, SNLinear) and m.bias is None and m.out_features % 4 == 0
-                                                 for m in mods):
+    # (from 16 rows: the grouped kernels tile 16 rows per wave, and below that the per-layer entry points take other kernels)
+    if ops.GROUPED_CCBN and y.dim() == 2 and y.shape[0] >= 16 and all(isinstance(m, SNLinear) and m.bias is None
+                                                                     and m.out_features % 4 == 0 for m in mods):
         sns = tuple(m.sn_state() for m in mods)
         ws = [m.weight if st.handle is None else st.handle for m, st in zip(mods, sns)]
         return ops.CcbnAffineFn.apply(y, sns, *ws)

@@ -9,7 +9,7 @@ is what the kernels address; `_cl` makes that true at module boundaries.
 from __future__ import annotations
 
 import os
-from dataclasses import dataclass
+from dataclasses import dataclass, replace
 from typing import Optional
 
 import torch
@@ -71,7 +71,8 @@ class SNState:
     #                                              rows cin R R; phase form dw_up / pooled form dw_down: 16 rows cin)
     handle: Optional[torch.Tensor] = None        # grouped spectral-norm backward (SNGroupFn): the tensor that stands for the weight
     #                                              in the layer's autograd node; its gradient is the raw weight gradient
-    raw_form: int = -1                           # which argument of icg_sn_backward that gradient is (0 hwio, 1 ohwi, 2 up, 3 down)
+    group_forms: Optional[tuple] = None          # (list shared with the SNGroupFn node, this layer's index): which argument of
+    #                                              icg_sn_backward the gradient is (0 hwio, 1 ohwi, 2 up, 3 down), written in backward
 
 
 def _sn_alloc(weight, need_dgrad, upsample, downsample, winograd=False):
@@ -197,7 +198,7 @@ def _sn_backward(dw_hwio, dw_ohwi, sn: SNState, like: torch.Tensor, dw_up=None, 
         given = [i for i, t in enumerate(forms) if t is not None]
         if len(given) != 1 or forms[given[0]].numel() != sn.raw_numel:
             raise RuntimeError("grouped spectral-norm backward: expected one raw weight gradient of %d elements" % sn.raw_numel)
-        sn.raw_form = given[0]
+        sn.group_forms[0][sn.group_forms[1]] = given[0]
         return forms[given[0]].reshape(-1)
     dw = torch.empty_like(like, memory_format=torch.contiguous_format)
     nb = L.query("icg_sn_backward_scratch_bytes", sn.rows, sn.cin, sn.R)
@@ -240,7 +241,15 @@ class SNGroupFn(Function):
 
     @staticmethod
     def forward(ctx, states, *weights):
-        ctx.states, ctx.likes = states, weights
+        # The node must not reference the SNStates: they hold the handles (= this node's outputs), and a cycle node -> state ->
+        # handle -> node keeps every step's saved activations alive until Python's cycle collector happens to run (GPU memory is
+        # invisible to it: the cfg3 bench ran out of 288 GB in 25 steps).  It keeps copies without the handle, and the list the
+        # layers' backward passes write their gradient form into.
+        ctx.forms = [-1] * len(states)
+        ctx.states = tuple(replace(st, handle=None, group_forms=None) for st in states)
+        ctx.likes = weights
+        for i, st in enumerate(states):
+            st.group_forms = (ctx.forms, i)
         ctx.set_materialize_grads(False)
         return tuple(w.new_empty(1).expand(st.raw_numel) for st, w in zip(states, weights))
 
@@ -249,9 +258,9 @@ class SNGroupFn(Function):
         items, where = [], []
         for i, (st, g, like) in enumerate(zip(ctx.states, grads, ctx.likes)):
             if g is not None and ctx.needs_input_grad[1 + i]:
-                if st.raw_form < 0:
+                if ctx.forms[i] < 0:
                     raise RuntimeError("grouped spectral-norm backward: a gradient arrived for a handle no layer consumed")
-                items.append((g, st.raw_form, st, like))
+                items.append((g, ctx.forms[i], st, like))
                 where.append(i)
         out = [None] * len(grads)
         if items:

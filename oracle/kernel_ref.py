@@ -1554,9 +1554,8 @@ def install(monkeypatch):
         for raw, form, sn, like in items:
             forms = [None] * 4
             forms[form] = raw.contiguous()
-            handle, sn.handle = sn.handle, None                 # the per-layer path
-            out.append(ops._sn_backward(forms[0], forms[1], sn, like, dw_up=forms[2], dw_down=forms[3]))
-            sn.handle = handle
+            out.append(ops._sn_backward(forms[0], forms[1], sn, like, dw_up=forms[2], dw_down=forms[3]))      # (sn.handle is None here:
+            #                                                          the node holds handle-free copies of the states)
         return out
 
     def linear_group_ref(mode, M, K, items):

@@ -224,7 +224,7 @@ def test_grouped_conditional_bn_projections_equal_the_four_linears(emu, monkeypa
     cfg = g["cfg"]
     _, G, _ = _build(g)
     G.load_state_dict(synth.synth_state(g["gspec"], 11))
-    z, lab, fg = synth.CondSampler(cfg, G.dim_z, 2, seed=5)()
+    z, lab, fg = synth.CondSampler(cfg, G.dim_z, 16, seed=5)()      # (the grouped form starts at 16 rows)
     calls = []
     real = ops._linear_group
     monkeypatch.setattr(ops, "_linear_group", lambda mode, M, K, items: (calls.append((mode, len(items))), real(mode, M, K, items))[1])
@@ -253,6 +253,42 @@ def test_grouped_conditional_bn_projections_equal_the_four_linears(emu, monkeypa
     for (k, v), (_, v2) in zip(Ga.state_dict().items(), Gb.state_dict().items()):
         if "weight" not in k:
             torch.testing.assert_close(v, v2, rtol=1e-5, atol=1e-6, msg=k)
+
+
+def test_training_passes_leave_no_reference_cycles(emu):
+    """A forward + backward pass must free its graph by reference counting alone: a cycle through an autograd node (e.g. node ->
+    SNState -> handle -> node) keeps every saved activation alive until Python's cycle collector runs, which does not see GPU memory
+    (the cfg3 bench ran out of 288 GB after 25 steps that way).  With the collector switched off the number of live tensors must not
+    grow from pass to pass."""
+    import gc
+    g = load_golden("cc_ic_r64")
+    cfg = g["cfg"]
+    _, G, D = _build(g)
+    G.load_state_dict(synth.synth_state(g["gspec"], 11))
+    D.load_state_dict(synth.synth_state(g["dspec"], 22))
+    G.train(); D.train()
+    z, lab, fg = synth.CondSampler(cfg, G.dim_z, 2, seed=5)()
+
+    def one_pass():
+        for p in list(G.parameters()) + list(D.parameters()):
+            p.grad = None
+        D(G(z, lab, fg), lab, fg).sum().backward()
+
+    def live():
+        return sum(1 for o in gc.get_objects() if isinstance(o, torch.Tensor))
+
+    one_pass(); one_pass()                       # layouts recorded, grouped paths active
+    gc.collect()
+    gc.disable()
+    try:
+        one_pass()
+        n0 = live()
+        for _ in range(3):
+            one_pass()
+        n1 = live()
+    finally:
+        gc.enable()
+    assert n1 <= n0 + 4, (n0, n1)
 
 
 def test_sn_prefetch_bookkeeping(emu):

@@ -118,6 +118,45 @@ def _forward(name, dev, monkeypatch):
         assert rel < 1e-3 * k, rel                 # north_star: generated samples within 1e-3 relative L2 (fp32 nets)
 
 
+def test_phases_leave_no_reference_cycles(monkeypatch):
+    """Every phase of the iteration (incl. the regularisers' double backward through the fused layers' second-order nodes) must free
+    its graphs by reference counting alone -- Python's cycle collector does not see GPU memory (tests/test_host_logic_cpu.py has the
+    BigGAN twin of this test).  Kernels emulated; collector off; the number of live tensors must not grow from iteration to iteration."""
+    import gc
+    from ic_gan_amd.stylegan2.loss import StyleGAN2Loss
+    kernel_ref.install(monkeypatch)
+    name = "ic_r32_fp16" if "ic_r32_fp16" in ALL_NETS else CASES[0]
+    cfg, G, D = _build(name, "cpu", monkeypatch)
+    b = cfg["batch"]
+    z, gc_, gh, img, rc, rh = sg2_inputs(cfg, 7, 4)
+    L = StyleGAN2Loss(device="cpu", G_mapping=G.mapping, G_synthesis=G.synthesis, D=D, **SG2_LOSS)
+
+    def iteration():
+        for phase in ("Gmain", "Greg", "Dmain", "Dreg"):
+            mod = G if phase[0] == "G" else D
+            mod.requires_grad_(True)
+            for p in mod.parameters():
+                p.grad = None
+            L.accumulate_gradients(phase=phase, real_img=img, real_c=rc, real_h=rh, gen_z=z[:b], gen_c=gc_[:b], gen_h=gh[:b], sync=True,
+                                   gain=1)
+            mod.requires_grad_(False)
+
+    def live():
+        return sum(1 for o in gc.get_objects() if isinstance(o, torch.Tensor))
+
+    iteration()
+    gc.collect()
+    gc.disable()
+    try:
+        iteration()
+        n0 = live()
+        iteration(); iteration()
+        n1 = live()
+    finally:
+        gc.enable()
+    assert n1 <= n0 + 8, (n0, n1)
+
+
 def _phase_grads(name, dev, monkeypatch):
     from ic_gan_amd.stylegan2.loss import StyleGAN2Loss
     g = _gold(name)
