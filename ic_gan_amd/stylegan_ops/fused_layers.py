@@ -17,10 +17,15 @@ of this repository ran the same op graph with HIP kernels behind each operation 
 with the weight-side work (gain / fp16 pre-normalisation, cast, gather layout, its adjoint, the demodulation table, Winograd / phase
 forms) done ONCE per optimiser step for all layers of a network in two launches (`refresh`, icg_sg2_weight_prep_multi).
 
-The Functions are first order only (`once_differentiable`): `loss.accumulate_gradients` enters `first_order()` for the Gmain and
-Dmain phases, which run every iteration; the lazy regularisers (path length every 4th, R1 every 16th iteration) differentiate twice
-and keep the composed operators (stylegan_ops/modconv.py, conv2d_resample.py, bias_act.py), as does any shape these kernels do not
-serve.  Without autograd (`torch.no_grad()`: sampling, the generator pass of Dmain) the fused forward is used as well.
+Two families of nodes.  `first_order()` (the Gmain and Dmain phases, every iteration; also `torch.no_grad()`: sampling, the generator
+pass of Dmain): `once_differentiable` Functions whose backward is a sequence of kernel calls.  `second_order()` (the path-length
+regulariser, every 4th iteration: loss.py:120-139 differentiates the generator's backward): `_ModConv2Fn` / `_ToRGB2Fn`, whose backward
+is ITSELF a node (`_ModConvBwdFn` / `_ToRGBBwdFn`) with a hand-written adjoint -- affine / pre-normalisation, the style algebra, the
+modulation (icg_sg2_mod2), the convolution K(u) with its weight gradient, the activation / demodulation block (icg_sg2_act_bwd2), K^T(cc),
+and the demodulation's second-derivative term of the weight (icg_sg2_weight_bwd_q).  Those nodes are called with the tensors the layer
+itself received (`x_in`, `wl_in`), never with re-laid-out copies, so that their cotangents reach the producer nodes.  R1 (every 16th
+iteration) and any shape these kernels do not serve keep the composed, arbitrarily differentiable operators (stylegan_ops/modconv.py,
+conv2d_resample.py, bias_act.py).
 Same arithmetic as the composed path, including the places where fp16 tensors round (csrc/sg2_fused.hip)."""
 import contextlib
 import os
