@@ -8,6 +8,7 @@
 // both ops are HBM-bound, so halving the bytes is the whole point: 16-byte accesses = 8 halves per lane.
 #include "icg_common.h"
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 extern "C" int icg_bias_act(const float* x, const float* b, const float* xref, const float* yref, const float* dy, float* y,
                             int64_t n, int64_t step_b, int size_b, int grad, int act, float alpha, float gain, float clamp,
@@ -338,12 +339,95 @@ __global__ __launch_bounds__(256) void upfirdn2d_nhwc_typed_kernel(const T* __re
   }
 }
 
+// Channels-last FIR without resampling (up = down = 1, filter <= 4 x 4: the 4 x 4 blur after an up-sampling convolution, before a
+// down-sampling one, and their adjoints -- 43 launches per cfg4 iteration) through an LDS tile, as upfirdn2d.cu:100-203 does for the
+// NCHW layout.  The kernel above has every thread fetch its (TY + 3) x 4 input vectors itself: 7 16-byte L1 requests per 16 output
+// bytes (0.32 - 0.46 of the HBM peak, profiles/r05_hbm_kernels_microbench.txt).  Measured gain of the tile: 8 % on the fp16 256 x 256
+// blur (0.104 -> 0.096 ms) -- the op is co-bound by the VALU: 128 FMAs + 28 fp16 -> fp32 conversions per 16 output bytes.  A workgroup owns a
+// 16 x 8 pixel tile of 8 channel vectors (8 x 16 bytes = 128 contiguous bytes per pixel): the (16 + 3) x (8 + 3) input pixels are
+// loaded once (1.6 loads per output instead of 7), zero outside the image, and every thread reads its 7 x 4 window from LDS
+// (consecutive lanes = consecutive 16-byte vectors: conflict-free) for a vertical strip of 4 outputs.  Taps are accumulated in the
+// order of the kernel above (rows, then columns), so finite inputs give the same bits.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void upfirdn2d_nhwc_tile_kernel(const T* __restrict__ x, const float* __restrict__ f,
+                                                                  T* __restrict__ y, int N, int H, int W, int CV, int fh, int fw,
+                                                                  int padx0, int pady0, int flip, float gain, int outH, int outW,
+                                                                  int tiles_x, int tiles_y) {
+  typedef typename Cvt<T>::S S;
+  constexpr int TW = 16, TH = 8, IW = TW + 3, IH = TH + 3, CG = 8;
+  __shared__ float fs[16];
+  __shared__ __attribute__((aligned(16))) char tile[IH * IW * CG * 16];
+  if (threadIdx.x < 16) {
+    const int ty = threadIdx.x >> 2, tx = threadIdx.x & 3;
+    fs[threadIdx.x] = (ty < fh && tx < fw) ? f[(flip ? ty : fh - 1 - ty) * fw + (flip ? tx : fw - 1 - tx)] * gain : 0.f;
+  }
+  const int cgroups = CV / CG;
+  unsigned t = blockIdx.x;
+  const int cg = (int)(t % (unsigned)cgroups);
+  t /= (unsigned)cgroups;
+  const int tx_ = (int)(t % (unsigned)tiles_x);
+  t /= (unsigned)tiles_x;
+  const int ty_ = (int)(t % (unsigned)tiles_y);
+  const int n = (int)(t / (unsigned)tiles_y);
+  const int ox0 = tx_ * TW, oy0 = ty_ * TH;
+  const int ix0 = ox0 - padx0, iy0 = oy0 - pady0;
+  const T* xn = x + ((long)n * H * W * CV + (long)cg * CG) * VEC;
+  for (int i = threadIdx.x; i < IH * IW * CG; i += 256) {
+    const int cv = i & (CG - 1), pc = i >> 3;
+    const int c = pc % IW, r = pc / IW;
+    const int iy = iy0 + r, ix = ix0 + c;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(xn + (((long)iy * W + ix) * CV + cv) * VEC);
+    reinterpret_cast<uint4*>(tile)[i] = v;
+  }
+  __syncthreads();
+  const int cv = threadIdx.x & 7, px = (threadIdx.x >> 3) & 15, ys = threadIdx.x >> 7;
+  S acc[4][VEC];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[j][e] = (S)0;
+  const T* tp = reinterpret_cast<const T*>(tile) + (((4 * ys) * IW + px) * CG + cv) * VEC;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      S v[VEC];
+      Pack<T, VEC>::ld(tp + ((r * IW + c) * CG) * VEC, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ty = r - j;
+        if (ty >= 0 && ty < 4) {
+          const S w = (S)fs[ty * 4 + c];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[j][e] += v[e] * w;
+        }
+      }
+    }
+  }
+  const int ox = ox0 + px;
+  if (ox >= outW) return;
+  T* yp = y + ((((long)n * outH + oy0 + 4 * ys) * outW + ox) * CV + (long)cg * CG + cv) * VEC;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (oy0 + 4 * ys + j < outH) Pack<T, VEC>::st(yp + (long)j * outW * CV * VEC, acc[j]);
+}
+
 template <typename T, int VEC>
 static int launch_upfirdn2d_typed(const void* x, const float* f, void* y, int N, int C, int H, int W, int fh, int fw, int upx,
                                   int upy, int downx, int downy, int padx0, int pady0, int flip, float gain, int outH, int outW,
                                   int channels_last, hipStream_t st) {
   if (channels_last) {
     ICG_REQUIRE(C % VEC == 0 && t_al16(x) && t_al16(y) && fh * fw <= 256);
+    static const bool tiled = [] { const char* e = getenv("ICG_FIR_TILE"); return !(e && e[0] == '0'); }();      // measurement switch
+    if (tiled && upx == 1 && upy == 1 && downx == 1 && downy == 1 && fh <= 4 && fw <= 4 && C % (8 * VEC) == 0) {
+      const int tiles_x = (outW + 15) / 16, tiles_y = (outH + 7) / 8;
+      const long blocks = (long)N * tiles_y * tiles_x * (C / (8 * VEC));
+      ICG_REQUIRE(blocks < 0x7fffffffL);
+      hipLaunchKernelGGL((upfirdn2d_nhwc_tile_kernel<T, VEC>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, f, (T*)y, N, H, W,
+                         C / VEC, fh, fw, padx0, pady0, flip, gain, outH, outW, tiles_x, tiles_y);
+      return icg_check_launch();
+    }
     constexpr int TY = 4;
     const long total = (long)N * ((outH + TY - 1) / TY) * outW * (C / VEC);
     long blocks = icg_cdiv(total, 256);

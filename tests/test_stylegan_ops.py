@@ -124,6 +124,31 @@ def test_upfirdn2d_nhwc_equals_nchw_kernel(shape, up, down, pad):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float64])
+@pytest.mark.parametrize("shape,taps,pad,flip", [((2, 64, 33, 33), [1, 3, 3, 1], [1, 1, 1, 1], False),      # blur after an up-sampling conv
+                                                 ((1, 128, 16, 24), [1, 3, 3, 1], [2, 2, 2, 2], True),       # ... before a down-sampling one (adjoint: flipped)
+                                                 ((2, 64, 9, 7), [1, 2, 1], [1, 1, 1, 1], False),            # 3 x 3 filter, a single ragged tile
+                                                 ((1, 192, 40, 17), [1, 3, 3, 1], [3, 0, 0, 3], False),      # three channel groups, one-sided padding
+                                                 ((3, 64, 5, 5), [1, 3, 3, 1], [0, 0, 0, 0], False)])        # 'valid': output 2 x 2
+def test_upfirdn2d_channels_last_lds_tile(dtype, shape, taps, pad, flip):
+    """upfirdn2d_nhwc_tile_kernel (csrc/stylegan_ops_typed.hip: channels-last FIR with up = down = 1 through an LDS tile, fp16 / fp64
+    storage) against the NCHW kernel on the same data: same taps in the same order, so equal up to the storage rounding."""
+    from ic_gan_amd.stylegan_ops import upfirdn2d as U
+    x = rnd(shape, 11).cuda().to(dtype)
+    f = U.setup_filter(taps, device="cuda")
+    a = U.upfirdn2d(x, f, padding=pad, flip_filter=flip, gain=1.3)
+    b = U.upfirdn2d(x.contiguous(memory_format=torch.channels_last), f, padding=pad, flip_filter=flip, gain=1.3)
+    assert b.dtype == dtype and b.is_contiguous(memory_format=torch.channels_last) and a.shape == b.shape
+    # (fp64: the channels-last kernels fold the gain into their fp32 filter taps, the NCHW kernel multiplies the fp64 sum by it)
+    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float16 else dict(rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(b.contiguous().double(), a.double(), **tol)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x.double(), pad), (f if flip else f.flip([0, 1])).double()[None, None].repeat(
+        shape[1], 1, 1, 1) * 1.3, groups=shape[1])
+    torch.testing.assert_close(b.contiguous().double(), ref, rtol=3e-3 if dtype == torch.float16 else 1e-6,
+                               atol=3e-3 if dtype == torch.float16 else 1e-6)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("act", ACTS)
 @pytest.mark.parametrize("cl", [False, True])
 def test_bias_act_vectorised_paths(act, cl):
