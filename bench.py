@@ -271,6 +271,8 @@ class KernelTimer:
                     kname = "void narrow_%s_kernel<%d, %d>" % ("wgrad" if last[1] else "fprop", last[2], lp)
             elif last[0] == -5:      # 1x1 convolution with <= 3 input channels (gemm_conv.hip: conv1x1_k3_kernel), write-bound
                 kname = "conv1x1_k3_kernel"
+            elif last[0] == 3:       # weight gradient of a prologue-free 1x1 convolution on the second-generation TN plane GEMM (one plane)
+                kname = "void icg_pgemm_tn_kernel<%d, %d>(PgemmTnP)" % (last[2], 1 if last[3] == 4 else 2)
             elif last[0] == 4:       # second-generation implicit-GEMM convolution (pgemm.hip): {4, ReLU prologue, NT, levels}
                 kname = "void icg_pconv_kernel<%d, %d, %d>(PconvP)" % (last[2], last[1], last[3])
             elif last[3] == 4:       # prologue-free 1x1 convolution on the persistent plain-GEMM body (single-level chains)

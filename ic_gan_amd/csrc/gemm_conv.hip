@@ -1770,11 +1770,30 @@ static WgradPlan wgrad_plan(long K, int M, int N) {
   return pl;
 }
 
+extern "C" size_t icg_gemm_tn_batched_workspace_bytes(int M, int N, int K, int batch);
+extern "C" int icg_gemm_tn_batched(const float* A, const float* B, float* C, int M, int N, int K, int64_t strideA,
+                                   int64_t strideB, int64_t strideC, int batch, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+
+// The weight gradient of a prologue-free 1x1 convolution is the plain product x^T dy over the pixels: the shape of the Winograd
+// weight-gradient plane GEMMs with ONE plane, so it runs on their second-generation kernel (icg_pgemm_tn_kernel, pgemm.hip: 0.74 of the
+// fp32 MFMA peak against 0.5 - 0.65 for the first-generation TN path on these K = 10^4 ... 10^5 chains) -- the 1x1 shortcuts of every
+// block and the attention block's projections.  (ICG_WGRAD_1X1_TN=0: the first-generation path, a measurement switch.)
+static bool wgrad_1x1_tn_ok(long K, int Cin, int Cout, int R, unsigned flags) {
+  static const bool on = [] { const char* e = getenv("ICG_WGRAD_1X1_TN"); return !(e && e[0] == '0'); }();
+  return on && R == 1 && !(flags & (ICG_UPSAMPLE2X | ICG_PRE_AFFINE | ICG_PRE_RELU)) && (Cout % 96 == 0 || Cout % 128 == 0) &&
+         Cin % 4 == 0 && Cin >= 64 && K % 32 == 0 && K >= 4096 && K < 0x7fffffffL;
+}
+
 extern "C" size_t icg_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int R) {
   const long K = (long)B * H * W;
   const int M = R * R * Cin;
   WgradPlan pl = wgrad_plan(K, M, Cout);
   size_t need = (pl.splits <= 1) ? 16 : (size_t)pl.splits * (size_t)M * (size_t)Cout * sizeof(float);
+  if (wgrad_1x1_tn_ok(K, Cin, Cout, R, 0)) {
+    const size_t nn = icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)K, 1);
+    if (nn > need) need = nn;
+  }
   if (icg_narrow_conv_ok(Cin, Cout, R, nullptr, nullptr, nullptr, 0)) {      // the direct kernel may be chosen at run time
     const size_t nn = icg_narrow_wgrad_workspace_bytes(B, H, W, Cin, Cout);
     if (nn > need) need = nn;
@@ -1815,6 +1834,13 @@ extern "C" int icg_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
       icg_skinny_ok(K, Cin, R)) {
     g_last_variant[0] = -3; g_last_variant[1] = 1; g_last_variant[2] = Cout; g_last_variant[3] = Cin;
     return icg_skinny_wgrad(x, dy, dw, (int)K, Cout, Cin, (hipStream_t)stream);
+  }
+  if (wgrad_1x1_tn_ok(K, Cin, Cout, R, flags) && aligned16(x) && aligned16(dy) && aligned16(dw) && workspace != nullptr &&
+      workspace_bytes >= icg_gemm_tn_batched_workspace_bytes(Cin, Cout, (int)K, 1)) {
+    icg_gemm_mark_planes(1);
+    const int rc = icg_gemm_tn_batched(x, dy, dw, Cin, Cout, (int)K, 0, 0, (int64_t)Cin * Cout, 1, workspace, workspace_bytes, stream);
+    icg_gemm_mark_planes(0);
+    return rc;
   }
   WgradPlan pl = wgrad_plan(K, M, Cout);
   const size_t need = (pl.splits <= 1) ? 0 : (size_t)pl.splits * M * Cout * sizeof(float);

@@ -179,6 +179,26 @@ def test_conv2d_wgrad(case):
     close(*pair, rtol=5e-5, atol_rel=5e-5, what=f"wgrad {case}")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 32, 32, 96, 192), (2, 64, 64, 288, 384), (8, 32, 32, 64, 96), (1, 64, 64, 1536, 128),
+                                            (4, 32, 32, 100, 96)])
+def test_conv2d_wgrad_1x1_on_the_tn_plane_gemm(B, H, W, Cin, Cout):
+    """prologue-free 1x1 weight gradients (block shortcuts, the attention projections) run on the second-generation TN plane GEMM with
+    one plane (wgrad_1x1_tn_ok, csrc/gemm_conv.hip): against fp64, deterministic, and with the minimum workspace of the query."""
+    L = _L()
+    x, dy = cl(B, Cin, H, W, seed=1), cl(B, Cout, H, W, seed=2)
+    nb = L.query("icg_conv2d_wgrad_workspace_bytes", B, H, W, Cin, Cout, 1)
+    dw = torch.empty(Cin * Cout)
+    (pair,) = run_pair("icg_conv2d_wgrad", [x, dy, dw, None, None, 0, B, H, W, Cin, Cout, 1, 0, torch.empty(max(nb, 16), dtype=torch.uint8), nb], [2])
+    close(*pair, rtol=5e-5, atol_rel=5e-5, what="1x1 wgrad")
+    ref = (x.permute(0, 2, 3, 1).reshape(-1, Cin).double().t() @ dy.permute(0, 2, 3, 1).reshape(-1, Cout).double()).float().reshape(-1)
+    close(pair[0], ref, rtol=2e-5, atol_rel=2e-5, what="1x1 wgrad vs fp64")
+    a, b = torch.empty_like(dw).cuda(), torch.empty_like(dw).cuda()
+    for o in (a, b):
+        L.call("icg_conv2d_wgrad", x.cuda(), dy.cuda(), o, None, None, 0, B, H, W, Cin, Cout, 1, 0,
+               torch.empty(max(nb, 16), dtype=torch.uint8, device="cuda"), nb)
+    assert torch.equal(a, b)
+
+
 def test_conv2d_wgrad_split_k_large():
     """many pixels, few channels: exercises split-K + the deterministic slab reduction."""
     B, H, W, Cin, Cout, R = 4, 64, 64, 16, 24, 3
