@@ -68,12 +68,17 @@ def _traffic_hook(state, bucket):
     return dist.all_reduce(buf, async_op=True).get_future().then(lambda f: f.value()[0])
 
 
-def _worker_step(rank, world, port, out, savings=True, accumulations=1):
+def _worker_step(rank, world, port, out, savings=True, accumulations=1, steps=1, sn_group=None):
     from torch.nn.parallel import DistributedDataParallel as DDP
-    from ic_gan_amd import train_fns, utils
+    from ic_gan_amd import ops, train_fns, utils
     from ic_gan_amd.optim import FusedAdam
     _init(rank, world, port)
     train_fns.COMM_SAVINGS = savings
+    if sn_group is not None:
+        ops.SN_BACKWARD_GROUP = sn_group
+    groups = []
+    many = ops.sn_backward_many
+    ops.sn_backward_many = lambda items: (groups.append(len(items)), many(items))[1]
     CFG = dict(globals()["CFG"], num_D_accumulations=accumulations, num_G_accumulations=accumulations)
     M, G, D = _models(CFG)
     if rank == 1:                       # perturb rank 1's buffers: the per-forward broadcast must overwrite them (F3)
@@ -93,7 +98,8 @@ def _worker_step(rank, world, port, out, savings=True, accumulations=1):
                                             embedded_optimizers=False, device="cpu", batch_size=gb)
     x, y, f = synth.synth_batch(CFG, gb * accumulations, seed=70 + rank)
     Gd.train(); Dd.train()
-    m = train(x, y, f)
+    for _ in range(steps):
+        m = train(x, y, f)
     flat = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
@@ -117,6 +123,7 @@ def _worker_step(rank, world, port, out, savings=True, accumulations=1):
         out["buffers_rank0_unchanged_by_sync"] = bool(torch.equal(bs[0], bg[0]))
         out["checkpoints_carry_rank0_buffers"] = all(bool(torch.equal(cg[0], g)) for g in cg[1:])
         out["identical"] = all(bool(torch.equal(gathered[0], g)) for g in gathered[1:])
+        out["sn_groups"] = list(groups)
         out["finite"] = bool(torch.isfinite(flat).all())
         out["loss"] = m
         out["flat"] = flat.clone()
@@ -215,6 +222,20 @@ def test_ddp_buffers_after_accumulation():
     assert out["buffers_identical_after_sync"] and out["buffers_rank0_unchanged_by_sync"] and out["checkpoints_carry_rank0_buffers"]
     ref = _spawn(_worker_step, False, 2)           # the reference pattern: every forward synchronises
     assert ref["identical"] and ref["buffers_identical_after_sync"]
+
+
+@pytest.mark.timeout(900)
+def test_ddp_grouped_spectral_norm_backward():
+    """From the second step on the spectral-norm backward of 8 consecutive layers runs in ONE autograd node (ops.SNGroupFn): under
+    DistributedDataParallel the parameter gradients of a group then reach the reducer together.  Two steps on two ranks: the groups
+    are really used, the replicas stay bit-identical, and the result equals the per-layer path (SN_BACKWARD_GROUP = 0) bit for bit."""
+    grouped, single = _spawn(_worker_step, True, 1, 2, 8), _spawn(_worker_step, True, 1, 2, 0)
+    assert grouped["finite"] and grouped["identical"] and single["identical"]
+    assert grouped["sn_groups"] and max(grouped["sn_groups"]) <= 8 and not single["sn_groups"]
+    assert grouped["loss"] == single["loss"]
+    assert torch.equal(grouped["flat"], single["flat"])
+    t = grouped["traffic"]
+    assert t["D"] == 2 * t["D_params"] and t["G"] == 2 * t["G_params"], t          # one pass over each network's parameters per step
 
 
 def test_ddp_step_world_size_4():
