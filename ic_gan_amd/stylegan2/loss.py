@@ -17,6 +17,19 @@ from ..stylegan_ops import conv2d_gradfix, fused_layers
 from . import networks
 
 
+def _mergeable(gen_z, real_img, gen_c, real_c, gen_h, real_h):
+    """can D(generated) and D(real) run as ONE pass?  equal batch sizes and conditioning tensors that concatenate (same trailing
+    shape, dtype and device); anything else keeps the reference's two passes"""
+    if gen_z.shape[0] != real_img.shape[0]:
+        return False
+    for a, b in ((gen_c, real_c), (gen_h, real_h)):
+        if (a is None) != (b is None):
+            return False
+        if a is not None and (a.shape != b.shape or a.dtype != b.dtype or a.device != b.device):
+            return False
+    return True
+
+
 MERGE_D_PASSES = True      # Dmain: D(generated) and D(real) as one pass over the concatenated batch (False: two passes, as the reference runs them)
 
 
@@ -102,7 +115,7 @@ class StyleGAN2Loss:
                 (gen_img[:, 0, 0, 0] * 0 + loss_Gpl).mean().mul(gain).backward()
 
         loss_Dgen = 0
-        if do_Dmain and not do_Dr1 and MERGE_D_PASSES and gen_z.shape[0] == real_img.shape[0]:
+        if do_Dmain and not do_Dr1 and MERGE_D_PASSES and _mergeable(gen_z, real_img, gen_c, real_c, gen_h, real_h):
             # Dmain alone (every iteration): the generated and the real batch go through D in ONE pass of 2 B images and one backward
             # -- the same gradients as the reference's two passes (loss.py:148-178: every layer of D acts per sample; the minibatch-
             # standard-deviation layer is told to keep the two halves apart), half the launches and one all-reduce under DDP

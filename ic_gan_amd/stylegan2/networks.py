@@ -394,7 +394,10 @@ class MinibatchStdLayer(torch.nn.Module):
         self.group_size, self.num_channels = group_size, num_channels
 
     def forward(self, x):
-        if _SEPARATE_BATCHES > 1 and x.shape[0] % _SEPARATE_BATCHES == 0:
+        if _SEPARATE_BATCHES > 1:
+            # (no silent fallback to joint statistics: groups mixing generated and real samples would give other gradients than the
+            # reference's two passes)
+            assert x.shape[0] % _SEPARATE_BATCHES == 0, "separate_batches(%d): batch of %d does not split" % (_SEPARATE_BATCHES, x.shape[0])
             return torch.cat([self._one(part) for part in x.chunk(_SEPARATE_BATCHES)])
         return self._one(x)
 

@@ -280,8 +280,8 @@ class _Matmul(torch.autograd.Function):
         ctx.mode, ctx.alpha = mode, float(alpha)
         ctx.save_for_backward(a, b)
         ctx.out_dtype = torch.promote_types(a.dtype, b.dtype)      # the reference's addmm / matmul return the operands' dtype
-        if ctx.out_dtype == torch.float64:
-            ctx.out_dtype = torch.float32      # one fp64 policy for every operator of this file (gather_conv likewise): computed and returned in fp32
+        # fp64 operands: computed in fp32 on the HIP GEMM, RETURNED in fp64 as the reference's addmm / matmul would (the value carries
+        # fp32 precision; callers that difference it numerically see a dtype-consistent graph)
         a, b = a.contiguous().float(), b.contiguous().float()
         if mode == 1 and a.shape[0] <= 32 and a.shape[1] >= 128:
             # a handful of rows (batch 16): the row-streaming kernel behind mode 0 (gemm_conv.hip: smallm_nt_kernel) wants K contiguous

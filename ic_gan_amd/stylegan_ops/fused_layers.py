@@ -263,6 +263,20 @@ def refresh(*roots):
         _ops.sg2_weight_prep_multi(items)
 
 
+def invalidate(*roots):
+    """Drop every prepared weight under the given modules (all of them without arguments): the next forward of a layer prepares its
+    weights again.  The prepared copies follow the parameter's version counter and storage pointer, which every in-place torch
+    operation, optimiser step, `load_state_dict` and `.to()` moves; a write that moves neither -- through `p.data`, a raw pointer or
+    a kernel of one's own -- must be followed by `ops.bump_version(p)` or by this call (the counterpart of
+    `layers.invalidate_sn_cache` for the StyleGAN2 layers)."""
+    if not roots:
+        _PREPS.clear()
+        return
+    for root in roots:
+        for m in root.modules():
+            _PREPS.pop(m, None)
+
+
 def _gemm_nt(a, b, alpha):
     """alpha a [M][K] b [N][K]^T on the HIP GEMM, fp32"""
     m, k = a.shape

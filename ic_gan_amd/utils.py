@@ -80,13 +80,10 @@ def save_weights(G, D, state_dict, weights_root, experiment_name, name_suffix=No
     root = "/".join([weights_root, experiment_name])
     os.makedirs(root, exist_ok=True)
     print("Saving weights to %s%s..." % (root, ("/" + name_suffix) if name_suffix else ""))
-    # under train_fns.COMM_SAVINGS the ranks' buffers (BN running statistics, spectral-norm u / sv) are re-aligned less often than
-    # DistributedDataParallel's own per-forward broadcast would: align them with rank 0's before they are written, so that a
-    # checkpoint is the same whichever rank writes it (a collective: every rank must reach save_weights, as with the reference's
-    # barrier-guarded saving; no-op without a process group)
-    for m in (G, D, G_ema):
-        if m is not None and hasattr(m, "no_sync") and hasattr(m, "module"):
-            sync_buffers(m)
+    # No collective in here: the reference writes checkpoints from rank 0 only (trainer.py:520 `... and rank == 0`,
+    # train_fns.py:330/338), and rank 0's buffers are the canonical ones (DistributedDataParallel broadcasts FROM rank 0), so a
+    # rank-0 checkpoint is right as it stands, with or without train_fns.COMM_SAVINGS.  A caller that writes from another rank, or
+    # evaluates on every rank, calls sync_buffers(module) on ALL ranks first.
 
     def path(stem):
         return "%s/%s.pth" % (root, join_strings("_", [stem, name_suffix]))

@@ -1,0 +1,161 @@
+"""Test-only poison mode (round-6 item 1b).  `install(kind)` replaces the uninitialised-allocation entry points of torch
+(torch.empty / empty_like / empty_strided, Tensor.new_empty) by versions that pre-fill every CUDA result:
+
+    kind "nan"   floating point <- NaN, integer / byte <- 0x7f... : a kernel that READS a slot nobody wrote turns its results non-finite
+    kind "big"   floating point <- +-3e4 alternating (finite in fp16), integers as above: the finite garbage a recycled block of the
+                 caching allocator holds in a long-running process -- what made GPUTEST_r05 differ between two boxes
+
+Every output tensor and workspace the host side hands to a C-ABI call is allocated through one of these entry points, so the whole
+-m gpu suite runs under `ICG_POISON=nan` (tests/conftest.py).  Not imported by the product."""
+import torch
+
+_ORIG = {}
+
+
+def _fill(t, kind):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.numel() == 0:
+        return t
+    with torch.no_grad():
+        if t.is_floating_point():
+            if kind == "nan":
+                t.fill_(float("nan"))
+            else:
+                t.fill_(3.0e4)
+                if t.is_contiguous():
+                    t.view(-1)[::2].neg_()
+        elif t.dtype == torch.bool:
+            pass
+        elif t.dtype == torch.uint8:
+            t.fill_(0x7f)
+        elif t.dtype == torch.int8:
+            t.fill_(0x7f)
+        elif t.dtype == torch.int16:
+            t.fill_(0x7f7f)
+        elif t.dtype == torch.int32:
+            t.fill_(0x7f7f7f7f)
+        elif t.dtype == torch.int64:
+            t.fill_(0x7f7f7f7f7f7f7f7f)
+    return t
+
+
+def install(kind="nan"):
+    if _ORIG:
+        uninstall()
+    assert kind in ("nan", "big")
+    _ORIG.update(empty=torch.empty, empty_like=torch.empty_like, empty_strided=torch.empty_strided, new_empty=torch.Tensor.new_empty)
+    o = dict(_ORIG)
+
+    def empty(*a, **k):
+        return _fill(o["empty"](*a, **k), kind)
+
+    def empty_like(*a, **k):
+        return _fill(o["empty_like"](*a, **k), kind)
+
+    def empty_strided(*a, **k):
+        return _fill(o["empty_strided"](*a, **k), kind)
+
+    def new_empty(self, *a, **k):
+        return _fill(o["new_empty"](self, *a, **k), kind)
+
+    torch.empty, torch.empty_like, torch.empty_strided, torch.Tensor.new_empty = empty, empty_like, empty_strided, new_empty
+
+
+def uninstall():
+    if _ORIG:
+        torch.empty, torch.empty_like, torch.empty_strided = _ORIG["empty"], _ORIG["empty_like"], _ORIG["empty_strided"]
+        torch.Tensor.new_empty = _ORIG["new_empty"]
+        _ORIG.clear()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# call-twice determinism harness (round-6 item 1c)
+# ---------------------------------------------------------------------------------------------------------------------------------
+# (entry point, argument name) pairs the header declares as non-const pointers although the kernel READS their previous contents
+# (in-place updates, accumulation targets): restored between the two calls instead of being poisoned.
+INOUT = {
+    ("icg_adam_multi", "*"), ("icg_ema_multi", "*"), ("icg_nan_to_num_multi", "*"),
+}
+
+
+class DoubleRun:
+    """Context manager: while active, EVERY `_lib.call(name, ...)` whose name matches `pattern` runs twice --
+        1. every writable tensor argument (non-const pointer in include/icgan_hip.h: outputs and workspaces) is filled with poison A
+           (NaN / 0x7f), the entry point is called, the results are snapshotted;
+        2. the same arguments are filled with poison B (-3e4 / 0x55), the entry point is called again;
+    and demands that both calls leave bit-identical bytes in every writable argument (workspaces / scratch excepted: poisoned, not compared): an output slot the kernel does not write, a
+    workspace slot it reads before writing, or a race shows up as a difference (A is NaN, B is finite).  Arguments that alias a
+    read-only argument, and the (name, arg) pairs of INOUT, are restored to their incoming values instead.  `calls` counts per name."""
+
+    def __init__(self, pattern=r"^icg_", inout=()):
+        import re
+        self.rx = re.compile(pattern)
+        self.inout = set(INOUT) | set(inout)
+        self.calls = {}
+        self.failures = []
+
+    def __enter__(self):
+        import ic_gan_amd._lib as L
+        self.L, self.orig = L, L.call
+        protos = L.protos()
+        me = self
+
+        def span(t):
+            if t.numel() == 0:
+                return (0, 0)
+            lo = t.data_ptr()
+            ext = sum((s - 1) * st for s, st in zip(t.shape, t.stride())) + 1
+            return (lo, lo + ext * t.element_size())
+
+        def call(name, *args):
+            if not me.rx.search(name) or name not in protos:
+                return me.orig(name, *args)
+            decl = protos[name][1]
+            writable, readonly = [], []
+            for (ctype, aname), a in zip(decl, args):
+                if isinstance(a, torch.Tensor) and a.is_cuda and a.numel():
+                    (writable if ("*" in ctype and "const" not in ctype) else readonly).append((aname, a))
+            if not writable:
+                return me.orig(name, *args)
+            ro = [span(a) for _, a in readonly]
+            plan = []
+            for aname, a in writable:
+                lo, hi = span(a)
+                keep = (name, aname) in me.inout or (name, "*") in me.inout or any(lo < h and l < hi for l, h in ro)
+                plan.append((aname, a, a.clone() if keep else None))
+
+            def prepare(kind):
+                for aname, a, saved in plan:
+                    if saved is not None:
+                        a.copy_(saved)
+                    elif a.is_floating_point():
+                        a.fill_(float("nan") if kind == 0 else -3.0e4)
+                    elif a.dtype != torch.bool:
+                        a.fill_(0x7f if kind == 0 else 0x55)
+
+            def bits(a):
+                a = a.contiguous() if not a.is_contiguous() else a
+                return a.view(torch.uint8) if a.element_size() == 1 else a.view({2: torch.int16, 4: torch.int32, 8: torch.int64}[a.element_size()])
+
+            prepare(0)
+            me.orig(name, *args)
+            first = [bits(a).clone() for _, a, _ in plan]
+            prepare(1)
+            me.orig(name, *args)
+            me.calls[name] = me.calls.get(name, 0) + 1
+            for (aname, a, saved), f in zip(plan, first):
+                if "workspace" in aname or "scratch" in aname:        # poisoned, not compared: a kernel may leave workspace slots unwritten
+                    continue
+                now = bits(a)
+                if not torch.equal(now, f):
+                    nd = int((now != f).sum())
+                    me.failures.append("%s(%s): %d of %d elements differ between two calls with differently poisoned outputs%s" % (
+                        name, aname, nd, now.numel(), " (in/out argument, restored)" if saved is not None else ""))
+            if me.failures:
+                raise AssertionError("; ".join(me.failures[-3:]))
+
+        L.call = call
+        return self
+
+    def __exit__(self, *exc):
+        self.L.call = self.orig
+        return False

@@ -10,6 +10,21 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    kind = os.environ.get("ICG_POISON", "")
+    if kind:          # ICG_POISON=nan|big: every torch.empty-family CUDA allocation is pre-filled (tests/_poison.py)
+        from tests import _poison
+        _poison.install(kind)
+    if os.environ.get("ICG_DOUBLE_RUN", ""):          # every C-ABI call twice with differently poisoned outputs, bit-equal (tests/_poison.py)
+        from tests import _poison
+        config._icg_double_run = _poison.DoubleRun(os.environ["ICG_DOUBLE_RUN"] if os.environ["ICG_DOUBLE_RUN"] != "1" else r"^icg_")
+        config._icg_double_run.__enter__()
+
+
+def pytest_unconfigure(config):
+    dr = getattr(config, "_icg_double_run", None)
+    if dr is not None:
+        dr.__exit__(None, None, None)
+        print("\nICG_DOUBLE_RUN: %d entry points called twice (%d double calls), %d failures" % (len(dr.calls), sum(dr.calls.values()), len(dr.failures)))
 
 
 def pytest_collection_modifyitems(config, items):
@@ -20,3 +35,20 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _seed_every_test(request):
+    """Every test starts from RNG state derived from its own id: in this torch build the default seed differs PER PROCESS
+    (torch.initial_seed() is drawn at import), so any tensor a test or a module constructor draws without an explicit generator
+    (StyleGAN2's `noise_const` buffer = torch.randn at construction) otherwise differs between two boxes -- the cause of the
+    one-box failure of GPUTEST_r05 (profiles/r06_sg2_nondeterminism.txt).  Kernels are deterministic; with this, so are the inputs."""
+    import random
+    import zlib
+    import numpy as np
+    import torch
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7fffffff
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    yield

@@ -106,10 +106,17 @@ def _worker_step(rank, world, port, out, savings=True, accumulations=1, steps=1,
     bufs = lambda: torch.cat([b.detach().reshape(-1).float() for b in list(G.buffers()) + list(D.buffers())])
     bg = [torch.empty_like(bufs()) for _ in range(world)]
     dist.all_gather(bg, bufs())
-    # a checkpoint written from ANY rank carries rank 0's buffers: utils.save_weights aligns DistributedDataParallel-wrapped modules
-    # itself (utils.sync_buffers, the explicit rank-0 broadcast of the train_fns docstring) before it writes
+    # utils.save_weights holds no collective (the reference saves under `rank == 0` only, trainer.py:520): rank 0 writes FIRST, alone,
+    # while rank 1 does not enter save_weights at all -- this would hang on gloo if a broadcast hid in there ...
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
+        if rank == 0:
+            utils.save_weights(Gd, Dd, {"itr": 1}, tmp, "exp", "alone", None, embedded_optimizers=False, G_optim=opt_g, D_optim=opt_d)
+            alone = torch.load("%s/exp/G_alone.pth" % tmp)
+            out["rank0_checkpoint_is_rank0_buffers"] = all(bool(torch.equal(alone["module." + k], b)) for k, b in G.named_buffers())
+        # ... and a checkpoint written from ANY rank carries rank 0's buffers once every rank has called utils.sync_buffers
+        for m in (Gd, Dd):
+            utils.sync_buffers(m)
         utils.save_weights(Gd, Dd, {"itr": 1}, tmp, "exp", "rank%d" % rank, None, embedded_optimizers=False, G_optim=opt_g, D_optim=opt_d)
         saved = torch.load("%s/exp/G_rank%d.pth" % (tmp, rank))
     ckpt = torch.cat([saved["module." + k].reshape(-1).float() for k, _ in G.named_buffers()])
@@ -220,6 +227,7 @@ def test_ddp_buffers_after_accumulation():
     out = _spawn(_worker_step, True, 2)
     assert out["identical"] and out["finite"]
     assert out["buffers_identical_after_sync"] and out["buffers_rank0_unchanged_by_sync"] and out["checkpoints_carry_rank0_buffers"]
+    assert out["rank0_checkpoint_is_rank0_buffers"]
     ref = _spawn(_worker_step, False, 2)           # the reference pattern: every forward synchronises
     assert ref["identical"] and ref["buffers_identical_after_sync"]
 

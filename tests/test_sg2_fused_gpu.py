@@ -219,6 +219,10 @@ def _init(mod, seed):
             if n.endswith("noise_strength"):
                 v = 0.3 * v
             p.copy_(v)
+    for i, (n, b) in enumerate(mod.named_buffers()):          # `noise_const` is torch.randn at construction: seeded here like the parameters
+        if b.is_floating_point() and "noise_const" in n:
+            with torch.no_grad():
+                b.copy_(rnd(*b.shape, seed=seed * 100 + 50 + i))
 
 
 def _grads(fn, params, inputs, fused):
