@@ -827,6 +827,9 @@ def main():
                     help="ablation: attention scores as GEMM + stand-alone softmax instead of the fused kernel (ops.FUSED_ATTENTION_SCORES)")
     ap.add_argument("--wgrad-stream", action="store_true",
                     help="opt-in: weight gradients on a side HIP stream, concurrently with the data gradient (ops.WGRAD_SIDE_STREAM)")
+    ap.add_argument("--reference-comm", action="store_true",
+                    help="N > 1: keep the reference's communication pattern (an all-reduce per accumulation round, D's reducer armed in the "
+                         "G phase, a buffer broadcast per forward) instead of train_fns.COMM_SAVINGS")
     ap.add_argument("--sync-bn", action="store_true", help="cross-replica BN statistics over RCCL (cfg3 variant)")
     ap.add_argument("--fp16", action="store_true", help="cfg4: the reference's cfg=auto precision (num_fp16_res=4, conv_clamp=256)")
     ap.add_argument("--accumulate", type=int, default=1,
@@ -908,6 +911,9 @@ def main():
     acc = max(args.accumulate, 1)
     cfg["num_D_accumulations"] = cfg["num_G_accumulations"] = acc
     from ic_gan_amd import train_fns, utils
+    # the library's default is the reference's communication pattern; the bench measures the trimmed one (same losses and parameters,
+    # tests/test_ddp_gloo_cpu.py) unless --reference-comm, and reports which in `comm.comm_savings`
+    train_fns.COMM_SAVINGS = not args.reference_comm
     utils.seed_rng(0 + rank)
     M, G, D, G_ema, ema, opt_g, opt_d, init = build_models(cfg, device, args.init)
     dim_z = G.dim_z

@@ -9,8 +9,10 @@
 Every forward/backward op, both Adam steps and the EMA run in the HIP kernels; this file is host control
 flow only.  Returns the same three floats (three device->host reads per step, as in the reference).
 
-Data-parallel traffic (G and D wrapped in DistributedDataParallel as trainer.py:196-210 does), COMM_SAVINGS (False restores
-the reference's pattern):
+Data-parallel traffic (G and D wrapped in DistributedDataParallel as trainer.py:196-210 does).  The DEFAULT is the reference's
+pattern (every backward all-reduces, every forward broadcasts rank 0's buffers: SURVEY F3 / F11), because a drop-in must not change
+when replicas exchange state behind the caller's back.  `COMM_SAVINGS = True` (or ICG_COMM_SAVINGS=1 in the environment; bench.py
+switches it on and says so in its JSON line) trims it:
   (1) accumulation rounds before the last run under DistributedDataParallel.no_sync() and accumulate locally; the last
       round's all-reduce carries the sum (mean of sums == sum of means up to the fp32 rounding of the all-reduce itself).  The
       reference all-reduces every round: num_*_accumulations x the bytes (4x for the shipped 16 x 4 schedule at 256x256);
@@ -29,12 +31,13 @@ explicit rank-0 broadcast; tests/test_ddp_gloo_cpu.py::test_ddp_buffers_after_ac
 from __future__ import annotations
 
 import contextlib
+import os
 
 import torch
 
 from . import losses, utils
 
-COMM_SAVINGS = True
+COMM_SAVINGS = os.environ.get("ICG_COMM_SAVINGS", "0") == "1"      # opt-in: the default is the reference's traffic pattern
 
 
 def _no_sync(module, on):

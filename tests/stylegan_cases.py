@@ -140,3 +140,92 @@ def sg2_inputs(cfg, seed, n_sets):
     img = torch.from_numpy((rs.randint(0, 256, size=(b, 3, g["img_resolution"], g["img_resolution"])) / 127.5 - 1).astype(np.float32))
     rc, rh = cond(b)
     return z, gc, gh, img, rc, rh
+
+
+# ---- N1: one synthesis / toRGB layer differentiated TWICE (what the path-length regulariser does, training/loss.py:120-139) ----------
+# kind, Cin, Cout, w_dim, resolution, up, noise_mode, conv_clamp, N   (widths the fused nodes of stylegan_ops/fused_layers.py serve)
+SG2_LAYER2 = [
+    ("synthesis", 64, 64, 64, 16, 1, "const", 256, 3),
+    ("synthesis", 64, 32, 64, 16, 2, "const", 256, 3),
+    ("synthesis", 32, 64, 48, 8, 2, "none", None, 2),
+    ("synthesis", 128, 128, 64, 8, 1, "const", 0.9, 2),            # a clamp that bites
+    ("torgb", 64, 3, 64, 16, 1, None, 256, 3),
+    ("torgb", 128, 3, 48, 8, 1, None, 0.5, 2),
+]
+
+
+def sg2_layer2_state(layer, seed):
+    """seeded values for every parameter AND the noise_const buffer of a layer (same rule on the reference's and on this repository's
+    modules: their state_dict keys agree)"""
+    out = {}
+    for i, (k, v) in enumerate(layer.state_dict().items()):
+        if k.endswith("resample_filter"):
+            continue
+        t = rnd(tuple(v.shape), seed * 100 + i) if v.dim() else rnd((1,), seed * 100 + i)[0]
+        if k.endswith("bias"):
+            t = 0.3 * t + (1.0 if "affine" in k else 0.0)
+        if k.endswith("noise_strength"):
+            t = 0.3 * t
+        out[k] = t
+    return out
+
+
+SG2_LAYER2_SALT = [4, 0, 0, 0, 0, 0]      # per case: added to the seed of x until no activation sits within 5e-6 of a kink (make_golden_sg2_layers2.py)
+
+
+def sg2_layer2_inputs(case, idx):
+    kind, cin, cout, wd, res, up, noise_mode, clamp, n = case
+    x = rnd((n, cin, res // up, res // up), 2000 + 10 * idx + 1000 * SG2_LAYER2_SALT[idx])
+    w = rnd((n, wd), 2001 + 10 * idx)
+    img = rnd((n, 3, res, res), 2002 + 10 * idx) if kind == "torgb" else None
+    return x, w, img
+
+
+def sg2_layer2_probes(idx, y_shape, g_shape, gx_shape):
+    """cotangent r, the extra differentiable factor rs (its gradient is the gradient w.r.t. the incoming cotangent), and the weights of
+    the scalar built from the first-order results"""
+    return dict(r=rnd(y_shape, 2003 + 10 * idx), rs=rnd(y_shape, 2004 + 10 * idx), q=rnd(g_shape, 2005 + 10 * idx),
+                qx=rnd(gx_shape, 2006 + 10 * idx), qy=rnd(y_shape, 2007 + 10 * idx))
+
+
+def sg2_layer2_run(idx, case, make_layer, dtype=torch.float64, device="cpu", act_dtype=None, torgb_call=None, context=None):
+    """the second-order pattern of training/loss.py:120-139 on ONE layer -> dict of float64 numpy arrays.  Shared by
+    tests/golden/make_golden_sg2_layers2.py (the reference's layer classes, float64, CPU) and by the tests (this repository's classes,
+    fp32 parameters, fp32 / fp16 activations, CPU-emulated or HIP kernels).  `torgb_call(layer, x, w, img)`: how the image accumulation
+    is expressed (the reference adds outside the layer, SynthesisBlock.forward 618-622); `context`: a context-manager factory entered
+    around the whole computation (fused_layers.second_order)."""
+    import contextlib
+    kind, cin, cout, wd, res, up, noise_mode, clamp, n = case
+    layer = make_layer(case)
+    sd = sg2_layer2_state(layer, 7 + idx)
+    cur = layer.state_dict()
+    layer.load_state_dict({k: sd.get(k, cur[k]) for k in cur})
+    layer = layer.to(dtype).to(device)
+    if hasattr(layer, "resample_filter"):                   # (conv2d_resample.py:109 insists on a float32 filter; upfirdn2d casts it to x's type)
+        layer.resample_filter = layer.resample_filter.float()
+    x, w, img = sg2_layer2_inputs(case, idx)
+    ins = [x.to(act_dtype or dtype).to(device).requires_grad_(True), w.to(dtype).to(device).requires_grad_(True)]
+    if img is not None:
+        ins.append(img.to(dtype).to(device).requires_grad_(True))
+    names = [n_ for n_, _ in layer.named_parameters()]
+    params = [p for _, p in layer.named_parameters()]
+    with (context() if context is not None else contextlib.nullcontext()):
+        if kind == "synthesis":
+            y = layer(ins[0], ins[1], noise_mode=noise_mode, fused_modconv=False)
+        elif torgb_call is not None:
+            y = torgb_call(layer, *ins)
+        else:
+            y = ins[2] + layer(ins[0], ins[1], fused_modconv=False).to(dtype)
+        y = y.to(dtype)
+        pr = {k: v.to(dtype).to(device) for k, v in sg2_layer2_probes(idx, tuple(y.shape), (n, wd), tuple(x.shape)).items()}
+        rs = pr["rs"].requires_grad_(True)
+        g, gx = torch.autograd.grad([(y * (pr["r"] * rs)).sum()], [ins[1], ins[0]], create_graph=True, only_inputs=True)
+        scalar = g.square().sum() * 0.5 + (g * pr["q"]).sum() + (gx.to(dtype) * pr["qx"]).sum() + (y * pr["qy"]).sum() * 0.1
+        grads = torch.autograd.grad(scalar, ins + [rs] + params, allow_unused=True)
+    out = {"y": y, "g": g, "gx": gx, "dd_x": grads[0], "dd_w": grads[1], "dd_rs": grads[len(ins)]}
+    if img is not None:
+        out["dd_img"] = grads[2]
+    for n_, gr in zip(names, grads[len(ins) + 1:]):
+        if gr is not None:
+            out["dd_p/" + n_] = gr
+    return {k: v.detach().double().cpu().numpy() for k, v in out.items()}

@@ -115,8 +115,8 @@ def _worker_step(rank, world, port, out, savings=True, accumulations=1, steps=1,
             alone = torch.load("%s/exp/G_alone.pth" % tmp)
             out["rank0_checkpoint_is_rank0_buffers"] = all(bool(torch.equal(alone["module." + k], b)) for k, b in G.named_buffers())
         # ... and a checkpoint written from ANY rank carries rank 0's buffers once every rank has called utils.sync_buffers
-        for m in (Gd, Dd):
-            utils.sync_buffers(m)
+        for wrapped in (Gd, Dd):
+            utils.sync_buffers(wrapped)
         utils.save_weights(Gd, Dd, {"itr": 1}, tmp, "exp", "rank%d" % rank, None, embedded_optimizers=False, G_optim=opt_g, D_optim=opt_d)
         saved = torch.load("%s/exp/G_rank%d.pth" % (tmp, rank))
     ckpt = torch.cat([saved["module." + k].reshape(-1).float() for k, _ in G.named_buffers()])
