@@ -827,7 +827,8 @@ def _bn_backward_begin(x, da, bn: BNOpt, gain, scale, shift, ssb, mean, invstd, 
     chan = work = None
     if bn.training:
         chan = torch.empty(2 * C + 1, device=dev, dtype=torch.float64)
-        L.call("icg_bn_bwd_channel_sums", sd, sx, gain, gb_rows, float(bn.gain_offset), invstd, B, C, chan)
+        # (the kernel owns chan[0 .. 2 C); slot 2 C is the element count of the cross-replica convention, written below)
+        L.call("icg_bn_bwd_channel_sums", sd, sx, gain, gb_rows, float(bn.gain_offset), invstd, B, C, chan[: 2 * C])
         if count_dev is not None:
             chan[2 * C:].copy_(count_dev)            # global element count of the forward (device side)
             if _sync_enabled(bn):
@@ -1150,7 +1151,15 @@ class AttnCoreFn(Function):
         dev = theta.device
         do = _cl(do)
         dg = torch.empty_like(g)           # dV = beta^T dO
-        L.call("icg_gemm_batched", beta, do, dg, m, dv, n, 1, 0, n * m, n * dv, m * dv, B, 1.0)
+        if ATTN_DV_PLANE_GEMM and dv % 96 == 0 and n % 32 == 0 and m % 4 == 0:
+            # a weight-gradient-shaped contraction (K = n = 4096 query rows per image, [m x dv] = [1024 x 192 | 96] outputs): the second-
+            # generation TN plane GEMM (csrc/pgemm.hip, LDS-DMA operands, K split in two slabs summed in fixed order) with one "plane" per
+            # image.  On the first-generation kernel this GEMM ran at ~53 TFLOP/s -- 4 launches x 1.93 ms per cfg3 step
+            # (`icg_gemm_kernel<1,1,3,2>` in profiles/r05_bench_cfg3_kernel_stats.csv).
+            nbw = L.query("icg_plane_gemm_tn_workspace_bytes", m, dv, n, B)
+            L.call("icg_plane_gemm_tn", beta, do, dg, m, dv, n, B, _bytes(nbw, dev), nbw)
+        else:
+            L.call("icg_gemm_batched", beta, do, dg, m, dv, n, 1, 0, n * m, n * dv, m * dv, B, 1.0)
         ds = torch.empty_like(beta)
         if FUSED_ATTENTION_SCORES and L.query("icg_attn_dscores_applies", n, m, dv):
             # dP = dO V^T with the softmax backward in its epilogue (csrc/attn.hip): the [B][n][m] dP tensor is never written
@@ -1168,6 +1177,7 @@ class AttnCoreFn(Function):
 
 
 FUSED_ATTENTION_PROJECTIONS = os.environ.get("ICG_ATTN_PROJ", "1") != "0"
+ATTN_DV_PLANE_GEMM = os.environ.get("ICG_ATTN_DV_TN", "1") != "0"      # dV = beta^T dO on the TN plane GEMM (measurement switch)
 
 
 def attn_projections_apply(x, d, dv) -> bool:
