@@ -12,6 +12,7 @@
 // lane (r, kk) with beta[row r][key 4 kk .. 4 kk + 3]: 16-byte stores.
 #include "icg_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 typedef float at_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -27,12 +28,14 @@ __device__ __forceinline__ float at_get(const float2& v, int s) { return s == 0 
 __device__ __forceinline__ float at_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 // V: k-values per lane and K-tile (a K-tile is 4 V wide); NKT: K-tiles (d = 4 V NKT); waves = m / 128 (blockDim = 64 waves)
-template <int V, int NKT>
+constexpr int AT_SROW = 136;       // floats per staged row of 128 keys: 544 bytes = 32 mod 256
+template <int V, int NKT, bool STAGE>
 __global__ __launch_bounds__(512, 4) void icg_attn_scores_softmax_kernel(const float* __restrict__ theta, const float* __restrict__ phi,
                                                                       float* __restrict__ beta, int n, int m) {
   typedef typename at_vec<V>::type vec;
   constexpr int D = 4 * V * NKT;
   __shared__ float red[2][8][32];
+  __shared__ __attribute__((aligned(16))) float stage[STAGE ? 8 * 16 * AT_SROW : 4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int r = lane & 15, kk = lane >> 4;
   const int rows_per_img = n >> 5;
@@ -105,12 +108,37 @@ __global__ __launch_bounds__(512, 4) void icg_attn_scores_softmax_kernel(const f
     for (int w = 1; w < nw; ++w) s += red[1][w][16 * i + r];
     inv[i] = 1.0f / s;
   }
-  float* __restrict__ out = beta + ((long)b * n + row0) * m + 128 * wv + 4 * kk;
+  if constexpr (STAGE) {
+    // beta leaves through LDS: in the accumulator layout a store instruction covers 16 rows x 64 bytes (half a cache line per row);
+    // re-laid-out per wave (16 rows x 128 keys, row stride 544 bytes = 32 mod 256: conflict-free 16-byte writes in the operand
+    // pattern and conflict-free row-contiguous reads) every store instruction writes two whole 512-byte row segments.
+    float* __restrict__ st = stage + wv * (16 * AT_SROW);
+    float* __restrict__ out = beta + ((long)b * n + row0) * m + 128 * wv + 4 * (lane & 31);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      *reinterpret_cast<at_f32x4*>(out + (long)(16 * i + r) * m + 16 * j) = acc[i][j] * inv[i];
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<at_f32x4*>(st + r * AT_SROW + 16 * j + 4 * kk) = acc[i][j] * inv[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int row = 2 * q + (lane >> 5);
+        const at_f32x4 v = *reinterpret_cast<const at_f32x4*>(st + row * AT_SROW + 4 * (lane & 31));
+        *reinterpret_cast<at_f32x4*>(out + (long)(16 * i + row) * m) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  } else {
+    float* __restrict__ out = beta + ((long)b * n + row0) * m + 128 * wv + 4 * kk;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<at_f32x4*>(out + (long)(16 * i + r) * m + 16 * j) = acc[i][j] * inv[i];
+  }
 }
 
 // 1 when the fused kernel serves the shape: n a multiple of 32, m a multiple of 128 up to 1024, d in {8, 16, 24, 32, 48, 64}
@@ -127,14 +155,21 @@ extern "C" int icg_attn_scores_softmax(const float* theta, const float* phi, flo
   ICG_REQUIRE(blocks < 0x7fffffffL);
   const dim3 grid((unsigned)blocks), block((unsigned)(64 * (m / 128)));
   hipStream_t st = (hipStream_t)stream;
+  static const bool stage = [] { const char* e = getenv("ICG_ATTN_STAGE"); return !(e && e[0] == '0'); }();
+#define AT_LAUNCH(V_, NKT_)                                                                                                  \
+  do {                                                                                                                       \
+    if (stage) hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<V_, NKT_, true>), grid, block, 0, st, theta, phi, beta, n, m);  \
+    else hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<V_, NKT_, false>), grid, block, 0, st, theta, phi, beta, n, m);   \
+  } while (0)
   switch (d) {
-    case 8: hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<2, 1>), grid, block, 0, st, theta, phi, beta, n, m); break;
-    case 16: hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<4, 1>), grid, block, 0, st, theta, phi, beta, n, m); break;
-    case 24: hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<2, 3>), grid, block, 0, st, theta, phi, beta, n, m); break;
-    case 32: hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<4, 2>), grid, block, 0, st, theta, phi, beta, n, m); break;
-    case 48: hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<4, 3>), grid, block, 0, st, theta, phi, beta, n, m); break;
-    default: hipLaunchKernelGGL((icg_attn_scores_softmax_kernel<4, 4>), grid, block, 0, st, theta, phi, beta, n, m); break;
+    case 8: AT_LAUNCH(2, 1); break;
+    case 16: AT_LAUNCH(4, 1); break;
+    case 24: AT_LAUNCH(2, 3); break;
+    case 32: AT_LAUNCH(4, 2); break;
+    case 48: AT_LAUNCH(4, 3); break;
+    default: AT_LAUNCH(4, 4); break;
   }
+#undef AT_LAUNCH
   return icg_check_launch();
 }
 

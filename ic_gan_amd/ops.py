@@ -376,7 +376,7 @@ def winograd_applies(cin, cout, h, w, batch):
 # round 4: with the fused narrow-layer kernel (csrc/fwino.hip) behind the same entry points the pool-fused 96 -> 96 @256 layer runs
 # 1.26x faster in the 25-plane domain than on the 4x4-stride-2 form (profiles/r04_fwino_microbench.txt): forward and data gradient
 # from 96 channels; its weight gradient stays on the direct kernel (no V planes are kept for it)
-RS_WINOGRAD_MIN_CHANNELS = {True: (96, 96, 96), False: (96, 96, 192)}         # upsample?: (fprop, dgrad, wgrad)
+RS_WINOGRAD_MIN_CHANNELS = {True: (96, 96, 96), False: (96, 96, int(os.environ.get("ICG_RS_POOL_WGRAD_MIN", "192")))}         # upsample?: (fprop, dgrad, wgrad)
 
 
 def fwino_applies(B, H, W, Cin, Cout) -> bool:

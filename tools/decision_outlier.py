@@ -41,9 +41,27 @@ def main():
     case = sys.argv[1] if len(sys.argv) > 1 else "cfg3_w96_r256_b16"
     from tests import decision_replay as R
     from ic_gan_amd import ops
+    big = 10 ** 9
+    saved = dict(rs=ops.RS_WINOGRAD_MIN_CHANNELS, w=ops.WINOGRAD_MIN_CHANNELS, w2=ops.WINOGRAD2_MIN_CHANNELS, w4=ops.WINOGRAD4_MIN_CHANNELS,
+                 wg=ops.WINOGRAD4_WGRAD_MIN_CHANNELS)
+
+    def restore():
+        ops.RS_WINOGRAD_MIN_CHANNELS, ops.WINOGRAD_MIN_CHANNELS, ops.WINOGRAD2_MIN_CHANNELS = saved["rs"], saved["w"], saved["w2"]
+        ops.WINOGRAD4_MIN_CHANNELS, ops.WINOGRAD4_WGRAD_MIN_CHANNELS = saved["w4"], saved["wg"]
+
+    def only_rs_off():          # the resample-fused layers (GBlock conv1, DBlock conv2) leave the 25-plane domain; stride-1 layers stay in F(4x4,3x3)
+        restore()
+        ops.RS_WINOGRAD_MIN_CHANNELS = {True: (big, big, big), False: (big, big, big)}
+
+    def only_wgrad_off():       # weight gradients leave the Winograd domain, forward / data gradients stay
+        restore()
+        ops.WINOGRAD4_WGRAD_MIN_CHANNELS = big
+        ops.RS_WINOGRAD_MIN_CHANNELS = {k: (v[0], v[1], big) for k, v in saved["rs"].items()}
+
     routes = [("default routes", lambda: None)]
-    routes.append(("ICG_FWINO off (three-kernel Winograd composites)", lambda: os.environ.__setitem__("ICG_FWINO", "0")))
-    routes.append(("no Winograd anywhere (implicit-GEMM / phase kernels only)", ops.disable_winograd))
+    routes.append(("resample-fused layers off the 25-plane domain (stride-1 layers stay in F(4x4,3x3))", only_rs_off))
+    routes.append(("weight gradients off the Winograd domain (forward / data gradients stay)", only_wgrad_off))
+    routes.append(("no Winograd anywhere (implicit-GEMM / phase kernels only)", lambda: (restore(), ops.disable_winograd())))
     for name, setup in routes:
         setup()
         samples, census, pools = R.hip_step(case, R.Nudger)
