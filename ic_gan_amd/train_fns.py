@@ -37,6 +37,13 @@ import torch
 
 from . import losses, utils
 
+# Host-side conditioning draw of the NEXT step taken at the end of the current one, while the GPU still has the step's queue to work through
+# and the host would otherwise sit in the three `.item()` reads: without it the device idles ~2.8 ms at the start of every cfg3 step
+# (profiles/r06_step_trace.txt: the kNN / class sampling of `sample_conditionings()` between the loss read-back and the first H2D copy).
+# Same draws in the same order from the sampler's own point of view; OPT-IN (ICG_PREFETCH_COND=1; bench.py switches it on and says so)
+# because a caller whose data loader shares the sampler's global numpy / torch RNG sees one draw of the sampler move ahead of its next
+# batch fetch -- a different (equally valid) random stream than the reference's interleaving.
+PREFETCH_CONDITIONING = os.environ.get("ICG_PREFETCH_COND", "0") == "1"
 COMM_SAVINGS = os.environ.get("ICG_COMM_SAVINGS", "0") == "1"      # opt-in: the default is the reference's traffic pattern
 
 
@@ -65,8 +72,16 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
             return G.optim, D.optim
         return GD.optimizer_G, GD.optimizer_D
 
+    pending = []          # [(key, device tensors)] drawn ahead by the previous call (PREFETCH_CONDITIONING)
+
     def draw(features, y, truncate):
         """Host-side conditioning draw -> device tensors (train_fns.py:70-85 / 135-149)."""
+        key = (features is not None, y is not None, bool(truncate))
+        if pending:
+            k, ready = pending.pop(0)
+            if k == key:
+                return ready
+            # (the caller changed its conditioning pattern between two steps: the draw taken ahead does not fit and is dropped)
         cond = sample_conditionings()
         labels_g = f_g = None
         if features is not None and y is not None:
@@ -135,6 +150,9 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
         opt_G.step()
         if config["ema"]:
             ema.update(state_dict["itr"])
+        if PREFETCH_CONDITIONING and config["num_D_steps"] > 0 and config["num_D_accumulations"] > 0:
+            del pending[:]
+            pending.append(((features is not None, y is not None, True), draw(features, y, truncate=True)))
         return {"G_loss": float(G_loss.item()), "D_loss_real": float(D_loss_real.item()),
                 "D_loss_fake": float(D_loss_fake.item())}
 

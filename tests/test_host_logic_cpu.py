@@ -116,6 +116,47 @@ def test_attention_stacked_projections_equal_the_three_convolutions(emu, monkeyp
     assert float(gg1.abs()) > 0 and float(go0.abs().max()) == 0 and float(go1.abs().max()) == 0
 
 
+@pytest.mark.parametrize("case", ["cc_ic_r64", "ic_r64_acc2"])
+def test_prefetched_conditioning_draw_is_the_same_training_run(case, emu, monkeypatch):
+    """train_fns.PREFETCH_CONDITIONING takes the NEXT step's first host-side draw at the end of the current step (under the GPU's queue):
+    the sampler is called once more per step boundary but in the same order, so a run of steps is bit-identical with and without it --
+    losses of every step and every parameter after the last one -- and the sampler is asked exactly one extra time (the draw waiting
+    for a step that never came)."""
+    from ic_gan_amd import train_fns, utils
+    from ic_gan_amd.optim import FusedAdam
+    g = load_golden(case)
+    cfg = g["cfg"]
+    gb, steps = int(g["g_batch"]), 3
+    dbatch = gb * cfg["num_D_accumulations"] * cfg["num_D_steps"]
+    runs = []
+    for prefetch in (False, True):
+        monkeypatch.setattr(train_fns, "PREFETCH_CONDITIONING", prefetch)
+        M, G, D = _build(g)
+        G.load_state_dict(synth.synth_state(g["gspec"], 11))
+        D.load_state_dict(synth.synth_state(g["dspec"], 22))
+        G_ema = M.Generator(**{**cfg, "skip_init": True, "no_optim": True})
+        ema = utils.ema(G, G_ema, cfg["ema_decay"], cfg["ema_start"])
+        opt_d = FusedAdam(D.parameters(), lr=cfg["D_lr"], betas=(cfg["D_B1"], cfg["D_B2"]), eps=cfg["adam_eps"])
+        opt_g = FusedAdam(G.parameters(), lr=cfg["G_lr"], betas=(cfg["G_B1"], cfg["G_B2"]), eps=cfg["adam_eps"])
+        GD = M.G_D(G, D, optimizer_G=opt_g, optimizer_D=opt_d)
+        state = {"itr": 0}
+        inner = synth.CondSampler(cfg, G.dim_z, gb, seed=7)
+        calls = []
+        samp = lambda: (calls.append(1), inner())[1]
+        train = train_fns.GAN_training_function(G, D, GD, ema, state, cfg, samp, embedded_optimizers=False, device="cpu", batch_size=gb)
+        losses = []
+        for s in range(steps):
+            x, y, f = synth.synth_batch(cfg, dbatch, seed=100 + s)
+            state["itr"] += 1
+            G.train(); D.train(); G_ema.train()
+            losses.append(train(x, y, f))
+        runs.append((losses, [p.detach().clone() for p in list(G.parameters()) + list(D.parameters())], len(calls)))
+    (l0, p0, c0), (l1, p1, c1) = runs
+    assert l0 == l1
+    assert all(torch.equal(a, b) for a, b in zip(p0, p1))
+    assert c1 == c0 + 1, (c0, c1)
+
+
 @pytest.mark.parametrize("wino", [0, 2, 4, 5])
 @pytest.mark.parametrize("case", ["cc_ic_r64", "ic_r64_acc2", "cc_r32_flat"])
 def test_train_step_host_logic(case, emu, wino, monkeypatch):
