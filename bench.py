@@ -827,9 +827,9 @@ def main():
                     help="ablation: attention scores as GEMM + stand-alone softmax instead of the fused kernel (ops.FUSED_ATTENTION_SCORES)")
     ap.add_argument("--wgrad-stream", action="store_true",
                     help="opt-in: weight gradients on a side HIP stream, concurrently with the data gradient (ops.WGRAD_SIDE_STREAM)")
-    ap.add_argument("--no-prefetch-conditioning", action="store_true",
-                    help="draw every conditioning batch where the reference does (start of the phase that uses it) instead of taking the next "
-                         "step's first draw at the end of the current one (train_fns.PREFETCH_CONDITIONING)")
+    ap.add_argument("--no-prefetch-next-step", action="store_true",
+                    help="issue every operation where the reference does instead of queueing the next step's first conditioning draw and "
+                         "generator forward behind the current step's EMA, before the loss read-back (train_fns.PREFETCH_NEXT_STEP)")
     ap.add_argument("--reference-comm", action="store_true",
                     help="N > 1: keep the reference's communication pattern (an all-reduce per accumulation round, D's reducer armed in the "
                          "G phase, a buffer broadcast per forward) instead of train_fns.COMM_SAVINGS")
@@ -917,7 +917,7 @@ def main():
     # the library's default is the reference's communication pattern; the bench measures the trimmed one (same losses and parameters,
     # tests/test_ddp_gloo_cpu.py) unless --reference-comm, and reports which in `comm.comm_savings`
     train_fns.COMM_SAVINGS = not args.reference_comm
-    train_fns.PREFETCH_CONDITIONING = not args.no_prefetch_conditioning
+    train_fns.PREFETCH_NEXT_STEP = not args.no_prefetch_next_step
     utils.seed_rng(0 + rank)
     M, G, D, G_ema, ema, opt_g, opt_d, init = build_models(cfg, device, args.init)
     dim_z = G.dim_z
@@ -1062,7 +1062,7 @@ def main():
                        "uninstrumented_images_per_sec": (round(batch * acc * world * args.steps / uninstr, 3) if uninstr is not None else None),
                        "comm": comm_report, "rank_host_resources": host,
                        "rccl_world_size": (dist.get_world_size() if use_ddp else 1), "init": init, "sync_bn": bool(args.sync_bn), "winograd": not args.no_winograd, "wgrad_side_stream": bool(args.wgrad_stream),
-                       "prefetch_conditioning": bool(train_fns.PREFETCH_CONDITIONING),   # the next step's first host-side draw taken under the current step's GPU work
+                       "prefetch_next_step": bool(train_fns.PREFETCH_NEXT_STEP),   # the next step's first draw + generator forward queued before the loss read-back
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), "losses_last_step": metrics},
             "roofline": roof,
         }

@@ -313,11 +313,16 @@ class G_D(nn.Module):
         self.optimizer_G, self.optimizer_D = optimizer_G, optimizer_D
 
     def forward(self, z, gy, feats_g=None, x=None, dy=None, feats=None, train_G=False, return_G_z=False,
-                split_D=False, policy=False, DA=False):
+                split_D=False, policy=False, DA=False, G_z=None):
+        """`G_z` (not in the reference's signature): the generator's output for exactly these (z, gy, feats_g), computed ahead by the
+        caller under torch.no_grad() (train_fns.PREFETCH_NEXT_STEP); only valid with train_G=False"""
         if DA:
             raise NotImplementedError("DiffAugment is disabled in every shipped IC-GAN config (SURVEY §2.1)")
-        with torch.set_grad_enabled(train_G):
-            G_z = self.G(z, gy, feats_g)
+        if G_z is None:
+            with torch.set_grad_enabled(train_G):
+                G_z = self.G(z, gy, feats_g)
+        else:
+            assert not train_G and not G_z.requires_grad
         if split_D:
             D_fake = self.D(G_z, gy, feats_g)
             if x is not None:

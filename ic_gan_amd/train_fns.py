@@ -37,13 +37,15 @@ import torch
 
 from . import losses, utils
 
-# Host-side conditioning draw of the NEXT step taken at the end of the current one, while the GPU still has the step's queue to work through
-# and the host would otherwise sit in the three `.item()` reads: without it the device idles ~2.8 ms at the start of every cfg3 step
-# (profiles/r06_step_trace.txt: the kNN / class sampling of `sample_conditionings()` between the loss read-back and the first H2D copy).
-# Same draws in the same order from the sampler's own point of view; OPT-IN (ICG_PREFETCH_COND=1; bench.py switches it on and says so)
-# because a caller whose data loader shares the sampler's global numpy / torch RNG sees one draw of the sampler move ahead of its next
-# batch fetch -- a different (equally valid) random stream than the reference's interleaving.
-PREFETCH_CONDITIONING = os.environ.get("ICG_PREFETCH_COND", "0") == "1"
+# The START of the next step -- its first host-side conditioning draw and the generator forward of its first D accumulation, which need
+# nothing from the next batch -- issued at the END of the current one, behind the G update and the EMA, before the three `.item()` reads
+# block the host.  Without it the device idles ~3.7 ms at the start of every cfg3 step (profiles/r06_step_trace.txt): the host comes back
+# from the loss read-back with an empty queue and needs ~12 ms to launch a generator forward whose first hundred kernels (4x4 ... 16x16
+# blocks) take microseconds each.  Same operations on the same values in the same order -- G is not touched between the end of a step and
+# its forward in the next one; the parameter / buffer version counters are re-checked when the stash is used and a stale one is dropped.
+# OPT-IN (ICG_PREFETCH_NEXT_STEP=1; bench.py switches it on and says so): a caller whose data loader shares the sampler's global numpy /
+# torch RNG sees one draw of the sampler move ahead of its next batch fetch -- a different (equally valid) stream than the reference's.
+PREFETCH_NEXT_STEP = os.environ.get("ICG_PREFETCH_NEXT_STEP", "0") == "1"
 COMM_SAVINGS = os.environ.get("ICG_COMM_SAVINGS", "0") == "1"      # opt-in: the default is the reference's traffic pattern
 
 
@@ -72,16 +74,14 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
             return G.optim, D.optim
         return GD.optimizer_G, GD.optimizer_D
 
-    pending = []          # [(key, device tensors)] drawn ahead by the previous call (PREFETCH_CONDITIONING)
+    ahead = {}            # the next step's first draw and generator output, issued by the previous call (PREFETCH_NEXT_STEP)
+
+    def g_versions():
+        m = G.module if hasattr(G, "module") else G
+        return tuple(t._version for t in m.parameters()) + tuple(t._version for t in m.buffers()) + (m.training,)
 
     def draw(features, y, truncate):
         """Host-side conditioning draw -> device tensors (train_fns.py:70-85 / 135-149)."""
-        key = (features is not None, y is not None, bool(truncate))
-        if pending:
-            k, ready = pending.pop(0)
-            if k == key:
-                return ready
-            # (the caller changed its conditioning pattern between two steps: the draw taken ahead does not fit and is dropped)
         cond = sample_conditionings()
         labels_g = f_g = None
         if features is not None and y is not None:
@@ -118,11 +118,20 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
         for _ in range(config["num_D_steps"]):
             opt_D.zero_grad()
             for acc in range(config["num_D_accumulations"]):
-                z_, labels_g, f_g = draw(features, y, truncate=True)
+                G_z = None
+                if ahead:
+                    st = dict(ahead)
+                    ahead.clear()
+                    if st["key"] == (features is not None, y is not None) and st["versions"] == g_versions():
+                        (z_, labels_g, f_g), G_z = st["cond"], st["G_z"]
+                    # (else: the caller changed its conditioning pattern or touched G between two steps; the stash is dropped)
+                if G_z is None:
+                    z_, labels_g, f_g = draw(features, y, truncate=True)
                 with _no_sync(D, acc + 1 < config["num_D_accumulations"]):     # earlier rounds accumulate locally
                     D_fake, D_real = GD(z_, labels_g, f_g, x[counter], y[counter] if y is not None else None,
                                         f_[counter] if f_ is not None else None, train_G=False,
-                                        split_D=config["split_D"], policy=config["DiffAugment"], DA=config["DA"])
+                                        split_D=config["split_D"], policy=config["DiffAugment"], DA=config["DA"],
+                                        **({"G_z": G_z} if G_z is not None else {}))
                     D_loss_real, D_loss_fake = losses.discriminator_loss(D_fake, D_real)
                     D_loss = (D_loss_real + D_loss_fake) / float(config["num_D_accumulations"])
                     D_loss.backward()
@@ -150,9 +159,12 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
         opt_G.step()
         if config["ema"]:
             ema.update(state_dict["itr"])
-        if PREFETCH_CONDITIONING and config["num_D_steps"] > 0 and config["num_D_accumulations"] > 0:
-            del pending[:]
-            pending.append(((features is not None, y is not None, True), draw(features, y, truncate=True)))
+        if PREFETCH_NEXT_STEP and config["num_D_steps"] > 0 and config["num_D_accumulations"] > 0 and not config["DA"]:
+            ahead.clear()
+            cond = draw(features, y, truncate=True)
+            with torch.no_grad():             # exactly what G_D.forward(train_G=False) does first
+                G_z = G(*cond)
+            ahead.update(key=(features is not None, y is not None), cond=cond, G_z=G_z, versions=g_versions())
         return {"G_loss": float(G_loss.item()), "D_loss_real": float(D_loss_real.item()),
                 "D_loss_fake": float(D_loss_fake.item())}
 

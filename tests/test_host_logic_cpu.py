@@ -117,11 +117,12 @@ def test_attention_stacked_projections_equal_the_three_convolutions(emu, monkeyp
 
 
 @pytest.mark.parametrize("case", ["cc_ic_r64", "ic_r64_acc2"])
-def test_prefetched_conditioning_draw_is_the_same_training_run(case, emu, monkeypatch):
-    """train_fns.PREFETCH_CONDITIONING takes the NEXT step's first host-side draw at the end of the current step (under the GPU's queue):
-    the sampler is called once more per step boundary but in the same order, so a run of steps is bit-identical with and without it --
-    losses of every step and every parameter after the last one -- and the sampler is asked exactly one extra time (the draw waiting
-    for a step that never came)."""
+def test_prefetched_start_of_the_next_step_is_the_same_training_run(case, emu, monkeypatch):
+    """train_fns.PREFETCH_NEXT_STEP issues the NEXT step's first host-side draw and generator forward at the end of the current step
+    (behind the EMA, before the loss read-back): the same operations in the same order, so a run of steps is bit-identical with and
+    without it -- losses of every step, every parameter of G and D and every buffer of D after the last one (G's buffers are one forward
+    ahead by construction: running statistics and power-iteration vectors of the forward already issued) -- and the sampler is asked
+    exactly one extra time (the draw waiting for a step that never came).  A stash whose generator was touched in between is dropped."""
     from ic_gan_amd import train_fns, utils
     from ic_gan_amd.optim import FusedAdam
     g = load_golden(case)
@@ -130,7 +131,7 @@ def test_prefetched_conditioning_draw_is_the_same_training_run(case, emu, monkey
     dbatch = gb * cfg["num_D_accumulations"] * cfg["num_D_steps"]
     runs = []
     for prefetch in (False, True):
-        monkeypatch.setattr(train_fns, "PREFETCH_CONDITIONING", prefetch)
+        monkeypatch.setattr(train_fns, "PREFETCH_NEXT_STEP", prefetch)
         M, G, D = _build(g)
         G.load_state_dict(synth.synth_state(g["gspec"], 11))
         D.load_state_dict(synth.synth_state(g["dspec"], 22))
@@ -150,7 +151,7 @@ def test_prefetched_conditioning_draw_is_the_same_training_run(case, emu, monkey
             state["itr"] += 1
             G.train(); D.train(); G_ema.train()
             losses.append(train(x, y, f))
-        runs.append((losses, [p.detach().clone() for p in list(G.parameters()) + list(D.parameters())], len(calls)))
+        runs.append((losses, [p.detach().clone() for p in list(G.parameters()) + list(D.parameters()) + list(D.buffers())], len(calls)))
     (l0, p0, c0), (l1, p1, c1) = runs
     assert l0 == l1
     assert all(torch.equal(a, b) for a, b in zip(p0, p1))
