@@ -986,8 +986,21 @@ class SNEmbeddingFn(Function):
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
         sn = ctx.sn
-        dw_ = torch.zeros(sn.rows, sn.cin, device=dout.device, dtype=torch.float32)
-        dw_.index_add_(0, idx.reshape(-1), dout.reshape(-1, sn.cin).float())
+        # dW[r] = sum over the samples with label r of dout[sample], IN SAMPLE ORDER: one-hot^T [rows x n] times dout [n x cin] on the HIP
+        # GEMM (a fixed-order K loop).  Round 6: this was `index_add_`, whose atomic adds land in whatever order the hardware schedules
+        # them -- with repeated labels in a batch (128 draws from 1000 classes: almost always) the gradient of D.embed differed in the last
+        # bits from process to process, the one nondeterministic operation of the step (profiles/r06_step_determinism.txt).  The
+        # reference's nn.Embedding backward sorts the indices and is deterministic as well (layers.py:171-200 -> F.embedding).
+        flat = idx.reshape(-1)
+        n = int(flat.numel())
+        d2 = dout.reshape(n, sn.cin).float().contiguous()
+        dw_ = torch.empty(sn.rows, sn.cin, device=dout.device, dtype=torch.float32)
+        if n * sn.rows <= (1 << 26):
+            onehot = torch.zeros(n, sn.rows, device=dout.device, dtype=torch.float32)
+            onehot.scatter_(1, flat.view(n, 1), 1.0)                  # (one element per row: no two writes meet)
+            L.call("icg_gemm_batched", onehot, d2, dw_, sn.rows, sn.cin, n, 1, 0, 0, 0, 0, 1, 1.0)
+        else:     # a table too large for the one-hot form: ATen's sort-based (deterministic) embedding backward
+            dw_ = torch.ops.aten.embedding_dense_backward(d2, flat, sn.rows, -1, False)
         return None, _sn_backward(None, dw_, sn, ctx.weight_like), None
 
 
