@@ -75,6 +75,7 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
         return GD.optimizer_G, GD.optimizer_D
 
     ahead = {}            # the next step's first draw and generator output, issued by the previous call (PREFETCH_NEXT_STEP)
+    ahead_host = {}       # pinned landing buffer of the three losses
 
     def g_versions():
         m = G.module if hasattr(G, "module") else G
@@ -160,11 +161,27 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
         if config["ema"]:
             ema.update(state_dict["itr"])
         if PREFETCH_NEXT_STEP and config["num_D_steps"] > 0 and config["num_D_accumulations"] > 0 and not config["DA"]:
+            # the three losses start their way to the host FIRST (one asynchronous copy into pinned memory + an event), then the next
+            # step's opening is queued, then the host waits for the event only: it comes back while the device still has the generator
+            # forward to run.  (`.item()` after the queued forward would wait for the forward too and give the idle gap back.)
+            read = None
+            if G_loss.is_cuda:
+                if "pinned" not in ahead_host:
+                    ahead_host["pinned"] = torch.empty(3, dtype=torch.float32, pin_memory=True)
+                vals = torch.stack([G_loss.detach().reshape(()).float(), D_loss_real.detach().reshape(()).float(),
+                                    D_loss_fake.detach().reshape(()).float()])
+                ahead_host["pinned"].copy_(vals, non_blocking=True)
+                read = torch.cuda.Event()
+                read.record()
             ahead.clear()
             cond = draw(features, y, truncate=True)
             with torch.no_grad():             # exactly what G_D.forward(train_G=False) does first
                 G_z = G(*cond)
             ahead.update(key=(features is not None, y is not None), cond=cond, G_z=G_z, versions=g_versions())
+            if read is not None:
+                read.synchronize()
+                g, dr, df = (float(v) for v in ahead_host["pinned"].tolist())
+                return {"G_loss": g, "D_loss_real": dr, "D_loss_fake": df}
         return {"G_loss": float(G_loss.item()), "D_loss_real": float(D_loss_real.item()),
                 "D_loss_fake": float(D_loss_fake.item())}
 
