@@ -68,12 +68,13 @@ def _traffic_hook(state, bucket):
     return dist.all_reduce(buf, async_op=True).get_future().then(lambda f: f.value()[0])
 
 
-def _worker_step(rank, world, port, out, savings=True, accumulations=1, steps=1, sn_group=None):
+def _worker_step(rank, world, port, out, savings=True, accumulations=1, steps=1, sn_group=None, prefetch=False):
     from torch.nn.parallel import DistributedDataParallel as DDP
     from ic_gan_amd import ops, train_fns, utils
     from ic_gan_amd.optim import FusedAdam
     _init(rank, world, port)
     train_fns.COMM_SAVINGS = savings
+    train_fns.PREFETCH_NEXT_STEP = prefetch
     if sn_group is not None:
         ops.SN_BACKWARD_GROUP = sn_group
     groups = []
@@ -244,6 +245,18 @@ def test_ddp_grouped_spectral_norm_backward():
     assert torch.equal(grouped["flat"], single["flat"])
     t = grouped["traffic"]
     assert t["D"] == 2 * t["D_params"] and t["G"] == 2 * t["G_params"], t          # one pass over each network's parameters per step
+
+
+@pytest.mark.timeout(900)
+def test_ddp_prefetched_next_step_opening_keeps_the_run():
+    """train_fns.PREFETCH_NEXT_STEP under DistributedDataParallel: the generator forward of the next step's first D accumulation is
+    issued at the end of the current step on every rank (the wrapper's rank-0 buffer broadcast with it, in the same order on all ranks).
+    Two steps on two ranks: replicas bit-identical, and the same parameters as without the prefetch."""
+    ahead = _spawn(_worker_step, True, 1, 2, None, True)
+    plain = _spawn(_worker_step, True, 1, 2, None, False)
+    assert ahead["finite"] and ahead["identical"] and plain["identical"]
+    assert ahead["loss"] == plain["loss"]
+    assert torch.equal(ahead["flat"], plain["flat"])
 
 
 def test_ddp_step_world_size_4():
