@@ -29,8 +29,8 @@ t0 = int(step[0]["Start_Timestamp"])
 tot = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step)
 print("last step of the process: %d launches, %.2f ms of kernels, %.2f ms wall" % (len(step), tot / 1e6, (int(step[-1]["End_Timestamp"]) - t0) / 1e6))
 def short(n):
-    n = re.sub(r"^void ", "", n)
-    return re.sub(r"\(.*", "", n)[:70]
+    n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "")
+    return re.sub(r"\(.*", "", n)[:90]
 print("---- the 60 longest launches")
 for r in sorted(step, key=lambda r: int(r["Start_Timestamp"]) - int(r["End_Timestamp"]))[:60]:
     print("%9.1f us  at %8.2f ms  grid %-18s wg %-5s %s" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, (int(r["Start_Timestamp"]) - t0) / 1e6,
@@ -63,7 +63,20 @@ gaps = []
 for a, b in zip(step, step[1:]):
     g = int(b["Start_Timestamp"]) - int(a["End_Timestamp"])
     gaps.append((g, a, b))
-short = lambda n: re.sub(r"\(.*", "", re.sub(r"^void ", "", n))[:50]
+short = lambda n: re.sub(r"\(.*", "", re.sub(r"^void ", "", n).replace("(anonymous namespace)::", ""))[:70]
+durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in step]
+print("---- launches by duration: " + "; ".join("%s us: %d launches, %.2f ms" % (lab, sum(1 for d in durs if lo <= d < hi), sum(d for d in durs if lo <= d < hi) / 1e3)
+                                             for lab, lo, hi in (("< 10", 0, 10), ("10 - 50", 10, 50), ("50 - 200", 50, 200), ("200 - 1000", 200, 1000), (">= 1000", 1000, 1e12))))
+fam = {}
+for r, d in zip(step, durs):
+    k = short(r["Kernel_Name"])
+    fam.setdefault(k, [0, 0.0])
+    fam[k][0] += 1
+    fam[k][1] += d
+print("---- per kernel in this step (>= 0.5 ms in total)")
+for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+    if t >= 500:
+        print("%8.2f ms  %4d launches  %s" % (t / 1e3, c, k))
 print("---- idle gaps between consecutive launches: total %.2f ms; > 20 us: %d gaps = %.2f ms; the 25 largest" % (
     sum(max(g[0], 0) for g in gaps) / 1e6, sum(1 for g in gaps if g[0] > 20000), sum(g[0] for g in gaps if g[0] > 20000) / 1e6))
 for g, a, b in sorted(gaps, key=lambda t: -t[0])[:25]:
