@@ -160,5 +160,8 @@ def call(name: str, *args):
 
 
 def query(name: str, *args) -> int:
-    """Call a `size_t icg_*_bytes` query."""
-    return int(getattr(lib(), name)(*[_conv(a) for a in args]))
+    """Call a `size_t icg_*_bytes` / `int icg_*_applies` query (host only; results are not cached: some read a switch per call)."""
+    fn = _bound.get(name)
+    if fn is None:
+        fn = _bound[name] = getattr(lib(), name)
+    return int(fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]))
