@@ -312,6 +312,10 @@ class G_D(nn.Module):
         self.G, self.D = G, D
         self.optimizer_G, self.optimizer_D = optimizer_G, optimizer_D
 
+    def generate(self, z, gy, feats_g=None):
+        """the generator call of `forward` (also what train_fns.PREFETCH_NEXT_STEP issues ahead, under no_grad)"""
+        return self.G(z, gy, feats_g)
+
     def forward(self, z, gy, feats_g=None, x=None, dy=None, feats=None, train_G=False, return_G_z=False,
                 split_D=False, policy=False, DA=False, G_z=None):
         """`G_z` (not in the reference's signature): the generator's output for exactly these (z, gy, feats_g), computed ahead by the
@@ -320,7 +324,7 @@ class G_D(nn.Module):
             raise NotImplementedError("DiffAugment is disabled in every shipped IC-GAN config (SURVEY §2.1)")
         if G_z is None:
             with torch.set_grad_enabled(train_G):
-                G_z = self.G(z, gy, feats_g)
+                G_z = self.generate(z, gy, feats_g)
         else:
             assert not train_G and not G_z.requires_grad
         if split_D:

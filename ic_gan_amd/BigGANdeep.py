@@ -351,14 +351,23 @@ class G_D(nn.Module):
     def _bare(self, m):
         return m.module if hasattr(m, "module") else m
 
+    def generate(self, z, gy, feats_g=None):
+        """the generator call of `forward` (what train_fns.PREFETCH_NEXT_STEP issues ahead, under no_grad)"""
+        if getattr(self._bare(self.G), "instance_cond", False):
+            return self.G(z, gy, feats_g)
+        return self.G(z, self._bare(self.G).shared(gy))
+
     def forward(self, z, gy, *args, **kwargs):
         if getattr(self._bare(self.G), "instance_cond", False):
             return self._forward_ic(z, gy, *args, **kwargs)
         return self._forward_cc(z, gy, *args, **kwargs)
 
-    def _forward_cc(self, z, gy, x=None, dy=None, train_G=False, return_G_z=False, split_D=False):
-        with torch.set_grad_enabled(train_G):
-            G_z = self.G(z, self._bare(self.G).shared(gy))
+    def _forward_cc(self, z, gy, x=None, dy=None, train_G=False, return_G_z=False, split_D=False, G_z=None):
+        if G_z is None:
+            with torch.set_grad_enabled(train_G):
+                G_z = self.generate(z, gy)
+        else:
+            assert not train_G and not G_z.requires_grad
         if split_D:
             D_fake = self.D(G_z, gy)
             if x is not None:
@@ -372,11 +381,15 @@ class G_D(nn.Module):
         return (D_out, G_z) if return_G_z else D_out
 
     def _forward_ic(self, z, gy, feats_g=None, x=None, dy=None, feats=None, train_G=False, return_G_z=False, split_D=False,
-                    policy=False, DA=False):
+                    policy=False, DA=False, G_z=None):
+        """`G_z`: the generator's output for these inputs computed ahead under no_grad (train_fns.PREFETCH_NEXT_STEP; BigGAN.G_D.forward)"""
         if DA:
             raise NotImplementedError("DiffAugment is disabled in every shipped IC-GAN config (SURVEY 2.1)")
-        with torch.set_grad_enabled(train_G):
-            G_z = self.G(z, gy, feats_g)
+        if G_z is None:
+            with torch.set_grad_enabled(train_G):
+                G_z = self.generate(z, gy, feats_g)
+        else:
+            assert not train_G and not G_z.requires_grad
         if split_D:
             D_fake = self.D(G_z, gy, feats_g)
             if x is not None:

@@ -75,6 +75,12 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
         return GD.optimizer_G, GD.optimizer_D
 
     ahead = {}            # the next step's first draw and generator output, issued by the previous call (PREFETCH_NEXT_STEP)
+    try:                  # a G_D wrapper without the `G_z` keyword (the reference's own, a user's): no opening is issued ahead
+        import inspect
+        fwd = inspect.signature(GD.forward).parameters
+        gd_takes_gz = callable(getattr(GD, "generate", None)) and ("G_z" in fwd or any(p.kind == p.VAR_KEYWORD for p in fwd.values()))
+    except (TypeError, ValueError):
+        gd_takes_gz = False
     ahead_host = {}       # pinned landing buffer of the three losses
 
     def g_versions():
@@ -160,7 +166,7 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
         opt_G.step()
         if config["ema"]:
             ema.update(state_dict["itr"])
-        if PREFETCH_NEXT_STEP and config["num_D_steps"] > 0 and config["num_D_accumulations"] > 0 and not config["DA"]:
+        if PREFETCH_NEXT_STEP and gd_takes_gz and config["num_D_steps"] > 0 and config["num_D_accumulations"] > 0 and not config["DA"]:
             # the three losses start their way to the host FIRST (one asynchronous copy into pinned memory + an event), then the next
             # step's opening is queued, then the host waits for the event only: it comes back while the device still has the generator
             # forward to run.  (`.item()` after the queued forward would wait for the forward too and give the idle gap back.)
@@ -176,7 +182,7 @@ def GAN_training_function(G, D, GD, ema, state_dict, config, sample_conditioning
             ahead.clear()
             cond = draw(features, y, truncate=True)
             with torch.no_grad():             # exactly what G_D.forward(train_G=False) does first
-                G_z = G(*cond)
+                G_z = GD.generate(*cond)
             ahead.update(key=(features is not None, y is not None), cond=cond, G_z=G_z, versions=g_versions())
             if read is not None:
                 read.synchronize()
