@@ -647,6 +647,130 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 4 : 3)) void icg_pgemm_tn_kern
   }
 }
 
+// ---- the same weight-gradient plane GEMM on a 96 x 96 workgroup tile owned by FOUR waves (2 x 2, 48 x 48 = 3 x 3 MFMA tiles each) for the narrow
+// layers (M, N multiples of 96: 96 / 192 channels), round 6.  The 6-wave form above keeps 2 workgroups = 12 waves on a CU; these GEMMs sit on
+// the ridge (24 FLOP per byte of V + M) and reached 0.53 - 0.60 of the MFMA peak and ~0.6 of the achievable HBM rate at once
+// (profiles/r06_pgemm_microbench.txt).  Here a CU holds 4 workgroups = 16 waves (36 KiB of LDS each): four independent barrier domains and
+// twice the tiles in flight; a wave issues 24 single-float LDS reads per 36 MFMAs instead of 20 per 24.  Same K order, same two-level
+// accumulation, same slab layout.  DMA: a K-tile image is 16 rows x 24 chunks = 384 chunks per operand = 96 per wave, fetched as 64 + 32 lanes
+// (4 DMA instructions per wave and K-tile: the counted vmcnt below is 4 per tile in flight).
+template <int LEVELS, int NBUF>
+__global__ __launch_bounds__(256, 3) void icg_pgemm_tn96_kernel(PgemmTnP p) {
+  constexpr int BM = 96, BN = 96, BK = 16, IT = 3, NT = 3;
+  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, SLOT = A_BYTES + B_BYTES;
+  constexpr int CH = BM / 4;                                        // 24 16-byte chunks per row (both operands)
+  __shared__ __attribute__((aligned(1024))) char lds[NBUF * SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..3
+  const int wm = wv & 1, wn = wv >> 1;
+  const int r = lane & 15, kk = lane >> 4;
+
+  unsigned t = blockIdx.x;
+  if (p.swz) {
+    const unsigned tot = p.total, q = tot >> 3, rr = tot & 7u, xcd = t & 7u;
+    t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (t >> 3);
+  }
+  const int zs = (int)(t / (unsigned)p.tiles_mn);
+  const int tile = (int)(t - (unsigned)zs * (unsigned)p.tiles_mn);
+  const int z = zs / p.slices, sl = zs - z * p.slices;
+  const int nt = tile % p.tiles_n, mt = tile / p.tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int kbeg = sl * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+  const int nk = (kend - kbeg) / BK;                                // even
+  const float* __restrict__ Ag = p.A + (long)z * p.sA + (long)kbeg * p.M;
+  const float* __restrict__ Bg = p.B + (long)z * p.sB + (long)kbeg * p.N;
+
+  // DMA role: the wave's 96 consecutive chunks of each image, as lanes 0..63 (chunks 96 wv ..) and lanes 0..31 (chunks 96 wv + 64 ..)
+  const int l0 = 96 * wv + lane, l1 = 96 * wv + 64 + (lane & 31);
+  const int ar0 = l0 / CH, ac0 = (l0 % CH) ^ (4 * (ar0 & 1)), ar1 = l1 / CH, ac1 = (l1 % CH) ^ (4 * (ar1 & 1));
+  const unsigned voffA0 = ((unsigned)ar0 * (unsigned)p.M + (unsigned)(m0 + 4 * ac0)) * 4u;
+  const unsigned voffA1 = ((unsigned)ar1 * (unsigned)p.M + (unsigned)(m0 + 4 * ac1)) * 4u;
+  const unsigned voffB0 = ((unsigned)ar0 * (unsigned)p.N + (unsigned)(n0 + 4 * ac0)) * 4u;
+  const unsigned voffB1 = ((unsigned)ar1 * (unsigned)p.N + (unsigned)(n0 + 4 * ac1)) * 4u;
+  const bool half = lane < 32;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned ldsA = lds_base + (unsigned)wv * 1536u, ldsB = lds_base + (unsigned)A_BYTES + (unsigned)wv * 1536u;
+  const long a_step = (long)BK * p.M, b_step = (long)BK * p.N;
+  auto issue = [&](int kt, unsigned slot_off) {
+    const int kc = min(kt, nk - 1);
+    pg_dma16(Ag + kc * a_step, voffA0, ldsA + slot_off);
+    if (half) pg_dma16(Ag + kc * a_step, voffA1, ldsA + 1024u + slot_off);
+    pg_dma16(Bg + kc * b_step, voffB0, ldsB + slot_off);
+    if (half) pg_dma16(Bg + kc * b_step, voffB1, ldsB + 1024u + slot_off);
+  };
+  auto next_slot = [](unsigned off) -> unsigned { return off == (unsigned)((NBUF - 1) * SLOT) ? 0u : off + (unsigned)SLOT; };
+
+  const int px = 16 * (kk & 1);
+  const char* fa[IT];
+  const char* fb[NT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) fa[i] = lds + kk * (BM * 4) + ((48 * wm + 16 * i + r) ^ px) * 4;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) fb[j] = lds + A_BYTES + kk * (BN * 4) + ((48 * wn + 16 * j + r) ^ px) * 4;
+
+  f32x4 acc[IT][NT], acc2[IT][NT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+#pragma unroll
+  for (int d = 0; d < NBUF - 1; ++d) issue(d, (unsigned)(d * SLOT));
+
+  auto tile_step = [&](int kt, unsigned cur, auto flush_c) {
+    constexpr bool FLUSH = decltype(flush_c)::value;
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (NBUF - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue(kt + NBUF - 1, cur == 0u ? (unsigned)((NBUF - 1) * SLOT) : cur - (unsigned)SLOT);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float a[IT], b[NT];
+#pragma unroll
+      for (int i = 0; i < IT; ++i) a[i] = *reinterpret_cast<const float*>(fa[i] + cur + s * (4 * BM * 4));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const float*>(fb[j] + cur + s * (4 * BN * 4));
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          if (LEVELS == 2 && FLUSH && s == 0) {
+            acc2[i][j] += acc[i][j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  unsigned cur = 0u;
+  for (int kt = 0; kt < nk; kt += 2) {
+    tile_step(kt, cur, std::true_type{});
+    cur = next_slot(cur);
+    tile_step(kt + 1, cur, std::false_type{});
+    cur = next_slot(cur);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* __restrict__ Cg = p.C + (long)zs * p.M * p.N;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int mrow = m0 + 48 * wm + 16 * i + 4 * kk;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + 48 * wn + 16 * j + r;
+      const f32x4 v = (LEVELS == 2) ? acc[i][j] + acc2[i][j] : acc[i][j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Cg[(long)(mrow + e) * p.N + n] = v[e];
+    }
+  }
+}
+
 // ---- second-generation implicit-GEMM convolution (forward / data-gradient shaped: A gathered from an NHWC activation, B = weights
 // [N][taps][Cin], K = taps x Cin in tap-minor order -- all taps of a 16-channel slice, then the next slice, like icg_gemm_body's
 // fast path).  Same pipeline as the plane GEMM; the A tile's DMA source address is recomputed per K-tile (one tap of one slice:
@@ -957,6 +1081,21 @@ int icg_pgemm_tn_launch(const float* A, const float* B, float* C, int M, int N, 
   p.swz = (total >= 16 && !no_swz) ? 1 : 0;
   dim3 grid((unsigned)total), block(512);
   static const int nbuf = pgemm_env_int("ICG_PGEMM_NBUF", 3);
+  static const int tn96 = pgemm_env_int("ICG_PGEMM_TN96", 1);       // 0: the 6-wave form (measurement switch); 4: with a 4-slot ring
+  if (tn96 && levels == 2 && M % 96 == 0 && N % 96 == 0 && (M % 128 != 0 || N % 128 != 0)) {
+    // 96 x 96 tiles on four waves, four workgroups per CU (see icg_pgemm_tn96_kernel)
+    p.tiles_n = N / 96;
+    const long tmn = (long)(M / 96) * p.tiles_n, tot2 = tmn * planes * slices;
+    if (tot2 > 0 && tot2 < 0x7fffffffL) {
+      p.tiles_mn = (int)tmn;
+      p.total = (unsigned)tot2;
+      p.swz = (tot2 >= 16 && !no_swz) ? 1 : 0;
+      if (tn96 == 4) hipLaunchKernelGGL((icg_pgemm_tn96_kernel<2, 4>), dim3((unsigned)tot2), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((icg_pgemm_tn96_kernel<2, 3>), dim3((unsigned)tot2), dim3(256), 0, st, p);
+      if (tn_out) *tn_out = 3;
+      return icg_check_launch();
+    }
+  }
   if (m96) {
     block = dim3(384);
     if (levels == 2 && nbuf == 4) hipLaunchKernelGGL((icg_pgemm_tn_kernel<3, 2, 3, 4>), grid, block, 0, st, p);
