@@ -1081,8 +1081,9 @@ int icg_pgemm_tn_launch(const float* A, const float* B, float* C, int M, int N, 
   p.swz = (total >= 16 && !no_swz) ? 1 : 0;
   dim3 grid((unsigned)total), block(512);
   static const int nbuf = pgemm_env_int("ICG_PGEMM_NBUF", 3);
-  static const int tn96 = pgemm_env_int("ICG_PGEMM_TN96", 1);       // 0: the 6-wave form (measurement switch); 4: with a 4-slot ring
-  if (tn96 && levels == 2 && M % 96 == 0 && N % 96 == 0 && (M % 128 != 0 || N % 128 != 0)) {
+  static const int tn96 = pgemm_env_int("ICG_PGEMM_TN96", 2);       // 2: every M, N multiple of 96 (also 384 / 768 / 1536: 0 - 10 % faster than the 128-tile form);
+  //                                                                   1: only where the 128-tile form pads; 0: the 6- / 8-wave forms; 4: 4-slot ring (measurement switches)
+  if (tn96 && levels == 2 && M % 96 == 0 && N % 96 == 0 && (tn96 == 2 || M % 128 != 0 || N % 128 != 0)) {
     // 96 x 96 tiles on four waves, four workgroups per CU (see icg_pgemm_tn96_kernel)
     p.tiles_n = N / 96;
     const long tmn = (long)(M / 96) * p.tiles_n, tot2 = tmn * planes * slices;
