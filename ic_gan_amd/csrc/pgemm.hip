@@ -650,8 +650,8 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? 4 : 3)) void icg_pgemm_tn_kern
 // ---- the same weight-gradient plane GEMM on a 96 x 96 workgroup tile owned by FOUR waves (2 x 2, 48 x 48 = 3 x 3 MFMA tiles each) for the narrow
 // layers (M, N multiples of 96: 96 / 192 channels), round 6.  The 6-wave form above keeps 2 workgroups = 12 waves on a CU; these GEMMs sit on
 // the ridge (24 FLOP per byte of V + M) and reached 0.53 - 0.60 of the MFMA peak and ~0.6 of the achievable HBM rate at once
-// (profiles/r06_pgemm_microbench.txt).  Here a CU holds 4 workgroups = 16 waves (36 KiB of LDS each): four independent barrier domains and
-// twice the tiles in flight; a wave issues 24 single-float LDS reads per 36 MFMAs instead of 20 per 24.  (The forward-shaped sibling of this
+// (profiles/r06_pgemm_microbench.txt).  Here a CU holds 3 workgroups of 4 waves (36 KiB of LDS each, 140 registers): three independent
+// barrier domains and 1.5 x the tiles in flight; a wave issues 24 single-float LDS reads per 36 MFMAs instead of 20 per 24.  (The forward-shaped sibling of this
 // tile was built and measured too: -11 % at 384 -> 192, +3 ... +9 % at K <= 192 and on every 128-multiple width, no gain in the step: not kept.)
 // Same K order, same two-level
 // accumulation, same slab layout.  DMA: a K-tile image is 16 rows x 24 chunks = 384 chunks per operand = 96 per wave, fetched as 64 + 32 lanes
