@@ -183,13 +183,17 @@ extern "C" int icg_attn_scores_softmax(const float* theta, const float* phi, flo
 // 16x16x4 operand pattern then see 16 distinct 16-byte slots), the V fragments come straight from L2 (every CU streams the
 // same m x dv matrix of its image), beta is read once with 16-byte loads in the accumulator layout, the row dot products go
 // through two wave shuffles and one LDS exchange in a fixed order, dS is written once.
-template <int DV>
+template <int DV, bool STAGE>
 __global__ __launch_bounds__(512) void icg_attn_dscores_kernel(const float* __restrict__ dO, const float* __restrict__ Vg,
                                                                 const float* __restrict__ beta, float* __restrict__ dS, int n, int m) {
   constexpr int STRIDE = DV + (((DV * 4) % 256 == 128) ? 40 : 8);   // floats per staged row: 544 / 800 bytes = 32 mod 256 for DV = 96 / 192
   static_assert((DV % 16) == 0 && ((STRIDE * 4) % 256) == 32, "LDS row stride must be 32 bytes mod 256");
   __shared__ __attribute__((aligned(16))) float qs[32 * STRIDE];
   __shared__ float red[8][32];
+  // STAGE (round 6): beta arrives and dS leaves through a wave-private LDS tile (16 rows x 128 keys, as in icg_attn_scores_softmax_kernel): the
+  // global accesses are whole 512-byte row segments instead of 64-byte pieces of 16 rows (in the accumulator layout this kernel moved its 2 x 128 KB
+  // per workgroup at 1.6 - 2.4 TB/s)
+  __shared__ __attribute__((aligned(16))) float stage[STAGE ? 8 * 16 * AT_SROW : 4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
   const int r = lane & 15, kk = lane >> 4;
   const int rows_per_img = n >> 5;
@@ -215,6 +219,7 @@ __global__ __launch_bounds__(512) void icg_attn_dscores_kernel(const float* __re
   // in turn and ran at 70 TF)
   constexpr int NKT = DV / 16;
   const long off = ((long)b * n + row0) * m + 128 * wv + 4 * kk;
+  const long offr = ((long)b * n + row0) * m + 128 * wv + 4 * (lane & 31);      // (STAGE: the row-contiguous view of the same 32 x 128 block)
   at_f32x4 bt[2][8];
   float4 kb[2][8];
 #pragma unroll
@@ -224,6 +229,12 @@ __global__ __launch_bounds__(512) void icg_attn_dscores_kernel(const float* __re
     if (t + 1 < NKT) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) kb[(t + 1) & 1][j] = *reinterpret_cast<const float4*>(Kp + (16 * j + r) * DV + 16 * (t + 1) + 4 * kk);
+    } else if constexpr (STAGE) {      // row-contiguous: instruction q of group i brings rows 2 q, 2 q + 1 (lane >> 5), 16 bytes at key 4 (lane & 31)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          bt[i][q] = *reinterpret_cast<const at_f32x4*>(beta + offr + (long)(16 * i + 2 * q + (lane >> 5)) * m);
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -245,6 +256,22 @@ __global__ __launch_bounds__(512) void icg_attn_dscores_kernel(const float* __re
   }
 
   // ---- epilogue: lane (r, kk) holds dbeta[row 16 i + r][key 128 wv + 16 j + 4 kk .. + 3]
+  float* __restrict__ stw = stage + (STAGE ? wv * (16 * AT_SROW) : 0);
+  if constexpr (STAGE) {             // beta: row-contiguous registers -> stage -> accumulator layout, one 16-row group at a time
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) *reinterpret_cast<at_f32x4*>(stw + (2 * q + (lane >> 5)) * AT_SROW + 4 * (lane & 31)) = bt[i][q];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bt[i][j] = *reinterpret_cast<const at_f32x4*>(stw + r * AT_SROW + 16 * j + 4 * kk);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
   float dot[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -266,14 +293,29 @@ __global__ __launch_bounds__(512) void icg_attn_dscores_kernel(const float* __re
     dot[i] = s;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       at_f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = bt[i][j][e] * (acc[i][j][e] - dot[i]);
-      *reinterpret_cast<at_f32x4*>(dS + off + (long)(16 * i + r) * m + 16 * j) = o;
+      if constexpr (STAGE) *reinterpret_cast<at_f32x4*>(stw + r * AT_SROW + 16 * j + 4 * kk) = o;
+      else *reinterpret_cast<at_f32x4*>(dS + off + (long)(16 * i + r) * m + 16 * j) = o;
     }
+    if constexpr (STAGE) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int row = 2 * q + (lane >> 5);
+        *reinterpret_cast<at_f32x4*>(dS + offr + (long)(16 * i + row) * m) = *reinterpret_cast<const at_f32x4*>(stw + row * AT_SROW + 4 * (lane & 31));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
 }
 
 // 1 when the fused backward serves the shape: n a multiple of 32, m a multiple of 128 up to 1024, dv in {96, 192}
@@ -292,8 +334,12 @@ extern "C" int icg_attn_dscores(const float* dO, const float* V, const float* be
   ICG_REQUIRE(blocks < 0x7fffffffL);
   const dim3 grid((unsigned)blocks), block((unsigned)(64 * (m / 128)));
   hipStream_t st = (hipStream_t)stream;
-  if (dv == 96) hipLaunchKernelGGL((icg_attn_dscores_kernel<96>), grid, block, 0, st, dO, V, beta, dS, n, m);
-  else hipLaunchKernelGGL((icg_attn_dscores_kernel<192>), grid, block, 0, st, dO, V, beta, dS, n, m);
+  static const bool stage = [] { const char* e = getenv("ICG_ATTN_STAGE"); return !(e && e[0] == '0'); }();
+  if (stage) {
+    if (dv == 96) hipLaunchKernelGGL((icg_attn_dscores_kernel<96, true>), grid, block, 0, st, dO, V, beta, dS, n, m);
+    else hipLaunchKernelGGL((icg_attn_dscores_kernel<192, true>), grid, block, 0, st, dO, V, beta, dS, n, m);
+  } else if (dv == 96) hipLaunchKernelGGL((icg_attn_dscores_kernel<96, false>), grid, block, 0, st, dO, V, beta, dS, n, m);
+  else hipLaunchKernelGGL((icg_attn_dscores_kernel<192, false>), grid, block, 0, st, dO, V, beta, dS, n, m);
   return icg_check_launch();
 }
 
